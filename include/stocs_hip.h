@@ -1,0 +1,159 @@
+/*
+ * stocs_hip.h -- C ABI of libstocs_hip.so: the MI355X (gfx950) implementation of the StoCS hot path
+ * of kuwt/model_matching (congruent-set sampling + rigid-transform estimation + LCP verification).
+ *
+ * The reference has no plugin/FFI interface: its boundary is the C++ class stocs::stocs_estimator
+ * (reference include/stocs.hpp:16-180) statically linked into stocs_single
+ * (reference src/stocs_match_one_object.cpp:51-185).  Each entry point below replaces one method
+ * (or a batch of calls to one method) of that class; include/stocs.hpp of THIS repo is the façade
+ * with the reference's method names on top of these calls, INTEGRATION.md shows the binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; every function returns 0 on success or
+ * a negative stocs_status; nothing throws across the boundary; output buffers are caller-owned with
+ * explicit capacities; 4x4 matrices are 16 floats COLUMN-major (Eigen::Matrix4f::data() layout);
+ * one context is bound to one HIP device and one stream, is not thread-safe, distinct contexts are
+ * independent.  There is no CPU fallback: without a usable HIP device stocs_ctx_create fails with
+ * STOCS_ERR_NO_DEVICE.
+ */
+#ifndef STOCS_HIP_H
+#define STOCS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct stocs_ctx stocs_ctx;
+
+typedef enum stocs_status {
+    STOCS_OK = 0,
+    STOCS_ERR_INVALID = -1,    /* bad argument */
+    STOCS_ERR_NO_DEVICE = -2,  /* no HIP device / HIP runtime error at init */
+    STOCS_ERR_HIP = -3,        /* HIP runtime error (see stocs_last_error) */
+    STOCS_ERR_CAPACITY = -4,   /* caller buffer too small; required count is returned */
+    STOCS_ERR_STATE = -5,      /* call order violated (e.g. no index, no bases) */
+    STOCS_ERR_NOMEM = -6
+} stocs_status;
+
+/* Parameters: the file-scope constants of reference src/stocs_match_one_object.cpp:7-17 and the
+ * hard-coded thresholds of reference src/stocs.cpp:368-370. */
+typedef struct stocs_params {
+    float distance_threshold;        /* 0.005  (:8)  epsilon of congruent-set matching and LCP   */
+    int   ppf_tr_discretization;     /* 5 mm   (:9)                                               */
+    int   ppf_rot_discretization;    /* 5 deg  (:10)                                              */
+    float plane_threshold;           /* 0.015  (stocs.cpp:368)                                    */
+    float min_distance_base;         /* 0.01   (stocs.cpp:369)                                    */
+    float internal_angle_threshold;  /* 30     (stocs.cpp:370)                                    */
+    float lcp_normal_angle;          /* 30     (stocs.cpp:1032)                                   */
+    int   image_width, image_height; /* 640x480 (:23-24); only used by instance-mode sampling     */
+    int   number_of_bases;           /* 100    (:16)                                              */
+    int   maximum_congruent_sets;    /* 200    (:17)                                              */
+} stocs_params;
+
+void stocs_default_params(stocs_params* p);
+const char* stocs_last_error(void);
+const char* stocs_version(void);
+
+/* ---- construction: replaces stocs_estimator::stocs_estimator (stocs.hpp:18-61):
+ * load_object_info + load_scene_info (clouds are handed over as flat arrays instead of PLY/PNG
+ * files), centroid_shift (stocs.cpp:943-964), kdtree_initialize (stocs.cpp:966-980; here a brick
+ * grid over the centred scene).  Normals are normalised as Point3D::set_normal does.  When
+ * build_index != 0 the model PPF index (reference PPFMapType, built offline by
+ * stocs::pre_process_model, stocs.cpp:63-78 + rgbd.cpp:123-154) is built on the device.
+ * scene_pixel2 (row,col per point) may be NULL.  device < 0 selects the current device. ---- */
+int stocs_ctx_create(const stocs_params* prm,
+                     const float* scene_pos3, const float* scene_nrm3, const float* scene_prob,
+                     const int32_t* scene_pixel2, int nS,
+                     const float* model_pos3, const float* model_nrm3, int nM,
+                     int build_index, int device, stocs_ctx** out);
+int stocs_ctx_destroy(stocs_ctx* ctx);
+
+/* getters: stocs.hpp:115-116 get_scene_centroid (+ model centroid) */
+int stocs_get_centroids(const stocs_ctx* ctx, float* scene3, float* model3);
+int stocs_get_sizes(const stocs_ctx* ctx, int* nS, int* nM);
+/* edge map (png values, image_height*image_width bytes): presence switches the driver to
+ * sample_instance_base, as the stat() of probability_maps/edge.png does (stocs_match_one_object.cpp:90) */
+int stocs_set_edge_map(stocs_ctx* ctx, const uint8_t* edge);
+
+/* ---- PPF index queries: replace ppf_map.find (call sites stocs.cpp:403,438,487,780,784) ---- */
+int stocs_ppf_compute_host(const float* p1, const float* n1, const float* p2, const float* n2,
+                           int tr, int rot, int32_t* key4);       /* rgbd.cpp:99-121 */
+int stocs_index_exists(const stocs_ctx* ctx, const int32_t* key4, int* exists);
+/* pairs of lookup(key) in lexicographic (id1,id2) order == the reference's insertion order */
+int stocs_index_lookup(stocs_ctx* ctx, const int32_t* key4, int32_t* pairs2, int64_t cap, int64_t* n);
+int stocs_index_stats(const stocs_ctx* ctx, int64_t* n_pairs, int64_t* n_buckets, int64_t* n_keys);
+
+/* ---- base sampling: batched form of the loop stocs_match_one_object.cpp:81-101 over
+ * sample_class_base (stocs.cpp:363-519) / sample_instance_base (stocs.cpp:559-751).
+ * mode 0 = class, 1 = instance.  Attempt i uses the seeded draws rng(seed, first_attempt+i, k).
+ * Outputs per attempt: ids (permuted by try_sampled_base, stocs.cpp:224-268), the two invariants,
+ * valid flag.  Valid bases are appended to the context's base set in attempt order. ---- */
+int stocs_sample_bases(stocs_ctx* ctx, int mode, uint64_t seed, int first_attempt, int n_attempts,
+                       float dispersion, int32_t* base_ids4, float* inv2, int32_t* valid);
+/* inject bases (already ordered, with their invariants) -- used by the parity tests and by callers
+ * that sample elsewhere; replaces the context's base set */
+int stocs_set_bases(stocs_ctx* ctx, int n, const int32_t* base_ids4, const float* inv2);
+int stocs_clear_bases(stocs_ctx* ctx);
+int stocs_num_bases(const stocs_ctx* ctx);
+/* one pass of the weight update for fixed base points (kernel-level parity with the oracle):
+ * pass k in 1..3, b3 = {P1,P2,P3} scene indices, w_in/w_out host arrays of nS floats */
+int stocs_class_pass(stocs_ctx* ctx, int pass, const int32_t* b3, const float* w_in, float* w_out);
+/* try_sampled_base on four scene indices (stocs.cpp:224-268) */
+int stocs_try_sampled_base(stocs_ctx* ctx, int32_t* ids4_inout, float* inv2, int* valid);
+/* the seeded weighted draw itself (stocs.cpp:133-148 replacement): index or -1 */
+int stocs_draw(stocs_ctx* ctx, const float* w, int n, uint64_t r64, int* index);
+
+/* ---- congruent sets: find_congruent_sets_on_model (stocs.cpp:753-869) for every base of the base
+ * set at once; then per-base read-back.  Quads are sorted as the reference's std::set orders them. ---- */
+int stocs_find_congruent_all(stocs_ctx* ctx, int64_t* total_quads);
+int stocs_get_quads(stocs_ctx* ctx, int base_slot, int32_t* quads4, int64_t cap, int64_t* n);
+
+/* ---- candidate transforms: the loop stocs_match_one_object.cpp:120-147 over
+ * get_rigid_transform_from_congruent_pair (stocs.cpp:871-941 -> ComputeRigidTransformation :270-361):
+ * at most max_per_base quads per base (all when fewer; a seeded subset otherwise). ---- */
+int stocs_make_transforms(stocs_ctx* ctx, int max_per_base, uint64_t seed, int* n_candidates);
+/* single (base ids, quad) -> transform; ok=0 when the reference would not append a candidate */
+int stocs_rigid_transform(stocs_ctx* ctx, const int32_t* ids4, const int32_t* quad4,
+                          float* T16_centred, float* pose16_camera, int* ok);
+int stocs_get_candidates(stocs_ctx* ctx, float* T16_centred, float* pose16_camera, float* lcp,
+                         int32_t* base_index, int cap, int* n);
+
+/* ---- verification: compute_alignment_score_for_rigid_transform (stocs.cpp:1006-1041), batched.
+ * THE METRIC KERNEL: one candidate pose verified per transform. ---- */
+int stocs_score_transforms(stocs_ctx* ctx, const float* T16_centred_host, int n, float* lcp_host);
+/* device-resident variant: d_T16 and d_lcp are device pointers on the context's device; the call is
+ * asynchronous on the context's stream (use stocs_sync) */
+int stocs_score_transforms_device(stocs_ctx* ctx, const void* d_T16, int n, void* d_lcp);
+/* per model point: index of the matched scene point (-1 none) and whether it was counted */
+int stocs_lcp_detail(stocs_ctx* ctx, const float* T16_centred_host, int32_t* hit, uint8_t* counted);
+/* compute_best_transform (stocs.cpp:982-1004): score every stored candidate, arg-max with first
+ * maximum winning; best_idx = -1 and best_lcp = 0 when every score is 0 */
+int stocs_verify_all(stocs_ctx* ctx, float* best_lcp, int* best_idx, float* best_pose16_camera);
+/* order-preserving key for the cross-GPU arg-max (max wins; lowest global id wins ties) */
+uint64_t stocs_pack_best(float lcp, uint32_t global_candidate_id);
+void stocs_unpack_best(uint64_t key, float* lcp, uint32_t* global_candidate_id);
+
+/* ---- pose post-processing: clustering::greedy_clustering (pose_clustering.cpp:79-121), host ---- */
+int stocs_cluster_poses(const float* poses16, const float* lcp, int n, float acceptable_fraction,
+                        float best_score, int maximum_pose_count, float min_distance, float min_angle,
+                        const float* sym3, int32_t* out_idx, int cap, int* n_out);
+
+/* ---- stream / timing plumbing ---- */
+int   stocs_sync(stocs_ctx* ctx);
+void* stocs_stream(stocs_ctx* ctx);          /* hipStream_t */
+/* times `reps` back-to-back launches of the LCP kernel on n device-resident transforms with HIP
+ * events on the context's stream; returns the average milliseconds per launch */
+int stocs_time_score_kernel(stocs_ctx* ctx, const void* d_T16, int n, void* d_lcp, int reps,
+                            float* avg_ms);
+/* device memory helpers so that callers without a HIP binding (ctypes) can keep inputs resident */
+int stocs_dev_alloc(stocs_ctx* ctx, int64_t bytes, void** dptr);
+int stocs_dev_free(stocs_ctx* ctx, void* dptr);
+int stocs_dev_upload(stocs_ctx* ctx, void* dptr, const void* host, int64_t bytes);
+int stocs_dev_download(stocs_ctx* ctx, void* host, const void* dptr, int64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

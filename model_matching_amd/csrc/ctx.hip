@@ -1,0 +1,442 @@
+// ctx.hip -- context construction for the MI355X StoCS engine.
+// Replaces the ctor of stocs::stocs_estimator (reference include/stocs.hpp:18-61): clouds in,
+// centroid_shift (reference src/stocs.cpp:943-964), spatial index over the scene (reference
+// kdtree_initialize, stocs.cpp:966-980 -> here a brick grid, see SceneGrid), model normalisation
+// into the unit cube (reference include/super4pcs/pairCreationFunctor.h:96-132).
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include <algorithm>
+#include <limits>
+#include <numeric>
+
+#include "stocs_ctx.h"
+
+namespace stocs {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static inline int32_t float_ord(float f) {
+    int32_t i;
+    memcpy(&i, &f, 4);
+    return i < 0 ? (int32_t)(0x80000000u - (uint32_t)i) : i;
+}
+static inline float ord_float(int32_t o) {
+    int32_t i = o < 0 ? (int32_t)(0x80000000u - (uint32_t)o) : o;
+    float f;
+    memcpy(&f, &i, 4);
+    return f;
+}
+
+// The acos-based predicates of the reference are monotone in the dot product, so each is an exact
+// float threshold.  The thresholds are found by bisection against THIS host's libm (the same libm
+// the reference binary would link), which reproduces the reference bit-for-bit without a device acos.
+//   LCP   (stocs.cpp:1028-1032): float angle_n = std::acos(d)*180/M_PI; counted iff angle_n < A
+//   base  (stocs.cpp:428-429,440): float a = acos(d)*180/M_PI; reject iff min(a, 180-a) < B
+template <class Pred>
+static float first_true_ascending(Pred pred) {  // pred false ... false true ... true on [-1, 1]
+    int32_t lo = float_ord(-1.0f), hi = float_ord(1.0f);
+    if (!pred(1.0f)) return std::numeric_limits<float>::infinity();
+    if (pred(-1.0f)) return -1.0f;
+    while (hi - lo > 1) {
+        int32_t mid = lo + (hi - lo) / 2;
+        if (pred(ord_float(mid))) hi = mid; else lo = mid;
+    }
+    return ord_float(hi);
+}
+template <class Pred>
+static float last_true_descending(Pred pred) {  // pred true ... true false ... false on [-1, 1]
+    int32_t lo = float_ord(-1.0f), hi = float_ord(1.0f);
+    if (!pred(-1.0f)) return -std::numeric_limits<float>::infinity();
+    if (pred(1.0f)) return 1.0f;
+    while (hi - lo > 1) {
+        int32_t mid = lo + (hi - lo) / 2;
+        if (pred(ord_float(mid))) lo = mid; else hi = mid;
+    }
+    return ord_float(lo);
+}
+
+void compute_thresholds(const stocs_params& prm, Thresholds* t) {
+    const float A = prm.lcp_normal_angle;
+    t->lcp_dot_lo = first_true_ascending([A](float d) {
+        float angle_n = (float)((double)(acosf(d) * 180) / M_PI);
+        return angle_n < A;
+    });
+    const float B = prm.internal_angle_threshold;
+    t->ang_dot_hi = first_true_ascending([B](float d) {
+        float a = (float)(acos((double)d) * 180 / M_PI);
+        return a < B;
+    });
+    t->ang_dot_lo = last_true_descending([B](float d) {
+        float a = (float)(acos((double)d) * 180 / M_PI);
+        float o = 180 - a;
+        return o < B;
+    });
+}
+
+int ensure_scratch(stocs_ctx* c, size_t bytes) {
+    if (bytes <= c->scratch_bytes) return STOCS_OK;
+    if (c->d_scratch) STOCS_HIP_CHECK(hipFree(c->d_scratch));
+    c->d_scratch = NULL;
+    c->scratch_bytes = 0;
+    size_t want = bytes + bytes / 4 + (1 << 20);
+    STOCS_HIP_CHECK(hipMalloc(&c->d_scratch, want));
+    c->scratch_bytes = want;
+    return STOCS_OK;
+}
+
+static inline uint32_t part1by2(uint32_t x) {
+    x &= 0x3ff;
+    x = (x | (x << 16)) & 0x30000ff;
+    x = (x | (x << 8)) & 0x300f00f;
+    x = (x | (x << 4)) & 0x30c30c3;
+    x = (x | (x << 2)) & 0x9249249;
+    return x;
+}
+
+template <class T>
+static int upload(T** dptr, const T* h, size_t n) {
+    *dptr = NULL;
+    if (n == 0) n = 1;
+    STOCS_HIP_CHECK(hipMalloc((void**)dptr, n * sizeof(T)));
+    if (h) STOCS_HIP_CHECK(hipMemcpy(*dptr, h, n * sizeof(T), hipMemcpyHostToDevice));
+    return STOCS_OK;
+}
+
+// ---- scene grid build (host) -------------------------------------------------------------------
+static int build_grid(stocs_ctx* c) {
+    SceneGrid& g = c->grid;
+    const int nS = c->nS;
+    const double eps = (double)c->prm.distance_threshold;
+    const double h = eps;
+    const double r = eps * 1.001;  // safety margin >> float rounding of the device cell computation
+    double mn[3] = {1e30, 1e30, 1e30}, mx[3] = {-1e30, -1e30, -1e30};
+    for (int i = 0; i < nS; ++i) {
+        const V3 p = c->h_spos[i];
+        const double v[3] = {p.x, p.y, p.z};
+        for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], v[k]); mx[k] = std::max(mx[k], v[k]); }
+    }
+    if (nS == 0) { for (int k = 0; k < 3; ++k) { mn[k] = 0; mx[k] = 0; } }
+    const double o[3] = {mn[0] - 2 * h, mn[1] - 2 * h, mn[2] - 2 * h};
+    int n[3];
+    for (int k = 0; k < 3; ++k) n[k] = (int)floor((mx[k] + 2 * h - o[k]) / h) + 1;
+    g.ox = (float)o[0]; g.oy = (float)o[1]; g.oz = (float)o[2];
+    // the device computes the cell as floor((q - o_f) * inv_h) with the float origin; re-derive the
+    // exact origin the host uses from the float value so both agree
+    const double of[3] = {g.ox, g.oy, g.oz};
+    g.inv_h = (float)(1.0 / h);
+    g.nx = n[0]; g.ny = n[1]; g.nz = n[2];
+    g.nbx = (n[0] + 7) / 8; g.nby = (n[1] + 7) / 8; g.nbz = (n[2] + 7) / 8;
+    const int64_t n_top = (int64_t)g.nbx * g.nby * g.nbz;
+    if (n_top > (int64_t)400 * 1000 * 1000) { set_error("scene extent too large for the brick grid"); return STOCS_ERR_INVALID; }
+
+    // (cell key, point) incidences: cell box [o + c*h, o + (c+1)*h]
+    struct Inc { uint64_t key; int32_t pt; };
+    std::vector<Inc> inc;
+    inc.reserve((size_t)nS * 24);
+    for (int i = 0; i < nS; ++i) {
+        const V3 pf = c->h_spos[i];
+        const double p[3] = {pf.x, pf.y, pf.z};
+        int lo[3], hi[3];
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::max(0, (int)floor((p[k] - r - of[k]) / h));
+            hi[k] = std::min(n[k] - 1, (int)floor((p[k] + r - of[k]) / h));
+        }
+        for (int cz = lo[2]; cz <= hi[2]; ++cz)
+            for (int cy = lo[1]; cy <= hi[1]; ++cy)
+                for (int cx = lo[0]; cx <= hi[0]; ++cx) {
+                    const int cc[3] = {cx, cy, cz};
+                    double d2 = 0;
+                    for (int k = 0; k < 3; ++k) {
+                        const double b0 = of[k] + cc[k] * h, b1 = b0 + h;
+                        const double d = p[k] < b0 ? b0 - p[k] : (p[k] > b1 ? p[k] - b1 : 0.0);
+                        d2 += d * d;
+                    }
+                    if (d2 > r * r) continue;
+                    const uint64_t brick = ((uint64_t)(cz >> 3) * g.nby + (uint64_t)(cy >> 3)) * g.nbx + (uint64_t)(cx >> 3);
+                    const uint32_t local = (uint32_t)(((cz & 7) << 6) | ((cy & 7) << 3) | (cx & 7));
+                    Inc e;
+                    e.key = (brick << 9) | local;
+                    e.pt = i;
+                    inc.push_back(e);
+                }
+    }
+    std::sort(inc.begin(), inc.end(), [](const Inc& a, const Inc& b) { return a.key != b.key ? a.key < b.key : a.pt < b.pt; });
+
+    std::vector<int32_t> top((size_t)n_top, -1);
+    std::vector<uint2> cells;
+    std::vector<float4> list(inc.size());
+    int n_bricks = 0;
+    uint64_t cur_brick = ~0ull;
+    for (size_t e = 0; e < inc.size(); ++e) {
+        const uint64_t brick = inc[e].key >> 9;
+        const uint32_t local = (uint32_t)(inc[e].key & 511);
+        if (brick != cur_brick) {
+            cur_brick = brick;
+            top[(size_t)brick] = n_bricks++;
+            uint2 z; z.x = 0; z.y = 0;
+            cells.resize((size_t)n_bricks * 512, z);
+        }
+        uint2& cw = cells[(size_t)(n_bricks - 1) * 512 + local];
+        if (cw.y == 0) cw.x = (uint32_t)e;
+        cw.y++;
+        const V3 p = c->h_spos[inc[e].pt];
+        float4 v; v.x = p.x; v.y = p.y; v.z = p.z;
+        memcpy(&v.w, &inc[e].pt, 4);
+        list[e] = v;
+    }
+    g.n_bricks = n_bricks;
+    g.n_entries = (int64_t)inc.size();
+    int rc;
+    if ((rc = upload(&g.d_top, top.data(), top.size()))) return rc;
+    if ((rc = upload(&g.d_cells, cells.data(), cells.size()))) return rc;
+    if ((rc = upload(&g.d_list, list.data(), list.size()))) return rc;
+    return STOCS_OK;
+}
+
+}  // namespace stocs
+
+using namespace stocs;
+
+extern "C" {
+
+const char* stocs_last_error(void) { return g_err; }
+const char* stocs_version(void) { return "stocs_hip 0.1 (gfx950)"; }
+
+void stocs_default_params(stocs_params* p) {
+    p->distance_threshold = 0.005f;
+    p->ppf_tr_discretization = 5;
+    p->ppf_rot_discretization = 5;
+    p->plane_threshold = 0.015f;
+    p->min_distance_base = 0.01f;
+    p->internal_angle_threshold = 30.0f;
+    p->lcp_normal_angle = 30.0f;
+    p->image_width = 640;
+    p->image_height = 480;
+    p->number_of_bases = 100;
+    p->maximum_congruent_sets = 200;
+}
+
+int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, const float* sprob,
+                     const int32_t* spix, int nS, const float* mp, const float* mn, int nM, int build_index,
+                     int device, stocs_ctx** out) {
+    if (!prm || !out || nS < 0 || nM < 0 || (nS && (!sp || !sn || !sprob)) || (nM && (!mp || !mn))) {
+        set_error("stocs_ctx_create: invalid argument");
+        return STOCS_ERR_INVALID;
+    }
+    if (nM > 65535) { set_error("model has %d points; at most 65535 supported (16-bit ids in packed pairs)", nM); return STOCS_ERR_INVALID; }
+    if (prm->ppf_rot_discretization <= 0 || prm->ppf_tr_discretization <= 0 || 180 % prm->ppf_rot_discretization) {
+        set_error("PPF discretisation must be positive and divide 180");
+        return STOCS_ERR_INVALID;
+    }
+    *out = NULL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available: this library has no CPU fallback");
+        return STOCS_ERR_NO_DEVICE;
+    }
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    if (device >= ndev) { set_error("device %d out of range (%d devices)", device, ndev); return STOCS_ERR_NO_DEVICE; }
+    if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice(%d) failed", device); return STOCS_ERR_NO_DEVICE; }
+
+    stocs_ctx* c = new stocs_ctx();
+    c->prm = *prm;
+    c->device = device;
+    c->nS = nS; c->nM = nM;
+    c->d_scratch = NULL; c->scratch_bytes = 0;
+    c->index.built = false;
+    c->index.d_bucket_start = NULL; c->index.d_pairs = NULL; c->index.d_exists = NULL;
+    c->best_lcp = 0; c->best_index = -1;
+    c->has_edge = false;
+    memset(&c->grid, 0, sizeof(c->grid));
+    c->d_spos = c->d_snrmw = c->d_mpos = c->d_mnrm = c->d_munit = c->d_mpos_raw = c->d_mpos_s = c->d_mnrm_s = NULL;
+    c->d_spix = NULL; c->d_mperm = NULL;
+    if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        set_error("stream/event creation failed");
+        delete c;
+        return STOCS_ERR_NO_DEVICE;
+    }
+    compute_thresholds(c->prm, &c->thr);
+
+    c->h_spos.resize(nS); c->h_snrm.resize(nS); c->h_sprob.assign(sprob, sprob + nS); c->h_spix.assign((size_t)2 * nS, 0);
+    for (int i = 0; i < nS; ++i) {
+        c->h_spos[i] = mk3(sp[3 * i], sp[3 * i + 1], sp[3 * i + 2]);
+        c->h_snrm[i] = normalized3(mk3(sn[3 * i], sn[3 * i + 1], sn[3 * i + 2]));  // set_normal, point3d.hpp:43-45
+        if (spix) { c->h_spix[2 * i] = spix[2 * i]; c->h_spix[2 * i + 1] = spix[2 * i + 1]; }
+    }
+    c->h_mpos.resize(nM); c->h_mnrm.resize(nM); c->h_mpos_raw.resize(nM);
+    for (int i = 0; i < nM; ++i) {
+        c->h_mpos_raw[i] = c->h_mpos[i] = mk3(mp[3 * i], mp[3 * i + 1], mp[3 * i + 2]);
+        c->h_mnrm[i] = normalized3(mk3(mn[3 * i], mn[3 * i + 1], mn[3 * i + 2]));
+    }
+    // centroid_shift -- stocs.cpp:943-964 (sequential float sums, then divide, then subtract)
+    V3 cs = mk3(0, 0, 0), cm = mk3(0, 0, 0);
+    for (int i = 0; i < nS; ++i) cs = cs + c->h_spos[i];
+    for (int i = 0; i < nM; ++i) cm = cm + c->h_mpos[i];
+    cs = cs / (float)nS;
+    cm = cm / (float)nM;
+    for (int i = 0; i < nS; ++i) c->h_spos[i] = c->h_spos[i] - cs;
+    for (int i = 0; i < nM; ++i) c->h_mpos[i] = c->h_mpos[i] - cm;
+    c->centroid_scene = cs; c->centroid_model = cm;
+
+    // PairCreationFunctor::synch3DContent -- pairCreationFunctor.h:96-132 (once, not per base)
+    {
+        const float big = std::numeric_limits<float>::max() / 2;
+        V3 bmn = mk3(big, big, big), bmx = mk3(-big, -big, -big);
+        for (int i = 0; i < nM; ++i) {
+            const V3 q = c->h_mpos[i];
+            if (q.x < bmn.x) bmn.x = q.x; if (q.y < bmn.y) bmn.y = q.y; if (q.z < bmn.z) bmn.z = q.z;
+            if (q.x > bmx.x) bmx.x = q.x; if (q.y > bmx.y) bmx.y = q.y; if (q.z > bmx.z) bmx.z = q.z;
+        }
+        c->gcenter = bmn + ((bmx - bmn) / 2.0f);
+        const V3 ext = bmx - bmn;
+        const double r = std::max((double)ext.z + 0.001, std::max((double)ext.y + 0.001, (double)ext.x + 0.001));
+        c->ratio = (float)r;
+        c->h_munit.resize(nM);
+        const V3 half = mk3(0.5f, 0.5f, 0.5f);
+        for (int i = 0; i < nM; ++i) c->h_munit[i] = (c->h_mpos[i] - c->gcenter) / c->ratio + half;
+    }
+
+    // Morton order of the centred model for the LCP kernel (spatially coherent wavefronts)
+    c->h_mperm.resize(nM);
+    {
+        std::vector<uint32_t> code(nM);
+        const V3 ext = mk3(c->ratio, c->ratio, c->ratio);
+        for (int i = 0; i < nM; ++i) {
+            const V3 u = c->h_munit[i];
+            auto q10 = [](float v) { int k = (int)(v * 1024.0f); return (uint32_t)(k < 0 ? 0 : (k > 1023 ? 1023 : k)); };
+            code[i] = (part1by2(q10(u.z)) << 2) | (part1by2(q10(u.y)) << 1) | part1by2(q10(u.x));
+        }
+        (void)ext;
+        std::iota(c->h_mperm.begin(), c->h_mperm.end(), 0);
+        std::stable_sort(c->h_mperm.begin(), c->h_mperm.end(), [&](int a, int b) { return code[a] < code[b]; });
+    }
+
+    int rc = STOCS_OK;
+    {
+        std::vector<float4> a(std::max(nS, 1)), b(std::max(nS, 1));
+        std::vector<int2> px(std::max(nS, 1));
+        for (int i = 0; i < nS; ++i) {
+            a[i] = make_float4(c->h_spos[i].x, c->h_spos[i].y, c->h_spos[i].z, c->h_sprob[i]);
+            b[i] = make_float4(c->h_snrm[i].x, c->h_snrm[i].y, c->h_snrm[i].z, c->h_sprob[i]);
+            px[i] = make_int2(c->h_spix[2 * i], c->h_spix[2 * i + 1]);
+        }
+        if (!rc) rc = upload(&c->d_spos, a.data(), a.size());
+        if (!rc) rc = upload(&c->d_snrmw, b.data(), b.size());
+        if (!rc) rc = upload(&c->d_spix, px.data(), px.size());
+    }
+    {
+        const int n = std::max(nM, 1);
+        std::vector<float4> a(n), b(n), u(n), raw(n), as(n), bs(n);
+        for (int i = 0; i < nM; ++i) {
+            a[i] = make_float4(c->h_mpos[i].x, c->h_mpos[i].y, c->h_mpos[i].z, 0.f);
+            b[i] = make_float4(c->h_mnrm[i].x, c->h_mnrm[i].y, c->h_mnrm[i].z, 0.f);
+            u[i] = make_float4(c->h_munit[i].x, c->h_munit[i].y, c->h_munit[i].z, 0.f);
+            raw[i] = make_float4(c->h_mpos_raw[i].x, c->h_mpos_raw[i].y, c->h_mpos_raw[i].z, 0.f);
+        }
+        for (int i = 0; i < nM; ++i) { as[i] = a[c->h_mperm[i]]; bs[i] = b[c->h_mperm[i]]; }
+        if (!rc) rc = upload(&c->d_mpos, a.data(), a.size());
+        if (!rc) rc = upload(&c->d_mnrm, b.data(), b.size());
+        if (!rc) rc = upload(&c->d_munit, u.data(), u.size());
+        if (!rc) rc = upload(&c->d_mpos_raw, raw.data(), raw.size());
+        if (!rc) rc = upload(&c->d_mpos_s, as.data(), as.size());
+        if (!rc) rc = upload(&c->d_mnrm_s, bs.data(), bs.size());
+        if (!rc) rc = upload(&c->d_mperm, c->h_mperm.data(), c->h_mperm.size());
+    }
+    if (!rc) rc = build_grid(c);
+    if (!rc && build_index) rc = build_ppf_index(c);
+    const size_t px = (size_t)prm->image_width * prm->image_height;
+    c->edge_map.assign(px, 0);
+    c->previous_segment.assign(px, 0);
+    c->segmentation_buffer.assign(px, 0);
+    if (rc) { stocs_ctx_destroy(c); return rc; }
+    *out = c;
+    return STOCS_OK;
+}
+
+int stocs_ctx_destroy(stocs_ctx* c) {
+    if (!c) return STOCS_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    void* ptrs[] = {c->d_spos, c->d_snrmw, c->d_spix, c->d_mpos, c->d_mnrm, c->d_munit, c->d_mpos_raw, c->d_mpos_s,
+                    c->d_mnrm_s, c->d_mperm, c->grid.d_top, c->grid.d_cells, c->grid.d_list, c->index.d_bucket_start,
+                    c->index.d_pairs, c->index.d_exists, c->d_scratch};
+    for (void* p : ptrs) if (p) hipFree(p);
+    hipEventDestroy(c->ev0);
+    hipEventDestroy(c->ev1);
+    hipStreamDestroy(c->stream);
+    delete c;
+    return STOCS_OK;
+}
+
+int stocs_get_centroids(const stocs_ctx* c, float* s, float* m) {
+    if (!c) return STOCS_ERR_INVALID;
+    if (s) { s[0] = c->centroid_scene.x; s[1] = c->centroid_scene.y; s[2] = c->centroid_scene.z; }
+    if (m) { m[0] = c->centroid_model.x; m[1] = c->centroid_model.y; m[2] = c->centroid_model.z; }
+    return STOCS_OK;
+}
+int stocs_get_sizes(const stocs_ctx* c, int* nS, int* nM) {
+    if (!c) return STOCS_ERR_INVALID;
+    if (nS) *nS = c->nS;
+    if (nM) *nM = c->nM;
+    return STOCS_OK;
+}
+int stocs_set_edge_map(stocs_ctx* c, const uint8_t* edge) {
+    if (!c || !edge) return STOCS_ERR_INVALID;
+    c->edge_map.assign(edge, edge + (size_t)c->prm.image_width * c->prm.image_height);
+    c->has_edge = true;
+    return STOCS_OK;
+}
+
+int stocs_sync(stocs_ctx* c) {
+    if (!c) return STOCS_ERR_INVALID;
+    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return STOCS_OK;
+}
+void* stocs_stream(stocs_ctx* c) { return c ? (void*)c->stream : NULL; }
+
+int stocs_dev_alloc(stocs_ctx* c, int64_t bytes, void** dptr) {
+    if (!c || !dptr || bytes < 0) return STOCS_ERR_INVALID;
+    STOCS_HIP_CHECK(hipSetDevice(c->device));
+    STOCS_HIP_CHECK(hipMalloc(dptr, (size_t)std::max<int64_t>(bytes, 16)));
+    return STOCS_OK;
+}
+int stocs_dev_free(stocs_ctx* c, void* dptr) {
+    if (!c) return STOCS_ERR_INVALID;
+    if (dptr) STOCS_HIP_CHECK(hipFree(dptr));
+    return STOCS_OK;
+}
+int stocs_dev_upload(stocs_ctx* c, void* dptr, const void* host, int64_t bytes) {
+    if (!c || !dptr || !host) return STOCS_ERR_INVALID;
+    STOCS_HIP_CHECK(hipMemcpyAsync(dptr, host, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return STOCS_OK;
+}
+int stocs_dev_download(stocs_ctx* c, void* host, const void* dptr, int64_t bytes) {
+    if (!c || !dptr || !host) return STOCS_ERR_INVALID;
+    STOCS_HIP_CHECK(hipMemcpyAsync(host, dptr, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return STOCS_OK;
+}
+
+uint64_t stocs_pack_best(float lcp, uint32_t id) {
+    uint32_t bits;
+    memcpy(&bits, &lcp, 4);
+    if (!(lcp > 0.0f)) bits = 0;  // scores are >= 0; NaN/negative never win
+    return ((uint64_t)bits << 32) | (uint64_t)(0xFFFFFFFFu - id);
+}
+void stocs_unpack_best(uint64_t key, float* lcp, uint32_t* id) {
+    uint32_t bits = (uint32_t)(key >> 32);
+    if (lcp) memcpy(lcp, &bits, 4);
+    if (id) *id = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu);
+}
+
+}  // extern "C"

@@ -1,0 +1,136 @@
+// stocs_ctx.h -- internal state behind the opaque stocs_ctx of include/stocs_hip.h.
+#ifndef STOCS_CTX_H
+#define STOCS_CTX_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/stocs_hip.h"
+#include "stocs_math.h"
+
+namespace stocs {
+
+void set_error(const char* fmt, ...);
+
+#define STOCS_HIP_CHECK(expr)                                                                  \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            stocs::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return STOCS_ERR_HIP;                                                              \
+        }                                                                                      \
+    } while (0)
+
+// Brick grid over the centred scene (replaces the kd-tree of kdtree.h for the restricted-radius
+// nearest-neighbour query).  Cell edge h = epsilon.  A cell's candidate list holds every scene
+// point whose distance to the cell's box is <= epsilon (+ a 0.1% safety margin), so ONE list scan
+// answers the query exactly.  Bricks of 8x8x8 cells exist only where some cell is non-empty.
+struct SceneGrid {
+    float ox, oy, oz, inv_h;
+    int nx, ny, nz;      // cells per axis
+    int nbx, nby, nbz;   // bricks per axis
+    int n_bricks;
+    int64_t n_entries;
+    int32_t* d_top;      // nbx*nby*nbz -> brick id or -1
+    uint2* d_cells;      // n_bricks*512: (offset, count) into d_list
+    float4* d_list;      // (x, y, z, bits(scene index))
+};
+
+// Model PPF index on the device: every ordered pair stored once under its own quantised key F
+// (CSR over the dense key space), plus the dilated existence bitmap ("is K a key of the
+// reference's 128-fold map?").
+struct PpfIndex {
+    bool built;
+    int tr, rot, NA, nD;          // angle bins NA = 180/rot + 1, distance bins nD
+    int64_t n_keys;               // nD*NA^3
+    int64_t n_pairs;
+    uint32_t* d_bucket_start;     // n_keys + 1
+    uint32_t* d_pairs;            // n_pairs: (id1 << 16) | id2, sorted inside each bucket
+    uint32_t* d_exists;           // bitmap over the key space, n_keys bits
+    std::vector<uint32_t> h_bucket_start;  // host copy (planning of the lookups)
+    std::vector<uint32_t> h_exists;        // host copy of the bitmap (single-key query API)
+    int64_t n_nonempty_buckets, n_exist_keys;
+};
+
+struct BaseRec {
+    int ids[4];
+    float inv1, inv2;
+};
+
+struct Candidate {
+    float T[16];     // centred frames (scored), stocs.cpp:923
+    float pose[16];  // camera frame (returned), stocs.cpp:925-937
+    float lcp;
+    int base_index;
+};
+
+struct Thresholds {
+    float lcp_dot_lo;   // normal test true  <=>  lcp_dot_lo <= dot <= 1
+    float ang_dot_hi;   // internal-angle reject <=> (ang_dot_hi <= dot <= 1) || (-1 <= dot <= ang_dot_lo)
+    float ang_dot_lo;
+};
+
+}  // namespace stocs
+
+struct stocs_ctx {
+    stocs_params prm;
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    int nS, nM;
+    stocs::Thresholds thr;
+
+    // host copies (centred unless stated)
+    std::vector<stocs::V3> h_spos, h_snrm, h_mpos, h_mnrm, h_mpos_raw, h_munit;
+    std::vector<float> h_sprob;       // class_probability_ (decays in instance mode)
+    std::vector<int32_t> h_spix;      // row, col
+    stocs::V3 centroid_scene, centroid_model, gcenter;
+    float ratio;
+    std::vector<int32_t> h_mperm;     // Morton order of the model used by the LCP kernel
+
+    // device clouds
+    float4* d_spos;    // xyz + class prob
+    float4* d_snrmw;   // unit normal + class prob weight (what LCP adds, stocs.cpp:1033)
+    int2* d_spix;
+    float4* d_mpos;    // centred model, original order (xyz, 0)
+    float4* d_mnrm;
+    float4* d_munit;   // unit-cube model (pairCreationFunctor.h:96-132)
+    float4* d_mpos_raw;  // un-shifted model positions (index build)
+    float4* d_mpos_s;  // Morton-sorted copies for the LCP kernel
+    float4* d_mnrm_s;
+    int32_t* d_mperm;
+
+    stocs::SceneGrid grid;
+    stocs::PpfIndex index;
+
+    // image-space state of instance mode (stocs.hpp:153-155)
+    bool has_edge;
+    std::vector<uint8_t> edge_map, previous_segment, segmentation_buffer;
+    std::vector<std::vector<uint8_t> > seg_masks;
+
+    // run state
+    std::vector<stocs::BaseRec> bases;
+    std::vector<std::vector<uint64_t> > quads;   // per base, sorted packed (a,b,c,d) 16 bits each
+    std::vector<stocs::Candidate> cands;
+    float best_lcp;
+    int best_index;
+
+    // scratch
+    void* d_scratch;
+    size_t scratch_bytes;
+};
+
+namespace stocs {
+int ensure_scratch(stocs_ctx* c, size_t bytes);
+int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d_hit, uint8_t* d_counted);
+int build_ppf_index(stocs_ctx* c);
+int plan_lookup(const PpfIndex& ix, const int* K, std::vector<std::pair<uint32_t, uint32_t> >* ranges);
+void compute_thresholds(const stocs_params& prm, Thresholds* t);
+}  // namespace stocs
+
+#endif

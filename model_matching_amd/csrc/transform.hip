@@ -1,0 +1,242 @@
+// transform.hip -- candidate rigid transforms from (base, congruent quad) pairs, and the
+// verification driver.  Replaces
+//   ComputeRigidTransformation                         reference src/stocs.cpp:270-361
+//   stocs_estimator::get_rigid_transform_from_congruent_pair      stocs.cpp:871-941
+//   the <=200-per-base loop of run_stocs_estimation     src/stocs_match_one_object.cpp:120-147
+//   stocs_estimator::compute_best_transform             stocs.cpp:982-1004
+// One thread per (base, quad): three-point frame alignment (no SVD, no MFMA: a 3x3*3x3 product per
+// candidate is not a dense contraction).  Pure IEEE float arithmetic in the order fixed by
+// stocs_math.h, so the result is bit-identical to the CPU restatement.
+#include <string.h>
+
+#include <algorithm>
+
+#include "stocs_ctx.h"
+
+namespace stocs {
+
+struct M3 { float m[3][3]; };
+__device__ __forceinline__ M3 mul33(const M3& A, const M3& B) {
+    M3 C;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            C.m[i][j] = A.m[i][0] * B.m[0][j] + (A.m[i][1] * B.m[1][j] + A.m[i][2] * B.m[2][j]);
+    return C;
+}
+__device__ __forceinline__ V3 mul3v(const M3& A, V3 v) {
+    return mk3(A.m[0][0] * v.x + (A.m[0][1] * v.y + A.m[0][2] * v.z),
+               A.m[1][0] * v.x + (A.m[1][1] * v.y + A.m[1][2] * v.z),
+               A.m[2][0] * v.x + (A.m[2][1] * v.y + A.m[2][2] * v.z));
+}
+__device__ __forceinline__ V3 ld3(const float4* a, int i) { float4 v = a[i]; return mk3(v.x, v.y, v.z); }
+
+struct XformJob { int32_t s[4]; int32_t q[4]; };  // scene base ids, model quad ids
+
+__global__ __launch_bounds__(256) void rigid_transform_kernel(const float4* __restrict__ spos, const float4* __restrict__ mpos,
+                                                              const XformJob* __restrict__ jobs, int n, V3 cscene, V3 cmodel,
+                                                              float* __restrict__ T_out, float* __restrict__ P_out,
+                                                              int32_t* __restrict__ ok_out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const XformJob job = jobs[j];
+    const V3 p0 = ld3(spos, job.s[0]), p1 = ld3(spos, job.s[1]), p2 = ld3(spos, job.s[2]);
+    const V3 q0 = ld3(mpos, job.q[0]), q1 = ld3(mpos, job.q[1]), q2 = ld3(mpos, job.q[2]);
+    const V3 centroid1 = ((p0 + p1) + p2) / 3.0f;  // stocs.cpp:885
+    const V3 centroid2 = ((q0 + q1) + q2) / 3.0f;  // stocs.cpp:907-909
+    int ok = 1;
+    // degenerate frames: the reference returns kLargeNumber from a bool function (true with an
+    // uninitialised matrix, Q2) -- deliberate divergence: reject.
+    V3 vp1 = p1 - p0;
+    if (sqn3(vp1) == 0) ok = 0;
+    vp1 = normalized3(vp1);
+    V3 vp2 = (p2 - p0) - (dot3(p2 - p0, vp1) * vp1);
+    if (sqn3(vp2) == 0) ok = 0;
+    vp2 = normalized3(vp2);
+    const V3 vp3 = cross3(vp1, vp2);
+    V3 vq1 = q1 - q0;
+    if (sqn3(vq1) == 0) ok = 0;
+    vq1 = normalized3(vq1);
+    V3 vq2 = (q2 - q0) - (dot3(q2 - q0, vq1) * vq1);
+    if (sqn3(vq2) == 0) ok = 0;
+    vq2 = normalized3(vq2);
+    const V3 vq3 = cross3(vq1, vq2);
+    // rotation = rotate_p.transpose() * rotate_q with the frames as rows (stocs.cpp:316-326)
+    M3 Pt, Q;
+    Pt.m[0][0] = vp1.x; Pt.m[1][0] = vp1.y; Pt.m[2][0] = vp1.z;
+    Pt.m[0][1] = vp2.x; Pt.m[1][1] = vp2.y; Pt.m[2][1] = vp2.z;
+    Pt.m[0][2] = vp3.x; Pt.m[1][2] = vp3.y; Pt.m[2][2] = vp3.z;
+    Q.m[0][0] = vq1.x; Q.m[0][1] = vq1.y; Q.m[0][2] = vq1.z;
+    Q.m[1][0] = vq2.x; Q.m[1][1] = vq2.y; Q.m[1][2] = vq2.z;
+    Q.m[2][0] = vq3.x; Q.m[2][1] = vq3.y; Q.m[2][2] = vq3.z;
+    const M3 R = mul33(Pt, Q);
+    // (rotation*rotation).diagonal() - 1 > 1e-6 (sic: R*R not R*R^T, Q3; stocs.cpp:329)
+    const M3 RR = mul33(R, R);
+    const float kSmall = 1e-6f;
+    if ((RR.m[0][0] - 1.0f > kSmall) || (RR.m[1][1] - 1.0f > kSmall) || (RR.m[2][2] - 1.0f > kSmall)) ok = 0;
+    // rms (stocs.cpp:334-346) only gates through "rms >= 0" (:922): false iff NaN
+    {
+        float rms = 0.0f;
+        rms += norm3((mul3v(R, 1.0f * q0 - centroid2) - p0) + centroid1);
+        rms += norm3((mul3v(R, 1.0f * q1 - centroid2) - p1) + centroid1);
+        rms += norm3((mul3v(R, 1.0f * q2 - centroid2) - p2) + centroid1);
+        rms /= 4.0f;
+        if (!(rms >= 0.0f)) ok = 0;
+    }
+    // etrans = I; scale(1); translate(c1); rotate(R); translate(-c2)  (stocs.cpp:348-357)
+    const V3 t = centroid1 + mul3v(R, -centroid2);
+    // camera-frame translation (stocs.cpp:925-933); rot*scale of computeRotationScaling == linear part
+    const V3 tc = (centroid1 + cscene) - mul3v(R, centroid2 + cmodel);
+    float* T = T_out + (size_t)j * 16;
+    float* P = P_out + (size_t)j * 16;
+#pragma unroll
+    for (int col = 0; col < 3; ++col) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { T[col * 4 + r] = R.m[r][col]; P[col * 4 + r] = R.m[r][col]; }
+        T[col * 4 + 3] = 0.0f; P[col * 4 + 3] = 0.0f;
+    }
+    T[12] = t.x; T[13] = t.y; T[14] = t.z; T[15] = 1.0f;
+    P[12] = tc.x; P[13] = tc.y; P[14] = tc.z; P[15] = 1.0f;
+    ok_out[j] = ok;
+}
+
+static int run_jobs(stocs_ctx* c, const std::vector<XformJob>& jobs, std::vector<float>& T, std::vector<float>& P,
+                    std::vector<int32_t>& ok) {
+    const size_t n = jobs.size();
+    T.resize(n * 16); P.resize(n * 16); ok.resize(n);
+    if (n == 0) return STOCS_OK;
+    const size_t jb = ((n * sizeof(XformJob) + 255) / 256) * 256, tb = n * 64, ob = ((n * 4 + 255) / 256) * 256;
+    int rc = ensure_scratch(c, jb + 2 * tb + ob);
+    if (rc) return rc;
+    char* base = (char*)c->d_scratch;
+    XformJob* dJ = (XformJob*)base;
+    float* dT = (float*)(base + jb);
+    float* dP = (float*)(base + jb + tb);
+    int32_t* dO = (int32_t*)(base + jb + 2 * tb);
+    STOCS_HIP_CHECK(hipMemcpyAsync(dJ, jobs.data(), n * sizeof(XformJob), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(rigid_transform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_spos, c->d_mpos,
+                       dJ, (int)n, c->centroid_scene, c->centroid_model, dT, dP, dO);
+    STOCS_HIP_CHECK(hipGetLastError());
+    STOCS_HIP_CHECK(hipMemcpyAsync(T.data(), dT, tb, hipMemcpyDeviceToHost, c->stream));
+    STOCS_HIP_CHECK(hipMemcpyAsync(P.data(), dP, tb, hipMemcpyDeviceToHost, c->stream));
+    STOCS_HIP_CHECK(hipMemcpyAsync(ok.data(), dO, n * 4, hipMemcpyDeviceToHost, c->stream));
+    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return STOCS_OK;
+}
+
+}  // namespace stocs
+
+using namespace stocs;
+
+extern "C" {
+
+int stocs_rigid_transform(stocs_ctx* c, const int32_t* ids4, const int32_t* quad4, float* T16, float* pose16, int* ok) {
+    if (!c || !ids4 || !quad4 || !ok) return STOCS_ERR_INVALID;
+    for (int k = 0; k < 4; ++k)
+        if (ids4[k] < 0 || ids4[k] >= c->nS || quad4[k] < 0 || quad4[k] >= c->nM) { set_error("index out of range"); return STOCS_ERR_INVALID; }
+    std::vector<XformJob> jobs(1);
+    for (int k = 0; k < 4; ++k) { jobs[0].s[k] = ids4[k]; jobs[0].q[k] = quad4[k]; }
+    std::vector<float> T, P;
+    std::vector<int32_t> o;
+    int rc = run_jobs(c, jobs, T, P, o);
+    if (rc) return rc;
+    if (T16) memcpy(T16, T.data(), 64);
+    if (pose16) memcpy(pose16, P.data(), 64);
+    *ok = o[0];
+    return STOCS_OK;
+}
+
+int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_candidates) {
+    if (!c || max_per_base <= 0) return STOCS_ERR_INVALID;
+    if (c->quads.size() != c->bases.size()) { set_error("stocs_make_transforms: call stocs_find_congruent_all first"); return STOCS_ERR_STATE; }
+    std::vector<XformJob> jobs;
+    std::vector<int> job_base;
+    for (size_t b = 0; b < c->bases.size(); ++b) {
+        const std::vector<uint64_t>& q = c->quads[b];
+        const int nq = (int)q.size();
+        std::vector<int> pick;
+        if (nq < max_per_base) {  // stocs_match_one_object.cpp:126: strictly fewer -> all
+            for (int i = 0; i < nq; ++i) pick.push_back(i);
+        } else {
+            // seeded sample without replacement (divergence Q5 from the biased 2N-vector shuffle,
+            // stocs_match_one_object.cpp:134-142): partial Fisher-Yates over the sorted quad list
+            std::vector<int> perm(nq);
+            for (int i = 0; i < nq; ++i) perm[i] = i;
+            for (int j = 0; j < max_per_base; ++j) {
+                const uint64_t r = rng64(seed, 0x5E1EC7ull + b, (uint64_t)j);
+                const int k = j + (int)mulhi64(r, (uint64_t)(nq - j));
+                std::swap(perm[j], perm[k]);
+                pick.push_back(perm[j]);
+            }
+        }
+        for (size_t i = 0; i < pick.size(); ++i) {
+            const uint64_t key = q[pick[i]];
+            XformJob job;
+            for (int k = 0; k < 4; ++k) job.s[k] = c->bases[b].ids[k];
+            job.q[0] = (int)((key >> 48) & 0xFFFF); job.q[1] = (int)((key >> 32) & 0xFFFF);
+            job.q[2] = (int)((key >> 16) & 0xFFFF); job.q[3] = (int)(key & 0xFFFF);
+            jobs.push_back(job);
+            job_base.push_back((int)b);
+        }
+    }
+    std::vector<float> T, P;
+    std::vector<int32_t> ok;
+    int rc = run_jobs(c, jobs, T, P, ok);
+    if (rc) return rc;
+    c->cands.clear();
+    c->best_lcp = 0; c->best_index = -1;
+    for (size_t j = 0; j < jobs.size(); ++j) {
+        if (!ok[j]) continue;
+        Candidate cd;
+        memcpy(cd.T, &T[j * 16], 64);
+        memcpy(cd.pose, &P[j * 16], 64);
+        cd.lcp = 0;                 // "score is not computed at this time" stocs.cpp:935-936
+        cd.base_index = job_base[j];
+        c->cands.push_back(cd);
+    }
+    if (n_candidates) *n_candidates = (int)c->cands.size();
+    return STOCS_OK;
+}
+
+int stocs_get_candidates(stocs_ctx* c, float* T16, float* pose16, float* lcp, int32_t* base_index, int cap, int* n) {
+    if (!c || !n) return STOCS_ERR_INVALID;
+    *n = (int)c->cands.size();
+    for (int i = 0; i < *n && i < cap; ++i) {
+        if (T16) memcpy(T16 + (size_t)i * 16, c->cands[i].T, 64);
+        if (pose16) memcpy(pose16 + (size_t)i * 16, c->cands[i].pose, 64);
+        if (lcp) lcp[i] = c->cands[i].lcp;
+        if (base_index) base_index[i] = c->cands[i].base_index;
+    }
+    return (*n > cap && (T16 || pose16 || lcp || base_index)) ? STOCS_ERR_CAPACITY : STOCS_OK;
+}
+
+int stocs_verify_all(stocs_ctx* c, float* best_lcp, int* best_idx, float* best_pose16) {
+    if (!c) return STOCS_ERR_INVALID;
+    const int n = (int)c->cands.size();
+    c->best_lcp = 0; c->best_index = -1;
+    if (n > 0) {
+        std::vector<float> T((size_t)n * 16), l(n);
+        for (int i = 0; i < n; ++i) memcpy(&T[(size_t)i * 16], c->cands[i].T, 64);
+        int rc = stocs_score_transforms(c, T.data(), n, l.data());
+        if (rc) return rc;
+        // compute_best_transform, stocs.cpp:987-998: strict > from 0 => first maximum wins (Q18)
+        float max_score = 0;
+        int index = -1;
+        for (int i = 0; i < n; ++i) {
+            c->cands[i].lcp = l[i];
+            if (l[i] > max_score) { max_score = l[i]; index = i; }
+        }
+        c->best_lcp = max_score;
+        c->best_index = index;
+    }
+    if (best_lcp) *best_lcp = c->best_lcp;
+    if (best_idx) *best_idx = c->best_index;
+    if (best_pose16) {
+        if (c->best_index >= 0) memcpy(best_pose16, c->cands[c->best_index].pose, 64);
+        else memset(best_pose16, 0, 64);
+    }
+    return STOCS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,220 @@
+"""Python mirror of the reference's ``stocs::stocs_estimator`` (reference include/stocs.hpp:16-180)
+over the C ABI of libstocs_hip.so.  Same method names and argument meaning as the reference class
+(flat clouds instead of PLY/PNG paths); every method forwards to the HIP library -- nothing is
+computed in Python."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class StocsEstimator:
+    def __init__(self, scene_pos, scene_nrm, scene_prob, scene_pixel, model_pos, model_nrm,
+                 params: capi.Params | None = None, build_index: bool = True, device: int = -1):
+        self.L = capi.load()
+        self.prm = params or capi.default_params()
+        self._sp, psp = capi.f32(scene_pos)
+        self._sn, psn = capi.f32(scene_nrm)
+        self._spr, pspr = capi.f32(scene_prob)
+        ppx = None
+        if scene_pixel is not None:
+            self._spx, ppx = capi.i32(scene_pixel)
+        self._mp, pmp = capi.f32(model_pos)
+        self._mn, pmn = capi.f32(model_nrm)
+        self.nS, self.nM = len(self._sp), len(self._mp)
+        self.h = C.c_void_p()
+        capi.check(self.L.stocs_ctx_create(C.byref(self.prm), psp, psn, pspr, ppx, self.nS, pmp, pmn, self.nM,
+                                           1 if build_index else 0, device, C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.stocs_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- getters (stocs.hpp:115-134) ----
+    def get_scene_centroid(self):
+        s = np.zeros(3, np.float32)
+        capi.check(self.L.stocs_get_centroids(self.h, s.ctypes.data_as(capi._fp), None))
+        return s
+
+    def get_model_centroid(self):
+        m = np.zeros(3, np.float32)
+        capi.check(self.L.stocs_get_centroids(self.h, None, m.ctypes.data_as(capi._fp)))
+        return m
+
+    def set_edge_map(self, edge):
+        e = np.ascontiguousarray(edge, np.uint8)
+        capi.check(self.L.stocs_set_edge_map(self.h, e.ctypes.data_as(capi._u8p)))
+
+    # ---- PPF index ----
+    def index_exists(self, key):
+        k, pk = capi.i32(key)
+        r = C.c_int(0)
+        capi.check(self.L.stocs_index_exists(self.h, pk, C.byref(r)))
+        return bool(r.value)
+
+    def index_lookup(self, key):
+        k, pk = capi.i32(key)
+        n = C.c_int64(0)
+        capi.check(self.L.stocs_index_lookup(self.h, pk, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 2), np.int32)
+        if n.value:
+            capi.check(self.L.stocs_index_lookup(self.h, pk, out.ctypes.data_as(capi._ip), n.value, C.byref(n)))
+        return out
+
+    def index_stats(self):
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        capi.check(self.L.stocs_index_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    # ---- base sampling (stocs.hpp:80-91) ----
+    def sample_bases(self, seed, n_attempts, first_attempt=0, mode=0, dispersion=0.9):
+        ids = np.zeros((n_attempts, 4), np.int32)
+        inv = np.zeros((n_attempts, 2), np.float32)
+        valid = np.zeros(n_attempts, np.int32)
+        capi.check(self.L.stocs_sample_bases(self.h, mode, seed, first_attempt, n_attempts, dispersion,
+                                             ids.ctypes.data_as(capi._ip), inv.ctypes.data_as(capi._fp),
+                                             valid.ctypes.data_as(capi._ip)))
+        return valid.astype(bool), ids, inv
+
+    def sample_class_base(self, seed, attempt):
+        v, ids, inv = self.sample_bases(seed, 1, attempt, 0)
+        return bool(v[0]), ids[0], inv[0]
+
+    def set_bases(self, ids, inv):
+        ids, pi = capi.i32(np.asarray(ids).reshape(-1, 4))
+        inv, pv = capi.f32(np.asarray(inv).reshape(-1, 2))
+        capi.check(self.L.stocs_set_bases(self.h, len(ids), pi, pv))
+
+    def class_pass(self, k, b3, w_in):
+        b, pb = capi.i32(b3)
+        w, pw = capi.f32(w_in)
+        out = np.zeros_like(w)
+        capi.check(self.L.stocs_class_pass(self.h, k, pb, pw, out.ctypes.data_as(capi._fp)))
+        return out
+
+    def try_sampled_base(self, ids):
+        ids, pi = capi.i32(np.array(ids).copy())
+        inv = np.zeros(2, np.float32)
+        ok = C.c_int(0)
+        capi.check(self.L.stocs_try_sampled_base(self.h, pi, inv.ctypes.data_as(capi._fp), C.byref(ok)))
+        return bool(ok.value), ids, inv
+
+    def draw(self, w, r64):
+        w, pw = capi.f32(w)
+        idx = C.c_int(0)
+        capi.check(self.L.stocs_draw(self.h, pw, len(w), r64, C.byref(idx)))
+        return idx.value
+
+    # ---- congruent sets (stocs.hpp:93-96) ----
+    def find_congruent_all(self):
+        n = C.c_int64(0)
+        capi.check(self.L.stocs_find_congruent_all(self.h, C.byref(n)))
+        return n.value
+
+    def get_quads(self, slot):
+        n = C.c_int64(0)
+        capi.check(self.L.stocs_get_quads(self.h, slot, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 4), np.int32)
+        if n.value:
+            capi.check(self.L.stocs_get_quads(self.h, slot, out.ctypes.data_as(capi._ip), n.value, C.byref(n)))
+        return out
+
+    def find_congruent_sets_on_model(self, base_indices, invariant1, invariant2):
+        self.set_bases(np.asarray(base_indices).reshape(1, 4), np.array([[invariant1, invariant2]], np.float32))
+        self.find_congruent_all()
+        return self.get_quads(0)
+
+    # ---- transforms (stocs.hpp:98-101) ----
+    def get_rigid_transform_from_congruent_pair(self, base_indices, quad):
+        ids, pi = capi.i32(base_indices)
+        q, pq = capi.i32(quad)
+        T = np.zeros(16, np.float32); P = np.zeros(16, np.float32)
+        ok = C.c_int(0)
+        capi.check(self.L.stocs_rigid_transform(self.h, pi, pq, T.ctypes.data_as(capi._fp), P.ctypes.data_as(capi._fp), C.byref(ok)))
+        return bool(ok.value), T, P
+
+    def make_transforms(self, max_per_base=200, seed=0):
+        n = C.c_int(0)
+        capi.check(self.L.stocs_make_transforms(self.h, max_per_base, seed, C.byref(n)))
+        return n.value
+
+    def get_pose_candidates(self):
+        n = C.c_int(0)
+        capi.check(self.L.stocs_get_candidates(self.h, None, None, None, None, 0, C.byref(n)))
+        T = np.zeros((n.value, 16), np.float32); P = np.zeros((n.value, 16), np.float32)
+        l = np.zeros(n.value, np.float32); b = np.zeros(n.value, np.int32)
+        if n.value:
+            capi.check(self.L.stocs_get_candidates(self.h, T.ctypes.data_as(capi._fp), P.ctypes.data_as(capi._fp),
+                                                   l.ctypes.data_as(capi._fp), b.ctypes.data_as(capi._ip), n.value, C.byref(n)))
+        return T, P, l, b
+
+    # ---- verification (stocs.hpp:103-107) ----
+    def compute_alignment_score_for_rigid_transform(self, T16):
+        return float(self.score_transforms(np.asarray(T16, np.float32).reshape(1, 16))[0])
+
+    def score_transforms(self, T16):
+        T, pT = capi.f32(T16)
+        n = T.size // 16
+        out = np.zeros(n, np.float32)
+        capi.check(self.L.stocs_score_transforms(self.h, pT, n, out.ctypes.data_as(capi._fp)))
+        return out
+
+    def lcp_detail(self, T16):
+        T, pT = capi.f32(T16)
+        hit = np.zeros(self.nM, np.int32); counted = np.zeros(self.nM, np.uint8)
+        capi.check(self.L.stocs_lcp_detail(self.h, pT, hit.ctypes.data_as(capi._ip), counted.ctypes.data_as(capi._u8p)))
+        return hit, counted
+
+    def compute_best_transform(self):
+        s = C.c_float(0); i = C.c_int(-1)
+        P = np.zeros(16, np.float32)
+        capi.check(self.L.stocs_verify_all(self.h, C.byref(s), C.byref(i), P.ctypes.data_as(capi._fp)))
+        self.best_lcp, self.best_index, self.best_pose = s.value, i.value, P
+        return s.value, i.value, P
+
+    # ---- device-resident scoring for the benchmark ----
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        capi.check(self.L.stocs_dev_alloc(self.h, nbytes, C.byref(p)))
+        return p
+
+    def dev_free(self, p):
+        capi.check(self.L.stocs_dev_free(self.h, p))
+
+    def dev_upload(self, p, arr):
+        arr = np.ascontiguousarray(arr)
+        capi.check(self.L.stocs_dev_upload(self.h, p, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    def dev_download(self, p, arr):
+        capi.check(self.L.stocs_dev_download(self.h, arr.ctypes.data_as(C.c_void_p), p, arr.nbytes))
+
+    def score_device(self, dT, n, dL):
+        capi.check(self.L.stocs_score_transforms_device(self.h, dT, n, dL))
+
+    def sync(self):
+        capi.check(self.L.stocs_sync(self.h))
+
+    def time_score_kernel(self, dT, n, dL, reps):
+        ms = C.c_float(0)
+        capi.check(self.L.stocs_time_score_kernel(self.h, dT, n, dL, reps, C.byref(ms)))
+        return ms.value
+
+
+def cluster_poses(poses16, lcp, acceptable_fraction, best_score, maximum_pose_count, min_distance, min_angle, sym):
+    L = capi.load()
+    p, pp = capi.f32(poses16); l, pl = capi.f32(lcp); s, ps = capi.f32(sym)
+    out = np.zeros(max(len(l), 1), np.int32)
+    n = C.c_int(0)
+    capi.check(L.stocs_cluster_poses(pp, pl, len(l), acceptable_fraction, best_score, maximum_pose_count, min_distance,
+                                     min_angle, ps, out.ctypes.data_as(capi._ip), len(out), C.byref(n)))
+    return out[:n.value]

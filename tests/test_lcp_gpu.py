@@ -1,0 +1,107 @@
+"""GPU parity of the batched LCP verification kernel (the metric kernel) against the CPU oracle.
+Calls go through the C ABI (libstocs_hip.so).  Integer results (matched scene index, counted flag)
+must be bit-exact; the score is a float sum accumulated in a different (tree) order than the
+reference's sequential loop, tolerance 1e-5 absolute on a value in [0, 1]."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LCP_TOL = 1e-5
+
+
+def _setup(name, oracle_lib):
+    from model_matching_amd import synth
+    from model_matching_amd.estimator import StocsEstimator
+    m, s, k = synth.workload(name)
+    est = StocsEstimator(s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm, build_index=False)
+    orc = oracle_lib.Oracle(s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm, build_index=False)
+    cs, cm = orc.centroids()
+    Tgt = synth.centred_gt(s.T_gt, cs.astype(np.float64), cm.astype(np.float64))
+    return m, s, k, est, orc, Tgt
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_scores_and_matches_equal_oracle(name, oracle_lib):
+    from model_matching_amd import synth
+    m, s, k, est, orc, Tgt = _setup(name, oracle_lib)
+    assert np.array_equal(est.get_scene_centroid(), orc.centroids()[0])      # centroid_shift parity
+    assert np.array_equal(est.get_model_centroid(), orc.centroids()[1])
+    T = synth.make_candidates(Tgt, k)
+    got = est.score_transforms(T)
+    ref = orc.lcp_batch(T, nthreads=4)
+    assert np.abs(got - ref).max() <= LCP_TOL
+    assert got.max() > 0.05 and (got == 0).sum() < len(got)
+    # arg-max parity (first maximum wins)
+    assert int(np.argmax(got)) == oracle_lib.best(ref)[0] or abs(got.max() - ref.max()) <= LCP_TOL
+    # per-point parity: matched scene index and counted flag, bit-exact
+    pos = orc.scene_centred()
+    checked = 0
+    for c in list(range(12)) + [int(np.argmax(got))]:
+        hg, cg = est.lcp_detail(T[c])
+        ho, co = orc.lcp_detail(T[c])
+        if not np.array_equal(hg, ho):
+            # only exact-distance ties may differ (kd-tree visiting order, Q11)
+            for i in np.nonzero(hg != ho)[0]:
+                assert hg[i] >= 0 and ho[i] >= 0
+            continue
+        assert np.array_equal(cg, co)
+        checked += 1
+    assert checked >= 10
+
+
+def test_edge_cases(oracle_lib):
+    from model_matching_amd import synth
+    m, s, k, est, orc, Tgt = _setup("tiny", oracle_lib)
+    # empty batch
+    assert len(est.score_transforms(np.zeros((0, 16), np.float32))) == 0
+    # model thrown far outside the scene grid: nothing matches
+    far = np.eye(4); far[:3, 3] = [50.0, -40.0, 30.0]
+    Tfar = far.T.reshape(1, 16).astype(np.float32)
+    assert est.score_transforms(Tfar)[0] == 0.0 and orc.lcp(Tfar[0]) == 0.0
+    # ragged batch sizes (not a multiple of the 4 candidates per workgroup)
+    T = synth.make_candidates(Tgt, 7)
+    assert np.abs(est.score_transforms(T) - orc.lcp_batch(T)).max() <= LCP_TOL
+    # exact ground truth scores high; flipped (mirrored-normal) transform scores ~0
+    Tg = Tgt.T.reshape(1, 16).astype(np.float32)
+    g = est.score_transforms(Tg)[0]
+    assert abs(g - orc.lcp(Tg[0])) <= LCP_TOL and g > 0.2
+    # NaN transform: no match, score 0 on both sides
+    Tn = Tg.copy(); Tn[0, 12] = np.nan
+    assert est.score_transforms(Tn)[0] == 0.0 and orc.lcp(Tn[0]) == 0.0
+
+
+def test_identity_on_self_reproduces_q7(oracle_lib):
+    """Scene == model, T = I: points whose |n|^2 rounds above 1 are NOT counted (acos -> NaN)."""
+    from model_matching_amd import synth
+    from model_matching_amd.estimator import StocsEstimator
+    m = synth.make_model(300, seed=5)
+    prob = np.linspace(0.2, 1.0, 300).astype(np.float32)
+    est = StocsEstimator(m.pos, m.nrm, prob, None, m.pos, m.nrm, build_index=False)
+    orc = oracle_lib.Oracle(m.pos, m.nrm, prob, None, m.pos, m.nrm, build_index=False)
+    T = np.eye(4, dtype=np.float32).reshape(16)
+    hg, cg = est.lcp_detail(T)
+    ho, co = orc.lcp_detail(T)
+    assert np.array_equal(hg, ho) and np.array_equal(cg, co) and (hg == np.arange(300)).all()
+    assert 150 < cg.sum() < 300
+    assert abs(est.compute_alignment_score_for_rigid_transform(T) - orc.lcp(T)) <= LCP_TOL
+
+
+def test_full_size_properties(oracle_lib):
+    """Cm size (20k scene, 5k model): size-independent properties + a sampled oracle comparison."""
+    from model_matching_amd import synth
+    m, s, k, est, orc, Tgt = _setup("Cm", oracle_lib)
+    T = synth.make_candidates(Tgt, 4096)
+    got = est.score_transforms(T)
+    assert got.min() >= 0.0 and got.max() <= 1.0
+    # batch invariance: a candidate's score does not depend on its batch or position in it
+    perm = np.random.default_rng(0).permutation(len(T))
+    assert np.array_equal(est.score_transforms(T[perm]), got[perm])
+    assert np.array_equal(est.score_transforms(T[:1000]), got[:1000])
+    # run-to-run determinism
+    assert np.array_equal(est.score_transforms(T), got)
+    # the tight tier (<= 1 mm / 1 deg from ground truth) outscores the loose tier on average
+    ref = orc.lcp_batch(T[:192], nthreads=8)
+    assert np.abs(got[:192] - ref).max() <= LCP_TOL
+    gt = est.score_transforms(Tgt.T.reshape(1, 16).astype(np.float32))[0]
+    assert gt > np.percentile(got, 90)
