@@ -41,13 +41,10 @@ STOCS_HD V3 operator*(V3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 STOCS_HD V3 operator/(V3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
 STOCS_HD float dot3(V3 a, V3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
 STOCS_HD float sqn3(V3 a) { return dot3(a, a); }
-STOCS_HD float stocs_sqrtf(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __fsqrt_rn(x);
-#else
-    return sqrtf(x);
-#endif
-}
+// sqrtf lowers to v_sqrt_f32 + two FMA correction steps (correctly rounded) on gfx950 under the
+// default -fhip-fp32-correctly-rounded-divide-sqrt; __fsqrt_rn lowers to the bare 1-ulp v_sqrt_f32
+// and must NOT be used here.
+STOCS_HD float stocs_sqrtf(float x) { return sqrtf(x); }
 STOCS_HD float norm3(V3 a) { return stocs_sqrtf(sqn3(a)); }
 STOCS_HD V3 cross3(V3 a, V3 b) {
     return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);

@@ -1,0 +1,205 @@
+"""GPU parity of base sampling (rows 1-7), congruent-set search (rows 8-10), candidate transforms
+(rows 11-12) and the verification driver (rows 16-17, 19) against the CPU oracle, through the C ABI.
+Integer / index results (PPF keys, pair lists, weights-zeroing decisions, drawn indices, quads) are
+bit-exact; transforms are bit-exact floats (same IEEE operation order, no contraction); LCP scores
+within 1e-5 absolute (different summation order)."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+LCP_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def setup(oracle_lib):
+    from model_matching_amd import synth
+    from model_matching_amd.estimator import StocsEstimator
+    m, s, k = synth.workload("tiny")
+    est = StocsEstimator(s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm, build_index=True)
+    orc = oracle_lib.Oracle(s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm, build_index=True)
+    return m, s, est, orc
+
+
+def test_ppf_index_equals_oracle(setup, oracle_lib):
+    m, s, est, orc = setup
+    n_pairs, n_buckets, n_keys = est.index_stats()
+    assert n_pairs == len(m.pos) * (len(m.pos) - 1) == oracle_lib.lib().orc_index_num_pairs(oracle_lib.lib().orc_ctx_index(orc.h))
+    rng = np.random.default_rng(0)
+    nrm = oracle_lib.normalize_rows(m.nrm)
+    keys = set()
+    for _ in range(150):
+        i, j = rng.integers(0, len(m.pos), 2)
+        if i != j:
+            f = oracle_lib.ppf_compute(m.pos[i], nrm[i], m.pos[j], nrm[j])
+            keys.add(tuple(int(f[k]) + 5 * int(rng.integers(-2, 2)) for k in range(4)))
+    for _ in range(300):
+        keys.add((int(rng.integers(0, 45)) * 5, int(rng.integers(-1, 38)) * 5, int(rng.integers(-1, 38)) * 5, int(rng.integers(-1, 38)) * 5))
+    keys.update([(5, 90, 90, 0), (10, 90, 90, 0), (50, -5, 90, 0), (10000, 90, 90, 90), (50, 185, 90, 90)])
+    nonempty = 0
+    for key in sorted(keys):
+        a = est.index_lookup(key)
+        b = orc.index_lookup(key)
+        assert a.shape == b.shape and (a == b).all(), key          # same pairs, same (insertion) order
+        assert est.index_exists(key) == orc.index_exists(key) == (len(b) > 0), key
+        nonempty += len(b) > 0
+    assert nonempty > 80
+
+
+def test_weight_passes_equal_oracle(setup):
+    m, s, est, orc = setup
+    rng = np.random.default_rng(2)
+    cp = orc.scene_class_prob()
+    n_checked = 0
+    for trial in range(6):
+        ok, ids, inv = orc.sample_class_base(100 + trial, trial)
+        b = rng.integers(0, len(cp), 3).astype(np.int32) if not ok else ids[:3].astype(np.int32)
+        w = cp.copy()
+        for k in (1, 2, 3):
+            wo = orc.class_pass(k, b, w)
+            wg = est.class_pass(k, b, w)
+            assert np.array_equal(wo, wg), (trial, k, int((wo != wg).sum()))
+            assert (wo == 0).sum() >= (w == 0).sum()
+            w = wo
+            n_checked += 1
+    assert n_checked == 18
+
+
+def test_draw_equals_oracle(setup, oracle_lib):
+    m, s, est, orc = setup
+    L = oracle_lib.lib()
+    rng = np.random.default_rng(4)
+    import ctypes as C
+    for n in (1, 5, 63, 1024, 1500, 4097):
+        w = rng.random(n).astype(np.float32)
+        w[rng.random(n) < 0.6] = 0
+        for t in range(8):
+            r = int(rng.integers(0, 2 ** 63)) * 2 + int(rng.integers(0, 2))
+            assert est.draw(w, r) == L.orc_draw(w.ctypes.data_as(C.POINTER(C.c_float)), n, r)
+        assert est.draw(w, 0) == L.orc_draw(w.ctypes.data_as(C.POINTER(C.c_float)), n, 0)
+        assert est.draw(w, 2 ** 64 - 1) == L.orc_draw(w.ctypes.data_as(C.POINTER(C.c_float)), n, 2 ** 64 - 1)
+    z = np.zeros(100, np.float32)
+    assert est.draw(z, 12345) == -1
+
+
+def test_class_bases_equal_oracle(setup):
+    m, s, est, orc = setup
+    seed, n = 4242, 40
+    valid, ids, inv = est.sample_bases(seed, n)
+    n_ok = 0
+    for a in range(n):
+        ok, oi, ov = orc.sample_class_base(seed, a)
+        assert ok == bool(valid[a]), a
+        if ok:
+            assert np.array_equal(oi, ids[a]) and np.array_equal(ov, inv[a]), a
+            n_ok += 1
+    assert n_ok >= 20
+    # attempts are independent: a sub-range reproduces the same bases
+    v2, i2, n2 = est.sample_bases(seed, 5, first_attempt=10)
+    assert np.array_equal(v2, valid[10:15]) and np.array_equal(i2[v2], ids[10:15][v2])
+
+
+def test_congruent_sets_and_transforms_equal_oracle(setup):
+    m, s, est, orc = setup
+    seed = 99
+    est.L.stocs_clear_bases(est.h)
+    valid, ids, inv = est.sample_bases(seed, 24)
+    assert est.L.stocs_num_bases(est.h) == int(valid.sum())
+    total = est.find_congruent_all()
+    slot = 0
+    tot_o = 0
+    n_nonempty = 0
+    for a in range(24):
+        if not valid[a]:
+            continue
+        qo = orc.find_congruent(ids[a], float(inv[a][0]), float(inv[a][1]))
+        qg = est.get_quads(slot)
+        assert qo.shape == qg.shape and np.array_equal(qo, qg), (a, qo.shape, qg.shape)
+        tot_o += len(qo)
+        n_nonempty += len(qo) > 0
+        # rows 11-12: transforms of the first quads, bit-exact
+        for q in qo[:5]:
+            oko, To, Po = orc.rigid_transform(ids[a], q)
+            okg, Tg, Pg = est.get_rigid_transform_from_congruent_pair(ids[a], q)
+            assert oko == okg
+            if oko:
+                assert np.array_equal(To, Tg) and np.array_equal(Po, Pg)
+        slot += 1
+    assert total == tot_o and n_nonempty >= 5
+    # single-base façade form
+    a = int(np.nonzero(valid)[0][0])
+    q1 = est.find_congruent_sets_on_model(ids[a], float(inv[a][0]), float(inv[a][1]))
+    assert np.array_equal(q1, orc.find_congruent(ids[a], float(inv[a][0]), float(inv[a][1])))
+    # degenerate triple is rejected on both sides (deliberate divergence Q2)
+    okg, _, _ = est.get_rigid_transform_from_congruent_pair(ids[a], np.array([3, 3, 9, 20], np.int32))
+    oko, _, _ = orc.rigid_transform(ids[a], np.array([3, 3, 9, 20], np.int32))
+    assert okg == oko == False
+
+
+def test_full_run_equals_oracle_and_recovers_pose(setup, oracle_lib):
+    """run_stocs_estimation (stocs_match_one_object.cpp:51-185), class mode, seeded."""
+    m, s, est, orc = setup
+    seed = 1234
+    r = orc.run(seed, 100, 200)
+    est.L.stocs_clear_bases(est.h)
+    valid, ids, inv = est.sample_bases(seed, 100)
+    assert int(valid.sum()) == r.n_bases
+    assert est.find_congruent_all() == r.n_quads_total
+    assert est.make_transforms(200, seed) == r.n_candidates
+    To, Po, bo = orc.candidates()
+    Tg, Pg, lg, bg = est.get_pose_candidates()
+    assert np.array_equal(To, Tg) and np.array_equal(Po, Pg) and np.array_equal(bo, bg)
+    best_lcp, best_idx, best_pose = est.compute_best_transform()
+    lo = orc.lcp_batch(To, nthreads=4)
+    Tg2, Pg2, lg2, bg2 = est.get_pose_candidates()
+    assert np.abs(lg2 - lo).max() <= LCP_TOL
+    assert abs(best_lcp - r.best_lcp) <= LCP_TOL
+    if best_idx != r.best_index:      # only a near-tie within the summation tolerance may differ
+        assert abs(lo[best_idx] - lo[r.best_index]) <= 2 * LCP_TOL
+    P = best_pose.reshape(4, 4).T
+    Po_best = np.array(r.best_pose16).reshape(4, 4).T
+    dR = P[:3, :3].T @ Po_best[:3, :3]
+    assert math.degrees(math.acos(min(1.0, (np.trace(dR) - 1) / 2))) <= 1.0       # <= 1 deg of the CPU path
+    assert np.linalg.norm(P[:3, 3] - Po_best[:3, 3]) <= 1e-3                        # <= 1 mm
+    dG = P[:3, :3].T @ s.T_gt[:3, :3]
+    assert math.degrees(math.acos(min(1.0, (np.trace(dG) - 1) / 2))) < 3.0
+    assert np.linalg.norm(P[:3, 3] - s.T_gt[:3, 3]) < 0.005
+    # clustering of the scored candidates (host function of the library) == oracle
+    from model_matching_amd.estimator import cluster_poses
+    sym = np.array([0, 0, 0], np.float32)
+    a = cluster_poses(Pg2, lo, 0.5, float(lo.max()), 10, 0.02, 15.0, sym)
+    b = oracle_lib.greedy_clustering(Pg2, lo, 0.5, float(lo.max()), 10, 0.02, 15.0, sym)
+    assert a.tolist() == b.tolist() and a[0] == r.best_index
+
+
+def test_instance_mode_equals_oracle(oracle_lib):
+    """sample_instance_base (stocs.cpp:559-751) with an in-memory edge map: sequential attempts,
+    compounding prior decay (Q8), flood-fill segments."""
+    from model_matching_amd import synth
+    from model_matching_amd.estimator import StocsEstimator
+    m, s, k = synth.workload("tiny")
+    H, W = 480, 640
+    edge = np.full((H, W), 255, np.uint8)          # 255 = no edge; 0 = edge (probability 1)
+    rows, cols = s.pixel[:s.n_object, 0], s.pixel[:s.n_object, 1]
+    r0, r1, c0, c1 = rows.min() - 3, rows.max() + 3, cols.min() - 3, cols.max() + 3
+    edge[r0, c0:c1 + 1] = 0; edge[r1, c0:c1 + 1] = 0; edge[r0:r1 + 1, c0] = 0; edge[r0:r1 + 1, c1] = 0
+    edge[::37, :] = 0                              # a few long edges through the clutter
+    est = StocsEstimator(s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm, build_index=True)
+    orc = oracle_lib.Oracle(s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm, build_index=True)
+    est.set_edge_map(edge); orc.set_edge_map(edge)
+    seed, n = 77, 14
+    valid, ids, inv = est.sample_bases(seed, n, mode=1, dispersion=0.9)
+    n_ok = 0
+    for a in range(n):
+        ok, oi, ov = orc.sample_instance_base(seed, a, 0.9, a + 1)
+        assert ok == bool(valid[a]), a
+        if ok:
+            assert np.array_equal(oi, ids[a]) and np.array_equal(ov, inv[a]), a
+            n_ok += 1
+    assert n_ok >= 3
+    # the decayed class probabilities are what the LCP adds afterwards (Q8)
+    cs, cm = orc.centroids()
+    T = synth.make_candidates(synth.centred_gt(s.T_gt, cs.astype(np.float64), cm.astype(np.float64)), 64)
+    assert np.abs(est.score_transforms(T) - orc.lcp_batch(T)).max() <= LCP_TOL
+    assert (orc.scene_class_prob() < s.prob - 1e-6).any()
