@@ -65,17 +65,14 @@ def main():
     dL = est.dev_alloc(kcand * 4)
     est.dev_upload(dT, T)
     lcp = np.zeros(kcand, np.float32)
-    best_key = torch.zeros(1, dtype=torch.int64, device="cuda")
+    from model_matching_amd import dist as sdist
 
     def step():
         est.score_device(dT, kcand, dL)            # async on the context's stream
         est.dev_download(dL, lcp)                   # syncs the stream; 256 KiB of scores
         i = int(np.argmax(lcp))                     # first maximum wins (stocs.cpp:994)
-        key = int(est.L.stocs_pack_best(float(lcp[i]), rank * kcand + i)) if lcp[i] > 0 else 0
-        if world > 1:
-            best_key.fill_(key - (1 << 64) if key >= (1 << 63) else key)
-            dist.all_reduce(best_key, op=dist.ReduceOp.MAX)   # RCCL over xGMI, 8 bytes
-        return key
+        # 8-byte max all-reduce of the packed (score, global candidate id) key: RCCL over xGMI
+        return sdist.allreduce_best(float(lcp[i]), rank * kcand + i, device="cuda")
 
     for _ in range(args.warmup):
         step()

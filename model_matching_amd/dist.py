@@ -1,0 +1,60 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" == RCCL over xGMI on
+ROCm; "gloo" in the CPU tests).  The hot path shards naturally -- StoCS trials / base attempts /
+candidate batches are independent given the read-only scene, model and index, which are replicated
+on every GPU -- so there is NO data-path collective.  The only exchange is the arg-max of
+compute_best_transform (reference src/stocs.cpp:982-1004) across ranks: one 8-byte max all-reduce
+of the packed (score, candidate id) key, then a 64-byte broadcast of the winner's pose."""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+
+def shard_range(n: int, rank: int, world: int):
+    """Contiguous block partition of n independent units (attempts / candidates) over ranks."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_attempts(n_attempts: int, rank: int, world: int):
+    """Round-robin assignment of base attempts: attempt g runs on rank g mod world."""
+    return list(range(rank, n_attempts, world))
+
+
+def pack_best(lcp: float, global_id: int) -> int:
+    """Same key as stocs_pack_best (include/stocs_hip.h): max wins, lowest id wins ties, scores <= 0
+    never win.  Positive float bit patterns are order-preserving and below 2^31, so the key fits a
+    signed 64-bit integer (what RCCL / gloo reduce)."""
+    bits = struct.unpack("<I", struct.pack("<f", lcp))[0] if lcp > 0 else 0
+    return (bits << 32) | (0xFFFFFFFF - (global_id & 0xFFFFFFFF))
+
+
+def unpack_best(key: int):
+    bits = (key >> 32) & 0xFFFFFFFF
+    return struct.unpack("<f", struct.pack("<I", bits))[0], 0xFFFFFFFF - (key & 0xFFFFFFFF)
+
+
+def allreduce_best(local_lcp: float, local_global_id: int, device="cpu"):
+    """Returns (best_lcp, best_global_id) over all ranks; (0.0, -1) when no rank has a positive score."""
+    import torch
+    import torch.distributed as dist
+    key = pack_best(local_lcp, local_global_id) if local_lcp > 0 else 0
+    t = torch.tensor([key], dtype=torch.int64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    key = int(t.item())
+    if key == 0:
+        return 0.0, -1
+    return unpack_best(key)
+
+
+def broadcast_pose(pose16, owner_rank: int, device="cpu"):
+    """64-byte broadcast of the winner's camera-frame pose from the rank that owns it."""
+    import torch
+    import torch.distributed as dist
+    t = torch.as_tensor(np.asarray(pose16, np.float32).reshape(16).copy(), device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(t, src=owner_rank)
+    return t.cpu().numpy()
