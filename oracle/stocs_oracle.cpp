@@ -160,6 +160,9 @@ struct KeyHash {
 struct orc_index {
     int tr, rot;
     std::unordered_map<std::array<int, 4>, std::vector<IPair>, KeyHash> base;  // key F -> pairs
+    // the key set of the reference's map (every F expanded by the 128 insertion offsets,
+    // rgbd.cpp:130-137): what ppf_map.find(K) != end() tests
+    std::unordered_map<std::array<int, 4>, char, KeyHash> keys;
     int64_t npairs;
 };
 
@@ -194,6 +197,10 @@ int64_t index_lookup(const orc_index* ix, const int* K, std::vector<IPair>* out)
 bool index_exists(const orc_index* ix, const int* K) {
     const int tr = ix->tr, rot = ix->rot;
     if (K[0] <= 5 || K[1] < 0 || K[2] < 0 || K[3] < 0) return false;
+    if (!ix->keys.empty()) {
+        std::array<int, 4> key = {{K[0], K[1], K[2], K[3]}};
+        return ix->keys.find(key) != ix->keys.end();
+    }
     for (int a = 0; a < 2; ++a)
         for (int b = 0; b < 4; ++b)
             for (int c = 0; c < 4; ++c)
@@ -977,6 +984,17 @@ orc_index* orc_index_build(const float* pos3, const float* nrm3, int n, int tr, 
             ix->base[F].push_back(IPair(id1, id2));
             ix->npairs++;
         }
+    for (auto it = ix->base.begin(); it != ix->base.end(); ++it) {
+        const std::array<int, 4>& F = it->first;
+        for (int p1 = F[0] - tr; p1 < F[0] + tr; p1 += tr)
+            for (int p2 = F[1] - 2 * rot; p2 < F[1] + 2 * rot; p2 += rot)
+                for (int p3 = F[2] - 2 * rot; p3 < F[2] + 2 * rot; p3 += rot)
+                    for (int p4 = F[3] - 2 * rot; p4 < F[3] + 2 * rot; p4 += rot) {
+                        if (p1 <= 5 || p2 < 0 || p3 < 0 || p4 < 0) continue;
+                        std::array<int, 4> key = {{p1, p2, p3, p4}};
+                        ix->keys[key] = 1;
+                    }
+    }
     return ix;
 }
 void orc_index_free(orc_index* ix) { delete ix; }

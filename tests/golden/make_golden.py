@@ -51,6 +51,18 @@ def main():
                         cand_T=T, cand_base=b, cand_lcp=lcp, synth_T=Tc, synth_lcp=lcp_c,
                         best_hit=hit, best_counted=counted)
     print("wrote", out, os.path.getsize(out), "bytes")
+    # summary of oracle runs on the fixtures derived from the reference's example data
+    import json
+    summ = {}
+    for name in ("ycb_024_bowl", "linemod_obj_06", "packed_dove"):
+        d = np.load(os.path.join(ROOT, "tests", "golden", "example_%s.npz" % name))
+        o = po.Oracle(d["scene_pos"], d["scene_nrm"], d["scene_prob"], d["scene_pixel"], d["model_pos"], d["model_nrm"])
+        r = o.run(7, 100, 200)
+        summ[name] = dict(nS=int(len(d["scene_pos"])), nM=int(len(d["model_pos"])), seed=7, n_bases=r.n_bases, n_quads=r.n_quads_total,
+                          n_candidates=r.n_candidates, best_index=r.best_index, best_lcp=float(np.float32(r.best_lcp)),
+                          best_pose16=[float(np.float32(v)) for v in r.best_pose16])
+    json.dump(summ, open(os.path.join(ROOT, "tests", "golden", "example_summary.json"), "w"), indent=1)
+    print("wrote example_summary.json")
 
 
 if __name__ == "__main__":
