@@ -140,6 +140,10 @@ int stocs_cluster_poses(const float* poses16, const float* lcp, int n, float acc
                         float best_score, int maximum_pose_count, float min_distance, float min_angle,
                         const float* sym3, int32_t* out_idx, int cap, int* n_out);
 
+/* ---- tuning knobs (never change results): "lcp_variant" 0 = lane-per-query list scan,
+ * 1 = cooperative 8-lane list scan (default) ---- */
+int stocs_set_option(stocs_ctx* ctx, const char* key, int value);
+
 /* ---- stream / timing plumbing ---- */
 int   stocs_sync(stocs_ctx* ctx);
 void* stocs_stream(stocs_ctx* ctx);          /* hipStream_t */

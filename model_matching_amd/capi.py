@@ -64,6 +64,7 @@ SIGNATURES = {
     "stocs_pack_best": (C.c_uint64, [C.c_float, C.c_uint32]),
     "stocs_unpack_best": (None, [C.c_uint64, _fp, C.POINTER(C.c_uint32)]),
     "stocs_cluster_poses": (C.c_int, [_fp, _fp, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, _fp, _ip, C.c_int, _intp]),
+    "stocs_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "stocs_sync": (C.c_int, [_vp]),
     "stocs_stream": (_vp, [_vp]),
     "stocs_time_score_kernel": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _fp]),

@@ -36,8 +36,10 @@ struct SceneGrid {
     int nbx, nby, nbz;   // bricks per axis
     int n_bricks;
     int64_t n_entries;
+    double avg_list_len;   // entries per non-empty cell
     int32_t* d_top;      // nbx*nby*nbz -> brick id or -1
-    uint2* d_cells;      // n_bricks*512: (offset, count) into d_list
+    uint4* d_cells;      // n_bricks*512: (offset, count, sub-cell mask lo, hi); mask bit s set <=> some scene
+                         // point lies within epsilon of sub-cell s (4x4x4 sub-cells, x fastest)
     float4* d_list;      // (x, y, z, bits(scene index))
 };
 
@@ -106,6 +108,7 @@ struct stocs_ctx {
     int32_t* d_mperm;
 
     stocs::SceneGrid grid;
+    int grid_div;   // cell edge = epsilon / grid_div
     stocs::PpfIndex index;
 
     // image-space state of instance mode (stocs.hpp:153-155)

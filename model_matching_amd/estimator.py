@@ -201,6 +201,9 @@ class StocsEstimator:
     def score_device(self, dT, n, dL):
         capi.check(self.L.stocs_score_transforms_device(self.h, dT, n, dL))
 
+    def set_option(self, key, value):
+        capi.check(self.L.stocs_set_option(self.h, key.encode(), int(value)))
+
     def sync(self):
         capi.check(self.L.stocs_sync(self.h))
 
