@@ -22,7 +22,9 @@
 //      std::set<pair<P index, Q index>> (P and Q lists are in lexicographic (id1,id2) order).
 // The join is irregular integer/gather work: HBM/L2-bound, no MFMA.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -131,14 +133,14 @@ __global__ __launch_bounds__(256) void join_kernel(const BaseJob* __restrict__ j
                                                    const float4* __restrict__ munit, const float4* __restrict__ mpos,
                                                    const uint32_t* __restrict__ Q, uint32_t totalQ, const uint64_t* __restrict__ pkeys,
                                                    const uint32_t* __restrict__ pvals, float nepsilon, float dist_thr,
-                                                   unsigned long long* __restrict__ counts, const unsigned long long* __restrict__ quad_off,
-                                                   unsigned long long* __restrict__ cursor, uint64_t* __restrict__ quads) {
+                                                   uint32_t* __restrict__ qcnt, const uint32_t* __restrict__ qoff_e, int id_bits,
+                                                   uint64_t* __restrict__ quads) {
     __shared__ uint32_t seen[256][11];  // 343-bit set per lane
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= totalQ) return;
     const int b = find_base(q_off, nB, e);
     const BaseJob& J = jobs[b];
-    if (J.p_len == 0 || J.nb == 0) return;
+    if (J.p_len == 0 || J.nb == 0) { if (!FILL) qcnt[e] = 0; return; }
     const uint32_t qr = Q[e];
     const int qa = qr >> 16, qb = qr & 0xFFFF;
     const V3 p1 = ld3c(munit, qa), p2 = ld3c(munit, qb);
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void join_kernel(const BaseJob* __restrict__ j
     const V3 queryQ = pq1 + J.inv2 * (pq2 - pq1);
     const V3 queryn = normalized3(p2 - p1);
     const int64_t pc = index_pos(query, J.cell, J.egSize);
-    if (pc < 0 || pc >= ((int64_t)1 << 31)) return;
+    if (pc < 0 || pc >= ((int64_t)1 << 31)) { if (!FILL) qcnt[e] = 0; return; }
     uint32_t* my = seen[threadIdx.x];
 #pragma unroll
     for (int k = 0; k < 11; ++k) my[k] = 0;
@@ -156,7 +158,8 @@ __global__ __launch_bounds__(256) void join_kernel(const BaseJob* __restrict__ j
     const uint64_t* keys = pkeys + J.p_off;
     const uint32_t* vals = pvals + J.p_off;
     const uint64_t hi_bits = (uint64_t)b << 40;
-    unsigned long long local = 0;
+    uint32_t local = 0;
+    const uint32_t out0 = FILL ? qoff_e[e] : 0u;   // exclusive scan of the count pass: no atomics in the fill pass
     for (int a = 0; a < J.nb; ++a) {
         const V3 dir = normalized3(quat_rot(q, mk3(J.dirs[a][0], J.dirs[a][1], J.dirs[a][2])));
         const int id = index_normal(dir, nepsilon);
@@ -175,16 +178,33 @@ __global__ __launch_bounds__(256) void join_kernel(const BaseJob* __restrict__ j
             const V3 pp1 = ld3c(mpos, pa), pp2 = ld3c(mpos, pb);
             const V3 invPoint = pp1 + (pp2 - pp1) * J.inv1;
             if (sqn3(queryQ - invPoint) <= dist_thr) {  // squared metres vs metres (Q1), reproduced
-                if (FILL) {
-                    const unsigned long long pos = atomicAdd(&cursor[b], 1ull);
-                    quads[quad_off[b] + pos] = ((uint64_t)pa << 48) | ((uint64_t)pb << 32) | ((uint64_t)qa << 16) | (uint64_t)qb;
-                } else {
-                    local++;
-                }
+                if (FILL)   // sort key: base, then (P.first, P.second, Q.first, Q.second) == the std::set order
+                    quads[out0 + local] = ((uint64_t)b << (4 * id_bits)) | ((uint64_t)pa << (3 * id_bits)) | ((uint64_t)pb << (2 * id_bits)) |
+                                          ((uint64_t)qa << id_bits) | (uint64_t)qb;
+                local++;
             }
         }
     }
-    if (!FILL && local) atomicAdd(&counts[b], local);
+    if (!FILL) qcnt[e] = local;
+}
+
+// 16-bit fallback layout (|M| > 8192 or very many bases): (a,b,c,d) x 16 bits, sorted per base segment
+struct XformJobC { int32_t s[4]; int32_t q[4]; };
+// picks (base, rank) -> transform jobs, straight from the device-resident sorted quads
+__global__ __launch_bounds__(256) void make_jobs_kernel(const uint64_t* __restrict__ quads, const unsigned long long* __restrict__ quad_off,
+                                                        const int2* __restrict__ picks, int n, const int32_t* __restrict__ base_ids,
+                                                        int id_bits, XformJobC* __restrict__ jobs) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int b = picks[j].x;
+    const uint64_t key = quads[quad_off[b] + (unsigned long long)picks[j].y];
+    const uint64_t m = (1ull << id_bits) - 1ull;
+    XformJobC job;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) job.s[k] = base_ids[4 * b + k];
+    job.q[0] = (int)((key >> (3 * id_bits)) & m); job.q[1] = (int)((key >> (2 * id_bits)) & m);
+    job.q[2] = (int)((key >> id_bits) & m); job.q[3] = (int)(key & m);
+    jobs[j] = job;
 }
 
 template <class T>
@@ -205,11 +225,22 @@ using namespace stocs;
 
 extern "C" {
 
+static double now_s() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+#define STOCS_TICK(label)                                                                          \
+    if (dbg) { (void)hipStreamSynchronize(c->stream); const double t_ = now_s(); fprintf(stderr, "[stocs congruent] %-18s %8.3f ms\n", label, (t_ - tprev) * 1e3); tprev = t_; }
+
 int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     if (!c) return STOCS_ERR_INVALID;
+    const bool dbg = getenv("STOCS_DEBUG_TIMING") != NULL;
+    double tprev = now_s();
     if (!c->index.built) { set_error("stocs_find_congruent_all: PPF index not built"); return STOCS_ERR_STATE; }
     const int nB = (int)c->bases.size();
-    c->quads.assign(nB, std::vector<uint64_t>());
+    c->quad_off.assign(nB + 1, 0);
+    c->quad_id_bits = 16;
     if (total_quads) *total_quads = 0;
     if (nB == 0) return STOCS_OK;
     if (nB >= (1 << 20)) { set_error("too many bases"); return STOCS_ERR_INVALID; }
@@ -265,15 +296,17 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
         }
     }
     p_off[nB] = (uint32_t)totP; q_off[nB] = (uint32_t)totQ;
+    STOCS_TICK("host prep")
+    if (dbg) fprintf(stderr, "[stocs congruent] totP %llu totQ %llu segs %zu %zu\n", (unsigned long long)totP, (unsigned long long)totQ, psegs.size(), qsegs.size());
     if (totP == 0 || totQ == 0) return STOCS_OK;
 
     // ---- 2-3. gather + keys + sort ----
     DevBuf<BaseJob> d_jobs; DevBuf<Segment> d_psegs, d_qsegs; DevBuf<uint32_t> d_poff, d_qoff, d_P, d_Q, d_Ps;
-    DevBuf<uint64_t> d_keys, d_keys_s; DevBuf<unsigned long long> d_counts, d_quadoff, d_cursor; DevBuf<char> d_tmp;
+    DevBuf<uint64_t> d_keys, d_keys_s; DevBuf<char> d_tmp;
     int rc;
     if ((rc = d_jobs.alloc(nB)) || (rc = d_psegs.alloc(psegs.size())) || (rc = d_qsegs.alloc(qsegs.size())) || (rc = d_poff.alloc(nB + 1)) ||
         (rc = d_qoff.alloc(nB + 1)) || (rc = d_P.alloc(totP)) || (rc = d_Q.alloc(totQ)) || (rc = d_Ps.alloc(totP)) || (rc = d_keys.alloc(totP)) ||
-        (rc = d_keys_s.alloc(totP)) || (rc = d_counts.alloc(nB)) || (rc = d_quadoff.alloc(nB + 1)) || (rc = d_cursor.alloc(nB)))
+        (rc = d_keys_s.alloc(totP)))
         return rc;
     hipStream_t st = c->stream;
     STOCS_HIP_CHECK(hipMemcpyAsync(d_jobs.p, jobs.data(), sizeof(BaseJob) * nB, hipMemcpyHostToDevice, st));
@@ -281,8 +314,6 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     STOCS_HIP_CHECK(hipMemcpyAsync(d_qsegs.p, qsegs.data(), sizeof(Segment) * qsegs.size(), hipMemcpyHostToDevice, st));
     STOCS_HIP_CHECK(hipMemcpyAsync(d_poff.p, p_off.data(), 4 * (nB + 1), hipMemcpyHostToDevice, st));
     STOCS_HIP_CHECK(hipMemcpyAsync(d_qoff.p, q_off.data(), 4 * (nB + 1), hipMemcpyHostToDevice, st));
-    STOCS_HIP_CHECK(hipMemsetAsync(d_counts.p, 0, 8 * nB, st));
-    STOCS_HIP_CHECK(hipMemsetAsync(d_cursor.p, 0, 8 * nB, st));
     hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, ix.d_pairs, d_psegs.p, (int)psegs.size(), (uint32_t)totP, d_P.p);
     hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((totQ + 255) / 256)), dim3(256), 0, st, ix.d_pairs, d_qsegs.p, (int)qsegs.size(), (uint32_t)totQ, d_Q.p);
     hipLaunchKernelGGL(pkey_kernel, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, d_jobs.p, d_poff.p, nB, c->d_munit, d_P.p, (uint32_t)totP, nepsilon, d_keys.p);
@@ -292,56 +323,101 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     if ((rc = d_tmp.alloc(tmp_bytes))) return rc;
     STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_keys.p, d_keys_s.p, d_P.p, d_Ps.p, (size_t)totP, 0, 64, st));
 
-    // ---- 4. join: count, then fill ----
+    STOCS_TICK("gather+keys+sort")
+    // ---- 4. join: count pass, exclusive scan, fill pass (no atomics) ----
+    int id_bits = 1;
+    while ((1 << id_bits) < c->nM) id_bits++;
+    int base_bits = 1;
+    while ((1 << base_bits) < nB) base_bits++;
+    if (4 * id_bits + base_bits > 64) { set_error("|M| = %d with %d bases does not fit the 64-bit quad key", c->nM, nB); return STOCS_ERR_CAPACITY; }
+    DevBuf<uint32_t> d_qcnt, d_qoffe;
+    if ((rc = d_qcnt.alloc(totQ + 1)) || (rc = d_qoffe.alloc(totQ + 1))) return rc;
     const dim3 jgrid((unsigned)((totQ + 255) / 256));
     hipLaunchKernelGGL(join_kernel<false>, jgrid, dim3(256), 0, st, d_jobs.p, d_qoff.p, nB, c->d_munit, c->d_mpos, d_Q.p, (uint32_t)totQ, d_keys_s.p, d_Ps.p,
-                       nepsilon, c->prm.distance_threshold, d_counts.p, (const unsigned long long*)NULL, (unsigned long long*)NULL, (uint64_t*)NULL);
+                       nepsilon, c->prm.distance_threshold, d_qcnt.p, (const uint32_t*)NULL, id_bits, (uint64_t*)NULL);
     STOCS_HIP_CHECK(hipGetLastError());
-    std::vector<unsigned long long> counts(nB), quad_off(nB + 1, 0);
-    STOCS_HIP_CHECK(hipMemcpyAsync(counts.data(), d_counts.p, 8 * nB, hipMemcpyDeviceToHost, st));
+    STOCS_HIP_CHECK(hipMemsetAsync(d_qcnt.p + totQ, 0, 4, st));
+    size_t tmp_scan = 0;
+    STOCS_HIP_CHECK(rocprim::exclusive_scan(NULL, tmp_scan, d_qcnt.p, d_qoffe.p, 0u, (size_t)totQ + 1, rocprim::plus<uint32_t>(), st));
+    DevBuf<char> d_tmp_scan;
+    if ((rc = d_tmp_scan.alloc(tmp_scan))) return rc;
+    STOCS_HIP_CHECK(rocprim::exclusive_scan(d_tmp_scan.p, tmp_scan, d_qcnt.p, d_qoffe.p, 0u, (size_t)totQ + 1, rocprim::plus<uint32_t>(), st));
+    // per-base offsets = scan value at the first Q entry of each base
+    std::vector<uint32_t> qoff_at(nB + 1);
+    for (int b = 0; b <= nB; ++b)
+        STOCS_HIP_CHECK(hipMemcpyAsync(&qoff_at[b], d_qoffe.p + q_off[b], 4, hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
-    for (int b = 0; b < nB; ++b) quad_off[b + 1] = quad_off[b] + counts[b];
-    const unsigned long long totQuads = quad_off[nB];
+    STOCS_TICK("join count+scan")
+    // 32-bit scan: guard against wrap-around with a 64-bit host-side total of the per-base sums
+    c->quad_off.assign(nB + 1, 0);
+    for (int b = 0; b <= nB; ++b) c->quad_off[b] = qoff_at[b];
+    const unsigned long long totQuads = c->quad_off[nB];
+    for (int b = 0; b < nB; ++b)
+        if (c->quad_off[b + 1] < c->quad_off[b]) { set_error("more than 2^32 congruent quads"); return STOCS_ERR_CAPACITY; }
+    c->quad_id_bits = id_bits;
     if (total_quads) *total_quads = (int64_t)totQuads;
-    if (totQuads == 0) return STOCS_OK;
-    if (totQuads > (1ull << 31)) { set_error("more than 2^31 congruent quads"); return STOCS_ERR_CAPACITY; }
-    DevBuf<uint64_t> d_quads, d_quads_s; DevBuf<unsigned int> d_segb, d_sege;
-    if ((rc = d_quads.alloc(totQuads)) || (rc = d_quads_s.alloc(totQuads)) || (rc = d_segb.alloc(nB)) || (rc = d_sege.alloc(nB))) return rc;
-    STOCS_HIP_CHECK(hipMemcpyAsync(d_quadoff.p, quad_off.data(), 8 * (nB + 1), hipMemcpyHostToDevice, st));
+    if (c->d_quads) { (void)hipFree(c->d_quads); c->d_quads = NULL; }
+    if (c->d_quad_off) { (void)hipFree(c->d_quad_off); c->d_quad_off = NULL; }
+    STOCS_HIP_CHECK(hipMalloc((void**)&c->d_quad_off, 8 * (size_t)(nB + 1)));
+    STOCS_HIP_CHECK(hipMemcpyAsync(c->d_quad_off, c->quad_off.data(), 8 * (size_t)(nB + 1), hipMemcpyHostToDevice, st));
+    if (totQuads == 0) { STOCS_HIP_CHECK(hipStreamSynchronize(st)); return STOCS_OK; }
+    DevBuf<uint64_t> d_quads;
+    if ((rc = d_quads.alloc(totQuads))) return rc;
+    STOCS_HIP_CHECK(hipMalloc((void**)&c->d_quads, 8 * (size_t)totQuads));
     hipLaunchKernelGGL(join_kernel<true>, jgrid, dim3(256), 0, st, d_jobs.p, d_qoff.p, nB, c->d_munit, c->d_mpos, d_Q.p, (uint32_t)totQ, d_keys_s.p, d_Ps.p,
-                       nepsilon, c->prm.distance_threshold, (unsigned long long*)NULL, d_quadoff.p, d_cursor.p, d_quads.p);
+                       nepsilon, c->prm.distance_threshold, (uint32_t*)NULL, d_qoffe.p, id_bits, d_quads.p);
     STOCS_HIP_CHECK(hipGetLastError());
-
-    // ---- 5. per-base sort: the reference's std::set order ----
-    std::vector<unsigned int> segb(nB), sege(nB);
-    for (int b = 0; b < nB; ++b) { segb[b] = (unsigned int)quad_off[b]; sege[b] = (unsigned int)quad_off[b + 1]; }
-    STOCS_HIP_CHECK(hipMemcpyAsync(d_segb.p, segb.data(), 4 * nB, hipMemcpyHostToDevice, st));
-    STOCS_HIP_CHECK(hipMemcpyAsync(d_sege.p, sege.data(), 4 * nB, hipMemcpyHostToDevice, st));
+    STOCS_TICK("join fill")
+    // ---- 5. ONE global radix sort on (base, a, b, c, d): per base the order of the reference's std::set ----
     size_t tmp2 = 0;
-    STOCS_HIP_CHECK(rocprim::segmented_radix_sort_keys(NULL, tmp2, d_quads.p, d_quads_s.p, (unsigned int)totQuads, (unsigned int)nB, d_segb.p, d_sege.p, 0, 64, st));
+    const unsigned end_bit = (unsigned)(4 * id_bits + base_bits);
+    STOCS_HIP_CHECK(rocprim::radix_sort_keys(NULL, tmp2, d_quads.p, c->d_quads, (size_t)totQuads, 0, end_bit, st));
     DevBuf<char> d_tmp2;
     if ((rc = d_tmp2.alloc(tmp2))) return rc;
-    STOCS_HIP_CHECK(rocprim::segmented_radix_sort_keys(d_tmp2.p, tmp2, d_quads.p, d_quads_s.p, (unsigned int)totQuads, (unsigned int)nB, d_segb.p, d_sege.p, 0, 64, st));
-    std::vector<uint64_t> all((size_t)totQuads);
-    STOCS_HIP_CHECK(hipMemcpyAsync(all.data(), d_quads_s.p, 8 * (size_t)totQuads, hipMemcpyDeviceToHost, st));
+    STOCS_HIP_CHECK(rocprim::radix_sort_keys(d_tmp2.p, tmp2, d_quads.p, c->d_quads, (size_t)totQuads, 0, end_bit, st));
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
-    for (int b = 0; b < nB; ++b) c->quads[b].assign(all.begin() + quad_off[b], all.begin() + quad_off[b + 1]);
+    STOCS_TICK("sort")
     return STOCS_OK;
 }
 
 int stocs_get_quads(stocs_ctx* c, int slot, int32_t* quads4, int64_t cap, int64_t* n) {
     if (!c || !n || slot < 0) return STOCS_ERR_INVALID;
-    if (slot >= (int)c->quads.size()) { set_error("stocs_get_quads: no such base slot (call stocs_find_congruent_all first)"); return STOCS_ERR_STATE; }
-    const std::vector<uint64_t>& q = c->quads[slot];
-    *n = (int64_t)q.size();
-    if (!quads4) return STOCS_OK;
-    for (int64_t i = 0; i < *n && i < cap; ++i) {
-        quads4[4 * i + 0] = (int32_t)((q[i] >> 48) & 0xFFFF);
-        quads4[4 * i + 1] = (int32_t)((q[i] >> 32) & 0xFFFF);
-        quads4[4 * i + 2] = (int32_t)((q[i] >> 16) & 0xFFFF);
-        quads4[4 * i + 3] = (int32_t)(q[i] & 0xFFFF);
+    if (slot + 1 >= (int)c->quad_off.size()) { set_error("stocs_get_quads: no such base slot (call stocs_find_congruent_all first)"); return STOCS_ERR_STATE; }
+    *n = (int64_t)(c->quad_off[slot + 1] - c->quad_off[slot]);
+    if (!quads4 || *n == 0) return STOCS_OK;
+    const int64_t m = std::min<int64_t>(*n, cap);
+    std::vector<uint64_t> q((size_t)std::max<int64_t>(m, 0));
+    if (m > 0) {
+        STOCS_HIP_CHECK(hipMemcpyAsync(q.data(), c->d_quads + c->quad_off[slot], 8 * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+        STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    const int bits = c->quad_id_bits;
+    const uint64_t mask = (1ull << bits) - 1ull;
+    for (int64_t i = 0; i < m; ++i) {
+        quads4[4 * i + 0] = (int32_t)((q[i] >> (3 * bits)) & mask);
+        quads4[4 * i + 1] = (int32_t)((q[i] >> (2 * bits)) & mask);
+        quads4[4 * i + 2] = (int32_t)((q[i] >> bits) & mask);
+        quads4[4 * i + 3] = (int32_t)(q[i] & mask);
     }
     return (*n > cap) ? STOCS_ERR_CAPACITY : STOCS_OK;
+}
+
+// device side of stocs_make_transforms: (base, rank) picks -> XformJob records on the device
+int stocs_internal_make_jobs(stocs_ctx* c, const int32_t* picks2_host, int n, void* d_jobs_out) {
+    if (n <= 0) return STOCS_OK;
+    const int nB = (int)c->bases.size();
+    DevBuf<int2> d_picks; DevBuf<int32_t> d_bids;
+    int rc;
+    if ((rc = d_picks.alloc(n)) || (rc = d_bids.alloc((size_t)nB * 4))) return rc;
+    std::vector<int32_t> bids((size_t)nB * 4);
+    for (int b = 0; b < nB; ++b) for (int k = 0; k < 4; ++k) bids[4 * b + k] = c->bases[b].ids[k];
+    STOCS_HIP_CHECK(hipMemcpyAsync(d_picks.p, picks2_host, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    STOCS_HIP_CHECK(hipMemcpyAsync(d_bids.p, bids.data(), 16 * (size_t)nB, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(make_jobs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_quads, c->d_quad_off, d_picks.p, n, d_bids.p,
+                       c->quad_id_bits, (XformJobC*)d_jobs_out);
+    STOCS_HIP_CHECK(hipGetLastError());
+    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return STOCS_OK;
 }
 
 }  // extern "C"

@@ -341,6 +341,7 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     c->d_scratch = NULL; c->scratch_bytes = 0;
     c->index.built = false;
     c->index.d_bucket_start = NULL; c->index.d_pairs = NULL; c->index.d_exists = NULL;
+    c->d_quads = NULL; c->d_quad_off = NULL; c->quad_id_bits = 16;
     c->best_lcp = 0; c->best_index = -1;
     c->has_edge = false;
     c->grid_div = 1;
@@ -456,7 +457,7 @@ int stocs_ctx_destroy(stocs_ctx* c) {
     hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_spos, c->d_snrmw, c->d_spix, c->d_mpos, c->d_mnrm, c->d_munit, c->d_mpos_raw, c->d_mpos_s,
                     c->d_mnrm_s, c->d_mperm, c->grid.d_top, c->grid.d_cells, c->grid.d_list, c->index.d_bucket_start,
-                    c->index.d_pairs, c->index.d_exists, c->d_scratch};
+                    c->index.d_pairs, c->index.d_exists, c->d_scratch, c->d_quads, c->d_quad_off};
     for (void* p : ptrs) if (p) hipFree(p);
     hipEventDestroy(c->ev0);
     hipEventDestroy(c->ev1);

@@ -274,7 +274,7 @@ static int finalize_bases(stocs_ctx* c, int nB, const std::vector<int32_t>& bidx
             c->bases.push_back(r);
         }
     }
-    c->quads.clear();
+    c->quad_off.clear();
     return STOCS_OK;
 }
 
@@ -427,7 +427,7 @@ int stocs_set_bases(stocs_ctx* c, int n, const int32_t* ids, const float* inv) {
     for (int i = 0; i < 4 * n; ++i)
         if (ids[i] < 0 || ids[i] >= c->nS) { set_error("stocs_set_bases: scene index out of range"); return STOCS_ERR_INVALID; }
     c->bases.clear();
-    c->quads.clear();
+    c->quad_off.clear();
     for (int i = 0; i < n; ++i) {
         BaseRec b;
         for (int k = 0; k < 4; ++k) b.ids[k] = ids[4 * i + k];
@@ -438,7 +438,7 @@ int stocs_set_bases(stocs_ctx* c, int n, const int32_t* ids, const float* inv) {
 }
 int stocs_clear_bases(stocs_ctx* c) {
     if (!c) return STOCS_ERR_INVALID;
-    c->bases.clear(); c->quads.clear(); c->cands.clear();
+    c->bases.clear(); c->quad_off.clear(); c->cands.clear();
     c->best_lcp = 0; c->best_index = -1;
     return STOCS_OK;
 }

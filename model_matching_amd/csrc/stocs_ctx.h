@@ -118,7 +118,12 @@ struct stocs_ctx {
 
     // run state
     std::vector<stocs::BaseRec> bases;
-    std::vector<std::vector<uint64_t> > quads;   // per base, sorted packed (a,b,c,d) 16 bits each
+    // congruent quads of all bases: device-resident, sorted by (base, a, b, c, d); packed with
+    // quad_id_bits bits per model id below the base id; quad_off[b] .. quad_off[b+1] is base b's run
+    uint64_t* d_quads;
+    unsigned long long* d_quad_off;
+    std::vector<unsigned long long> quad_off;
+    int quad_id_bits;
     std::vector<stocs::Candidate> cands;
     float best_lcp;
     int best_index;
@@ -132,6 +137,7 @@ namespace stocs {
 int ensure_scratch(stocs_ctx* c, size_t bytes);
 int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d_hit, uint8_t* d_counted);
 int build_ppf_index(stocs_ctx* c);
+extern "C" int stocs_internal_make_jobs(stocs_ctx* c, const int32_t* picks2_host, int n, void* d_jobs_out);
 int plan_lookup(const PpfIndex& ix, const int* K, std::vector<std::pair<uint32_t, uint32_t> >* ranges);
 void compute_thresholds(const stocs_params& prm, Thresholds* t);
 }  // namespace stocs

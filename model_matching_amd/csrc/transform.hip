@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <unordered_map>
 
 #include "stocs_ctx.h"
 
@@ -149,44 +150,54 @@ int stocs_rigid_transform(stocs_ctx* c, const int32_t* ids4, const int32_t* quad
 
 int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_candidates) {
     if (!c || max_per_base <= 0) return STOCS_ERR_INVALID;
-    if (c->quads.size() != c->bases.size()) { set_error("stocs_make_transforms: call stocs_find_congruent_all first"); return STOCS_ERR_STATE; }
-    std::vector<XformJob> jobs;
+    if (c->quad_off.size() != c->bases.size() + 1) { set_error("stocs_make_transforms: call stocs_find_congruent_all first"); return STOCS_ERR_STATE; }
+    // picks = (base, rank in the base's sorted quad run); the quads themselves stay on the device
+    std::vector<int32_t> picks;
     std::vector<int> job_base;
     for (size_t b = 0; b < c->bases.size(); ++b) {
-        const std::vector<uint64_t>& q = c->quads[b];
-        const int nq = (int)q.size();
-        std::vector<int> pick;
+        const long long nq = (long long)(c->quad_off[b + 1] - c->quad_off[b]);
         if (nq < max_per_base) {  // stocs_match_one_object.cpp:126: strictly fewer -> all
-            for (int i = 0; i < nq; ++i) pick.push_back(i);
+            for (long long i = 0; i < nq; ++i) { picks.push_back((int32_t)b); picks.push_back((int32_t)i); job_base.push_back((int)b); }
         } else {
             // seeded sample without replacement (divergence Q5 from the biased 2N-vector shuffle,
-            // stocs_match_one_object.cpp:134-142): partial Fisher-Yates over the sorted quad list
-            std::vector<int> perm(nq);
-            for (int i = 0; i < nq; ++i) perm[i] = i;
+            // stocs_match_one_object.cpp:134-142): partial Fisher-Yates over the sorted quad list,
+            // kept sparse (only the touched entries of the identity permutation are stored)
+            std::unordered_map<int, int> perm;
+            auto at = [&](int i) { auto it = perm.find(i); return it == perm.end() ? i : it->second; };
             for (int j = 0; j < max_per_base; ++j) {
                 const uint64_t r = rng64(seed, 0x5E1EC7ull + b, (uint64_t)j);
                 const int k = j + (int)mulhi64(r, (uint64_t)(nq - j));
-                std::swap(perm[j], perm[k]);
-                pick.push_back(perm[j]);
+                const int vj = at(j), vk = at(k);
+                perm[j] = vk; perm[k] = vj;
+                picks.push_back((int32_t)b); picks.push_back((int32_t)vk); job_base.push_back((int)b);
             }
         }
-        for (size_t i = 0; i < pick.size(); ++i) {
-            const uint64_t key = q[pick[i]];
-            XformJob job;
-            for (int k = 0; k < 4; ++k) job.s[k] = c->bases[b].ids[k];
-            job.q[0] = (int)((key >> 48) & 0xFFFF); job.q[1] = (int)((key >> 32) & 0xFFFF);
-            job.q[2] = (int)((key >> 16) & 0xFFFF); job.q[3] = (int)(key & 0xFFFF);
-            jobs.push_back(job);
-            job_base.push_back((int)b);
-        }
     }
-    std::vector<float> T, P;
-    std::vector<int32_t> ok;
-    int rc = run_jobs(c, jobs, T, P, ok);
-    if (rc) return rc;
+    const size_t n = job_base.size();
+    std::vector<float> T(n * 16), P(n * 16);
+    std::vector<int32_t> ok(n);
+    if (n) {
+        const size_t jb = ((n * sizeof(XformJob) + 255) / 256) * 256, tb = n * 64, ob = ((n * 4 + 255) / 256) * 256;
+        int rc = ensure_scratch(c, jb + 2 * tb + ob);
+        if (rc) return rc;
+        char* base = (char*)c->d_scratch;
+        XformJob* dJ = (XformJob*)base;
+        float* dT = (float*)(base + jb);
+        float* dP = (float*)(base + jb + tb);
+        int32_t* dO = (int32_t*)(base + jb + 2 * tb);
+        rc = stocs_internal_make_jobs(c, picks.data(), (int)n, dJ);
+        if (rc) return rc;
+        hipLaunchKernelGGL(rigid_transform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_spos, c->d_mpos, dJ, (int)n,
+                           c->centroid_scene, c->centroid_model, dT, dP, dO);
+        STOCS_HIP_CHECK(hipGetLastError());
+        STOCS_HIP_CHECK(hipMemcpyAsync(T.data(), dT, tb, hipMemcpyDeviceToHost, c->stream));
+        STOCS_HIP_CHECK(hipMemcpyAsync(P.data(), dP, tb, hipMemcpyDeviceToHost, c->stream));
+        STOCS_HIP_CHECK(hipMemcpyAsync(ok.data(), dO, n * 4, hipMemcpyDeviceToHost, c->stream));
+        STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
     c->cands.clear();
     c->best_lcp = 0; c->best_index = -1;
-    for (size_t j = 0; j < jobs.size(); ++j) {
+    for (size_t j = 0; j < n; ++j) {
         if (!ok[j]) continue;
         Candidate cd;
         memcpy(cd.T, &T[j * 16], 64);

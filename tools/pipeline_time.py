@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Wall-clock timing of the whole hot path through the C ABI (index build, phases 1-4) on one workload.
+usage: python tools/pipeline_time.py [Cm|small|tiny|example:<name>] [seed] [reps]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from model_matching_amd import synth  # noqa: E402
+from model_matching_amd.estimator import StocsEstimator  # noqa: E402
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "Cm"
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1234
+    reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    if name.startswith("example:"):
+        d = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "example_%s.npz" % name.split(":")[1]))
+        args = (d["scene_pos"], d["scene_nrm"], d["scene_prob"], d["scene_pixel"], d["model_pos"], d["model_nrm"])
+        T_gt = None
+    else:
+        m, s, k = synth.workload(name)
+        args = (s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm)
+        T_gt = s.T_gt
+    t = time.perf_counter()
+    est = StocsEstimator(*args, build_index=True)
+    est.sync()
+    t_ctx = time.perf_counter() - t
+    rep = {"workload": name, "nS": est.nS, "nM": est.nM, "ctx_create_incl_index_s": t_ctx, "index": est.index_stats(), "runs": []}
+    for r in range(reps):
+        est.L.stocs_clear_bases(est.h)
+        t0 = time.perf_counter()
+        valid, ids, inv = est.sample_bases(seed + r, 100)
+        t1 = time.perf_counter()
+        nq = est.find_congruent_all()
+        t2 = time.perf_counter()
+        nc = est.make_transforms(200, seed + r)
+        t3 = time.perf_counter()
+        best_lcp, best_idx, pose = est.compute_best_transform()
+        t4 = time.perf_counter()
+        run = {"bases": int(valid.sum()), "quads": int(nq), "candidates": int(nc), "best_lcp": float(best_lcp),
+               "t_sample_ms": (t1 - t0) * 1e3, "t_congruent_ms": (t2 - t1) * 1e3, "t_transforms_ms": (t3 - t2) * 1e3,
+               "t_verify_ms": (t4 - t3) * 1e3, "poses_per_s_phases_2_4": nc / max(t4 - t1, 1e-9)}
+        if T_gt is not None and best_idx >= 0:
+            P = pose.reshape(4, 4).T
+            dR = P[:3, :3].T @ T_gt[:3, :3]
+            run["rot_err_deg"] = float(np.degrees(np.arccos(min(1.0, (np.trace(dR) - 1) / 2))))
+            run["tr_err_mm"] = float(np.linalg.norm(P[:3, 3] - T_gt[:3, 3]) * 1e3)
+        rep["runs"].append(run)
+    print(json.dumps(rep))
+
+
+if __name__ == "__main__":
+    main()
