@@ -253,6 +253,139 @@ __global__ __launch_bounds__(256) void lcp_coop_kernel(LcpArgs a, const float* _
 }
 
 // ---------------------------------------------------------------------------------------------
+// Variant 20 ("coop8 + queue"): the cooperative scan of variant 1 fed from a per-wave LDS ring that
+// collects the hit queries of successive steps (ballot + mbcnt compaction), so that every 8-lane group
+// always owns a query (with ~11 hits per 64-point step the groups of variant 1 are ~69 % busy) and the
+// normal test runs on full wavefronts.  Lane <-> point assignment of the accumulation differs from v0,
+// so scores agree with v0 to rounding (1e-7), not bitwise; still run-to-run deterministic.
+// ---------------------------------------------------------------------------------------------
+template <bool DETAIL, int UNR>
+__global__ __launch_bounds__(256) void lcp_coopq_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
+                                                        int n, int32_t* __restrict__ hit_out, uint8_t* __restrict__ cnt_out) {
+    __shared__ float4 qt[4][128];     // qx, qy, qz, bits(list offset)
+    __shared__ uint32_t qn[4][128];   // list length
+    __shared__ uint32_t qs[4][128];   // model slot (Morton order)
+    __shared__ int ri[4][128];        // best scene index
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & 7, grp = lane >> 3;
+    const int w = threadIdx.x >> 6;
+    const int cand = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w);
+    if (cand >= n) return;
+    const float* T = T16 + (size_t)cand * 16;
+    const float t0 = T[0], t1 = T[1], t2 = T[2], t4 = T[4], t5 = T[5], t6 = T[6], t8 = T[8], t9 = T[9], t10 = T[10],
+                t12 = T[12], t13 = T[13], t14 = T[14];
+    float acc = 0.0f;
+    int head = 0, tail = 0;
+
+    auto process = [&](int nq) {
+        for (int s = 0; s < nq; s += 8) {
+            const int slot = s + grp;
+            const bool gact = slot < nq;
+            const int idx = (head + slot) & 127;
+            const float4 qq = qt[w][idx];
+            const uint32_t c = gact ? qn[w][idx] : 0u;
+            const float4* lp = a.list + (uint32_t)__float_as_int(qq.w) + sub;
+            float gd = a.sq_eps;
+            int gi = -1;
+            for (uint32_t k = 0; __any(k < c); k += 8 * UNR) {
+                float4 e[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    e[u] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(-1));
+                    if (k + 8 * u < c) e[u] = lp[k + 8 * u];
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const float dx = qq.x - e[u].x, dy = qq.y - e[u].y, dz = qq.z - e[u].z;
+                    const float d = dx * dx + (dy * dy + dz * dz);
+                    if (d <= gd) { gd = d; gi = __float_as_int(e[u].w); }
+                }
+            }
+            float dm = fminf(gd, dpp_f32<DPP_QUAD_XOR1>(gd));
+            dm = fminf(dm, dpp_f32<DPP_QUAD_XOR2>(dm));
+            dm = fminf(dm, dpp_f32<DPP_HALF_MIRROR>(dm));
+            int im = (gd == dm) ? gi : -1;
+            im = max(im, dpp_i32<DPP_QUAD_XOR1>(im));
+            im = max(im, dpp_i32<DPP_QUAD_XOR2>(im));
+            im = max(im, dpp_i32<DPP_HALF_MIRROR>(im));
+            if (gact && sub == 0) ri[w][idx] = im;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nq) {
+            const int idx = (head + lane) & 127;
+            const int best = ri[w][idx];
+            const uint32_t slot_i = qs[w][idx];
+            bool counted = false;
+            if (best >= 0) {
+                const float4 nm = a.mnrm[slot_i];
+                const float nx = t0 * nm.x + (t4 * nm.y + t8 * nm.z);
+                const float ny = t1 * nm.x + (t5 * nm.y + t9 * nm.z);
+                const float nz = t2 * nm.x + (t6 * nm.y + t10 * nm.z);
+                const float4 sn = a.snrmw[best];
+                const float d = sn.x * nx + (sn.y * ny + sn.z * nz);
+                counted = (d >= a.dot_lo) && (d <= 1.0f);
+                if (counted) acc += sn.w;
+            }
+            if (DETAIL) {
+                const int orig = a.mperm[slot_i];
+                hit_out[(size_t)cand * a.M + orig] = best;
+                cnt_out[(size_t)cand * a.M + orig] = counted ? 1 : 0;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    for (int base = 0; base < a.M; base += 64) {
+        const int i = base + lane;
+        float qx = 0.f, qy = 0.f, qz = 0.f;
+        uint32_t off = 0, cnt = 0;
+        if (i < a.M) {
+            const float4 p = a.mpos[i];
+            qx = ((t0 * p.x + t4 * p.y) + t8 * p.z) + t12;
+            qy = ((t1 * p.x + t5 * p.y) + t9 * p.z) + t13;
+            qz = ((t2 * p.x + t6 * p.y) + t10 * p.z) + t14;
+            const float ux = (qx - a.ox) * a.inv_h, uy = (qy - a.oy) * a.inv_h, uz = (qz - a.oz) * a.inv_h;
+            const float fx = floorf(ux), fy = floorf(uy), fz = floorf(uz);
+            if (fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float)a.nx && fy < (float)a.ny && fz < (float)a.nz) {
+                const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
+                const int brick = a.top[((cz >> 3) * a.nby + (cy >> 3)) * a.nbx + (cx >> 3)];
+                if (brick >= 0) {
+                    const uint4 cw = a.cells[(size_t)brick * 512 + (((cz & 7) << 6) | ((cy & 7) << 3) | (cx & 7))];
+                    const int sb = ((int)((uz - fz) * 4.0f) << 4) | ((int)((uy - fy) * 4.0f) << 2) | (int)((ux - fx) * 4.0f);
+                    const uint32_t mw = sb < 32 ? cw.z : cw.w;
+                    off = cw.x; cnt = ((mw >> (sb & 31)) & 1u) ? cw.y : 0u;
+                }
+            }
+            if (DETAIL && cnt == 0) {
+                const int orig = a.mperm[i];
+                hit_out[(size_t)cand * a.M + orig] = -1;
+                cnt_out[(size_t)cand * a.M + orig] = 0;
+            }
+        }
+        const bool hit = cnt != 0;
+        const unsigned long long mask = __ballot(hit);
+        if (mask) {
+            if (hit) {
+                const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+                const int sl = (tail + rank) & 127;
+                qt[w][sl] = make_float4(qx, qy, qz, __int_as_float((int)off));
+                qn[w][sl] = cnt;
+                qs[w][sl] = (uint32_t)i;
+            }
+            tail += __popcll(mask);
+            __builtin_amdgcn_wave_barrier();
+            if (tail - head >= 64) {
+                process(64);
+                head += 64;
+            }
+        }
+    }
+    if (tail - head > 0) process(tail - head);
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) out[cand] = acc / (float)a.M;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Variant 3 ("queue"): the profile of v0 (rocprofv3 counters + stage ablation, profiles/) shows the
 // cost is the list-scan gather INSTRUCTIONS: a divergent 16-byte gather costs ~16-21 CU clocks at the
 // L1 whether 64 or 18 lanes are active, and only ~28 % of the queries land in a non-empty cell.
@@ -556,10 +689,8 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
     if (variant == 99) {
         // cooperative kernel; unroll depth from the average candidate-list length of this scene
         const double avg = c->grid.avg_list_len;
-        variant = avg <= 10.0 ? 9 : (avg <= 24.0 ? 15 : 16);
-        // a batch that cannot even fill the chip once is latency-bound per wave: the plain
-        // lane-per-query loop has the shorter dependent chain there (measured, tools/lcp_ab.py small)
-        if (n < 4096 && avg <= 10.0) variant = 0;
+        variant = avg <= 10.0 ? 20 : (avg <= 24.0 ? 15 : 16);   // measured: tools/lcp_ab.py (Cm, C5)
+        // (the choice must not depend on the batch size: a candidate's score is batch-invariant)
     }
     if (variant >= 10 && variant <= 14 && !d_hit) {
         if (variant == 10) hipLaunchKernelGGL((lcp_kernel<false, 1>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
@@ -567,6 +698,17 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
         if (variant == 12) hipLaunchKernelGGL((lcp_kernel<false, 3>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
         if (variant == 14) hipLaunchKernelGGL((lcp_kernel<false, 5>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
         if (variant == 13) hipLaunchKernelGGL((lcp_kernel<false, 4>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
+    } else if (variant >= 20 && variant <= 23) {
+        if (d_hit)
+            hipLaunchKernelGGL((lcp_coopq_kernel<true, 2>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
+        else if (variant == 20)
+            hipLaunchKernelGGL((lcp_coopq_kernel<false, 1>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
+        else if (variant == 21)
+            hipLaunchKernelGGL((lcp_coopq_kernel<false, 2>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
+        else if (variant == 22)
+            hipLaunchKernelGGL((lcp_coopq_kernel<false, 4>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
+        else
+            hipLaunchKernelGGL((lcp_coopq_kernel<false, 8>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
     } else if (variant == 4 || variant == 5 || variant == 6) {
         if (d_hit)
             hipLaunchKernelGGL((lcp_items_kernel<true, 1>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
