@@ -131,6 +131,10 @@ int stocs_lcp_detail(stocs_ctx* ctx, const float* T16_centred_host, int32_t* hit
 /* compute_best_transform (stocs.cpp:982-1004): score every stored candidate, arg-max with first
  * maximum winning; best_idx = -1 and best_lcp = 0 when every score is 0 */
 int stocs_verify_all(stocs_ctx* ctx, float* best_lcp, int* best_idx, float* best_pose16_camera);
+/* arg-max of n device-resident scores on the device: *key = max over i of
+ * stocs_pack_best(lcp[i], id_offset + i), 0 when no score is positive (first maximum wins, as the
+ * strict > of stocs.cpp:994).  Synchronises the context's stream; 8 bytes cross PCIe. */
+int stocs_best_device(stocs_ctx* ctx, const void* d_lcp, int n, uint32_t id_offset, uint64_t* key);
 /* order-preserving key for the cross-GPU arg-max (max wins; lowest global id wins ties) */
 uint64_t stocs_pack_best(float lcp, uint32_t global_candidate_id);
 void stocs_unpack_best(uint64_t key, float* lcp, uint32_t* global_candidate_id);

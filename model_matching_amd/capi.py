@@ -61,6 +61,7 @@ SIGNATURES = {
     "stocs_score_transforms_device": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "stocs_lcp_detail": (C.c_int, [_vp, _fp, _ip, _u8p]),
     "stocs_verify_all": (C.c_int, [_vp, _fp, _intp, _fp]),
+    "stocs_best_device": (C.c_int, [_vp, _vp, C.c_int, C.c_uint32, C.POINTER(C.c_uint64)]),
     "stocs_pack_best": (C.c_uint64, [C.c_float, C.c_uint32]),
     "stocs_unpack_best": (None, [C.c_uint64, _fp, C.POINTER(C.c_uint32)]),
     "stocs_cluster_poses": (C.c_int, [_fp, _fp, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, _fp, _ip, C.c_int, _intp]),

@@ -319,6 +319,10 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
         set_error("stocs_ctx_create: invalid argument");
         return STOCS_ERR_INVALID;
     }
+    if (nS == 0 || nM == 0) {  // the reference indexes an empty vector here (stocs.cpp:386); refuse instead
+        set_error("stocs_ctx_create: empty scene or model cloud");
+        return STOCS_ERR_INVALID;
+    }
     if (nM > 65535) { set_error("model has %d points; at most 65535 supported (16-bit ids in packed pairs)", nM); return STOCS_ERR_INVALID; }
     if (prm->ppf_rot_discretization <= 0 || prm->ppf_tr_discretization <= 0 || 180 % prm->ppf_rot_discretization) {
         set_error("PPF discretisation must be positive and divide 180");
@@ -342,6 +346,7 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     c->index.built = false;
     c->index.d_bucket_start = NULL; c->index.d_pairs = NULL; c->index.d_exists = NULL;
     c->d_quads = NULL; c->d_quad_off = NULL; c->quad_id_bits = 16;
+    c->d_best = NULL;
     c->best_lcp = 0; c->best_index = -1;
     c->has_edge = false;
     c->grid_div = 1;
@@ -457,7 +462,7 @@ int stocs_ctx_destroy(stocs_ctx* c) {
     hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_spos, c->d_snrmw, c->d_spix, c->d_mpos, c->d_mnrm, c->d_munit, c->d_mpos_raw, c->d_mpos_s,
                     c->d_mnrm_s, c->d_mperm, c->grid.d_top, c->grid.d_cells, c->grid.d_list, c->index.d_bucket_start,
-                    c->index.d_pairs, c->index.d_exists, c->d_scratch, c->d_quads, c->d_quad_off};
+                    c->index.d_pairs, c->index.d_exists, c->d_scratch, c->d_quads, c->d_quad_off, c->d_best};
     for (void* p : ptrs) if (p) hipFree(p);
     hipEventDestroy(c->ev0);
     hipEventDestroy(c->ev1);

@@ -17,6 +17,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "stocs_ctx.h"
 
 namespace stocs {
@@ -665,6 +667,24 @@ __global__ __launch_bounds__(256) void lcp_items_kernel(LcpArgs a, const float* 
     if (lane == 0) out[cand] = acc / (float)a.M;
 }
 
+// compute_best_transform (stocs.cpp:982-1004) on the device: max of the packed (score, ~id) keys --
+// larger score wins, lower id wins ties, non-positive scores never win.  Integer max: order independent.
+__global__ __launch_bounds__(256) void best_kernel(const float* __restrict__ lcp, int n, uint32_t id_offset, unsigned long long* __restrict__ best) {
+    unsigned long long k = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float s = lcp[i];
+        if (s > 0.0f) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned long long)(0xFFFFFFFFu - (id_offset + (uint32_t)i));
+            k = key > k ? key : k;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(k, off, 64);
+        k = o > k ? o : k;
+    }
+    if ((threadIdx.x & 63) == 0 && k) atomicMax(best, k);
+}
+
 static int lcp_variant() {
     static int v = -1;
     if (v < 0) {
@@ -797,6 +817,20 @@ int stocs_lcp_detail(stocs_ctx* c, const float* T_host, int32_t* hit, uint8_t* c
     if (rc) return rc;
     STOCS_HIP_CHECK(hipMemcpyAsync(hit, dH, M * 4, hipMemcpyDeviceToHost, c->stream));
     STOCS_HIP_CHECK(hipMemcpyAsync(counted, dC, M, hipMemcpyDeviceToHost, c->stream));
+    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return STOCS_OK;
+}
+
+int stocs_best_device(stocs_ctx* c, const void* d_lcp, int n, uint32_t id_offset, uint64_t* key) {
+    if (!c || !key || n < 0 || (n && !d_lcp)) return STOCS_ERR_INVALID;
+    *key = 0;
+    if (n == 0) return STOCS_OK;
+    if (!c->d_best) STOCS_HIP_CHECK(hipMalloc((void**)&c->d_best, 8));
+    STOCS_HIP_CHECK(hipMemsetAsync(c->d_best, 0, 8, c->stream));
+    const int blocks = std::min((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(best_kernel, dim3(blocks), dim3(256), 0, c->stream, (const float*)d_lcp, n, id_offset, c->d_best);
+    STOCS_HIP_CHECK(hipGetLastError());
+    STOCS_HIP_CHECK(hipMemcpyAsync(key, c->d_best, 8, hipMemcpyDeviceToHost, c->stream));
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
     return STOCS_OK;
 }

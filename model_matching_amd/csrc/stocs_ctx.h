@@ -128,6 +128,8 @@ struct stocs_ctx {
     float best_lcp;
     int best_index;
 
+    unsigned long long* d_best;   // 8-byte arg-max key
+
     // scratch
     void* d_scratch;
     size_t scratch_bytes;

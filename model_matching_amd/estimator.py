@@ -204,6 +204,16 @@ class StocsEstimator:
     def set_option(self, key, value):
         capi.check(self.L.stocs_set_option(self.h, key.encode(), int(value)))
 
+    def best_device(self, dL, n, id_offset=0):
+        """(best_lcp, global id) of n device-resident scores; (0.0, -1) when none is positive."""
+        key = C.c_uint64(0)
+        capi.check(self.L.stocs_best_device(self.h, dL, n, id_offset, C.byref(key)))
+        if key.value == 0:
+            return 0.0, -1, 0
+        s = C.c_float(0); i = C.c_uint32(0)
+        self.L.stocs_unpack_best(key.value, C.byref(s), C.byref(i))
+        return s.value, int(i.value), int(key.value)
+
     def sync(self):
         capi.check(self.L.stocs_sync(self.h))
 

@@ -1,0 +1,103 @@
+"""Error behaviour of the C ABI on the GPU box: status codes instead of exceptions/crashes, the
+call-order contract, capacity reporting, degenerate inputs (the edge cases a caller of the reference
+class can hit: no valid base, no congruent set, no candidate, all-zero scores)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(build_index=True, prob=None, n_scene=600, n_model=150):
+    from model_matching_amd import synth
+    from model_matching_amd.estimator import StocsEstimator
+    m = synth.make_model(n_model, seed=21)
+    s = synth.make_scene(m, n_scene, seed=22)
+    p = s.prob if prob is None else np.full(len(s.pos), prob, np.float32)
+    return m, s, StocsEstimator(s.pos, s.nrm, p, s.pixel, m.pos, m.nrm, build_index=build_index)
+
+
+def test_invalid_arguments_are_status_codes():
+    from model_matching_amd import capi, synth
+    L = capi.load()
+    m = synth.make_model(100, seed=1)
+    pos, pp = capi.f32(m.pos); nrm, pn = capi.f32(m.nrm); w, pw = capi.f32(np.ones(100))
+    h = C.c_void_p()
+    prm = capi.default_params()
+    assert L.stocs_ctx_create(C.byref(prm), pp, pn, pw, None, 0, pp, pn, 100, 0, -1, C.byref(h)) == -1      # empty scene
+    assert L.stocs_ctx_create(C.byref(prm), pp, pn, pw, None, 100, pp, pn, 0, 0, -1, C.byref(h)) == -1      # empty model
+    assert L.stocs_ctx_create(C.byref(prm), None, pn, pw, None, 100, pp, pn, 100, 0, -1, C.byref(h)) == -1   # NULL cloud
+    assert L.stocs_ctx_create(C.byref(prm), pp, pn, pw, None, 100, pp, pn, 70000, 0, -1, C.byref(h)) == -1   # > 65535 model points
+    bad = capi.default_params(ppf_rot_discretization=7)
+    assert L.stocs_ctx_create(C.byref(bad), pp, pn, pw, None, 100, pp, pn, 100, 0, -1, C.byref(h)) == -1
+    assert L.stocs_ctx_create(C.byref(prm), pp, pn, pw, None, 100, pp, pn, 100, 0, 99, C.byref(h)) == -2     # no such device
+    assert not h.value and len(L.stocs_last_error()) > 0
+    assert L.stocs_ctx_destroy(None) == 0 and L.stocs_sync(None) == -1
+
+
+def test_call_order_contract():
+    from model_matching_amd import capi
+    m, s, est = _mk(build_index=False)
+    with pytest.raises(capi.StocsError) as e:
+        est.sample_bases(1, 4)
+    assert e.value.code == -5                                    # STATE: no index
+    with pytest.raises(capi.StocsError):
+        est.index_lookup((50, 90, 90, 0))
+    with pytest.raises(capi.StocsError):
+        est.find_congruent_all()
+    # scoring works without an index
+    assert est.score_transforms(np.eye(4, dtype=np.float32).reshape(1, 16)).shape == (1,)
+    m, s, est = _mk(build_index=True)
+    with pytest.raises(capi.StocsError) as e:
+        est.make_transforms(200, 1)                              # before find_congruent_all
+    assert e.value.code == -5
+    with pytest.raises(capi.StocsError):
+        est.get_quads(0)
+    assert est.find_congruent_all() == 0                         # no bases: nothing to do, not an error
+    assert est.make_transforms(200, 1) == 0
+    assert est.compute_best_transform()[:2] == (0.0, -1)         # no candidates: best_index -1 (NULL best pose)
+    with pytest.raises(capi.StocsError):
+        est.set_bases(np.array([[0, 1, 2, 10 ** 6]]), np.zeros((1, 2)))   # scene index out of range
+    with pytest.raises(capi.StocsError):
+        est.set_option("no_such_option", 1)
+
+
+def test_capacity_is_reported_not_overrun():
+    from model_matching_amd import capi
+    m, s, est = _mk()
+    valid, ids, inv = est.sample_bases(5, 30)
+    assert est.find_congruent_all() > 0
+    L = capi.load()
+    n = C.c_int64(0)
+    slot = next(i for i in range(int(valid.sum())) if len(est.get_quads(i)) > 3)
+    buf = np.full((2, 4), -7, np.int32)
+    rc = L.stocs_get_quads(est.h, slot, buf.ctypes.data_as(capi._ip), 2, C.byref(n))
+    assert rc == -4 and n.value > 2 and (buf >= 0).all()         # CAPACITY: first 2 written, needed count returned
+    full = est.get_quads(slot)
+    assert np.array_equal(full[:2], buf)
+    est.make_transforms(200, 5)
+    nc = C.c_int(0)
+    T = np.zeros((1, 16), np.float32)
+    rc = L.stocs_get_candidates(est.h, T.ctypes.data_as(capi._fp), None, None, None, 1, C.byref(nc))
+    assert nc.value > 1 and rc == -4
+
+
+def test_degenerate_scenes():
+    # class probability zero everywhere: every attempt fails on its first draw ("Zero probability returned")
+    m, s, est = _mk(prob=0.0)
+    valid, ids, inv = est.sample_bases(3, 10)
+    assert not valid.any() and est.L.stocs_num_bases(est.h) == 0
+    # a model far bigger than anything in the scene: bases exist, no congruent sets, no candidates, no pose
+    from model_matching_amd import synth
+    from model_matching_amd.estimator import StocsEstimator
+    big = synth.make_model(150, seed=5, scale=8.0)
+    sc = synth.make_scene(synth.make_model(150, seed=21), 600, seed=22)
+    est = StocsEstimator(sc.pos, sc.nrm, sc.prob, sc.pixel, big.pos, big.nrm, build_index=True)
+    valid, ids, inv = est.sample_bases(3, 20)
+    nq = est.find_congruent_all()
+    nc = est.make_transforms(200, 3)
+    lcp, idx, pose = est.compute_best_transform()
+    assert nc <= nq and (idx == -1) == (lcp == 0.0)
+    if idx == -1:
+        assert not pose.any()

@@ -105,3 +105,25 @@ def test_full_size_properties(oracle_lib):
     assert np.abs(got[:192] - ref).max() <= LCP_TOL
     gt = est.score_transforms(Tgt.T.reshape(1, 16).astype(np.float32))[0]
     assert gt > np.percentile(got, 90)
+
+
+def test_device_argmax_matches_reference_rule(oracle_lib):
+    """stocs_best_device == compute_best_transform's arg-max (stocs.cpp:982-1004): first maximum, none if all zero."""
+    from model_matching_amd import synth
+    m, s, k, est, orc, Tgt = _setup("tiny", oracle_lib)
+    T = synth.make_candidates(Tgt, 777)
+    T[500] = T[100]                      # an exact tie: the lower id must win
+    got = est.score_transforms(T)
+    dT, dL = est.dev_alloc(T.nbytes), est.dev_alloc(len(T) * 4)
+    est.dev_upload(dT, T)
+    est.score_device(dT, len(T), dL)
+    sc, gid, key = est.best_device(dL, len(T), 1000)
+    i, ref = oracle_lib.best(got)
+    assert gid == 1000 + i and sc == ref
+    got2 = got.copy(); got2[:] = 0.0
+    est.dev_upload(dL, got2)
+    assert est.best_device(dL, len(T))[:2] == (0.0, -1)
+    got2[100] = got2[500] = 0.25
+    est.dev_upload(dL, got2)
+    assert est.best_device(dL, len(T))[:2] == (0.25, 100)
+    est.dev_free(dT); est.dev_free(dL)
