@@ -244,6 +244,11 @@ def workload(name: str = "Cm"):
     if name == "tiny":
         m = make_model(400, seed=SEED_MODEL + 7)
         return m, make_scene(m, 1500, seed=SEED_SCENE + 7), 256
+    if name == "dense":
+        # C5-like density at a CPU-checkable size: ~1.6 mm scene spacing -> ~60 candidates per grid list,
+        # which switches the library to the epsilon/2 grid and the deep-unroll scan
+        m = make_model(3000, seed=SEED_MODEL + 13, scale=0.5)
+        return m, make_scene(m, 24000, seed=SEED_SCENE + 13, lattice=0.0016), 512
     if name == "small":
         m = make_model(1000, seed=SEED_MODEL + 11)
         return m, make_scene(m, 5000, seed=SEED_SCENE + 11), 2048

@@ -127,3 +127,25 @@ def test_device_argmax_matches_reference_rule(oracle_lib):
     est.dev_upload(dL, got2)
     assert est.best_device(dL, len(T))[:2] == (0.25, 100)
     est.dev_free(dT); est.dev_free(dL)
+
+
+def test_dense_scene_and_all_scan_variants(oracle_lib):
+    """Dense scene (~1.6 mm spacing): long candidate lists -> epsilon/2 grid + unrolled cooperative scan.
+    Every scan variant must agree with the oracle (per-point matches bit-exact) and with each other."""
+    from model_matching_amd import synth
+    m, s, k, est, orc, Tgt = _setup("dense", oracle_lib)
+    T = synth.make_candidates(Tgt, k)
+    ref = orc.lcp_batch(T, nthreads=8)
+    got = est.score_transforms(T)                      # automatic choice
+    assert np.abs(got - ref).max() <= LCP_TOL and got.max() > 0.05
+    best = int(np.argmax(ref))
+    ho, co = orc.lcp_detail(T[best])
+    for v in (0, 1, 9, 15, 16, 20, 21, 22, 3, 7, 4, 5):
+        est.set_option("lcp_variant", v)
+        gv = est.score_transforms(T)
+        assert np.abs(gv - ref).max() <= LCP_TOL, v
+        hg, cg = est.lcp_detail(T[best])
+        same = hg == ho
+        assert same.mean() > 0.999, v                  # only exact-distance ties may differ (Q11)
+        assert np.array_equal(cg[same], co[same]), v
+    est.set_option("lcp_variant", 99)
