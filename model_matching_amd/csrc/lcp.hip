@@ -261,13 +261,14 @@ __global__ __launch_bounds__(256) void lcp_coop_kernel(LcpArgs a, const float* _
 // normal test runs on full wavefronts.  Lane <-> point assignment of the accumulation differs from v0,
 // so scores agree with v0 to rounding (1e-7), not bitwise; still run-to-run deterministic.
 // ---------------------------------------------------------------------------------------------
-template <bool DETAIL, int UNR>
+template <bool DETAIL, int UNR, bool SORTQ = false>
 __global__ __launch_bounds__(256) void lcp_coopq_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
                                                         int n, int32_t* __restrict__ hit_out, uint8_t* __restrict__ cnt_out) {
     __shared__ float4 qt[4][128];     // qx, qy, qz, bits(list offset)
     __shared__ uint32_t qn[4][128];   // list length
     __shared__ uint32_t qs[4][128];   // model slot (Morton order)
     __shared__ int ri[4][128];        // best scene index
+    __shared__ uint8_t ord[4][64];    // batch order sorted by list length (SORTQ)
     const int lane = threadIdx.x & 63;
     const int sub = lane & 7, grp = lane >> 3;
     const int w = threadIdx.x >> 6;
@@ -280,10 +281,25 @@ __global__ __launch_bounds__(256) void lcp_coopq_kernel(LcpArgs a, const float* 
     int head = 0, tail = 0;
 
     auto process = [&](int nq) {
+        // order the pending queries by list length (number of 128-byte chunks) so that the eight
+        // groups of a step stream lists of similar length: a counting sort on <= 8 classes with ballots
+        if (SORTQ) {
+            uint32_t cls = 8;
+            if (lane < nq) { const uint32_t nch = (qn[w][(head + lane) & 127] + 7u) >> 3; cls = nch < 8u ? nch - 1u : 7u; }
+            int pos = 0, basep = 0;
+#pragma unroll
+            for (uint32_t cidx = 0; cidx < 8; ++cidx) {
+                const unsigned long long mc = __ballot(cls == cidx);
+                if (cls == cidx) pos = basep + __popcll(mc & ((1ull << lane) - 1ull));
+                basep += __popcll(mc);
+            }
+            if (lane < nq) ord[w][pos] = (uint8_t)lane;
+            __builtin_amdgcn_wave_barrier();
+        }
         for (int s = 0; s < nq; s += 8) {
             const int slot = s + grp;
             const bool gact = slot < nq;
-            const int idx = (head + slot) & 127;
+            const int idx = (head + (SORTQ ? (int)ord[w][gact ? slot : 0] : slot)) & 127;
             const float4 qq = qt[w][idx];
             const uint32_t c = gact ? qn[w][idx] : 0u;
             const float4* lp = a.list + (uint32_t)__float_as_int(qq.w) + sub;
@@ -337,12 +353,17 @@ __global__ __launch_bounds__(256) void lcp_coopq_kernel(LcpArgs a, const float* 
         __builtin_amdgcn_wave_barrier();
     };
 
+    // the model point of the NEXT step is requested one step ahead (takes one of the three dependent
+    // loads of the look-up chain off the critical path)
+    float4 p_next = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < a.M) p_next = a.mpos[lane];
     for (int base = 0; base < a.M; base += 64) {
         const int i = base + lane;
         float qx = 0.f, qy = 0.f, qz = 0.f;
         uint32_t off = 0, cnt = 0;
+        const float4 p = p_next;
+        if (i + 64 < a.M) p_next = a.mpos[i + 64];
         if (i < a.M) {
-            const float4 p = a.mpos[i];
             qx = ((t0 * p.x + t4 * p.y) + t8 * p.z) + t12;
             qy = ((t1 * p.x + t5 * p.y) + t9 * p.z) + t13;
             qz = ((t2 * p.x + t6 * p.y) + t10 * p.z) + t14;
@@ -709,7 +730,7 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
     if (variant == 99) {
         // cooperative kernel; unroll depth from the average candidate-list length of this scene
         const double avg = c->grid.avg_list_len;
-        variant = avg <= 10.0 ? 20 : (avg <= 24.0 ? 15 : 16);   // measured: tools/lcp_ab.py (Cm, C5)
+        variant = avg <= 10.0 ? 24 : (avg <= 24.0 ? 15 : 16);   // measured: tools/lcp_ab.py (Cm, C5)
         // (the choice must not depend on the batch size: a candidate's score is batch-invariant)
     }
     if (variant >= 10 && variant <= 14 && !d_hit) {
@@ -718,9 +739,13 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
         if (variant == 12) hipLaunchKernelGGL((lcp_kernel<false, 3>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
         if (variant == 14) hipLaunchKernelGGL((lcp_kernel<false, 5>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
         if (variant == 13) hipLaunchKernelGGL((lcp_kernel<false, 4>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-    } else if (variant >= 20 && variant <= 23) {
+    } else if (variant >= 20 && variant <= 25) {
         if (d_hit)
-            hipLaunchKernelGGL((lcp_coopq_kernel<true, 2>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
+            hipLaunchKernelGGL((lcp_coopq_kernel<true, 1, true>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
+        else if (variant == 24)
+            hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
+        else if (variant == 25)
+            hipLaunchKernelGGL((lcp_coopq_kernel<false, 2, true>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
         else if (variant == 20)
             hipLaunchKernelGGL((lcp_coopq_kernel<false, 1>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
         else if (variant == 21)
