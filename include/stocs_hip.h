@@ -84,6 +84,12 @@ int stocs_index_exists(const stocs_ctx* ctx, const int32_t* key4, int* exists);
 /* pairs of lookup(key) in lexicographic (id1,id2) order == the reference's insertion order */
 int stocs_index_lookup(stocs_ctx* ctx, const int32_t* key4, int32_t* pairs2, int64_t cap, int64_t* n);
 int stocs_index_stats(const stocs_ctx* ctx, int64_t* n_pairs, int64_t* n_buckets, int64_t* n_keys);
+/* on-disk form of the index: replaces rgbd::save_ppf_map / load_ppf_map (rgbd.cpp:156-177; a Boost
+ * binary archive of the std::map there, compiler/Boost-version specific) by a flat, versioned,
+ * little-endian CSR file.  load requires a context created with build_index = 0 for the SAME model
+ * cloud and discretisation (checked through a hash stored in the file). */
+int stocs_index_save(stocs_ctx* ctx, const char* path);
+int stocs_index_load(stocs_ctx* ctx, const char* path);
 
 /* ---- base sampling: batched form of the loop stocs_match_one_object.cpp:81-101 over
  * sample_class_base (stocs.cpp:363-519) / sample_instance_base (stocs.cpp:559-751).
@@ -126,6 +132,8 @@ int stocs_score_transforms(stocs_ctx* ctx, const float* T16_centred_host, int n,
 /* device-resident variant: d_T16 and d_lcp are device pointers on the context's device; the call is
  * asynchronous on the context's stream (use stocs_sync) */
 int stocs_score_transforms_device(stocs_ctx* ctx, const void* d_T16, int n, void* d_lcp);
+/* score + device arg-max in one call (one host round trip): key as stocs_best_device */
+int stocs_score_best_device(stocs_ctx* ctx, const void* d_T16, int n, void* d_lcp, uint32_t id_offset, uint64_t* key);
 /* per model point: index of the matched scene point (-1 none) and whether it was counted */
 int stocs_lcp_detail(stocs_ctx* ctx, const float* T16_centred_host, int32_t* hit, uint8_t* counted);
 /* compute_best_transform (stocs.cpp:982-1004): score every stored candidate, arg-max with first
@@ -149,6 +157,13 @@ int stocs_cluster_poses(const float* poses16, const float* lcp, int n, float acc
 int stocs_set_option(stocs_ctx* ctx, const char* key, int value);
 
 /* ---- stream / timing plumbing ---- */
+/* run the context's work on a caller-owned HIP stream (e.g. PyTorch's current stream, so that RCCL
+ * collectives issued through torch.distributed are ordered after the kernels without a host sync);
+ * NULL restores the context's own stream.  The caller keeps the stream alive. */
+int stocs_set_stream(stocs_ctx* ctx, void* hip_stream);
+/* asynchronous arg-max: writes the packed key (see stocs_best_device) to the 8 bytes at d_key8 on the
+ * context's stream; no synchronisation */
+int stocs_best_device_async(stocs_ctx* ctx, const void* d_lcp, int n, uint32_t id_offset, void* d_key8);
 int   stocs_sync(stocs_ctx* ctx);
 void* stocs_stream(stocs_ctx* ctx);          /* hipStream_t */
 /* times `reps` back-to-back launches of the LCP kernel on n device-resident transforms with HIP

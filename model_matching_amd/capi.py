@@ -45,6 +45,8 @@ SIGNATURES = {
     "stocs_index_exists": (C.c_int, [_vp, _ip, _intp]),
     "stocs_index_lookup": (C.c_int, [_vp, _ip, _ip, C.c_int64, _i64p]),
     "stocs_index_stats": (C.c_int, [_vp, _i64p, _i64p, _i64p]),
+    "stocs_index_save": (C.c_int, [_vp, C.c_char_p]),
+    "stocs_index_load": (C.c_int, [_vp, C.c_char_p]),
     "stocs_sample_bases": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_float, _ip, _fp, _ip]),
     "stocs_set_bases": (C.c_int, [_vp, C.c_int, _ip, _fp]),
     "stocs_clear_bases": (C.c_int, [_vp]),
@@ -59,6 +61,7 @@ SIGNATURES = {
     "stocs_get_candidates": (C.c_int, [_vp, _fp, _fp, _fp, _ip, C.c_int, _intp]),
     "stocs_score_transforms": (C.c_int, [_vp, _fp, C.c_int, _fp]),
     "stocs_score_transforms_device": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "stocs_score_best_device": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_uint32, C.POINTER(C.c_uint64)]),
     "stocs_lcp_detail": (C.c_int, [_vp, _fp, _ip, _u8p]),
     "stocs_verify_all": (C.c_int, [_vp, _fp, _intp, _fp]),
     "stocs_best_device": (C.c_int, [_vp, _vp, C.c_int, C.c_uint32, C.POINTER(C.c_uint64)]),
@@ -66,6 +69,8 @@ SIGNATURES = {
     "stocs_unpack_best": (None, [C.c_uint64, _fp, C.POINTER(C.c_uint32)]),
     "stocs_cluster_poses": (C.c_int, [_fp, _fp, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, _fp, _ip, C.c_int, _intp]),
     "stocs_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "stocs_set_stream": (C.c_int, [_vp, _vp]),
+    "stocs_best_device_async": (C.c_int, [_vp, _vp, C.c_int, C.c_uint32, _vp]),
     "stocs_sync": (C.c_int, [_vp]),
     "stocs_stream": (_vp, [_vp]),
     "stocs_time_score_kernel": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _fp]),

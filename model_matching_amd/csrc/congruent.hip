@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void join_kernel(const BaseJob* __restrict__ j
                                                    const float4* __restrict__ munit, const float4* __restrict__ mpos,
                                                    const uint32_t* __restrict__ Q, uint32_t totalQ, const uint64_t* __restrict__ pkeys,
                                                    const uint32_t* __restrict__ pvals, float nepsilon, float dist_thr,
-                                                   uint32_t* __restrict__ qcnt, const uint32_t* __restrict__ qoff_e, int id_bits,
+                                                   unsigned long long* __restrict__ qcnt, const unsigned long long* __restrict__ qoff_e, int id_bits,
                                                    uint64_t* __restrict__ quads) {
     __shared__ uint32_t seen[256][11];  // 343-bit set per lane
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -158,8 +158,8 @@ __global__ __launch_bounds__(256) void join_kernel(const BaseJob* __restrict__ j
     const uint64_t* keys = pkeys + J.p_off;
     const uint32_t* vals = pvals + J.p_off;
     const uint64_t hi_bits = (uint64_t)b << 40;
-    uint32_t local = 0;
-    const uint32_t out0 = FILL ? qoff_e[e] : 0u;   // exclusive scan of the count pass: no atomics in the fill pass
+    unsigned long long local = 0;
+    const unsigned long long out0 = FILL ? qoff_e[e] : 0ull;   // exclusive scan of the count pass: no atomics in the fill pass
     for (int a = 0; a < J.nb; ++a) {
         const V3 dir = normalized3(quat_rot(q, mk3(J.dirs[a][0], J.dirs[a][1], J.dirs[a][2])));
         const int id = index_normal(dir, nepsilon);
@@ -330,30 +330,33 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     int base_bits = 1;
     while ((1 << base_bits) < nB) base_bits++;
     if (4 * id_bits + base_bits > 64) { set_error("|M| = %d with %d bases does not fit the 64-bit quad key", c->nM, nB); return STOCS_ERR_CAPACITY; }
-    DevBuf<uint32_t> d_qcnt, d_qoffe;
+    DevBuf<unsigned long long> d_qcnt, d_qoffe;   // 64-bit: the total can exceed 2^32 before the capacity check
     if ((rc = d_qcnt.alloc(totQ + 1)) || (rc = d_qoffe.alloc(totQ + 1))) return rc;
     const dim3 jgrid((unsigned)((totQ + 255) / 256));
     hipLaunchKernelGGL(join_kernel<false>, jgrid, dim3(256), 0, st, d_jobs.p, d_qoff.p, nB, c->d_munit, c->d_mpos, d_Q.p, (uint32_t)totQ, d_keys_s.p, d_Ps.p,
-                       nepsilon, c->prm.distance_threshold, d_qcnt.p, (const uint32_t*)NULL, id_bits, (uint64_t*)NULL);
+                       nepsilon, c->prm.distance_threshold, d_qcnt.p, (const unsigned long long*)NULL, id_bits, (uint64_t*)NULL);
     STOCS_HIP_CHECK(hipGetLastError());
-    STOCS_HIP_CHECK(hipMemsetAsync(d_qcnt.p + totQ, 0, 4, st));
+    STOCS_HIP_CHECK(hipMemsetAsync(d_qcnt.p + totQ, 0, 8, st));
     size_t tmp_scan = 0;
-    STOCS_HIP_CHECK(rocprim::exclusive_scan(NULL, tmp_scan, d_qcnt.p, d_qoffe.p, 0u, (size_t)totQ + 1, rocprim::plus<uint32_t>(), st));
+    STOCS_HIP_CHECK(rocprim::exclusive_scan(NULL, tmp_scan, d_qcnt.p, d_qoffe.p, 0ull, (size_t)totQ + 1, rocprim::plus<unsigned long long>(), st));
     DevBuf<char> d_tmp_scan;
     if ((rc = d_tmp_scan.alloc(tmp_scan))) return rc;
-    STOCS_HIP_CHECK(rocprim::exclusive_scan(d_tmp_scan.p, tmp_scan, d_qcnt.p, d_qoffe.p, 0u, (size_t)totQ + 1, rocprim::plus<uint32_t>(), st));
+    STOCS_HIP_CHECK(rocprim::exclusive_scan(d_tmp_scan.p, tmp_scan, d_qcnt.p, d_qoffe.p, 0ull, (size_t)totQ + 1, rocprim::plus<unsigned long long>(), st));
     // per-base offsets = scan value at the first Q entry of each base
-    std::vector<uint32_t> qoff_at(nB + 1);
+    std::vector<unsigned long long> qoff_at(nB + 1);
     for (int b = 0; b <= nB; ++b)
-        STOCS_HIP_CHECK(hipMemcpyAsync(&qoff_at[b], d_qoffe.p + q_off[b], 4, hipMemcpyDeviceToHost, st));
+        STOCS_HIP_CHECK(hipMemcpyAsync(&qoff_at[b], d_qoffe.p + q_off[b], 8, hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
     STOCS_TICK("join count+scan")
-    // 32-bit scan: guard against wrap-around with a 64-bit host-side total of the per-base sums
     c->quad_off.assign(nB + 1, 0);
     for (int b = 0; b <= nB; ++b) c->quad_off[b] = qoff_at[b];
     const unsigned long long totQuads = c->quad_off[nB];
-    for (int b = 0; b < nB; ++b)
-        if (c->quad_off[b + 1] < c->quad_off[b]) { set_error("more than 2^32 congruent quads"); return STOCS_ERR_CAPACITY; }
+    if (totQuads > (1ull << 31)) {  // 16 GiB of packed quads + as much sort scratch
+        if (total_quads) *total_quads = (int64_t)totQuads;
+        c->quad_off.assign(nB + 1, 0);
+        set_error("%llu congruent quads: more than 2^31, refusing to materialise them", totQuads);
+        return STOCS_ERR_CAPACITY;
+    }
     c->quad_id_bits = id_bits;
     if (total_quads) *total_quads = (int64_t)totQuads;
     if (c->d_quads) { (void)hipFree(c->d_quads); c->d_quads = NULL; }
@@ -365,7 +368,7 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     if ((rc = d_quads.alloc(totQuads))) return rc;
     STOCS_HIP_CHECK(hipMalloc((void**)&c->d_quads, 8 * (size_t)totQuads));
     hipLaunchKernelGGL(join_kernel<true>, jgrid, dim3(256), 0, st, d_jobs.p, d_qoff.p, nB, c->d_munit, c->d_mpos, d_Q.p, (uint32_t)totQ, d_keys_s.p, d_Ps.p,
-                       nepsilon, c->prm.distance_threshold, (uint32_t*)NULL, d_qoffe.p, id_bits, d_quads.p);
+                       nepsilon, c->prm.distance_threshold, (unsigned long long*)NULL, d_qoffe.p, id_bits, d_quads.p);
     STOCS_HIP_CHECK(hipGetLastError());
     STOCS_TICK("join fill")
     // ---- 5. ONE global radix sort on (base, a, b, c, d): per base the order of the reference's std::set ----

@@ -353,11 +353,13 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     memset(&c->grid, 0, sizeof(c->grid));
     c->d_spos = c->d_snrmw = c->d_mpos = c->d_mnrm = c->d_munit = c->d_mpos_raw = c->d_mpos_s = c->d_mnrm_s = NULL;
     c->d_spix = NULL; c->d_mperm = NULL;
-    if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    c->stream = NULL; c->own_stream = NULL;
+    if (hipStreamCreate(&c->own_stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         set_error("stream/event creation failed");
         delete c;
         return STOCS_ERR_NO_DEVICE;
     }
+    c->stream = c->own_stream;
     compute_thresholds(c->prm, &c->thr);
 
     c->h_spos.resize(nS); c->h_snrm.resize(nS); c->h_sprob.assign(sprob, sprob + nS); c->h_spix.assign((size_t)2 * nS, 0);
@@ -459,14 +461,14 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
 int stocs_ctx_destroy(stocs_ctx* c) {
     if (!c) return STOCS_OK;
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    if (c->stream) hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_spos, c->d_snrmw, c->d_spix, c->d_mpos, c->d_mnrm, c->d_munit, c->d_mpos_raw, c->d_mpos_s,
                     c->d_mnrm_s, c->d_mperm, c->grid.d_top, c->grid.d_cells, c->grid.d_list, c->index.d_bucket_start,
                     c->index.d_pairs, c->index.d_exists, c->d_scratch, c->d_quads, c->d_quad_off, c->d_best};
     for (void* p : ptrs) if (p) hipFree(p);
     hipEventDestroy(c->ev0);
     hipEventDestroy(c->ev1);
-    hipStreamDestroy(c->stream);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
     return STOCS_OK;
 }
@@ -496,6 +498,12 @@ int stocs_sync(stocs_ctx* c) {
     return STOCS_OK;
 }
 void* stocs_stream(stocs_ctx* c) { return c ? (void*)c->stream : NULL; }
+int stocs_set_stream(stocs_ctx* c, void* hip_stream) {
+    if (!c) return STOCS_ERR_INVALID;
+    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));   // nothing of the old stream may still be in flight
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return STOCS_OK;
+}
 
 int stocs_dev_alloc(stocs_ctx* c, int64_t bytes, void** dptr) {
     if (!c || !dptr || bytes < 0) return STOCS_ERR_INVALID;

@@ -860,6 +860,22 @@ int stocs_best_device(stocs_ctx* c, const void* d_lcp, int n, uint32_t id_offset
     return STOCS_OK;
 }
 
+int stocs_best_device_async(stocs_ctx* c, const void* d_lcp, int n, uint32_t id_offset, void* d_key8) {
+    if (!c || !d_key8 || n < 0 || (n && !d_lcp)) return STOCS_ERR_INVALID;
+    STOCS_HIP_CHECK(hipMemsetAsync(d_key8, 0, 8, c->stream));
+    if (n == 0) return STOCS_OK;
+    const int blocks = std::min((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(best_kernel, dim3(blocks), dim3(256), 0, c->stream, (const float*)d_lcp, n, id_offset, (unsigned long long*)d_key8);
+    STOCS_HIP_CHECK(hipGetLastError());
+    return STOCS_OK;
+}
+
+int stocs_score_best_device(stocs_ctx* c, const void* d_T16, int n, void* d_lcp, uint32_t id_offset, uint64_t* key) {
+    int rc = stocs_score_transforms_device(c, d_T16, n, d_lcp);
+    if (rc) return rc;
+    return stocs_best_device(c, d_lcp, n, id_offset, key);
+}
+
 int stocs_set_option(stocs_ctx* c, const char* key, int value) {
     if (!c || !key) return STOCS_ERR_INVALID;
     if (!strcmp(key, "lcp_variant") && value >= 0 && value <= 99) { g_lcp_variant_override = value; return STOCS_OK; }

@@ -9,6 +9,7 @@
 //   exists(K)  = bit K of a bitmap that has the 128 offset keys of every non-empty bucket set;
 //   lookup(K)  = union of the <=128 buckets F = K - o, merged in (id1,id2) order,
 // which is exactly the reference's map content and insertion order (id1 outer, id2 inner loop).
+#include <stdio.h>
 #include <string.h>
 #include <cstring>
 
@@ -224,6 +225,86 @@ int stocs_index_lookup(stocs_ctx* c, const int32_t* K, int32_t* pairs2, int64_t 
     std::sort(all.begin(), all.end());  // (id1<<16|id2) ascending == lexicographic (id1,id2)
     for (int64_t i = 0; i < *n && i < cap; ++i) { pairs2[2 * i] = (int32_t)(all[(size_t)i] >> 16); pairs2[2 * i + 1] = (int32_t)(all[(size_t)i] & 0xFFFF); }
     return (*n > cap) ? STOCS_ERR_CAPACITY : STOCS_OK;
+}
+
+// ---- on-disk index (flat little-endian file; replaces the Boost archive of rgbd.cpp:156-177) ----
+struct IndexFileHeader {
+    char magic[8];       // "STOCSIX1"
+    int32_t tr, rot, NA, nD, nM, reserved;
+    int64_t n_keys, n_pairs;
+    uint64_t model_hash; // FNV-1a over the raw model positions and the normalised normals
+};
+static uint64_t model_hash(const stocs_ctx* c) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
+    mix(c->h_mpos_raw.data(), c->h_mpos_raw.size() * sizeof(V3));
+    mix(c->h_mnrm.data(), c->h_mnrm.size() * sizeof(V3));
+    return h;
+}
+
+int stocs_index_save(stocs_ctx* c, const char* path) {
+    if (!c || !path) return STOCS_ERR_INVALID;
+    if (!c->index.built) { set_error("stocs_index_save: PPF index not built"); return STOCS_ERR_STATE; }
+    const PpfIndex& ix = c->index;
+    std::vector<uint32_t> pairs((size_t)std::max<int64_t>(ix.n_pairs, 1));
+    STOCS_HIP_CHECK(hipMemcpyAsync(pairs.data(), ix.d_pairs, (size_t)ix.n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    FILE* f = fopen(path, "wb");
+    if (!f) { set_error("stocs_index_save: cannot open %s", path); return STOCS_ERR_INVALID; }
+    IndexFileHeader h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, "STOCSIX1", 8);
+    h.tr = ix.tr; h.rot = ix.rot; h.NA = ix.NA; h.nD = ix.nD; h.nM = c->nM; h.n_keys = ix.n_keys; h.n_pairs = ix.n_pairs;
+    h.model_hash = model_hash(c);
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(ix.h_bucket_start.data(), 4, (size_t)ix.n_keys + 1, f) == (size_t)ix.n_keys + 1 &&
+              fwrite(pairs.data(), 4, (size_t)ix.n_pairs, f) == (size_t)ix.n_pairs &&
+              fwrite(ix.h_exists.data(), 4, ix.h_exists.size(), f) == ix.h_exists.size();
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { set_error("stocs_index_save: write to %s failed", path); return STOCS_ERR_INVALID; }
+    return STOCS_OK;
+}
+
+int stocs_index_load(stocs_ctx* c, const char* path) {
+    if (!c || !path) return STOCS_ERR_INVALID;
+    if (c->index.built) { set_error("stocs_index_load: the context already has an index"); return STOCS_ERR_STATE; }
+    FILE* f = fopen(path, "rb");
+    if (!f) { set_error("stocs_index_load: cannot open %s", path); return STOCS_ERR_INVALID; }
+    IndexFileHeader h;
+    PpfIndex& ix = c->index;
+    int rc = STOCS_OK;
+    std::vector<uint32_t> pairs;
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "STOCSIX1", 8) != 0) { set_error("stocs_index_load: %s is not a STOCSIX1 file", path); rc = STOCS_ERR_INVALID; }
+    else if (h.nM != c->nM || h.tr != c->prm.ppf_tr_discretization || h.rot != c->prm.ppf_rot_discretization || h.model_hash != model_hash(c)) {
+        set_error("stocs_index_load: %s was built for another model cloud or discretisation", path); rc = STOCS_ERR_INVALID;
+    } else if (h.n_keys <= 0 || h.n_keys > ((int64_t)1 << 31) || h.n_pairs < 0 || h.n_pairs > (int64_t)400 * 1000 * 1000 || h.NA != 180 / h.rot + 1 ||
+               h.n_keys != (int64_t)h.nD * h.NA * h.NA * h.NA) {
+        set_error("stocs_index_load: corrupt header in %s", path); rc = STOCS_ERR_INVALID;
+    } else {
+        const size_t words = (size_t)((h.n_keys + 31) / 32);
+        ix.h_bucket_start.assign((size_t)h.n_keys + 1, 0);
+        pairs.resize((size_t)std::max<int64_t>(h.n_pairs, 1));
+        ix.h_exists.assign(std::max<size_t>(words, 1), 0);
+        if (fread(ix.h_bucket_start.data(), 4, (size_t)h.n_keys + 1, f) != (size_t)h.n_keys + 1 || fread(pairs.data(), 4, (size_t)h.n_pairs, f) != (size_t)h.n_pairs ||
+            fread(ix.h_exists.data(), 4, words, f) != words || ix.h_bucket_start[(size_t)h.n_keys] != (uint32_t)h.n_pairs) {
+            set_error("stocs_index_load: truncated or inconsistent file %s", path); rc = STOCS_ERR_INVALID;
+        }
+    }
+    fclose(f);
+    if (rc) return rc;
+    ix.tr = h.tr; ix.rot = h.rot; ix.NA = h.NA; ix.nD = h.nD; ix.n_keys = h.n_keys; ix.n_pairs = h.n_pairs;
+    ix.n_nonempty_buckets = 0;
+    for (int64_t k = 0; k < ix.n_keys; ++k) ix.n_nonempty_buckets += ix.h_bucket_start[(size_t)k + 1] != ix.h_bucket_start[(size_t)k];
+    ix.n_exist_keys = 0;
+    for (size_t w = 0; w < ix.h_exists.size(); ++w) ix.n_exist_keys += __builtin_popcount(ix.h_exists[w]);
+    STOCS_HIP_CHECK(hipMalloc((void**)&ix.d_bucket_start, (size_t)(ix.n_keys + 1) * 4));
+    STOCS_HIP_CHECK(hipMalloc((void**)&ix.d_pairs, (size_t)std::max<int64_t>(ix.n_pairs, 1) * 4));
+    STOCS_HIP_CHECK(hipMalloc((void**)&ix.d_exists, ix.h_exists.size() * 4));
+    STOCS_HIP_CHECK(hipMemcpyAsync(ix.d_bucket_start, ix.h_bucket_start.data(), (size_t)(ix.n_keys + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    STOCS_HIP_CHECK(hipMemcpyAsync(ix.d_pairs, pairs.data(), (size_t)ix.n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    STOCS_HIP_CHECK(hipMemcpyAsync(ix.d_exists, ix.h_exists.data(), ix.h_exists.size() * 4, hipMemcpyHostToDevice, c->stream));
+    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    ix.built = true;
+    return STOCS_OK;
 }
 
 int stocs_index_stats(const stocs_ctx* c, int64_t* n_pairs, int64_t* n_buckets, int64_t* n_keys) {

@@ -82,7 +82,8 @@ struct Thresholds {
 struct stocs_ctx {
     stocs_params prm;
     int device;
-    hipStream_t stream;
+    hipStream_t stream;       // the stream all work is issued on
+    hipStream_t own_stream;   // created with the context; `stream` may point to a caller's stream instead
     hipEvent_t ev0, ev1;
     int nS, nM;
     stocs::Thresholds thr;

@@ -71,6 +71,12 @@ class StocsEstimator:
             capi.check(self.L.stocs_index_lookup(self.h, pk, out.ctypes.data_as(capi._ip), n.value, C.byref(n)))
         return out
 
+    def index_save(self, path):
+        capi.check(self.L.stocs_index_save(self.h, str(path).encode()))
+
+    def index_load(self, path):
+        capi.check(self.L.stocs_index_load(self.h, str(path).encode()))
+
     def index_stats(self):
         a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         capi.check(self.L.stocs_index_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
@@ -213,6 +219,21 @@ class StocsEstimator:
         s = C.c_float(0); i = C.c_uint32(0)
         self.L.stocs_unpack_best(key.value, C.byref(s), C.byref(i))
         return s.value, int(i.value), int(key.value)
+
+    def score_best_device(self, dT, n, dL, id_offset=0):
+        key = C.c_uint64(0)
+        capi.check(self.L.stocs_score_best_device(self.h, dT, n, dL, id_offset, C.byref(key)))
+        if key.value == 0:
+            return 0.0, -1
+        s = C.c_float(0); i = C.c_uint32(0)
+        self.L.stocs_unpack_best(key.value, C.byref(s), C.byref(i))
+        return s.value, int(i.value)
+
+    def set_stream(self, hip_stream):
+        capi.check(self.L.stocs_set_stream(self.h, C.c_void_p(hip_stream)))
+
+    def best_device_async(self, dL, n, id_offset, d_key8):
+        capi.check(self.L.stocs_best_device_async(self.h, dL, n, id_offset, C.c_void_p(d_key8)))
 
     def sync(self):
         capi.check(self.L.stocs_sync(self.h))

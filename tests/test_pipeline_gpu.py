@@ -203,3 +203,33 @@ def test_instance_mode_equals_oracle(oracle_lib):
     T = synth.make_candidates(synth.centred_gt(s.T_gt, cs.astype(np.float64), cm.astype(np.float64)), 64)
     assert np.abs(est.score_transforms(T) - orc.lcp_batch(T)).max() <= LCP_TOL
     assert (orc.scene_class_prob() < s.prob - 1e-6).any()
+
+
+def test_index_file_round_trip(setup, tmp_path):
+    """stocs_index_save / stocs_index_load (flat CSR file replacing the Boost archive of rgbd.cpp:156-177)."""
+    from model_matching_amd import capi, synth
+    from model_matching_amd.estimator import StocsEstimator
+    m, s, est, orc = setup
+    path = tmp_path / "ppf_index.stix"
+    est.index_save(path)
+    est2 = StocsEstimator(s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm, build_index=False)
+    with pytest.raises(capi.StocsError):
+        est2.sample_bases(1, 2)                     # no index yet
+    est2.index_load(path)
+    assert est2.index_stats() == est.index_stats()
+    for key in [(50, 90, 90, 0), (30, 45, 120, 60), (100, 90, 90, 180), (5, 90, 90, 0)]:
+        assert np.array_equal(est2.index_lookup(key), est.index_lookup(key)) and est2.index_exists(key) == est.index_exists(key)
+    v1, i1, n1 = est.sample_bases(77, 12)
+    v2, i2, n2 = est2.sample_bases(77, 12)
+    assert np.array_equal(v1, v2) and np.array_equal(i1[v1], i2[v2]) and np.array_equal(n1[v1], n2[v2])
+    with pytest.raises(capi.StocsError):
+        est2.index_load(path)                       # already has an index
+    # a file built for another model is refused
+    other = synth.make_model(len(m.pos), seed=999)
+    est3 = StocsEstimator(s.pos, s.nrm, s.prob, s.pixel, other.pos, other.nrm, build_index=False)
+    with pytest.raises(capi.StocsError):
+        est3.index_load(path)
+    bad = tmp_path / "bad.stix"
+    bad.write_bytes(b"not an index")
+    with pytest.raises(capi.StocsError):
+        est3.index_load(bad)
