@@ -102,6 +102,29 @@ __global__ __launch_bounds__(256) void pkey_kernel(const BaseJob* __restrict__ j
     keys[e] = key;
 }
 
+// After the sort: direction cell of every P entry, and for every (base, position cell) the run of its
+// P entries.  Replaces the pointer grid _grid[pId] -> AngularGrid of normalset.h:87-88.
+__global__ __launch_bounds__(256) void cell_ranges_kernel(const uint64_t* __restrict__ keys, uint32_t totalP, const uint32_t* __restrict__ p_off,
+                                                          long long NC, uint16_t* __restrict__ pdir, uint32_t* __restrict__ cfirst,
+                                                          uint32_t* __restrict__ cend) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= totalP) return;
+    const uint64_t key = keys[e];
+    const uint64_t kk = key & 0xFFFFFFFFFFull;
+    const uint32_t b = (uint32_t)(key >> 40);
+    if (kk == 0xFFFFFFFFFFull) { pdir[e] = 0xFFFF; return; }
+    const uint64_t pc = kk / 343ull;
+    pdir[e] = (uint16_t)(kk - pc * 343ull);
+    if (!cfirst) return;
+    const uint64_t grp = key - (kk - pc * 343ull);   // (base, position cell) part
+    bool first = (e == p_off[b]);
+    if (!first) { const uint64_t pk = keys[e - 1]; const uint64_t pkk = pk & 0xFFFFFFFFFFull; first = (pk - (pkk - (pkk / 343ull) * 343ull)) != grp || pkk == 0xFFFFFFFFFFull; }
+    bool last = (e + 1 == p_off[b + 1]);
+    if (!last) { const uint64_t nk = keys[e + 1]; const uint64_t nkk = nk & 0xFFFFFFFFFFull; last = nkk == 0xFFFFFFFFFFull || (nk - (nkk - (nkk / 343ull) * 343ull)) != grp; }
+    if (first) cfirst[(long long)b * NC + (long long)pc] = e;
+    if (last) cend[(long long)b * NC + (long long)pc] = e + 1;
+}
+
 // Eigen Quaternion::setFromTwoVectors((0,0,1), n) and q * v (see DESIGN.md "numerics")
 __device__ __forceinline__ void quat_from_z(V3 n, float q[4]) {
     const V3 v0 = normalized3(mk3(0.f, 0.f, 1.f));
@@ -132,7 +155,9 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void join_kernel(const BaseJob* __restrict__ jobs, const uint32_t* __restrict__ q_off, int nB,
                                                    const float4* __restrict__ munit, const float4* __restrict__ mpos,
                                                    const uint32_t* __restrict__ Q, uint32_t totalQ, const uint64_t* __restrict__ pkeys,
-                                                   const uint32_t* __restrict__ pvals, float nepsilon, float dist_thr,
+                                                   const uint32_t* __restrict__ pvals, const uint16_t* __restrict__ pdir,
+                                                   const uint32_t* __restrict__ cfirst, const uint32_t* __restrict__ cend, long long NC,
+                                                   float nepsilon, float dist_thr,
                                                    unsigned long long* __restrict__ qcnt, const unsigned long long* __restrict__ qoff_e, int id_bits,
                                                    uint64_t* __restrict__ quads) {
     __shared__ uint32_t seen[256][11];  // 343-bit set per lane
@@ -150,39 +175,50 @@ __global__ __launch_bounds__(256) void join_kernel(const BaseJob* __restrict__ j
     const V3 queryn = normalized3(p2 - p1);
     const int64_t pc = index_pos(query, J.cell, J.egSize);
     if (pc < 0 || pc >= ((int64_t)1 << 31)) { if (!FILL) qcnt[e] = 0; return; }
+    // the run of P entries that live in this query's position cell (only that cell is inspected, Q9)
+    uint32_t lo, hi;
+    if (cfirst) {
+        if (pc >= NC) { if (!FILL) qcnt[e] = 0; return; }
+        lo = cfirst[(long long)b * NC + pc];
+        hi = cend[(long long)b * NC + pc];
+    } else {
+        const uint64_t* keys = pkeys + J.p_off;
+        const uint64_t k0 = ((uint64_t)b << 40) | ((uint64_t)pc * 343ull), k1 = k0 + 343ull;
+        uint32_t l = 0, h = J.p_len;
+        while (l < h) { const uint32_t mid = (l + h) >> 1; if (keys[mid] < k0) l = mid + 1; else h = mid; }
+        lo = J.p_off + l;
+        h = J.p_len;
+        while (l < h) { const uint32_t mid = (l + h) >> 1; if (keys[mid] < k1) l = mid + 1; else h = mid; }
+        hi = J.p_off + l;
+    }
+    if (lo >= hi) { if (!FILL) qcnt[e] = 0; return; }
+    // direction cells hit by the sampled cone (std::set<unsigned> colored of normalset.hpp:188-204)
     uint32_t* my = seen[threadIdx.x];
 #pragma unroll
     for (int k = 0; k < 11; ++k) my[k] = 0;
     float q[4];
     quat_from_z(queryn, q);
-    const uint64_t* keys = pkeys + J.p_off;
-    const uint32_t* vals = pvals + J.p_off;
-    const uint64_t hi_bits = (uint64_t)b << 40;
-    unsigned long long local = 0;
-    const unsigned long long out0 = FILL ? qoff_e[e] : 0ull;   // exclusive scan of the count pass: no atomics in the fill pass
     for (int a = 0; a < J.nb; ++a) {
         const V3 dir = normalized3(quat_rot(q, mk3(J.dirs[a][0], J.dirs[a][1], J.dirs[a][2])));
         const int id = index_normal(dir, nepsilon);
         if (id < 0 || id >= 343) continue;  // std::array::at would throw (NaN direction)
-        if ((my[id >> 5] >> (id & 31)) & 1u) continue;  // std::set<unsigned> colored
         my[id >> 5] |= 1u << (id & 31);
-        const uint64_t key = hi_bits | ((uint64_t)pc * 343ull + (uint64_t)id);
-        uint32_t lo = 0, hi = J.p_len;  // lower_bound
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (keys[mid] < key) lo = mid + 1; else hi = mid;
-        }
-        for (uint32_t k = lo; k < J.p_len && keys[k] == key; ++k) {
-            const uint32_t pr = vals[k];
-            const int pa = pr >> 16, pb = pr & 0xFFFF;
-            const V3 pp1 = ld3c(mpos, pa), pp2 = ld3c(mpos, pb);
-            const V3 invPoint = pp1 + (pp2 - pp1) * J.inv1;
-            if (sqn3(queryQ - invPoint) <= dist_thr) {  // squared metres vs metres (Q1), reproduced
-                if (FILL)   // sort key: base, then (P.first, P.second, Q.first, Q.second) == the std::set order
-                    quads[out0 + local] = ((uint64_t)b << (4 * id_bits)) | ((uint64_t)pa << (3 * id_bits)) | ((uint64_t)pb << (2 * id_bits)) |
-                                          ((uint64_t)qa << id_bits) | (uint64_t)qb;
-                local++;
-            }
+    }
+    // one linear pass over the position cell's P entries against the direction bitset
+    unsigned long long local = 0;
+    const unsigned long long out0 = FILL ? qoff_e[e] : 0ull;   // exclusive scan of the count pass: no atomics in the fill pass
+    for (uint32_t k = lo; k < hi; ++k) {
+        const uint32_t dc = pdir[k];
+        if (dc >= 343u || !((my[dc >> 5] >> (dc & 31)) & 1u)) continue;
+        const uint32_t pr = pvals[k];
+        const int pa = pr >> 16, pb = pr & 0xFFFF;
+        const V3 pp1 = ld3c(mpos, pa), pp2 = ld3c(mpos, pb);
+        const V3 invPoint = pp1 + (pp2 - pp1) * J.inv1;
+        if (sqn3(queryQ - invPoint) <= dist_thr) {  // squared metres vs metres (Q1), reproduced
+            if (FILL)   // sort key: base, then (P.first, P.second, Q.first, Q.second) == the std::set order
+                quads[out0 + local] = ((uint64_t)b << (4 * id_bits)) | ((uint64_t)pa << (3 * id_bits)) | ((uint64_t)pb << (2 * id_bits)) |
+                                      ((uint64_t)qa << id_bits) | (uint64_t)qb;
+            local++;
         }
     }
     if (!FILL) qcnt[e] = local;
@@ -323,6 +359,19 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     if ((rc = d_tmp.alloc(tmp_bytes))) return rc;
     STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_keys.p, d_keys_s.p, d_P.p, d_Ps.p, (size_t)totP, 0, 64, st));
 
+    // direction cells + per-(base, position cell) runs
+    const long long NC = (long long)egSize * egSize * egSize;
+    const bool use_table = NC > 0 && NC * (long long)nB <= (long long)32 * 1024 * 1024;
+    DevBuf<uint16_t> d_pdir; DevBuf<uint32_t> d_cfirst, d_cend;
+    if ((rc = d_pdir.alloc(totP))) return rc;
+    if (use_table) {
+        if ((rc = d_cfirst.alloc((size_t)(NC * nB))) || (rc = d_cend.alloc((size_t)(NC * nB)))) return rc;
+        STOCS_HIP_CHECK(hipMemsetAsync(d_cfirst.p, 0, 4 * (size_t)(NC * nB), st));
+        STOCS_HIP_CHECK(hipMemsetAsync(d_cend.p, 0, 4 * (size_t)(NC * nB), st));
+    }
+    hipLaunchKernelGGL(cell_ranges_kernel, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, d_keys_s.p, (uint32_t)totP, d_poff.p, NC, d_pdir.p,
+                       use_table ? d_cfirst.p : (uint32_t*)NULL, use_table ? d_cend.p : (uint32_t*)NULL);
+    STOCS_HIP_CHECK(hipGetLastError());
     STOCS_TICK("gather+keys+sort")
     // ---- 4. join: count pass, exclusive scan, fill pass (no atomics) ----
     int id_bits = 1;
@@ -334,6 +383,7 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     if ((rc = d_qcnt.alloc(totQ + 1)) || (rc = d_qoffe.alloc(totQ + 1))) return rc;
     const dim3 jgrid((unsigned)((totQ + 255) / 256));
     hipLaunchKernelGGL(join_kernel<false>, jgrid, dim3(256), 0, st, d_jobs.p, d_qoff.p, nB, c->d_munit, c->d_mpos, d_Q.p, (uint32_t)totQ, d_keys_s.p, d_Ps.p,
+                       d_pdir.p, use_table ? d_cfirst.p : (const uint32_t*)NULL, use_table ? d_cend.p : (const uint32_t*)NULL, NC,
                        nepsilon, c->prm.distance_threshold, d_qcnt.p, (const unsigned long long*)NULL, id_bits, (uint64_t*)NULL);
     STOCS_HIP_CHECK(hipGetLastError());
     STOCS_HIP_CHECK(hipMemsetAsync(d_qcnt.p + totQ, 0, 8, st));
@@ -368,6 +418,7 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     if ((rc = d_quads.alloc(totQuads))) return rc;
     STOCS_HIP_CHECK(hipMalloc((void**)&c->d_quads, 8 * (size_t)totQuads));
     hipLaunchKernelGGL(join_kernel<true>, jgrid, dim3(256), 0, st, d_jobs.p, d_qoff.p, nB, c->d_munit, c->d_mpos, d_Q.p, (uint32_t)totQ, d_keys_s.p, d_Ps.p,
+                       d_pdir.p, use_table ? d_cfirst.p : (const uint32_t*)NULL, use_table ? d_cend.p : (const uint32_t*)NULL, NC,
                        nepsilon, c->prm.distance_threshold, (unsigned long long*)NULL, d_qoffe.p, id_bits, d_quads.p);
     STOCS_HIP_CHECK(hipGetLastError());
     STOCS_TICK("join fill")
