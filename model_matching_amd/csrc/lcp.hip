@@ -32,7 +32,7 @@ struct LcpArgs {
     const uint4* cells;
     const float4* list;
     const float4* snrmw;  // scene unit normal + class-probability weight
-    float ox, oy, oz, inv_h;
+    float ox, oy, oz, inv_h, inv_h4;
     int nx, ny, nz, nbx, nby;
     float sq_eps, dot_lo;
 };
@@ -367,14 +367,17 @@ __global__ __launch_bounds__(256) void lcp_coopq_kernel(LcpArgs a, const float* 
             qx = ((t0 * p.x + t4 * p.y) + t8 * p.z) + t12;
             qy = ((t1 * p.x + t5 * p.y) + t9 * p.z) + t13;
             qz = ((t2 * p.x + t6 * p.y) + t10 * p.z) + t14;
-            const float ux = (qx - a.ox) * a.inv_h, uy = (qy - a.oy) * a.inv_h, uz = (qz - a.oz) * a.inv_h;
-            const float fx = floorf(ux), fy = floorf(uy), fz = floorf(uz);
-            if (fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float)a.nx && fy < (float)a.ny && fz < (float)a.nz) {
-                const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
+            // one floor per axis at quarter-cell resolution gives both the cell (>> 2) and the sub-cell
+            // (& 3); unsigned compares do the bounds test (a NaN query floors to 0, scans cell 0 and
+            // matches nothing because every NaN distance fails d <= best)
+            const int c4x = __float2int_rd((qx - a.ox) * a.inv_h4), c4y = __float2int_rd((qy - a.oy) * a.inv_h4),
+                      c4z = __float2int_rd((qz - a.oz) * a.inv_h4);
+            const int cx = c4x >> 2, cy = c4y >> 2, cz = c4z >> 2;
+            if ((unsigned)cx < (unsigned)a.nx && (unsigned)cy < (unsigned)a.ny && (unsigned)cz < (unsigned)a.nz) {
                 const int brick = a.top[((cz >> 3) * a.nby + (cy >> 3)) * a.nbx + (cx >> 3)];
                 if (brick >= 0) {
-                    const uint4 cw = a.cells[(size_t)brick * 512 + (((cz & 7) << 6) | ((cy & 7) << 3) | (cx & 7))];
-                    const int sb = ((int)((uz - fz) * 4.0f) << 4) | ((int)((uy - fy) * 4.0f) << 2) | (int)((ux - fx) * 4.0f);
+                    const uint4 cw = a.cells[(uint32_t)brick * 512u + (uint32_t)(((cz & 7) << 6) | ((cy & 7) << 3) | (cx & 7))];
+                    const int sb = ((c4z & 3) << 4) | ((c4y & 3) << 2) | (c4x & 3);
                     const uint32_t mw = sb < 32 ? cw.z : cw.w;
                     off = cw.x; cnt = ((mw >> (sb & 31)) & 1u) ? cw.y : 0u;
                 }
@@ -721,7 +724,7 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
     LcpArgs a;
     a.mpos = c->d_mpos_s; a.mnrm = c->d_mnrm_s; a.mperm = c->d_mperm; a.M = c->nM;
     a.top = c->grid.d_top; a.cells = c->grid.d_cells; a.list = c->grid.d_list; a.snrmw = c->d_snrmw;
-    a.ox = c->grid.ox; a.oy = c->grid.oy; a.oz = c->grid.oz; a.inv_h = c->grid.inv_h;
+    a.ox = c->grid.ox; a.oy = c->grid.oy; a.oz = c->grid.oz; a.inv_h = c->grid.inv_h; a.inv_h4 = c->grid.inv_h * 4.0f;
     a.nx = c->grid.nx; a.ny = c->grid.ny; a.nz = c->grid.nz; a.nbx = c->grid.nbx; a.nby = c->grid.nby;
     a.sq_eps = c->prm.distance_threshold * c->prm.distance_threshold;  // sq_eps = epsilon*epsilon, stocs.cpp:1014
     a.dot_lo = c->thr.lcp_dot_lo;
