@@ -152,6 +152,24 @@ int stocs_cluster_poses(const float* poses16, const float* lcp, int n, float acc
                         float best_score, int maximum_pose_count, float min_distance, float min_angle,
                         const float* sym3, int32_t* out_idx, int cap, int* n_out);
 
+/* ---- upstream rows, GPU implementations.  PARITY WITH THE REFERENCE IS UNPINNED:
+ * their arithmetic lives in PCL / OpenCV-contrib, absent here; these are pinned against this repo's
+ * numpy restatement (oracle/ingest_oracle.py).  Stand-alone calls (no context). ---- */
+typedef struct stocs_camera {
+    float fx, cx, fy, cy;      /* stocs_match_one_object.cpp:20 */
+    float depth_scale;         /* :21 */
+    int width, height;         /* :23-24 */
+} stocs_camera;
+/* rgbd::load_rgbd_data_sampled (rgbd.cpp:179-281): depth + class-probability images (uint16) -> voxelised,
+ * outlier-filtered, oriented scene cloud with class probability and (row, col) pixel per point */
+int stocs_ingest_scene(const stocs_camera* cam, const uint16_t* depth, const uint16_t* class_prob, float voxel_size,
+                       float class_threshold, int device, float* pos3, float* nrm3, float* prob, int32_t* pixel2,
+                       int cap, int* n_out);
+/* cloud part of stocs::pre_process_model (stocs.cpp:43-60): raw vertices -> radius normals pointing away
+ * from the model origin -> voxel grid (positions and normals averaged per leaf) -> scale */
+int stocs_preprocess_model(const float* raw_pos3, int n_raw, float normal_radius, float voxel_size, float model_scale,
+                           int device, float* pos3, float* nrm3, int cap, int* n_out);
+
 /* ---- tuning knobs (never change results): "lcp_variant" 0 = lane-per-query list scan,
  * 1 = cooperative 8-lane list scan (default) ---- */
 int stocs_set_option(stocs_ctx* ctx, const char* key, int value);

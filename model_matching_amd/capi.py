@@ -28,6 +28,11 @@ class Params(C.Structure):
                 ("number_of_bases", C.c_int), ("maximum_congruent_sets", C.c_int)]
 
 
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_float), ("cx", C.c_float), ("fy", C.c_float), ("cy", C.c_float), ("depth_scale", C.c_float),
+                ("width", C.c_int), ("height", C.c_int)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/stocs_hip.h
 _fp, _ip, _u8p, _vp = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.c_void_p
 _i64p = C.POINTER(C.c_int64)
@@ -68,6 +73,8 @@ SIGNATURES = {
     "stocs_pack_best": (C.c_uint64, [C.c_float, C.c_uint32]),
     "stocs_unpack_best": (None, [C.c_uint64, _fp, C.POINTER(C.c_uint32)]),
     "stocs_cluster_poses": (C.c_int, [_fp, _fp, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, _fp, _ip, C.c_int, _intp]),
+    "stocs_ingest_scene": (C.c_int, [C.POINTER(Camera), C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.c_float, C.c_float, C.c_int, _fp, _fp, _fp, _ip, C.c_int, _intp]),
+    "stocs_preprocess_model": (C.c_int, [_fp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, _fp, _fp, C.c_int, _intp]),
     "stocs_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "stocs_set_stream": (C.c_int, [_vp, _vp]),
     "stocs_best_device_async": (C.c_int, [_vp, _vp, C.c_int, C.c_uint32, _vp]),

@@ -252,3 +252,31 @@ def cluster_poses(poses16, lcp, acceptable_fraction, best_score, maximum_pose_co
     capi.check(L.stocs_cluster_poses(pp, pl, len(l), acceptable_fraction, best_score, maximum_pose_count, min_distance,
                                      min_angle, ps, out.ctypes.data_as(capi._ip), len(out), C.byref(n)))
     return out[:n.value]
+
+
+def ingest_scene(depth_u16, prob_u16, K, depth_scale, voxel_size=0.005, class_threshold=0.10, device=-1):
+    """GPU scene ingest (stocs_ingest_scene): returns pos, nrm, prob, pixel arrays."""
+    L = capi.load()
+    d = np.ascontiguousarray(depth_u16, np.uint16); p = np.ascontiguousarray(prob_u16, np.uint16)
+    H, W = d.shape
+    cam = capi.Camera(K[0], K[1], K[2], K[3], depth_scale, W, H)
+    cap = W * H
+    pos = np.zeros((cap, 3), np.float32); nrm = np.zeros((cap, 3), np.float32); pr = np.zeros(cap, np.float32); px = np.zeros((cap, 2), np.int32)
+    n = C.c_int(0)
+    capi.check(L.stocs_ingest_scene(C.byref(cam), d.ctypes.data_as(C.POINTER(C.c_uint16)), p.ctypes.data_as(C.POINTER(C.c_uint16)), voxel_size,
+                                    class_threshold, device, pos.ctypes.data_as(capi._fp), nrm.ctypes.data_as(capi._fp), pr.ctypes.data_as(capi._fp),
+                                    px.ctypes.data_as(capi._ip), cap, C.byref(n)))
+    k = n.value
+    return pos[:k].copy(), nrm[:k].copy(), pr[:k].copy(), px[:k].copy()
+
+
+def preprocess_model(raw_pos, normal_radius, voxel_size, model_scale=1.0, device=-1):
+    """GPU model preprocessing (stocs_preprocess_model): returns voxelised pos, unit nrm."""
+    L = capi.load()
+    raw, pr = capi.f32(raw_pos)
+    cap = len(raw)
+    pos = np.zeros((cap, 3), np.float32); nrm = np.zeros((cap, 3), np.float32)
+    n = C.c_int(0)
+    capi.check(L.stocs_preprocess_model(pr, len(raw), normal_radius, voxel_size, model_scale, device, pos.ctypes.data_as(capi._fp),
+                                        nrm.ctypes.data_as(capi._fp), cap, C.byref(n)))
+    return pos[:n.value].copy(), nrm[:n.value].copy()
