@@ -9,7 +9,10 @@
 // outside the hot path.
 //
 // usage: stocs_single <scene.stcl> <model.stcl> [--edge edge.u8] [--seed N] [--out pose.txt]
-//                     [--bases 100] [--max-sets 200] [--device 0]
+//                     [--bases 100] [--max-sets 200] [--device 0] [--dbg DIR] [--cluster 1]
+// --dbg DIR writes best_pose.ply / scene.ply as stocs_estimator::visualize_best_pose does (reference
+// include/stocs.hpp:136-149); --cluster 1 additionally runs clustering::greedy_clustering (reference
+// src/pose_clustering.cpp:79-121, which has no caller in the reference) on the scored candidates.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -31,6 +34,18 @@ static float sample_dispersion = 0.9f;
 static int number_of_bases = 100;
 static int maximum_congruent_sets = 200;
 static int image_width = 640, image_height = 480;
+
+// ASCII PLY with positions and normals (stand-in for rgbd::save_as_ply, reference src/rgbd.cpp:35-56)
+static bool write_ply(const std::string& path, const std::vector<float>& pos, const std::vector<float>& nrm) {
+    std::ofstream f(path);
+    if (!f) return false;
+    const size_t n = pos.size() / 3;
+    f << "ply\nformat ascii 1.0\nelement vertex " << n << "\nproperty float x\nproperty float y\nproperty float z\n"
+      << "property float normal_x\nproperty float normal_y\nproperty float normal_z\nend_header\n";
+    for (size_t i = 0; i < n; ++i)
+        f << pos[3 * i] << " " << pos[3 * i + 1] << " " << pos[3 * i + 2] << " " << nrm[3 * i] << " " << nrm[3 * i + 1] << " " << nrm[3 * i + 2] << "\n";
+    return (bool)f;
+}
 
 static bool read_stcl(const std::string& path, std::vector<float>& pos, std::vector<float>& nrm, std::vector<float>* prob,
                       std::vector<int32_t>* pixel) {
@@ -62,7 +77,8 @@ int main(int argc, char** argv) {
         std::cout << "usage: stocs_single <scene.stcl> <model.stcl> [--edge edge.u8] [--seed N] [--out pose.txt]" << std::endl;
         return -1;
     }
-    std::string edge_path, out_path = "best_pose_candidate.txt";
+    std::string edge_path, out_path = "best_pose_candidate.txt", dbg_dir;
+    int do_cluster = 0;
     uint64_t seed = 1;
     int device = -1;
     for (int i = 3; i + 1 < argc; i += 2) {
@@ -73,6 +89,8 @@ int main(int argc, char** argv) {
         else if (k == "--bases") number_of_bases = atoi(argv[i + 1]);
         else if (k == "--max-sets") maximum_congruent_sets = atoi(argv[i + 1]);
         else if (k == "--device") device = atoi(argv[i + 1]);
+        else if (k == "--dbg") dbg_dir = argv[i + 1];
+        else if (k == "--cluster") do_cluster = atoi(argv[i + 1]);
     }
     stocs::SceneCloud scene;
     stocs::ModelCloud model;
@@ -151,6 +169,27 @@ int main(int argc, char** argv) {
         const stocs::Mat4f& t = best_pose->transform;
         out_file_ptr << t(0, 0) << " " << t(0, 1) << " " << t(0, 2) << " " << t(0, 3) << " " << t(1, 0) << " " << t(1, 1) << " " << t(1, 2) << " "
                      << t(1, 3) << " " << t(2, 0) << " " << t(2, 1) << " " << t(2, 2) << " " << t(2, 3) << std::endl;
+        if (!dbg_dir.empty()) {  // visualize_best_pose (stocs.hpp:136-149): model under the best camera-frame pose + the scene
+            std::vector<float> mp(model.pos.size()), mn(model.nrm.size());
+            for (size_t i = 0; i < model.pos.size() / 3; ++i)
+                for (int r = 0; r < 3; ++r) {
+                    mp[3 * i + r] = t(r, 0) * model.pos[3 * i] + t(r, 1) * model.pos[3 * i + 1] + t(r, 2) * model.pos[3 * i + 2] + t(r, 3);
+                    mn[3 * i + r] = t(r, 0) * model.nrm[3 * i] + t(r, 1) * model.nrm[3 * i + 1] + t(r, 2) * model.nrm[3 * i + 2];
+                }
+            write_ply(dbg_dir + "/best_pose.ply", mp, mn);
+            write_ply(dbg_dir + "/scene.ply", scene.pos, scene.nrm);
+        }
+        if (do_cluster) {  // greedy_clustering(hypotheses, 0.8, best, 10, 2 cm, 15 deg, no symmetry)
+            std::vector<stocs::PoseCandidate*> all = stocs_ptr.get_pose_candidates();
+            std::vector<float> poses(all.size() * 16), lcp(all.size());
+            for (size_t i = 0; i < all.size(); ++i) { std::memcpy(&poses[16 * i], all[i]->transform.data(), 64); lcp[i] = all[i]->lcp; }
+            std::vector<int32_t> keep(all.size() + 1);
+            const float sym[3] = {0, 0, 0};
+            int nk = 0;
+            stocs_cluster_poses(poses.data(), lcp.data(), (int)all.size(), 0.8f, stocs_ptr.get_best_score(), 10, 0.02f, 15.0f, sym, keep.data(), (int)keep.size(), &nk);
+            std::cout << "clustered hypotheses: " << nk << std::endl;
+            for (int i = 0; i < nk; ++i) std::cout << "  cluster " << i << ": candidate " << keep[i] << " lcp " << lcp[keep[i]] << std::endl;
+        }
     } else {
         std::cout << "no pose found" << std::endl;
     }

@@ -18,11 +18,14 @@ def test_stocs_single_recovers_pose(tmp_path):
     cloudio.write_stcl(tmp_path / "scene.stcl", s.pos, s.nrm, s.prob, s.pixel)
     cloudio.write_stcl(tmp_path / "model.stcl", m.pos, m.nrm)
     out = tmp_path / "best_pose_candidate_obj.txt"
-    r = subprocess.run([APP, str(tmp_path / "scene.stcl"), str(tmp_path / "model.stcl"), "--seed", "1234", "--out", str(out)],
-                       capture_output=True, text=True, timeout=300)
+    r = subprocess.run([APP, str(tmp_path / "scene.stcl"), str(tmp_path / "model.stcl"), "--seed", "1234", "--out", str(out),
+                        "--dbg", str(tmp_path), "--cluster", "1"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     for needle in ("Sampled ", " bases in ", "found ", " congruent sets in ", "evaluated transforms in ", "microseconds"):
         assert needle in r.stdout
+    assert "clustered hypotheses:" in r.stdout and "cluster 0: candidate" in r.stdout
+    ply = (tmp_path / "best_pose.ply").read_text().splitlines()
+    assert ply[0] == "ply" and ("element vertex %d" % len(m.pos)) in ply[:4] and (tmp_path / "scene.ply").exists()
     vals = np.array(out.read_text().split(), float)
     assert vals.shape == (12,)                      # 3x4 row-major, stocs_match_one_object.cpp:171-180
     P = vals.reshape(3, 4)
@@ -46,3 +49,27 @@ def test_stocs_single_fails_loudly_without_gpu(tmp_path):
     cloudio.write_stcl(tmp_path / "a.stcl", m.pos, m.nrm, np.ones(50, np.float32))
     r = subprocess.run([APP, str(tmp_path / "a.stcl"), str(tmp_path / "a.stcl")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 2 and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_trial_sharding_tool_single_and_two_ranks():
+    """tools/trials.py (BASELINE config 4): the 2-rank run (sharing the one GPU, gloo rehearsal) must pick
+    the same winner as the single-process run over the same trials."""
+    import json, socket, sys
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trials.py"), "--trials", "6", "--seed", "3"], capture_output=True, text=True,
+                         timeout=600, env=env, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    r1 = json.loads(one.stdout.strip().splitlines()[-1])
+    assert r1["mode"] == "instance" and r1["best_lcp"] > 0.05 and r1["candidates_verified"] > 1000  # decayed class probabilities (Q8) keep instance-mode scores low
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    env2 = dict(env, STOCS_BENCH_REHEARSAL="1")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "tools", "trials.py"), "--trials", "6", "--seed", "3"],
+                         capture_output=True, text=True, timeout=900, env=env2, cwd=ROOT)
+    assert two.returncode == 0, two.stderr[-3000:]
+    r2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert r2["n_gpus"] == 2 and r2["rehearsal"] is True
+    assert (r2["best_lcp"], r2["best_trial"], r2["best_candidate"]) == (r1["best_lcp"], r1["best_trial"], r1["best_candidate"])
+    assert r2["best_pose_row_major_3x4"] == r1["best_pose_row_major_3x4"] and r2["candidates_verified"] == r1["candidates_verified"]

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Config 4 of BASELINE.json: T independent StoCS trial streams (each a full run: 100 base attempts ->
+congruent sets -> <= 200 transforms per base -> verification) sharded over the ranks, one process per
+GPU, combined by ONE 8-byte RCCL max all-reduce of the packed (score, trial, candidate) key and a
+64-byte broadcast of the winner's pose.  Instance-mode sampling (edge map present) is sequential inside a
+trial, so sharding is across trials.
+
+  python tools/trials.py --example packed_dove --trials 64
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/trials.py --trials 64
+(STOCS_BENCH_REHEARSAL=1 lets several ranks share GPU 0 over gloo -- rehearsal of the code path only.)"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--example", default="packed_dove")
+    ap.add_argument("--trials", type=int, default=64)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--bases", type=int, default=100)
+    ap.add_argument("--max-sets", type=int, default=200)
+    args = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    rehearsal = os.environ.get("STOCS_BENCH_REHEARSAL") == "1"
+    import torch
+    import torch.distributed as dist
+    if rehearsal:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo") if rehearsal else dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from model_matching_amd import dist as sd
+    from model_matching_amd.estimator import StocsEstimator
+    d = np.load(os.path.join(ROOT, "tests", "golden", "example_%s.npz" % args.example))
+    cloud = (d["scene_pos"], d["scene_nrm"], d["scene_prob"], d["scene_pixel"], d["model_pos"], d["model_nrm"])
+    mode = 1 if "edge_map" in d.files else 0
+    lo, hi = sd.shard_range(args.trials, rank, world)
+    best = (0.0, -1, None)
+    n_cand = 0
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(lo, hi):
+        est = StocsEstimator(*cloud, build_index=True, device=local_rank)   # fresh class prior per trial (instance mode decays it)
+        if mode:
+            est.set_edge_map(d["edge_map"])
+        est.sample_bases(args.seed + t, args.bases, mode=mode, dispersion=0.9)
+        est.find_congruent_all()
+        n_cand += est.make_transforms(args.max_sets, args.seed + t)
+        lcp, idx, pose = est.compute_best_transform()
+        if idx >= 0 and lcp > best[0]:
+            best = (lcp, (t << 16) | idx, pose.copy())
+        est.close()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    dev = "cpu" if rehearsal or world == 1 else "cuda"
+    g_lcp, g_id = sd.allreduce_best(best[0], best[1] if best[1] >= 0 else 0, device=dev)
+    owner = 0
+    if world > 1:
+        mine = torch.tensor([rank if (best[1] == g_id and g_id >= 0) else -1], dtype=torch.int64, device=dev)
+        dist.all_reduce(mine, op=dist.ReduceOp.MAX)
+        owner = max(int(mine.item()), 0)
+        tt = torch.tensor([dt, float(n_cand)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0].item())
+        cc = torch.tensor([float(n_cand)], dtype=torch.float64, device=dev)
+        dist.all_reduce(cc, op=dist.ReduceOp.SUM)
+        n_cand = int(cc.item())
+    pose = sd.broadcast_pose(best[2] if (rank == owner and best[2] is not None) else np.zeros(16, np.float32), owner, device=dev)
+    if rank == 0:
+        print(json.dumps({"example": args.example, "mode": "instance" if mode else "class", "trials": args.trials, "n_gpus": world, "rehearsal": rehearsal,
+                          "seconds": dt, "trials_per_s": args.trials / dt, "candidates_verified": n_cand, "candidates_per_s": n_cand / dt,
+                          "best_lcp": g_lcp, "best_trial": (g_id >> 16) if g_id >= 0 else -1, "best_candidate": (g_id & 0xFFFF) if g_id >= 0 else -1,
+                          "best_pose_row_major_3x4": [float(pose.reshape(4, 4).T[r, c]) for r in range(3) for c in range(4)]}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
