@@ -44,7 +44,7 @@ struct LcpArgs {
 #define DPP_HALF_MIRROR 0x141 /* lane k <-> 7-k inside each group of 8 */
 #define DPP_ROW_SHR(n) (0x110 + (n))
 
-template <bool DETAIL, int ABL = 0, bool CHUNK8 = false>
+template <bool DETAIL, int ABL = 0>
 __global__ __launch_bounds__(256) void lcp_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
                                                   int n, int32_t* __restrict__ hit_out, uint8_t* __restrict__ cnt_out) {
     const int lane = threadIdx.x & 63;
@@ -73,29 +73,12 @@ __global__ __launch_bounds__(256) void lcp_kernel(LcpArgs a, const float* __rest
                 const uint4 cw = a.cells[(size_t)brick * 512 + (((cz & 7) << 6) | ((cy & 7) << 3) | (cx & 7))];
                 if (ABL == 3) { acc += (float)(cw.x + cw.y); continue; }
                 float bd = a.sq_eps;
-                if (CHUNK8) {
-                    // lists are padded to multiples of 8 with far-away sentinels: 8 independent
-                    // 16-byte loads in flight per chunk instead of one dependent round trip per entry
-                    const float4* lp = a.list + cw.x;
-                    for (uint32_t k = 0; k < cw.y; k += 8, lp += 8) {
-                        float4 e[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) e[u] = lp[u];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const float dx = qx - e[u].x, dy = qy - e[u].y, dz = qz - e[u].z;
-                            const float d = dx * dx + (dy * dy + dz * dz);
-                            if (d <= bd) { bd = d; best = __float_as_int(e[u].w); }
-                        }
-                    }
-                } else {
                 for (uint32_t k = 0; k < cw.y; ++k) {
                     // ABL 5: timing-only, every lane reads the same few lines (cost of the gather itself)
                     const float4 s = (ABL == 5) ? a.list[(cw.x & 8u) + k] : a.list[cw.x + k];
                     const float dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
                     const float d = dx * dx + (dy * dy + dz * dz);
                     if (d <= bd) { bd = d; best = __float_as_int(s.w); }  // inclusive radius (kdtree.h:424)
-                }
                 }
             }
         }
@@ -261,7 +244,7 @@ __global__ __launch_bounds__(256) void lcp_coop_kernel(LcpArgs a, const float* _
 // normal test runs on full wavefronts.  Lane <-> point assignment of the accumulation differs from v0,
 // so scores agree with v0 to rounding (1e-7), not bitwise; still run-to-run deterministic.
 // ---------------------------------------------------------------------------------------------
-template <bool DETAIL, int UNR, bool SORTQ = false>
+template <bool DETAIL, int UNR, bool SORTQ = false, int PIPE = 4>
 __global__ __launch_bounds__(256) void lcp_coopq_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
                                                         int n, int32_t* __restrict__ hit_out, uint8_t* __restrict__ cnt_out) {
     __shared__ float4 qt[4][128];     // qx, qy, qz, bits(list offset)
@@ -296,37 +279,56 @@ __global__ __launch_bounds__(256) void lcp_coopq_kernel(LcpArgs a, const float* 
             if (lane < nq) ord[w][pos] = (uint8_t)lane;
             __builtin_amdgcn_wave_barrier();
         }
-        for (int s = 0; s < nq; s += 8) {
-            const int slot = s + grp;
-            const bool gact = slot < nq;
-            const int idx = (head + (SORTQ ? (int)ord[w][gact ? slot : 0] : slot)) & 127;
-            const float4 qq = qt[w][idx];
-            const uint32_t c = gact ? qn[w][idx] : 0u;
-            const float4* lp = a.list + (uint32_t)__float_as_int(qq.w) + sub;
-            float gd = a.sq_eps;
-            int gi = -1;
-            for (uint32_t k = 0; __any(k < c); k += 8 * UNR) {
-                float4 e[UNR];
+        // PIPE query-steps are in flight together: their first 128-byte list lines (most lists are a single
+        // line) are requested back to back, so one memory round trip serves PIPE*8 queries
+        for (int s0 = 0; s0 < nq; s0 += 8 * PIPE) {
+            float4 e0[PIPE];
+            int idxs[PIPE];
+            uint32_t cs[PIPE];
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    e[u] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(-1));
-                    if (k + 8 * u < c) e[u] = lp[k + 8 * u];
-                }
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const float dx = qq.x - e[u].x, dy = qq.y - e[u].y, dz = qq.z - e[u].z;
-                    const float d = dx * dx + (dy * dy + dz * dz);
-                    if (d <= gd) { gd = d; gi = __float_as_int(e[u].w); }
-                }
+            for (int u = 0; u < PIPE; ++u) {
+                const int slot = s0 + 8 * u + grp;
+                const bool gact = slot < nq;
+                idxs[u] = (head + (SORTQ ? (int)ord[w][gact ? slot : 0] : slot)) & 127;
+                cs[u] = gact ? qn[w][idxs[u]] : 0u;
+                e0[u] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(-1));
+                if (cs[u]) e0[u] = a.list[(uint32_t)__float_as_int(qt[w][idxs[u]].w) + sub];
             }
-            float dm = fminf(gd, dpp_f32<DPP_QUAD_XOR1>(gd));
-            dm = fminf(dm, dpp_f32<DPP_QUAD_XOR2>(dm));
-            dm = fminf(dm, dpp_f32<DPP_HALF_MIRROR>(dm));
-            int im = (gd == dm) ? gi : -1;
-            im = max(im, dpp_i32<DPP_QUAD_XOR1>(im));
-            im = max(im, dpp_i32<DPP_QUAD_XOR2>(im));
-            im = max(im, dpp_i32<DPP_HALF_MIRROR>(im));
-            if (gact && sub == 0) ri[w][idx] = im;
+#pragma unroll
+            for (int u = 0; u < PIPE; ++u) {
+                const float4 qq = qt[w][idxs[u]];
+                const uint32_t c = cs[u];
+                const float4* lp = a.list + (uint32_t)__float_as_int(qq.w) + sub;
+                float gd = a.sq_eps;
+                int gi = -1;
+                {
+                    const float dx = qq.x - e0[u].x, dy = qq.y - e0[u].y, dz = qq.z - e0[u].z;
+                    const float d = dx * dx + (dy * dy + dz * dz);
+                    if (d <= gd) { gd = d; gi = __float_as_int(e0[u].w); }
+                }
+                for (uint32_t k = 8; __any(k < c); k += 8 * UNR) {
+                    float4 e[UNR];
+#pragma unroll
+                    for (int v = 0; v < UNR; ++v) {
+                        e[v] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(-1));
+                        if (k + 8 * v < c) e[v] = lp[k + 8 * v];
+                    }
+#pragma unroll
+                    for (int v = 0; v < UNR; ++v) {
+                        const float dx = qq.x - e[v].x, dy = qq.y - e[v].y, dz = qq.z - e[v].z;
+                        const float d = dx * dx + (dy * dy + dz * dz);
+                        if (d <= gd) { gd = d; gi = __float_as_int(e[v].w); }
+                    }
+                }
+                float dm = fminf(gd, dpp_f32<DPP_QUAD_XOR1>(gd));
+                dm = fminf(dm, dpp_f32<DPP_QUAD_XOR2>(dm));
+                dm = fminf(dm, dpp_f32<DPP_HALF_MIRROR>(dm));
+                int im = (gd == dm) ? gi : -1;
+                im = max(im, dpp_i32<DPP_QUAD_XOR1>(im));
+                im = max(im, dpp_i32<DPP_QUAD_XOR2>(im));
+                im = max(im, dpp_i32<DPP_HALF_MIRROR>(im));
+                if (c && sub == 0) ri[w][idxs[u]] = im;
+            }
         }
         __builtin_amdgcn_wave_barrier();
         if (lane < nq) {
@@ -411,286 +413,6 @@ __global__ __launch_bounds__(256) void lcp_coopq_kernel(LcpArgs a, const float* 
     if (lane == 0) out[cand] = acc / (float)a.M;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Variant 3 ("queue"): the profile of v0 (rocprofv3 counters + stage ablation, profiles/) shows the
-// cost is the list-scan gather INSTRUCTIONS: a divergent 16-byte gather costs ~16-21 CU clocks at the
-// L1 whether 64 or 18 lanes are active, and only ~28 % of the queries land in a non-empty cell.
-// So queries with a non-empty cell are deferred into a per-wave LDS ring (ballot + mbcnt compaction)
-// and their lists are scanned 64 at a time with every lane busy; empty-cell queries never reach the
-// scan.  Same per-query arithmetic and tie rule as v0 (smallest d^2, then largest scene index).
-// ---------------------------------------------------------------------------------------------
-template <bool DETAIL, int NCLS>
-__global__ __launch_bounds__(256) void lcp_queue_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
-                                                        int n, int32_t* __restrict__ hit_out, uint8_t* __restrict__ cnt_out) {
-    // one ring per list-length class (NCLS = 1: all; 2: <= 8 | > 8; 3: <= 4 | <= 12 | > 12), so the
-    // scan loop of a batch runs to a maximum that is close to the typical length of its class
-    __shared__ float4 q4[4][NCLS][128];     // qx, qy, qz, bits(list offset)
-    __shared__ uint32_t qc[4][NCLS][128];   // (count << 16) | model slot
-    const int lane = threadIdx.x & 63;
-    const int w = threadIdx.x >> 6;
-    const int cand = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w);
-    if (cand >= n) return;
-    const float* T = T16 + (size_t)cand * 16;
-    const float t0 = T[0], t1 = T[1], t2 = T[2], t4 = T[4], t5 = T[5], t6 = T[6], t8 = T[8], t9 = T[9], t10 = T[10],
-                t12 = T[12], t13 = T[13], t14 = T[14];
-    float acc = 0.0f;
-    int head[NCLS], tail[NCLS];  // wave-uniform ring indices (monotone; slots are taken mod 128)
-#pragma unroll
-    for (int c = 0; c < NCLS; ++c) { head[c] = 0; tail[c] = 0; }
-
-    auto process = [&](int cls, int hd, int nact) {
-        const bool act = lane < nact;
-        float qx = 0.f, qy = 0.f, qz = 0.f;
-        uint32_t off = 0, cnt = 0, slot = 0;
-        if (act) {
-            const float4 e = q4[w][cls][(hd + lane) & 127];
-            const uint32_t c = qc[w][cls][(hd + lane) & 127];
-            qx = e.x; qy = e.y; qz = e.z; off = (uint32_t)__float_as_int(e.w);
-            cnt = c >> 16; slot = c & 0xFFFFu;
-        }
-        float bd = a.sq_eps;
-        int best = -1;
-        const float4* lp = a.list + off;
-        for (uint32_t k = 0; __any(k < cnt); ++k) {
-            if (k < cnt) {
-                const float4 s = lp[k];
-                const float dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
-                const float d = dx * dx + (dy * dy + dz * dz);
-                if (d <= bd) { bd = d; best = __float_as_int(s.w); }  // inclusive radius (kdtree.h:424)
-            }
-        }
-        bool counted = false;
-        if (best >= 0) {
-            const float4 nm = a.mnrm[slot];
-            const float nx = t0 * nm.x + (t4 * nm.y + t8 * nm.z);
-            const float ny = t1 * nm.x + (t5 * nm.y + t9 * nm.z);
-            const float nz = t2 * nm.x + (t6 * nm.y + t10 * nm.z);
-            const float4 sn = a.snrmw[best];
-            const float d = sn.x * nx + (sn.y * ny + sn.z * nz);
-            counted = (d >= a.dot_lo) && (d <= 1.0f);
-            if (counted) acc += sn.w;
-        }
-        if (DETAIL && act) {
-            const int orig = a.mperm[slot];
-            hit_out[(size_t)cand * a.M + orig] = best;
-            cnt_out[(size_t)cand * a.M + orig] = counted ? 1 : 0;
-        }
-    };
-
-    for (int base = 0; base < a.M; base += 64) {
-        const int i = base + lane;
-        float qx = 0.f, qy = 0.f, qz = 0.f;
-        uint32_t off = 0, cnt = 0;
-        if (i < a.M) {
-            const float4 p = a.mpos[i];
-            qx = ((t0 * p.x + t4 * p.y) + t8 * p.z) + t12;
-            qy = ((t1 * p.x + t5 * p.y) + t9 * p.z) + t13;
-            qz = ((t2 * p.x + t6 * p.y) + t10 * p.z) + t14;
-            const float fx = floorf((qx - a.ox) * a.inv_h);
-            const float fy = floorf((qy - a.oy) * a.inv_h);
-            const float fz = floorf((qz - a.oz) * a.inv_h);
-            if (fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float)a.nx && fy < (float)a.ny && fz < (float)a.nz) {
-                const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
-                const int brick = a.top[((cz >> 3) * a.nby + (cy >> 3)) * a.nbx + (cx >> 3)];
-                if (brick >= 0) {
-                    const uint4 cw = a.cells[(size_t)brick * 512 + (((cz & 7) << 6) | ((cy & 7) << 3) | (cx & 7))];
-                    off = cw.x; cnt = cw.y;
-                }
-            }
-            if (DETAIL && cnt == 0) {
-                const int orig = a.mperm[i];
-                hit_out[(size_t)cand * a.M + orig] = -1;
-                cnt_out[(size_t)cand * a.M + orig] = 0;
-            }
-        }
-        if (__ballot(cnt != 0) == 0ull) continue;
-#pragma unroll
-        for (int c = 0; c < NCLS; ++c) {
-            bool mine = cnt != 0;
-            if (NCLS == 2) mine = mine && (c == 0 ? cnt <= 8u : cnt > 8u);
-            if (NCLS == 3) mine = mine && (c == 0 ? cnt <= 4u : (c == 1 ? (cnt > 4u && cnt <= 12u) : cnt > 12u));
-            const unsigned long long mask = __ballot(mine);
-            if (mask) {
-                if (mine) {
-                    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-                    const int sl = (tail[c] + rank) & 127;
-                    q4[w][c][sl] = make_float4(qx, qy, qz, __int_as_float((int)off));
-                    qc[w][c][sl] = (cnt << 16) | (uint32_t)i;
-                }
-                tail[c] += __popcll(mask);
-                __builtin_amdgcn_wave_barrier();
-                if (tail[c] - head[c] >= 64) {
-                    process(c, head[c], 64);
-                    head[c] += 64;
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < NCLS; ++c)
-        if (tail[c] - head[c] > 0) process(c, head[c], tail[c] - head[c]);
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (lane == 0) out[cand] = acc / (float)a.M;
-}
-
-// ---- DPP helpers (pure VALU cross-lane moves; ds_bpermute/__shfl go through the LDS pipeline) ----
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
-}
-// minimum of a 64-bit key over each aligned group of 8 lanes; every lane gets the result
-__device__ __forceinline__ unsigned long long group8_min_u64(unsigned long long k) {
-    uint32_t lo = (uint32_t)k, hi = (uint32_t)(k >> 32);
-#define STOCS_MIN_STEP(CTRL)                                                         \
-    {                                                                                \
-        const uint32_t olo = dpp_u32<CTRL>(lo), ohi = dpp_u32<CTRL>(hi);             \
-        const bool take = (ohi < hi) || (ohi == hi && olo < lo);                     \
-        lo = take ? olo : lo;                                                        \
-        hi = take ? ohi : hi;                                                        \
-    }
-    STOCS_MIN_STEP(DPP_QUAD_XOR1)
-    STOCS_MIN_STEP(DPP_QUAD_XOR2)
-    STOCS_MIN_STEP(DPP_HALF_MIRROR)
-#undef STOCS_MIN_STEP
-    return ((unsigned long long)hi << 32) | lo;
-}
-// inclusive prefix sum over the 64 lanes: row-local Hillis-Steele with row_shr (zero fill), then the
-// three row totals through readlane
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
-    v += dpp_u32<DPP_ROW_SHR(1)>(v);
-    v += dpp_u32<DPP_ROW_SHR(2)>(v);
-    v += dpp_u32<DPP_ROW_SHR(4)>(v);
-    v += dpp_u32<DPP_ROW_SHR(8)>(v);
-    const uint32_t t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
-    const int row = lane >> 4;
-    return v + (row >= 1 ? t0 : 0u) + (row >= 2 ? t1 : 0u) + (row >= 3 ? t2 : 0u);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Variant 4 ("chunk items"): measured facts behind it (profiles/r01_lcp_analysis.md): the texture
-// addresser is ~100 % busy in v0; a wave-level gather costs ~16-20 TA clocks however few lanes are
-// active; ~28 % of the lanes of a step have a list, list lengths are skewed (avg 6, max 39 at Cm).
-// So a step's list work is flattened into (query, 8-entry chunk) items: hit lanes publish their
-// query and their items in LDS, every 8-lane group takes one item and reads one whole 128-byte line
-// of the (8-padded) list, reduces (d^2, index) inside the group and merges per query with a 64-bit
-// LDS atomicMin on the packed key  d^2 bits << 32 | (0xFFFFFFFF - index)  (= smallest d^2, then
-// largest index: the tie rule of v0).  Same lane -> point assignment as v0 => bitwise equal scores.
-// ---------------------------------------------------------------------------------------------
-template <bool DETAIL, int UNR>
-__global__ __launch_bounds__(256) void lcp_items_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
-                                                        int n, int32_t* __restrict__ hit_out, uint8_t* __restrict__ cnt_out) {
-    __shared__ float4 qt[4][64];                  // per lane: qx, qy, qz, bits(list offset)
-    __shared__ unsigned long long res[4][64];     // per lane: packed best
-    __shared__ uint32_t wq[4][512];               // items: lane << 4 | chunk   (<= 8 chunks per lane)
-    const int lane = threadIdx.x & 63;
-    const int sub = lane & 7, grp = lane >> 3;
-    const int w = threadIdx.x >> 6;
-    const int cand = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w);
-    if (cand >= n) return;
-    const float* T = T16 + (size_t)cand * 16;
-    const float t0 = T[0], t1 = T[1], t2 = T[2], t4 = T[4], t5 = T[5], t6 = T[6], t8 = T[8], t9 = T[9], t10 = T[10],
-                t12 = T[12], t13 = T[13], t14 = T[14];
-    const unsigned long long NONE = ~0ull;
-    float acc = 0.0f;
-    for (int base = 0; base < a.M; base += 64) {
-        const int i = base + lane;
-        float qx = 0.f, qy = 0.f, qz = 0.f;
-        uint32_t off = 0, cnt = 0;
-        if (i < a.M) {
-            const float4 p = a.mpos[i];
-            qx = ((t0 * p.x + t4 * p.y) + t8 * p.z) + t12;
-            qy = ((t1 * p.x + t5 * p.y) + t9 * p.z) + t13;
-            qz = ((t2 * p.x + t6 * p.y) + t10 * p.z) + t14;
-            const float fx = floorf((qx - a.ox) * a.inv_h);
-            const float fy = floorf((qy - a.oy) * a.inv_h);
-            const float fz = floorf((qz - a.oz) * a.inv_h);
-            if (fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float)a.nx && fy < (float)a.ny && fz < (float)a.nz) {
-                const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
-                const int brick = a.top[((cz >> 3) * a.nby + (cy >> 3)) * a.nbx + (cx >> 3)];
-                if (brick >= 0) {
-                    const uint4 cw = a.cells[(size_t)brick * 512 + (((cz & 7) << 6) | ((cy & 7) << 3) | (cx & 7))];
-                    off = cw.x; cnt = cw.y;
-                }
-            }
-        }
-        const uint32_t nch_all = (cnt + 7u) >> 3;
-        const uint32_t nch = nch_all < 8u ? nch_all : 8u;
-        // inclusive wave scan of the item counts
-        const uint32_t incl = wave_incl_scan_u32(nch, lane);
-        const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-        int best = -1;
-        if (total) {
-            if (nch) {
-                qt[w][lane] = make_float4(qx, qy, qz, __int_as_float((int)off));
-                res[w][lane] = NONE;
-                const uint32_t excl = incl - nch;
-                for (uint32_t c = 0; c < nch; ++c) wq[w][excl + c] = ((uint32_t)lane << 4) | c;
-            }
-            __builtin_amdgcn_wave_barrier();
-            // UNR item-steps per trip: all their list loads are issued before the first reduction,
-            // so one L2 round trip covers UNR*8 items
-            for (uint32_t t0i = 0; t0i < total; t0i += 8 * UNR) {
-                float4 e[UNR], qq[UNR];
-                uint32_t L[UNR];
-                bool act[UNR];
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const uint32_t t = t0i + u * 8 + grp;
-                    act[u] = t < total;
-                    const uint32_t item = act[u] ? wq[w][t] : 0u;
-                    L[u] = item >> 4;
-                    qq[u] = qt[w][L[u]];
-                    e[u] = make_float4(1e30f, 1e30f, 1e30f, 0.f);
-                    if (act[u]) e[u] = a.list[(uint32_t)__float_as_int(qq[u].w) + ((item & 15u) << 3) + sub];
-                }
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    unsigned long long key = NONE;
-                    const float dx = qq[u].x - e[u].x, dy = qq[u].y - e[u].y, dz = qq[u].z - e[u].z;
-                    const float d = dx * dx + (dy * dy + dz * dz);
-                    if (act[u] && d <= a.sq_eps)  // inclusive radius (kdtree.h:424); sentinels and NaN fail
-                        key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)__float_as_int(e[u].w));
-                    key = group8_min_u64(key);
-                    if (act[u] && sub == 0 && key != NONE) atomicMin(&res[w][L[u]], key);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (nch) {
-                unsigned long long r = res[w][lane];
-                float bd = a.sq_eps;
-                if (r != NONE) { best = (int)(0xFFFFFFFFu - (uint32_t)(r & 0xFFFFFFFFull)); bd = __uint_as_float((uint32_t)(r >> 32)); }
-                // lists longer than 64 entries (never at 5 mm voxels): the owner finishes alone
-                for (uint32_t k = 64; k < cnt; ++k) {
-                    const float4 e = a.list[off + k];
-                    const float dx = qx - e.x, dy = qy - e.y, dz = qz - e.z;
-                    const float d = dx * dx + (dy * dy + dz * dz);
-                    if (d <= bd) { bd = d; best = __float_as_int(e.w); }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        bool counted = false;
-        if (best >= 0) {
-            const float4 nm = a.mnrm[i];
-            const float nx = t0 * nm.x + (t4 * nm.y + t8 * nm.z);
-            const float ny = t1 * nm.x + (t5 * nm.y + t9 * nm.z);
-            const float nz = t2 * nm.x + (t6 * nm.y + t10 * nm.z);
-            const float4 sn = a.snrmw[best];
-            const float d = sn.x * nx + (sn.y * ny + sn.z * nz);
-            counted = (d >= a.dot_lo) && (d <= 1.0f);
-            if (counted) acc += sn.w;
-        }
-        if (DETAIL && i < a.M) {
-            const int orig = a.mperm[i];
-            hit_out[(size_t)cand * a.M + orig] = best;
-            cnt_out[(size_t)cand * a.M + orig] = counted ? 1 : 0;
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (lane == 0) out[cand] = acc / (float)a.M;
-}
-
 // compute_best_transform (stocs.cpp:982-1004) on the device: max of the packed (score, ~id) keys --
 // larger score wins, lower id wins ties, non-positive scores never win.  Integer max: order independent.
 __global__ __launch_bounds__(256) void best_kernel(const float* __restrict__ lcp, int n, uint32_t id_offset, unsigned long long* __restrict__ best) {
@@ -742,9 +464,15 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
         if (variant == 12) hipLaunchKernelGGL((lcp_kernel<false, 3>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
         if (variant == 14) hipLaunchKernelGGL((lcp_kernel<false, 5>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
         if (variant == 13) hipLaunchKernelGGL((lcp_kernel<false, 4>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-    } else if (variant >= 20 && variant <= 25) {
+    } else if (variant >= 20 && variant <= 28) {
         if (d_hit)
             hipLaunchKernelGGL((lcp_coopq_kernel<true, 1, true>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
+        else if (variant == 26)
+            hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 1>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
+        else if (variant == 27)
+            hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 2>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
+        else if (variant == 28)
+            hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 8>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
         else if (variant == 24)
             hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
         else if (variant == 25)
@@ -757,29 +485,6 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
             hipLaunchKernelGGL((lcp_coopq_kernel<false, 4>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
         else
             hipLaunchKernelGGL((lcp_coopq_kernel<false, 8>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-    } else if (variant == 4 || variant == 5 || variant == 6) {
-        if (d_hit)
-            hipLaunchKernelGGL((lcp_items_kernel<true, 1>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
-        else if (variant == 4)
-            hipLaunchKernelGGL((lcp_items_kernel<false, 1>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-        else if (variant == 5)
-            hipLaunchKernelGGL((lcp_items_kernel<false, 2>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-        else
-            hipLaunchKernelGGL((lcp_items_kernel<false, 4>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-    } else if (variant == 3 || variant == 7 || variant == 8) {
-        if (d_hit)
-            hipLaunchKernelGGL((lcp_queue_kernel<true, 2>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
-        else if (variant == 3)
-            hipLaunchKernelGGL((lcp_queue_kernel<false, 1>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-        else if (variant == 7)
-            hipLaunchKernelGGL((lcp_queue_kernel<false, 2>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-        else
-            hipLaunchKernelGGL((lcp_queue_kernel<false, 3>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-    } else if (variant == 2) {
-        if (d_hit)
-            hipLaunchKernelGGL((lcp_kernel<true, 0, true>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
-        else
-            hipLaunchKernelGGL((lcp_kernel<false, 0, true>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
     } else if (variant == 0) {
         if (d_hit)
             hipLaunchKernelGGL((lcp_kernel<true, 0>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);

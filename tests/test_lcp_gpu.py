@@ -140,7 +140,7 @@ def test_dense_scene_and_all_scan_variants(oracle_lib):
     assert np.abs(got - ref).max() <= LCP_TOL and got.max() > 0.05
     best = int(np.argmax(ref))
     ho, co = orc.lcp_detail(T[best])
-    for v in (0, 1, 9, 15, 16, 20, 21, 22, 3, 7, 4, 5):
+    for v in (0, 1, 9, 15, 16, 17, 20, 21, 22, 24, 25, 26, 27, 28):
         est.set_option("lcp_variant", v)
         gv = est.score_transforms(T)
         assert np.abs(gv - ref).max() <= LCP_TOL, v
