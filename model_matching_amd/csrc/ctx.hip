@@ -350,6 +350,7 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     c->best_lcp = 0; c->best_index = -1;
     c->has_edge = false;
     c->grid_div = 1;
+    c->lcp_variant = -1;
     memset(&c->grid, 0, sizeof(c->grid));
     c->d_spos = c->d_snrmw = c->d_mpos = c->d_mnrm = c->d_munit = c->d_mpos_raw = c->d_mpos_s = c->d_mnrm_s = NULL;
     c->d_spix = NULL; c->d_mperm = NULL;

@@ -439,7 +439,6 @@ static int lcp_variant() {
     }
     return v;
 }
-int g_lcp_variant_override = -1;
 
 int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d_hit, uint8_t* d_counted) {
     if (n <= 0) return STOCS_OK;
@@ -451,7 +450,7 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
     a.sq_eps = c->prm.distance_threshold * c->prm.distance_threshold;  // sq_eps = epsilon*epsilon, stocs.cpp:1014
     a.dot_lo = c->thr.lcp_dot_lo;
     const int blocks = (n + 3) / 4;
-    int variant = g_lcp_variant_override >= 0 ? g_lcp_variant_override : lcp_variant();
+    int variant = c->lcp_variant >= 0 ? c->lcp_variant : lcp_variant();
     if (variant == 99) {
         // cooperative kernel; unroll depth from the average candidate-list length of this scene
         const double avg = c->grid.avg_list_len;
@@ -586,7 +585,7 @@ int stocs_score_best_device(stocs_ctx* c, const void* d_T16, int n, void* d_lcp,
 
 int stocs_set_option(stocs_ctx* c, const char* key, int value) {
     if (!c || !key) return STOCS_ERR_INVALID;
-    if (!strcmp(key, "lcp_variant") && value >= 0 && value <= 99) { g_lcp_variant_override = value; return STOCS_OK; }
+    if (!strcmp(key, "lcp_variant") && value >= 0 && value <= 99) { c->lcp_variant = value; return STOCS_OK; }
     set_error("stocs_set_option: unknown option or value");
     return STOCS_ERR_INVALID;
 }

@@ -110,6 +110,7 @@ struct stocs_ctx {
 
     stocs::SceneGrid grid;
     int grid_div;   // cell edge = epsilon / grid_div
+    int lcp_variant;   // -1: STOCS_LCP_VARIANT or automatic; else stocs_set_option("lcp_variant")
     stocs::PpfIndex index;
 
     // image-space state of instance mode (stocs.hpp:153-155)

@@ -73,3 +73,23 @@ def test_trial_sharding_tool_single_and_two_ranks():
     assert r2["n_gpus"] == 2 and r2["rehearsal"] is True
     assert (r2["best_lcp"], r2["best_trial"], r2["best_candidate"]) == (r1["best_lcp"], r1["best_trial"], r1["best_candidate"])
     assert r2["best_pose_row_major_3x4"] == r1["best_pose_row_major_3x4"] and r2["candidates_verified"] == r1["candidates_verified"]
+
+
+@pytest.mark.gpu
+def test_stocs_single_instance_mode_on_packed_dove(tmp_path):
+    """edge map present -> the driver takes the sample_instance_base path (stocs_match_one_object.cpp:90)."""
+    from model_matching_amd import cloudio
+    d = np.load(os.path.join(ROOT, "tests", "golden", "example_packed_dove.npz"))
+    cloudio.write_stcl(tmp_path / "scene.stcl", d["scene_pos"], d["scene_nrm"], d["scene_prob"], d["scene_pixel"])
+    cloudio.write_stcl(tmp_path / "model.stcl", d["model_pos"], d["model_nrm"])
+    d["edge_map"].astype(np.uint8).tofile(tmp_path / "edge.u8")
+    out = tmp_path / "pose.txt"
+    r = subprocess.run([APP, str(tmp_path / "scene.stcl"), str(tmp_path / "model.stcl"), "--edge", str(tmp_path / "edge.u8"), "--seed", "5",
+                        "--out", str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Sampled " in r.stdout and "Transforms to verify: " in r.stdout
+    n_tf = int(r.stdout.split("Transforms to verify: ")[1].split()[0])
+    score = float(r.stdout.split("maximum score: ")[1].split()[0])
+    assert n_tf > 500 and score > 0.03
+    P = np.array(out.read_text().split(), float).reshape(3, 4)
+    assert abs(np.linalg.det(P[:, :3]) - 1.0) < 1e-3 and 0.2 < P[2, 3] < 1.5      # a rotation, in front of the camera
