@@ -76,6 +76,11 @@ int stocs_get_sizes(const stocs_ctx* ctx, int* nS, int* nM);
 /* edge map (png values, image_height*image_width bytes): presence switches the driver to
  * sample_instance_base, as the stat() of probability_maps/edge.png does (stocs_match_one_object.cpp:90) */
 int stocs_set_edge_map(stocs_ctx* ctx, const uint8_t* edge);
+/* start a new trial stream on the same scene: restores the class probabilities given at construction
+ * (instance-mode sampling decays them in place, stocs.cpp:572-580) and clears the segmentation state,
+ * bases, quads and candidates.  Equivalent to constructing a new estimator, without rebuilding the grid
+ * and the index. */
+int stocs_reset_trial(stocs_ctx* ctx);
 
 /* ---- PPF index queries: replace ppf_map.find (call sites stocs.cpp:403,438,487,780,784) ---- */
 int stocs_ppf_compute_host(const float* p1, const float* n1, const float* p2, const float* n2,

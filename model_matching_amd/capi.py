@@ -46,6 +46,7 @@ SIGNATURES = {
     "stocs_get_centroids": (C.c_int, [_vp, _fp, _fp]),
     "stocs_get_sizes": (C.c_int, [_vp, _intp, _intp]),
     "stocs_set_edge_map": (C.c_int, [_vp, _u8p]),
+    "stocs_reset_trial": (C.c_int, [_vp]),
     "stocs_ppf_compute_host": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, _ip]),
     "stocs_index_exists": (C.c_int, [_vp, _ip, _intp]),
     "stocs_index_lookup": (C.c_int, [_vp, _ip, _ip, C.c_int64, _i64p]),

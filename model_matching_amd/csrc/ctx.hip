@@ -363,7 +363,7 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     c->stream = c->own_stream;
     compute_thresholds(c->prm, &c->thr);
 
-    c->h_spos.resize(nS); c->h_snrm.resize(nS); c->h_sprob.assign(sprob, sprob + nS); c->h_spix.assign((size_t)2 * nS, 0);
+    c->h_spos.resize(nS); c->h_snrm.resize(nS); c->h_sprob.assign(sprob, sprob + nS); c->h_sprob0 = c->h_sprob; c->h_spix.assign((size_t)2 * nS, 0);
     for (int i = 0; i < nS; ++i) {
         c->h_spos[i] = mk3(sp[3 * i], sp[3 * i + 1], sp[3 * i + 2]);
         c->h_snrm[i] = normalized3(mk3(sn[3 * i], sn[3 * i + 1], sn[3 * i + 2]));  // set_normal, point3d.hpp:43-45

@@ -422,6 +422,17 @@ int stocs_sample_bases(stocs_ctx* c, int mode, uint64_t seed, int first_attempt,
     return refresh_class_prob_on_device(c);
 }
 
+int stocs_reset_trial(stocs_ctx* c) {
+    if (!c) return STOCS_ERR_INVALID;
+    c->h_sprob = c->h_sprob0;
+    std::fill(c->previous_segment.begin(), c->previous_segment.end(), 0);
+    std::fill(c->segmentation_buffer.begin(), c->segmentation_buffer.end(), 0);
+    c->seg_masks.clear();
+    c->bases.clear(); c->quad_off.clear(); c->cands.clear();
+    c->best_lcp = 0; c->best_index = -1;
+    return refresh_class_prob_on_device(c);
+}
+
 int stocs_set_bases(stocs_ctx* c, int n, const int32_t* ids, const float* inv) {
     if (!c || n < 0 || (n && (!ids || !inv))) return STOCS_ERR_INVALID;
     for (int i = 0; i < 4 * n; ++i)

@@ -91,6 +91,7 @@ struct stocs_ctx {
     // host copies (centred unless stated)
     std::vector<stocs::V3> h_spos, h_snrm, h_mpos, h_mnrm, h_mpos_raw, h_munit;
     std::vector<float> h_sprob;       // class_probability_ (decays in instance mode)
+    std::vector<float> h_sprob0;      // class probabilities as given at construction (stocs_reset_trial)
     std::vector<int32_t> h_spix;      // row, col
     stocs::V3 centroid_scene, centroid_model, gcenter;
     float ratio;

@@ -55,6 +55,9 @@ class StocsEstimator:
         e = np.ascontiguousarray(edge, np.uint8)
         capi.check(self.L.stocs_set_edge_map(self.h, e.ctypes.data_as(capi._u8p)))
 
+    def reset_trial(self):
+        capi.check(self.L.stocs_reset_trial(self.h))
+
     # ---- PPF index ----
     def index_exists(self, key):
         k, pk = capi.i32(key)

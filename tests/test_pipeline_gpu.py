@@ -233,3 +233,23 @@ def test_index_file_round_trip(setup, tmp_path):
     bad.write_bytes(b"not an index")
     with pytest.raises(capi.StocsError):
         est3.index_load(bad)
+
+
+def test_reset_trial_equals_fresh_estimator(oracle_lib):
+    """stocs_reset_trial == constructing a new estimator (instance mode decays the class prior in place)."""
+    from model_matching_amd.estimator import StocsEstimator
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "example_packed_dove.npz"))
+    args = (d["scene_pos"], d["scene_nrm"], d["scene_prob"], d["scene_pixel"], d["model_pos"], d["model_nrm"])
+    est = StocsEstimator(*args, build_index=True); est.set_edge_map(d["edge_map"])
+    v1, i1, n1 = est.sample_bases(11, 20, mode=1)
+    est.find_congruent_all(); est.make_transforms(200, 11); r1 = est.compute_best_transform()
+    v2, i2, n2 = est.sample_bases(12, 20, mode=1)          # continues the same stream: decayed prior
+    est.reset_trial()
+    v3, i3, n3 = est.sample_bases(11, 20, mode=1)
+    est.find_congruent_all(); est.make_transforms(200, 11); r3 = est.compute_best_transform()
+    assert np.array_equal(v1, v3) and np.array_equal(i1[v1], i3[v3]) and np.array_equal(n1[v1], n3[v3])
+    assert r1[0] == r3[0] and r1[1] == r3[1] and np.array_equal(r1[2], r3[2])
+    fresh = StocsEstimator(*args, build_index=True); fresh.set_edge_map(d["edge_map"])
+    v4, i4, n4 = fresh.sample_bases(11, 20, mode=1)
+    assert np.array_equal(v1, v4) and np.array_equal(i1[v1], i4[v4])

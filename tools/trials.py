@@ -50,17 +50,17 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    est = StocsEstimator(*cloud, build_index=True, device=local_rank)
+    if mode:
+        est.set_edge_map(d["edge_map"])
     for t in range(lo, hi):
-        est = StocsEstimator(*cloud, build_index=True, device=local_rank)   # fresh class prior per trial (instance mode decays it)
-        if mode:
-            est.set_edge_map(d["edge_map"])
+        est.reset_trial()                                                    # fresh class prior per trial (instance mode decays it)
         est.sample_bases(args.seed + t, args.bases, mode=mode, dispersion=0.9)
         est.find_congruent_all()
         n_cand += est.make_transforms(args.max_sets, args.seed + t)
         lcp, idx, pose = est.compute_best_transform()
         if idx >= 0 and lcp > best[0]:
             best = (lcp, (t << 16) | idx, pose.copy())
-        est.close()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
