@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Copies the summaries of tools/profile_round.sh from gpurun_out/<tag>/ into profiles/ (tracked).
+usage: python tools/collect_profiles.py r01"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = os.path.join(ROOT, "gpurun_out", tag)
+    dst = os.path.join(ROOT, "profiles")
+    shutil.copy(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, "%s_final_bench_kernel_stats.csv" % tag))
+    shutil.copy(glob.glob(os.path.join(src, "pipe", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, "%s_pipeline_Cm_kernel_stats.csv" % tag))
+    shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "%s_final_bench.json" % tag))
+    out = {}
+    for d in ("fetch", "write", "sq", "tcp", "ta"):
+        f = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))[0]
+        acc = collections.defaultdict(list)
+        kern = None
+        for r in csv.DictReader(open(f)):
+            if "lcp_" in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                kern = r["Kernel_Name"].split("(")[0]
+        for k, v in acc.items():
+            out[k] = {"per_launch_mean": sum(v) / len(v), "launches": len(v)}
+        out["kernel"] = kern
+    out["note"] = ("rocprofv3 --pmc, one pass per counter group (tools/profile_round.sh); FETCH_SIZE/WRITE_SIZE in KB. gfx950 correction "
+                   "(MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 1/2 of wide reads -> x2; WRITE_SIZE exact.")
+    out["hbm_bytes_per_launch_corrected"] = (2 * out["FETCH_SIZE"]["per_launch_mean"] + out["WRITE_SIZE"]["per_launch_mean"]) * 1024
+    json.dump(out, open(os.path.join(dst, "%s_final_lcp_pmc.json" % tag), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
