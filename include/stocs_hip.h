@@ -152,6 +152,16 @@ int stocs_best_device(stocs_ctx* ctx, const void* d_lcp, int n, uint32_t id_offs
 uint64_t stocs_pack_best(float lcp, uint32_t global_candidate_id);
 void stocs_unpack_best(uint64_t key, float* lcp, uint32_t* global_candidate_id);
 
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI (librccl is opened lazily).  The path has a single
+ * exchange: the arg-max of compute_best_transform across ranks. ---- */
+typedef struct stocs_comm stocs_comm;
+int stocs_comm_unique_id(void* id128);                       /* rank 0: 128-byte ncclUniqueId to hand to the others */
+int stocs_comm_create(const void* id128, int nranks, int rank, int device, stocs_comm** out);
+int stocs_comm_destroy(stocs_comm* comm);
+/* in: this rank's packed key (0 = none) and pose; out: the global maximum and the winner's pose.
+ * Global ids must satisfy id / ids_per_rank == owning rank. */
+int stocs_allreduce_best(stocs_comm* comm, void* hip_stream, uint64_t* key_inout, float* pose16_inout, uint32_t ids_per_rank);
+
 /* ---- pose post-processing: clustering::greedy_clustering (pose_clustering.cpp:79-121), host ---- */
 int stocs_cluster_poses(const float* poses16, const float* lcp, int n, float acceptable_fraction,
                         float best_score, int maximum_pose_count, float min_distance, float min_angle,

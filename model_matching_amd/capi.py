@@ -73,6 +73,10 @@ SIGNATURES = {
     "stocs_best_device": (C.c_int, [_vp, _vp, C.c_int, C.c_uint32, C.POINTER(C.c_uint64)]),
     "stocs_pack_best": (C.c_uint64, [C.c_float, C.c_uint32]),
     "stocs_unpack_best": (None, [C.c_uint64, _fp, C.POINTER(C.c_uint32)]),
+    "stocs_comm_unique_id": (C.c_int, [_vp]),
+    "stocs_comm_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "stocs_comm_destroy": (C.c_int, [_vp]),
+    "stocs_allreduce_best": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint64), _fp, C.c_uint32]),
     "stocs_cluster_poses": (C.c_int, [_fp, _fp, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, _fp, _ip, C.c_int, _intp]),
     "stocs_ingest_scene": (C.c_int, [C.POINTER(Camera), C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.c_float, C.c_float, C.c_int, _fp, _fp, _fp, _ip, C.c_int, _intp]),
     "stocs_preprocess_model": (C.c_int, [_fp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, _fp, _fp, C.c_int, _intp]),

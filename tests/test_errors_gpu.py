@@ -101,3 +101,28 @@ def test_degenerate_scenes():
     assert nc <= nq and (idx == -1) == (lcp == 0.0)
     if idx == -1:
         assert not pose.any()
+
+
+def test_native_rccl_allreduce_single_rank():
+    """stocs_allreduce_best over RCCL with a one-rank communicator (the only size a one-GPU box allows):
+    the key and pose come back unchanged; the all-zero key means "no pose" (Q18)."""
+    from model_matching_amd import capi
+    L = capi.load()
+    uid = (C.c_char * 128)()
+    assert L.stocs_comm_unique_id(uid) == 0, L.stocs_last_error()
+    comm = C.c_void_p()
+    assert L.stocs_comm_create(uid, 1, 0, 0, C.byref(comm)) == 0, L.stocs_last_error()
+    key = C.c_uint64(L.stocs_pack_best(C.c_float(0.375), 1234))
+    pose = np.arange(16, dtype=np.float32)
+    p2 = pose.copy()
+    assert L.stocs_allreduce_best(comm, None, C.byref(key), p2.ctypes.data_as(capi._fp), 65536) == 0, L.stocs_last_error()
+    s, i = C.c_float(), C.c_uint32()
+    L.stocs_unpack_best(key.value, C.byref(s), C.byref(i))
+    assert (s.value, i.value) == (0.375, 1234) and np.array_equal(p2, pose)
+    key = C.c_uint64(0)
+    assert L.stocs_allreduce_best(comm, None, C.byref(key), p2.ctypes.data_as(capi._fp), 65536) == 0
+    assert key.value == 0 and not p2.any()
+    key = C.c_uint64(L.stocs_pack_best(C.c_float(0.5), 70000))      # id maps to rank 1 of a 1-rank job
+    assert L.stocs_allreduce_best(comm, None, C.byref(key), p2.ctypes.data_as(capi._fp), 65536) == -1
+    assert L.stocs_comm_destroy(comm) == 0
+    assert L.stocs_comm_create(uid, 2, 5, 0, C.byref(comm)) == -1   # rank out of range
