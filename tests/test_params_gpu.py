@@ -1,0 +1,113 @@
+"""Differential tests of the whole pipeline against the oracle under NON-default parameters and at the
+full size of the metric configuration (phases 1-3; the LCP kernel is covered at full size in
+test_lcp_gpu.py).  Integer / index outputs bit-exact, transforms bit-exact, scores within 1e-5."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+LCP_TOL = 1e-5
+
+
+def _pair(workload, **prm):
+    from model_matching_amd import capi, synth
+    from model_matching_amd.estimator import StocsEstimator
+    from oracle import pyoracle
+    m, s, k = synth.workload(workload)
+    gp = capi.default_params(**prm)
+    op = pyoracle.default_params(**{k_: v for k_, v in prm.items() if k_ != "lcp_normal_angle"})
+    est = StocsEstimator(s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm, params=gp, build_index=True)
+    orc = pyoracle.Oracle(s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm, params=op)
+    return m, s, est, orc
+
+
+@pytest.mark.parametrize("prm", [
+    dict(distance_threshold=0.008, ppf_tr_discretization=10, ppf_rot_discretization=10),
+    dict(distance_threshold=0.003, ppf_tr_discretization=4, ppf_rot_discretization=6, plane_threshold=0.03, min_distance_base=0.02),
+    dict(internal_angle_threshold=20.0, ppf_tr_discretization=5, ppf_rot_discretization=15),
+])
+def test_pipeline_with_other_parameters(prm):
+    from model_matching_amd import synth
+    m, s, est, orc = _pair("tiny", **prm)
+    seed = 31
+    valid, ids, inv = est.sample_bases(seed, 40)
+    n_ok = 0
+    for a in range(40):
+        ok, oi, ov = orc.sample_class_base(seed, a)
+        assert ok == bool(valid[a]), (prm, a)
+        if ok:
+            assert np.array_equal(oi, ids[a]) and np.array_equal(ov, inv[a]), (prm, a)
+            n_ok += 1
+    total = est.find_congruent_all()
+    slot, tot_o = 0, 0
+    for a in range(40):
+        if not valid[a]:
+            continue
+        qo = orc.find_congruent(ids[a], float(inv[a][0]), float(inv[a][1]))
+        qg = est.get_quads(slot); slot += 1
+        assert np.array_equal(qo, qg), (prm, a, qo.shape, qg.shape)
+        tot_o += len(qo)
+        for q in qo[:3]:
+            oko, To, Po = orc.rigid_transform(ids[a], q)
+            okg, Tg, Pg = est.get_rigid_transform_from_congruent_pair(ids[a], q)
+            assert oko == okg and (not oko or (np.array_equal(To, Tg) and np.array_equal(Po, Pg)))
+    assert total == tot_o
+    cs, cm = orc.centroids()
+    T = synth.make_candidates(synth.centred_gt(s.T_gt, cs.astype(np.float64), cm.astype(np.float64)), 300)
+    assert np.abs(est.score_transforms(T) - orc.lcp_batch(T)).max() <= LCP_TOL
+    hg, cg = est.lcp_detail(T[0]); ho, co = orc.lcp_detail(T[0])
+    assert np.array_equal(hg, ho) and np.array_equal(cg, co)
+
+
+def test_phases_1_to_3_at_metric_size():
+    """Cm: 20 000-point scene, 5 000-point model (25 M indexed pairs): sampling, index queries, congruent
+    sets of two bases and their transforms against the oracle."""
+    m, s, est, orc = _pair("Cm")
+    n_pairs, n_buckets, n_keys = est.index_stats()
+    assert n_pairs == 5000 * 4999
+    seed = 1234
+    valid, ids, inv = est.sample_bases(seed, 16)
+    for a in range(16):
+        ok, oi, ov = orc.sample_class_base(seed, a)
+        assert ok == bool(valid[a]), a
+        if ok:
+            assert np.array_equal(oi, ids[a]) and np.array_equal(ov, inv[a]), a
+    assert valid.sum() >= 10
+    rng = np.random.default_rng(0)
+    nrm = None
+    for a in np.nonzero(valid)[0][:3]:
+        # the two index look-ups of this base (stocs.cpp:771-786): same pairs in the same order
+        pos = orc.scene_centred()
+        from oracle import pyoracle
+        if nrm is None:
+            nrm = pyoracle.normalize_rows(s.nrm)
+        k1 = pyoracle.ppf_compute(pos[ids[a][0]], nrm[ids[a][0]], pos[ids[a][1]], nrm[ids[a][1]])
+        lo, lg = orc.index_lookup(k1), est.index_lookup(k1)
+        assert lo.shape == lg.shape and np.array_equal(lo, lg)
+    # congruent sets: pick the two valid bases with the fewest quads to keep the oracle's std::set small
+    est.find_congruent_all()
+    counts = [(len(est.get_quads(sl)) if False else 0) for sl in range(int(valid.sum()))]
+    import ctypes as C
+    from model_matching_amd import capi
+    sizes = []
+    for sl in range(int(valid.sum())):
+        n = C.c_int64(0)
+        capi.check(est.L.stocs_get_quads(est.h, sl, None, 0, C.byref(n)))
+        sizes.append(n.value)
+    order = np.argsort(sizes)
+    slots_to_attempt = np.nonzero(valid)[0]
+    checked = 0
+    for sl in order:
+        if sizes[sl] == 0 or sizes[sl] > 1500000:
+            continue
+        a = slots_to_attempt[sl]
+        qo = orc.find_congruent(ids[a], float(inv[a][0]), float(inv[a][1]))
+        qg = est.get_quads(int(sl))
+        assert qo.shape == qg.shape and np.array_equal(qo, qg), (a, qo.shape, qg.shape)
+        for q in qo[:: max(1, len(qo) // 50)]:
+            oko, To, Po = orc.rigid_transform(ids[a], q)
+            okg, Tg, Pg = est.get_rigid_transform_from_congruent_pair(ids[a], q)
+            assert oko == okg and (not oko or (np.array_equal(To, Tg) and np.array_equal(Po, Pg)))
+        checked += 1
+        if checked == 2:
+            break
+    assert checked == 2
