@@ -187,9 +187,10 @@ int stocs_preprocess_model(const float* raw_pos3, int n_raw, float normal_radius
 
 /* ---- tuning knobs (never change results beyond float summation order): "lcp_variant"
  * 99 = automatic (default): cooperative 8-lane scan fed from an LDS queue for scenes with short
- * candidate lists, deep-unrolled cooperative scan for dense scenes; 0 = lane-per-query scan (the first
- * kernel of round 1); 1/9/15/16 = cooperative scan with 1/2/4/8 list lines in flight; 20-28 = queue
- * variants; 10-14 = timing-only ablations of the lane-per-query kernel (wrong results) ---- */
+ * candidate lists (24), centre-sorted lists with triangle-inequality early exit for dense scenes (31);
+ * 0 = lane-per-query scan (the first kernel of round 1); 1/9/15/16 = cooperative scan with 1/2/4/8 list
+ * lines in flight; 20-28 = queue variants; 30-32 = early-exit variants (dense grids only);
+ * 10-14 = timing-only ablations of the lane-per-query kernel (wrong results) ---- */
 int stocs_set_option(stocs_ctx* ctx, const char* key, int value);
 
 /* ---- stream / timing plumbing ---- */

@@ -186,6 +186,7 @@ static int build_grid_div(stocs_ctx* c, int div_in) {
     float4 sentinel; sentinel.x = sentinel.y = sentinel.z = 1.0e30f;
     { const int32_t m1 = -1; memcpy(&sentinel.w, &m1, 4); }
     int n_bricks = 0;
+    std::vector<uint64_t> brick_lin;   // brick id -> linear brick index
     uint64_t cur_brick = ~0ull, cur_key = ~0ull;
     for (size_t e = 0; e < inc.size(); ++e) {
         const uint64_t brick = inc[e].key >> 9;
@@ -193,6 +194,7 @@ static int build_grid_div(stocs_ctx* c, int div_in) {
         if (brick != cur_brick) {
             cur_brick = brick;
             top[(size_t)brick] = n_bricks++;
+            brick_lin.push_back(brick);
             uint4 z; z.x = 0; z.y = 0; z.z = 0; z.w = 0;
             cells.resize((size_t)n_bricks * 512, z);
         }
@@ -265,7 +267,38 @@ static int build_grid_div(stocs_ctx* c, int div_in) {
     }
     g.n_bricks = n_bricks;
     g.n_entries = (int64_t)list.size();
+    g.h = (float)h;
+    g.d_chunk_r = NULL;
     int rc;
+    // Dense scenes (long lists): order every list by distance from its cell centre and keep, per 8-entry
+    // chunk, a lower bound of that distance.  For a query q of the cell, |q - p| >= |p - c| - |q - c|, so the
+    // scan may stop at the first chunk whose bound exceeds sqrt(best d^2) + |q - c|.
+    if (g.avg_list_len > 16.0) {
+        std::vector<float> chunk_r(list.size() / 8, 0.0f);
+        std::vector<std::pair<double, float4> > tmp;
+        for (int bidx = 0; bidx < n_bricks; ++bidx) {
+            const uint64_t bl = brick_lin[bidx];
+            const int bx = (int)(bl % g.nbx), by = (int)((bl / g.nbx) % g.nby), bz = (int)(bl / ((uint64_t)g.nbx * g.nby));
+            for (int local = 0; local < 512; ++local) {
+                const uint4 cw = cells[(size_t)bidx * 512 + local];
+                if (!cw.y) continue;
+                const int cx = bx * 8 + (local & 7), cy = by * 8 + ((local >> 3) & 7), cz = bz * 8 + (local >> 6);
+                const double ccx = of[0] + (cx + 0.5) * h, ccy = of[1] + (cy + 0.5) * h, ccz = of[2] + (cz + 0.5) * h;
+                tmp.clear();
+                for (uint32_t k = 0; k < cw.y; ++k) {
+                    const float4 e = list[cw.x + k];
+                    const double dx = e.x - ccx, dy = e.y - ccy, dz = e.z - ccz;
+                    tmp.push_back(std::make_pair(sqrt(dx * dx + dy * dy + dz * dz), e));
+                }
+                std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<double, float4>& a, const std::pair<double, float4>& b) { return a.first < b.first; });
+                for (uint32_t k = 0; k < cw.y; ++k) {
+                    list[cw.x + k] = tmp[k].second;
+                    if ((k & 7) == 0) chunk_r[(cw.x + k) >> 3] = (float)(tmp[k].first - 2e-6);
+                }
+            }
+        }
+        if ((rc = upload(&g.d_chunk_r, chunk_r.data(), chunk_r.size()))) return rc;
+    }
     if ((rc = upload(&g.d_top, top.data(), top.size()))) return rc;
     if ((rc = upload(&g.d_cells, cells.data(), cells.size()))) return rc;
     if ((rc = upload(&g.d_list, list.data(), list.size()))) return rc;
@@ -283,7 +316,8 @@ static int build_grid(stocs_ctx* c) {
     if (rc) return rc;
     if (!e && c->grid_div == 1 && c->grid.avg_list_len > 16.0 && c->grid.n_entries * 4 < (int64_t)1 << 30) {
         (void)hipFree(c->grid.d_top); (void)hipFree(c->grid.d_cells); (void)hipFree(c->grid.d_list);
-        c->grid.d_top = NULL; c->grid.d_cells = NULL; c->grid.d_list = NULL;
+        if (c->grid.d_chunk_r) (void)hipFree(c->grid.d_chunk_r);
+        c->grid.d_top = NULL; c->grid.d_cells = NULL; c->grid.d_list = NULL; c->grid.d_chunk_r = NULL;
         rc = build_grid_div(c, 2);
     }
     return rc;
@@ -464,7 +498,7 @@ int stocs_ctx_destroy(stocs_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_spos, c->d_snrmw, c->d_spix, c->d_mpos, c->d_mnrm, c->d_munit, c->d_mpos_raw, c->d_mpos_s,
-                    c->d_mnrm_s, c->d_mperm, c->grid.d_top, c->grid.d_cells, c->grid.d_list, c->index.d_bucket_start,
+                    c->d_mnrm_s, c->d_mperm, c->grid.d_top, c->grid.d_cells, c->grid.d_list, c->grid.d_chunk_r, c->index.d_bucket_start,
                     c->index.d_pairs, c->index.d_exists, c->d_scratch, c->d_quads, c->d_quad_off, c->d_best};
     for (void* p : ptrs) if (p) hipFree(p);
     hipEventDestroy(c->ev0);

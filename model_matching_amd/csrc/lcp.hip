@@ -32,7 +32,8 @@ struct LcpArgs {
     const uint4* cells;
     const float4* list;
     const float4* snrmw;  // scene unit normal + class-probability weight
-    float ox, oy, oz, inv_h, inv_h4;
+    const float* chunk_r; // per 8-entry chunk: lower bound of |entry - cell centre| (dense scenes), else NULL
+    float ox, oy, oz, inv_h, inv_h4, h;
     int nx, ny, nz, nbx, nby;
     float sq_eps, dot_lo;
 };
@@ -44,7 +45,15 @@ struct LcpArgs {
 #define DPP_HALF_MIRROR 0x141 /* lane k <-> 7-k inside each group of 8 */
 #define DPP_ROW_SHR(n) (0x110 + (n))
 
-template <bool DETAIL, int ABL = 0>
+// candidate update: inclusive radius (kdtree.h:424), ties -> larger scene index.  When a list is stored in
+// ascending index order (IDX: every grid except the dense, centre-sorted one) `<=` implements the tie rule.
+template <bool IDX>
+__device__ __forceinline__ void take_if_better(float d, int ei, float& gd, int& gi) {
+    if (IDX) { if (d <= gd) { gd = d; gi = ei; } }
+    else { if (d < gd || (d == gd && ei > gi)) { gd = d; gi = ei; } }
+}
+
+template <bool DETAIL, int ABL = 0, bool IDX = true>
 __global__ __launch_bounds__(256) void lcp_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
                                                   int n, int32_t* __restrict__ hit_out, uint8_t* __restrict__ cnt_out) {
     const int lane = threadIdx.x & 63;
@@ -78,7 +87,7 @@ __global__ __launch_bounds__(256) void lcp_kernel(LcpArgs a, const float* __rest
                     const float4 s = (ABL == 5) ? a.list[(cw.x & 8u) + k] : a.list[cw.x + k];
                     const float dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
                     const float d = dx * dx + (dy * dy + dz * dz);
-                    if (d <= bd) { bd = d; best = __float_as_int(s.w); }  // inclusive radius (kdtree.h:424)
+                    take_if_better<IDX>(d, __float_as_int(s.w), bd, best);
                 }
             }
         }
@@ -127,7 +136,7 @@ __device__ __forceinline__ int dpp_i32(int v) {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
 
-template <bool DETAIL, int UNR, bool MASK = true>
+template <bool DETAIL, int UNR, bool MASK = true, bool EARLY = false, bool IDX = true>
 __global__ __launch_bounds__(256) void lcp_coop_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
                                                        int n, int32_t* __restrict__ hit_out, uint8_t* __restrict__ cnt_out) {
     __shared__ float4 qt[4][64];     // per lane: qx, qy, qz, bits(list offset)
@@ -135,6 +144,7 @@ __global__ __launch_bounds__(256) void lcp_coop_kernel(LcpArgs a, const float* _
     __shared__ uint32_t hl[4][64];   // compacted hit list: r-th hit lane
     __shared__ float rd[4][64];      // per lane: best d^2
     __shared__ int ri[4][64];        // per lane: best scene index
+    __shared__ float qd[4][64];      // per lane: |query - cell centre| (EARLY)
     const int lane = threadIdx.x & 63;
     const int sub = lane & 7, grp = lane >> 3;
     const int w = threadIdx.x >> 6;
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(256) void lcp_coop_kernel(LcpArgs a, const float* _
     float acc = 0.0f;
     for (int base = 0; base < a.M; base += 64) {
         const int i = base + lane;
-        float qx = 0.f, qy = 0.f, qz = 0.f;
+        float qx = 0.f, qy = 0.f, qz = 0.f, qcd = 0.f;
         uint32_t off = 0, cnt = 0;
         if (i < a.M) {
             const float4 p = a.mpos[i];
@@ -164,6 +174,11 @@ __global__ __launch_bounds__(256) void lcp_coop_kernel(LcpArgs a, const float* _
                     const int sb = ((int)((uz - fz) * 4.0f) << 4) | ((int)((uy - fy) * 4.0f) << 2) | (int)((ux - fx) * 4.0f);
                     const uint32_t mw = sb < 32 ? cw.z : cw.w;
                     off = cw.x; cnt = (!MASK || ((mw >> (sb & 31)) & 1u)) ? cw.y : 0u;
+                    if (EARLY) {
+                        const float ex = qx - (a.ox + ((float)cx + 0.5f) * a.h), ey = qy - (a.oy + ((float)cy + 0.5f) * a.h),
+                                    ez = qz - (a.oz + ((float)cz + 0.5f) * a.h);
+                        qcd = sqrtf(ex * ex + (ey * ey + ez * ez));
+                    }
                 }
             }
         }
@@ -177,6 +192,7 @@ __global__ __launch_bounds__(256) void lcp_coop_kernel(LcpArgs a, const float* _
                 hl[w][rank] = (uint32_t)lane;
                 qt[w][lane] = make_float4(qx, qy, qz, __int_as_float((int)off));
                 qn[w][lane] = cnt;
+                if (EARLY) qd[w][lane] = qcd;
             }
             __builtin_amdgcn_wave_barrier();
             for (int s = 0; s < nh; s += 8) {
@@ -188,6 +204,33 @@ __global__ __launch_bounds__(256) void lcp_coop_kernel(LcpArgs a, const float* _
                 const float4* lp = a.list + (uint32_t)__float_as_int(qq.w) + sub;
                 float gd = a.sq_eps;
                 int gi = -1;
+                if (EARLY) {
+                    // lists are sorted by distance from the cell centre: stop at the first chunk that the
+                    // triangle inequality rules out (|q - p| >= |p - c| - |q - c| > sqrt(best) for all later p)
+                    const float qcg = qd[w][L];
+                    const uint32_t chunk0 = (uint32_t)__float_as_int(qq.w) >> 3;
+                    uint32_t nchunks = (c + 7u) >> 3;
+                    float gb = a.sq_eps;   // best d^2 of the whole group so far
+                    for (uint32_t j = 0; __any(j < nchunks); j += UNR) {
+                        if (j < nchunks && j > 0 && a.chunk_r[chunk0 + j] - qcg > sqrtf(gb) + 2e-6f) nchunks = 0;
+                        float4 e[UNR];
+#pragma unroll
+                        for (int u = 0; u < UNR; ++u) {
+                            e[u] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(-1));
+                            if (j + u < nchunks) e[u] = lp[(j + u) << 3];
+                        }
+#pragma unroll
+                        for (int u = 0; u < UNR; ++u) {
+                            const float dx = qq.x - e[u].x, dy = qq.y - e[u].y, dz = qq.z - e[u].z;
+                            const float d = dx * dx + (dy * dy + dz * dz);
+                            const int ei = __float_as_int(e[u].w);
+                            if (d < gd || (d == gd && ei > gi)) { gd = d; gi = ei; }   // lists are no longer in index order
+                        }
+                        gb = fminf(gd, dpp_f32<DPP_QUAD_XOR1>(gd));
+                        gb = fminf(gb, dpp_f32<DPP_QUAD_XOR2>(gb));
+                        gb = fminf(gb, dpp_f32<DPP_HALF_MIRROR>(gb));
+                    }
+                } else
                 for (uint32_t k = 0; __any(k < c); k += 8 * UNR) {
                     float4 e[UNR];
 #pragma unroll
@@ -199,7 +242,7 @@ __global__ __launch_bounds__(256) void lcp_coop_kernel(LcpArgs a, const float* _
                     for (int u = 0; u < UNR; ++u) {
                         const float dx = qq.x - e[u].x, dy = qq.y - e[u].y, dz = qq.z - e[u].z;
                         const float d = dx * dx + (dy * dy + dz * dz);
-                        if (d <= gd) { gd = d; gi = __float_as_int(e[u].w); }  // ascending index inside a lane
+                        take_if_better<IDX>(d, __float_as_int(e[u].w), gd, gi);
                     }
                 }
                 // group minimum of d^2 (DPP), then the largest index among the lanes that hold it
@@ -244,7 +287,7 @@ __global__ __launch_bounds__(256) void lcp_coop_kernel(LcpArgs a, const float* _
 // normal test runs on full wavefronts.  Lane <-> point assignment of the accumulation differs from v0,
 // so scores agree with v0 to rounding (1e-7), not bitwise; still run-to-run deterministic.
 // ---------------------------------------------------------------------------------------------
-template <bool DETAIL, int UNR, bool SORTQ = false, int PIPE = 4>
+template <bool DETAIL, int UNR, bool SORTQ = false, int PIPE = 4, bool IDX = true>
 __global__ __launch_bounds__(256) void lcp_coopq_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
                                                         int n, int32_t* __restrict__ hit_out, uint8_t* __restrict__ cnt_out) {
     __shared__ float4 qt[4][128];     // qx, qy, qz, bits(list offset)
@@ -304,7 +347,7 @@ __global__ __launch_bounds__(256) void lcp_coopq_kernel(LcpArgs a, const float* 
                 {
                     const float dx = qq.x - e0[u].x, dy = qq.y - e0[u].y, dz = qq.z - e0[u].z;
                     const float d = dx * dx + (dy * dy + dz * dz);
-                    if (d <= gd) { gd = d; gi = __float_as_int(e0[u].w); }
+                    take_if_better<IDX>(d, __float_as_int(e0[u].w), gd, gi);
                 }
                 for (uint32_t k = 8; __any(k < c); k += 8 * UNR) {
                     float4 e[UNR];
@@ -317,7 +360,7 @@ __global__ __launch_bounds__(256) void lcp_coopq_kernel(LcpArgs a, const float* 
                     for (int v = 0; v < UNR; ++v) {
                         const float dx = qq.x - e[v].x, dy = qq.y - e[v].y, dz = qq.z - e[v].z;
                         const float d = dx * dx + (dy * dy + dz * dz);
-                        if (d <= gd) { gd = d; gi = __float_as_int(e[v].w); }
+                        take_if_better<IDX>(d, __float_as_int(e[v].w), gd, gi);
                     }
                 }
                 float dm = fminf(gd, dpp_f32<DPP_QUAD_XOR1>(gd));
@@ -445,64 +488,55 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
     LcpArgs a;
     a.mpos = c->d_mpos_s; a.mnrm = c->d_mnrm_s; a.mperm = c->d_mperm; a.M = c->nM;
     a.top = c->grid.d_top; a.cells = c->grid.d_cells; a.list = c->grid.d_list; a.snrmw = c->d_snrmw;
-    a.ox = c->grid.ox; a.oy = c->grid.oy; a.oz = c->grid.oz; a.inv_h = c->grid.inv_h; a.inv_h4 = c->grid.inv_h * 4.0f;
+    a.ox = c->grid.ox; a.oy = c->grid.oy; a.oz = c->grid.oz; a.inv_h = c->grid.inv_h; a.inv_h4 = c->grid.inv_h * 4.0f; a.h = c->grid.h; a.chunk_r = c->grid.d_chunk_r;
     a.nx = c->grid.nx; a.ny = c->grid.ny; a.nz = c->grid.nz; a.nbx = c->grid.nbx; a.nby = c->grid.nby;
     a.sq_eps = c->prm.distance_threshold * c->prm.distance_threshold;  // sq_eps = epsilon*epsilon, stocs.cpp:1014
     a.dot_lo = c->thr.lcp_dot_lo;
     const int blocks = (n + 3) / 4;
     int variant = c->lcp_variant >= 0 ? c->lcp_variant : lcp_variant();
-    if (variant == 99) {
-        // cooperative kernel; unroll depth from the average candidate-list length of this scene
-        const double avg = c->grid.avg_list_len;
-        variant = avg <= 10.0 ? 24 : (avg <= 24.0 ? 15 : 16);   // measured: tools/lcp_ab.py (Cm, C5)
-        // (the choice must not depend on the batch size: a candidate's score is batch-invariant)
-    }
-    if (variant >= 10 && variant <= 14 && !d_hit) {
-        if (variant == 10) hipLaunchKernelGGL((lcp_kernel<false, 1>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-        if (variant == 11) hipLaunchKernelGGL((lcp_kernel<false, 2>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-        if (variant == 12) hipLaunchKernelGGL((lcp_kernel<false, 3>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-        if (variant == 14) hipLaunchKernelGGL((lcp_kernel<false, 5>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-        if (variant == 13) hipLaunchKernelGGL((lcp_kernel<false, 4>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-    } else if (variant >= 20 && variant <= 28) {
-        if (d_hit)
-            hipLaunchKernelGGL((lcp_coopq_kernel<true, 1, true>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
-        else if (variant == 26)
-            hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 1>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-        else if (variant == 27)
-            hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 2>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-        else if (variant == 28)
-            hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 8>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-        else if (variant == 24)
-            hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-        else if (variant == 25)
-            hipLaunchKernelGGL((lcp_coopq_kernel<false, 2, true>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-        else if (variant == 20)
-            hipLaunchKernelGGL((lcp_coopq_kernel<false, 1>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-        else if (variant == 21)
-            hipLaunchKernelGGL((lcp_coopq_kernel<false, 2>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-        else if (variant == 22)
-            hipLaunchKernelGGL((lcp_coopq_kernel<false, 4>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-        else
-            hipLaunchKernelGGL((lcp_coopq_kernel<false, 8>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-    } else if (variant == 0) {
-        if (d_hit)
-            hipLaunchKernelGGL((lcp_kernel<true, 0>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
-        else
-            hipLaunchKernelGGL((lcp_kernel<false, 0>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
+    // dense grids keep their lists sorted by distance from the cell centre (not by index): only kernels
+    // instantiated with the order-independent tie rule may scan them
+    const bool dense = c->grid.d_chunk_r != NULL;
+    if (variant == 99)   // automatic; must not depend on the batch size (a candidate's score is batch-invariant)
+        variant = dense ? 31 : (c->grid.avg_list_len <= 10.0 ? 24 : 15);   // measured: tools/lcp_ab.py (Cm, C5)
+    if (dense && !(variant == 0 || variant == 16 || (variant >= 30 && variant <= 32))) variant = 31;
+    if (!dense && variant >= 30 && variant <= 32) variant = 24;
+#define STOCS_LCP_LAUNCH(...) hipLaunchKernelGGL((__VA_ARGS__), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted)
+    if (d_hit) {   // per-point detail (parity tests)
+        if (dense) STOCS_LCP_LAUNCH(lcp_coop_kernel<true, 2, true, true, false>);
+        else if (variant == 0) STOCS_LCP_LAUNCH(lcp_kernel<true, 0, true>);
+        else if (variant >= 20 && variant <= 28) STOCS_LCP_LAUNCH(lcp_coopq_kernel<true, 1, true, 4, true>);
+        else STOCS_LCP_LAUNCH(lcp_coop_kernel<true, 1, true, false, true>);
+    } else if (dense) {
+        switch (variant) {
+            case 0: STOCS_LCP_LAUNCH(lcp_kernel<false, 0, false>); break;
+            case 16: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 8, true, false, false>); break;
+            case 30: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 1, true, true, false>); break;
+            case 32: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 4, true, true, false>); break;
+            default: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 2, true, true, false>); break;   // 31
+        }
     } else {
-        if (d_hit)
-            hipLaunchKernelGGL((lcp_coop_kernel<true, 1>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
-        else if (variant == 9)
-            hipLaunchKernelGGL((lcp_coop_kernel<false, 2>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-        else if (variant == 15)
-            hipLaunchKernelGGL((lcp_coop_kernel<false, 4>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-        else if (variant == 17)
-            hipLaunchKernelGGL((lcp_coop_kernel<false, 2, false>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-        else if (variant == 16)
-            hipLaunchKernelGGL((lcp_coop_kernel<false, 8>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
-        else
-            hipLaunchKernelGGL((lcp_coop_kernel<false, 1>), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, (int32_t*)NULL, (uint8_t*)NULL);
+        switch (variant) {
+            case 0: STOCS_LCP_LAUNCH(lcp_kernel<false, 0, true>); break;
+            case 10: STOCS_LCP_LAUNCH(lcp_kernel<false, 1, true>); break;   // 10-14: timing-only ablations
+            case 11: STOCS_LCP_LAUNCH(lcp_kernel<false, 2, true>); break;
+            case 12: STOCS_LCP_LAUNCH(lcp_kernel<false, 3, true>); break;
+            case 13: STOCS_LCP_LAUNCH(lcp_kernel<false, 4, true>); break;
+            case 14: STOCS_LCP_LAUNCH(lcp_kernel<false, 5, true>); break;
+            case 1: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 1, true, false, true>); break;
+            case 9: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 2, true, false, true>); break;
+            case 15: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 4, true, false, true>); break;
+            case 16: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 8, true, false, true>); break;
+            case 17: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 2, false, false, true>); break;   // no sub-cell mask
+            case 20: STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, false, 4, true>); break;
+            case 26: STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 1, true>); break;
+            case 27: STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 2, true>); break;
+            case 28: STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 8, true>); break;
+            case 25: STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 2, true, 4, true>); break;
+            default: STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 4, true>); break;       // 24
+        }
     }
+#undef STOCS_LCP_LAUNCH
     STOCS_HIP_CHECK(hipGetLastError());
     return STOCS_OK;
 }

@@ -41,6 +41,9 @@ struct SceneGrid {
     uint4* d_cells;      // n_bricks*512: (offset, count, sub-cell mask lo, hi); mask bit s set <=> some scene
                          // point lies within epsilon of sub-cell s (4x4x4 sub-cells, x fastest)
     float4* d_list;      // (x, y, z, bits(scene index))
+    float* d_chunk_r;    // dense scenes only: lists sorted by distance from the cell centre; per 8-entry chunk a
+                         // lower bound of that distance (early exit by the triangle inequality); else NULL
+    float h;             // cell edge
 };
 
 // Model PPF index on the device: every ordered pair stored once under its own quantised key F
