@@ -185,6 +185,13 @@ int stocs_ingest_scene(const stocs_camera* cam, const uint16_t* depth, const uin
 int stocs_preprocess_model(const float* raw_pos3, int n_raw, float normal_radius, float voxel_size, float model_scale,
                            int device, float* pos3, float* nrm3, int cap, int* n_out);
 
+/* clustering::point_to_plane_icp (pose_clustering.cpp:123-140: PCL IterativeClosestPointWithNormals, 5
+ * iterations, 3.5 cm): own linearised point-to-plane ICP; T16_out maps the source cloud onto the target
+ * (column-major).  Stand-alone; parity with PCL unpinned. */
+int stocs_icp_point_to_plane(const float* src_pos3, int nsrc, const float* tgt_pos3, const float* tgt_nrm3, int ntgt,
+                             int max_iterations, float max_correspondence_distance, int device, float* T16_out,
+                             int* n_correspondences);
+
 /* ---- tuning knobs (never change results beyond float summation order): "lcp_variant"
  * 99 = automatic (default): cooperative 8-lane scan fed from an LDS queue for scenes with short
  * candidate lists (24), centre-sorted lists with triangle-inequality early exit for dense scenes (31);

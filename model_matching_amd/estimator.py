@@ -283,3 +283,14 @@ def preprocess_model(raw_pos, normal_radius, voxel_size, model_scale=1.0, device
     capi.check(L.stocs_preprocess_model(pr, len(raw), normal_radius, voxel_size, model_scale, device, pos.ctypes.data_as(capi._fp),
                                         nrm.ctypes.data_as(capi._fp), cap, C.byref(n)))
     return pos[:n.value].copy(), nrm[:n.value].copy()
+
+
+def icp_point_to_plane(src_pos, tgt_pos, tgt_nrm, max_iterations=5, max_correspondence_distance=0.035, device=-1):
+    """GPU point-to-plane ICP (stocs_icp_point_to_plane): returns (T 4x4 float32 source->target, n_correspondences)."""
+    L = capi.load()
+    s, ps = capi.f32(src_pos); t, pt = capi.f32(tgt_pos); n, pn = capi.f32(tgt_nrm)
+    T = np.zeros(16, np.float32)
+    nc = C.c_int(0)
+    capi.check(L.stocs_icp_point_to_plane(ps, len(s), pt, pn, len(t), max_iterations, max_correspondence_distance, device,
+                                          T.ctypes.data_as(capi._fp), C.byref(nc)))
+    return T.reshape(4, 4).T.copy(), nc.value

@@ -120,3 +120,32 @@ def preprocess_model(raw_xyz, normal_radius, voxel, model_scale):
     cen, navg, ln = cen[fin], navg[fin], ln[fin]
     navg = (navg.astype(np.float64) / ln[:, None]).astype(np.float32)                            # set_normal, point3d.hpp:43-45
     return (cen * np.float32(model_scale)).astype(np.float32), navg
+
+
+def icp(src, tgt, tgt_nrm, max_iterations=5, max_corr=0.035):
+    """Linearised point-to-plane ICP (the algorithm behind pcl::IterativeClosestPointWithNormals as used by
+    clustering::point_to_plane_icp, reference src/pose_clustering.cpp:123-140).  Returns (T 4x4, n_corr)."""
+    src = np.asarray(src, np.float32).astype(np.float64)
+    tgt = np.asarray(tgt, np.float32).astype(np.float64)
+    nrm = np.asarray(tgt_nrm, np.float32).astype(np.float64)
+    tree = cKDTree(tgt)
+    T = np.eye(4)
+    ncorr = 0
+    for _ in range(max_iterations):
+        s = src @ T[:3, :3].T + T[:3, 3]
+        d, j = tree.query(s)
+        ok = d * d <= float(np.float32(max_corr)) ** 2
+        ncorr = int(ok.sum())
+        if ncorr < 6:
+            break
+        s, t, n = s[ok], tgt[j[ok]], nrm[j[ok]]
+        A = np.concatenate([np.cross(s, n), n], axis=1)
+        b = ((t - s) * n).sum(1)
+        x = np.linalg.solve(A.T @ A, A.T @ b)
+        ca, sa, cb, sb, cg, sg = np.cos(x[0]), np.sin(x[0]), np.cos(x[1]), np.sin(x[1]), np.cos(x[2]), np.sin(x[2])
+        U = np.eye(4)
+        U[:3, :3] = [[cg * cb, cg * sb * sa - sg * ca, cg * sb * ca + sg * sa], [sg * cb, sg * sb * sa + cg * ca, sg * sb * ca - cg * sa],
+                     [-sb, cb * sa, cb * ca]]
+        U[:3, 3] = x[3:]
+        T = U @ T
+    return T, ncorr
