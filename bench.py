@@ -173,9 +173,17 @@ def main():
             t0 = time.perf_counter(); valid, _, _ = pe.sample_bases(1234 + r, 100)
             t1 = time.perf_counter(); nq = pe.find_congruent_all()
             t2 = time.perf_counter(); nc = pe.make_transforms(200, 1234 + r)
-            t3 = time.perf_counter(); bl, bi, _ = pe.compute_best_transform()
+            t3 = time.perf_counter(); bl, bi, P = pe.compute_best_transform()
             t4 = time.perf_counter()
+            # winner vs the synthetic ground truth (camera frame, SURVEY.md 8(d): <= 1 mm / 1 deg is the oracle-vs-GPU
+            # bar; against the noisy scene the estimate itself is limited by eps = 5 mm)
+            Pm = P.reshape(4, 4).T.astype(np.float64)
+            dR = Pm[:3, :3] @ np.asarray(scene.T_gt, np.float64)[:3, :3].T
+            rot_err = float(np.degrees(np.arccos(np.clip((np.trace(dR) - 1.0) / 2.0, -1.0, 1.0))))
+            c0 = model.pos.astype(np.float64).mean(0)
+            tr_err = float(np.linalg.norm((Pm[:3, :3] @ c0 + Pm[:3, 3]) - (np.asarray(scene.T_gt)[:3, :3] @ c0 + np.asarray(scene.T_gt)[:3, 3])) * 1e3)
             runs.append({"bases": int(valid.sum()), "congruent_quads": int(nq), "candidates": int(nc), "best_lcp": float(bl),
+                         "winner_rot_err_deg_vs_gt": rot_err, "winner_centroid_err_mm_vs_gt": tr_err,
                          "sample_ms": (t1 - t0) * 1e3, "congruent_ms": (t2 - t1) * 1e3, "transforms_ms": (t3 - t2) * 1e3,
                          "verify_ms": (t4 - t3) * 1e3, "poses_per_s_phases_2_4": nc / max(t4 - t1, 1e-9)})
         out["pipeline"] = {"note": "one StoCS trial stream of 100 base attempts, <=200 quads per base, host wall clock incl. launches "

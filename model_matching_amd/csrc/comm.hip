@@ -8,6 +8,8 @@
 // librccl is opened lazily with dlopen so that libstocs_hip.so keeps working where RCCL is absent;
 // Python callers use torch.distributed (backend "nccl" == RCCL) through model_matching_amd/dist.py.
 #include <dlfcn.h>
+
+#include <mutex>
 #include <rccl/rccl.h>
 #include <string.h>
 
@@ -28,6 +30,8 @@ struct Rccl {
 static Rccl* rccl() {
     static Rccl r;
     static int state = 0;  // 0 untried, 1 ok, -1 failed
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
     if (state == 0) {
         r.lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
         if (!r.lib) r.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);

@@ -271,6 +271,7 @@ static double now_s() {
 
 int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     if (!c) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     const bool dbg = getenv("STOCS_DEBUG_TIMING") != NULL;
     double tprev = now_s();
     if (!c->index.built) { set_error("stocs_find_congruent_all: PPF index not built"); return STOCS_ERR_STATE; }
@@ -436,6 +437,7 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
 
 int stocs_get_quads(stocs_ctx* c, int slot, int32_t* quads4, int64_t cap, int64_t* n) {
     if (!c || !n || slot < 0) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     if (slot + 1 >= (int)c->quad_off.size()) { set_error("stocs_get_quads: no such base slot (call stocs_find_congruent_all first)"); return STOCS_ERR_STATE; }
     *n = (int64_t)(c->quad_off[slot + 1] - c->quad_off[slot]);
     if (!quads4 || *n == 0) return STOCS_OK;

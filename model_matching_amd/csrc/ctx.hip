@@ -370,7 +370,8 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     }
     if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
     if (device >= ndev) { set_error("device %d out of range (%d devices)", device, ndev); return STOCS_ERR_NO_DEVICE; }
-    if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice(%d) failed", device); return STOCS_ERR_NO_DEVICE; }
+    DeviceGuard dev_guard(device);   // the caller's current device is restored on return
+    { int cur = -1; if (hipGetDevice(&cur) != hipSuccess || cur != device) { set_error("hipSetDevice(%d) failed", device); return STOCS_ERR_NO_DEVICE; } }
 
     stocs_ctx* c = new stocs_ctx();
     c->prm = *prm;
@@ -389,7 +390,7 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     c->d_spos = c->d_snrmw = c->d_mpos = c->d_mnrm = c->d_munit = c->d_mpos_raw = c->d_mpos_s = c->d_mnrm_s = NULL;
     c->d_spix = NULL; c->d_mperm = NULL;
     c->stream = NULL; c->own_stream = NULL;
-    if (hipStreamCreate(&c->own_stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         set_error("stream/event creation failed");
         delete c;
         return STOCS_ERR_NO_DEVICE;
@@ -495,7 +496,7 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
 
 int stocs_ctx_destroy(stocs_ctx* c) {
     if (!c) return STOCS_OK;
-    hipSetDevice(c->device);
+    DeviceGuard dev_guard(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_spos, c->d_snrmw, c->d_spix, c->d_mpos, c->d_mnrm, c->d_munit, c->d_mpos_raw, c->d_mpos_s,
                     c->d_mnrm_s, c->d_mperm, c->grid.d_top, c->grid.d_cells, c->grid.d_list, c->grid.d_chunk_r, c->index.d_bucket_start,
@@ -522,6 +523,7 @@ int stocs_get_sizes(const stocs_ctx* c, int* nS, int* nM) {
 }
 int stocs_set_edge_map(stocs_ctx* c, const uint8_t* edge) {
     if (!c || !edge) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     c->edge_map.assign(edge, edge + (size_t)c->prm.image_width * c->prm.image_height);
     c->has_edge = true;
     return STOCS_OK;
@@ -529,6 +531,7 @@ int stocs_set_edge_map(stocs_ctx* c, const uint8_t* edge) {
 
 int stocs_sync(stocs_ctx* c) {
     if (!c) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
     return STOCS_OK;
 }
@@ -542,23 +545,26 @@ int stocs_set_stream(stocs_ctx* c, void* hip_stream) {
 
 int stocs_dev_alloc(stocs_ctx* c, int64_t bytes, void** dptr) {
     if (!c || !dptr || bytes < 0) return STOCS_ERR_INVALID;
-    STOCS_HIP_CHECK(hipSetDevice(c->device));
+    DeviceGuard dev_guard(c->device);
     STOCS_HIP_CHECK(hipMalloc(dptr, (size_t)std::max<int64_t>(bytes, 16)));
     return STOCS_OK;
 }
 int stocs_dev_free(stocs_ctx* c, void* dptr) {
     if (!c) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     if (dptr) STOCS_HIP_CHECK(hipFree(dptr));
     return STOCS_OK;
 }
 int stocs_dev_upload(stocs_ctx* c, void* dptr, const void* host, int64_t bytes) {
     if (!c || !dptr || !host) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     STOCS_HIP_CHECK(hipMemcpyAsync(dptr, host, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
     return STOCS_OK;
 }
 int stocs_dev_download(stocs_ctx* c, void* host, const void* dptr, int64_t bytes) {
     if (!c || !dptr || !host) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     STOCS_HIP_CHECK(hipMemcpyAsync(host, dptr, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
     return STOCS_OK;

@@ -549,11 +549,13 @@ extern "C" {
 
 int stocs_score_transforms_device(stocs_ctx* c, const void* d_T16, int n, void* d_lcp) {
     if (!c || n < 0 || (n && (!d_T16 || !d_lcp))) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     return launch_lcp(c, (const float*)d_T16, n, (float*)d_lcp, NULL, NULL);
 }
 
 int stocs_score_transforms(stocs_ctx* c, const float* T_host, int n, float* lcp_host) {
     if (!c || n < 0 || (n && (!T_host || !lcp_host))) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     if (n == 0) return STOCS_OK;
     const size_t tb = (size_t)n * 64, lb = (size_t)n * 4;
     int rc = ensure_scratch(c, tb + lb + 256);
@@ -570,6 +572,7 @@ int stocs_score_transforms(stocs_ctx* c, const float* T_host, int n, float* lcp_
 
 int stocs_lcp_detail(stocs_ctx* c, const float* T_host, int32_t* hit, uint8_t* counted) {
     if (!c || !T_host || !hit || !counted) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     const size_t M = (size_t)c->nM;
     int rc = ensure_scratch(c, 256 + 256 + M * 4 + 256 + M);
     if (rc) return rc;
@@ -589,6 +592,7 @@ int stocs_lcp_detail(stocs_ctx* c, const float* T_host, int32_t* hit, uint8_t* c
 
 int stocs_best_device(stocs_ctx* c, const void* d_lcp, int n, uint32_t id_offset, uint64_t* key) {
     if (!c || !key || n < 0 || (n && !d_lcp)) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     *key = 0;
     if (n == 0) return STOCS_OK;
     if (!c->d_best) STOCS_HIP_CHECK(hipMalloc((void**)&c->d_best, 8));
@@ -603,6 +607,7 @@ int stocs_best_device(stocs_ctx* c, const void* d_lcp, int n, uint32_t id_offset
 
 int stocs_best_device_async(stocs_ctx* c, const void* d_lcp, int n, uint32_t id_offset, void* d_key8) {
     if (!c || !d_key8 || n < 0 || (n && !d_lcp)) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     STOCS_HIP_CHECK(hipMemsetAsync(d_key8, 0, 8, c->stream));
     if (n == 0) return STOCS_OK;
     const int blocks = std::min((n + 255) / 256, 1024);
@@ -626,6 +631,7 @@ int stocs_set_option(stocs_ctx* c, const char* key, int value) {
 
 int stocs_time_score_kernel(stocs_ctx* c, const void* d_T16, int n, void* d_lcp, int reps, float* avg_ms) {
     if (!c || !avg_ms || reps <= 0 || n <= 0) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     STOCS_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
     for (int r = 0; r < reps; ++r) {
         int rc = launch_lcp(c, (const float*)d_T16, n, (float*)d_lcp, NULL, NULL);

@@ -195,6 +195,7 @@ int stocs_ppf_compute_host(const float* p1, const float* n1, const float* p2, co
 
 int stocs_index_exists(const stocs_ctx* c, const int32_t* K, int* exists) {
     if (!c || !K || !exists) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     if (!c->index.built) { set_error("PPF index not built"); return STOCS_ERR_STATE; }
     const PpfIndex& ix = c->index;
     *exists = 0;
@@ -209,6 +210,7 @@ int stocs_index_exists(const stocs_ctx* c, const int32_t* K, int* exists) {
 
 int stocs_index_lookup(stocs_ctx* c, const int32_t* K, int32_t* pairs2, int64_t cap, int64_t* n) {
     if (!c || !K || !n) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     if (!c->index.built) { set_error("PPF index not built"); return STOCS_ERR_STATE; }
     std::vector<std::pair<uint32_t, uint32_t> > ranges;
     int key[4] = {K[0], K[1], K[2], K[3]};
@@ -244,6 +246,7 @@ static uint64_t model_hash(const stocs_ctx* c) {
 
 int stocs_index_save(stocs_ctx* c, const char* path) {
     if (!c || !path) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     if (!c->index.built) { set_error("stocs_index_save: PPF index not built"); return STOCS_ERR_STATE; }
     const PpfIndex& ix = c->index;
     std::vector<uint32_t> pairs((size_t)std::max<int64_t>(ix.n_pairs, 1));
@@ -266,6 +269,7 @@ int stocs_index_save(stocs_ctx* c, const char* path) {
 
 int stocs_index_load(stocs_ctx* c, const char* path) {
     if (!c || !path) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     if (c->index.built) { set_error("stocs_index_load: the context already has an index"); return STOCS_ERR_STATE; }
     FILE* f = fopen(path, "rb");
     if (!f) { set_error("stocs_index_load: cannot open %s", path); return STOCS_ERR_INVALID; }

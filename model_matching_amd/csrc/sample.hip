@@ -406,6 +406,7 @@ extern "C" {
 int stocs_sample_bases(stocs_ctx* c, int mode, uint64_t seed, int first_attempt, int n_attempts, float dispersion,
                        int32_t* base_ids4, float* inv2, int32_t* valid) {
     if (!c || n_attempts < 0 || first_attempt < 0 || (mode != 0 && mode != 1)) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     if (!c->index.built) { set_error("stocs_sample_bases: PPF index not built"); return STOCS_ERR_STATE; }
     if (n_attempts == 0) return STOCS_OK;
     if (c->nS == 0) {  // the reference would index an empty vector here (stocs.cpp:386); report no bases
@@ -424,6 +425,7 @@ int stocs_sample_bases(stocs_ctx* c, int mode, uint64_t seed, int first_attempt,
 
 int stocs_reset_trial(stocs_ctx* c) {
     if (!c) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     c->h_sprob = c->h_sprob0;
     std::fill(c->previous_segment.begin(), c->previous_segment.end(), 0);
     std::fill(c->segmentation_buffer.begin(), c->segmentation_buffer.end(), 0);
@@ -457,6 +459,7 @@ int stocs_num_bases(const stocs_ctx* c) { return c ? (int)c->bases.size() : STOC
 
 int stocs_class_pass(stocs_ctx* c, int pass, const int32_t* b3, const float* w_in, float* w_out) {
     if (!c || pass < 1 || pass > 3 || !b3 || !w_in || !w_out) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     if (!c->index.built) { set_error("stocs_class_pass: PPF index not built"); return STOCS_ERR_STATE; }
     for (int k = 0; k < pass; ++k) if (b3[k] < 0 || b3[k] >= c->nS) return STOCS_ERR_INVALID;
     SampleBuffers sb;
@@ -475,6 +478,7 @@ int stocs_class_pass(stocs_ctx* c, int pass, const int32_t* b3, const float* w_i
 
 int stocs_try_sampled_base(stocs_ctx* c, int32_t* ids4, float* inv2, int* valid) {
     if (!c || !ids4 || !inv2 || !valid) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     for (int k = 0; k < 4; ++k) if (ids4[k] < 0 || ids4[k] >= c->nS) return STOCS_ERR_INVALID;
     int ids[4] = {ids4[0], ids4[1], ids4[2], ids4[3]};
     const V3 base[4] = {c->h_spos[ids[0]], c->h_spos[ids[1]], c->h_spos[ids[2]], c->h_spos[ids[3]]};
@@ -487,6 +491,7 @@ int stocs_try_sampled_base(stocs_ctx* c, int32_t* ids4, float* inv2, int* valid)
 
 int stocs_draw(stocs_ctx* c, const float* w, int n, uint64_t r64, int* index) {
     if (!c || !w || n <= 0 || !index) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     auto al = [](size_t x) { return (x + 255) / 256 * 256; };
     int rc = ensure_scratch(c, al((size_t)n * 4) + 1024);
     if (rc) return rc;

@@ -26,6 +26,19 @@ void set_error(const char* fmt, ...);
         }                                                                                      \
     } while (0)
 
+// Binds the calling thread to the context's device for the duration of an entry point and restores the
+// caller's device afterwards (a context may be driven from any thread, one thread at a time).
+struct DeviceGuard {
+    int prev = -1, dev = -1;
+    explicit DeviceGuard(int d) : dev(d) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 // Brick grid over the centred scene (replaces the kd-tree of kdtree.h for the restricted-radius
 // nearest-neighbour query).  Cell edge h = epsilon.  A cell's candidate list holds every scene
 // point whose distance to the cell's box is <= epsilon (+ a 0.1% safety margin), so ONE list scan

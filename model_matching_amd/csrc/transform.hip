@@ -134,6 +134,7 @@ extern "C" {
 
 int stocs_rigid_transform(stocs_ctx* c, const int32_t* ids4, const int32_t* quad4, float* T16, float* pose16, int* ok) {
     if (!c || !ids4 || !quad4 || !ok) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     for (int k = 0; k < 4; ++k)
         if (ids4[k] < 0 || ids4[k] >= c->nS || quad4[k] < 0 || quad4[k] >= c->nM) { set_error("index out of range"); return STOCS_ERR_INVALID; }
     std::vector<XformJob> jobs(1);
@@ -150,6 +151,7 @@ int stocs_rigid_transform(stocs_ctx* c, const int32_t* ids4, const int32_t* quad
 
 int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_candidates) {
     if (!c || max_per_base <= 0) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     if (c->quad_off.size() != c->bases.size() + 1) { set_error("stocs_make_transforms: call stocs_find_congruent_all first"); return STOCS_ERR_STATE; }
     // picks = (base, rank in the base's sorted quad run); the quads themselves stay on the device
     std::vector<int32_t> picks;
@@ -224,6 +226,7 @@ int stocs_get_candidates(stocs_ctx* c, float* T16, float* pose16, float* lcp, in
 
 int stocs_verify_all(stocs_ctx* c, float* best_lcp, int* best_idx, float* best_pose16) {
     if (!c) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     const int n = (int)c->cands.size();
     c->best_lcp = 0; c->best_index = -1;
     if (n > 0) {

@@ -253,3 +253,31 @@ def test_reset_trial_equals_fresh_estimator(oracle_lib):
     fresh = StocsEstimator(*args, build_index=True); fresh.set_edge_map(d["edge_map"])
     v4, i4, n4 = fresh.sample_bases(11, 20, mode=1)
     assert np.array_equal(v1, v4) and np.array_equal(i1[v1], i4[v4])
+
+
+def test_concurrent_contexts_on_threads_equal_sequential():
+    """Distinct contexts are independent: four trial streams driven from four host threads at once (each on
+    its own non-blocking HIP stream) give exactly the results of running them one after the other."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    from model_matching_amd.estimator import StocsEstimator
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "example_packed_dove.npz"))
+    args = (d["scene_pos"], d["scene_nrm"], d["scene_prob"], d["scene_pixel"], d["model_pos"], d["model_nrm"])
+
+    def trial(est, seed):
+        est.reset_trial()
+        v, ids, inv = est.sample_bases(seed, 40, mode=0)
+        nq = est.find_congruent_all()
+        nc = est.make_transforms(200, seed)
+        lcp, idx, pose = est.compute_best_transform()
+        return int(v.sum()), int(nq), int(nc), float(lcp), int(idx), pose.copy()
+
+    ests = [StocsEstimator(*args, build_index=True) for _ in range(4)]
+    seq = [trial(e, 100 + i) for i, e in enumerate(ests)]
+    with ThreadPoolExecutor(4) as ex:
+        for _ in range(3):
+            par = list(ex.map(lambda ie: trial(ie[1], 100 + ie[0]), enumerate(ests)))
+            for a, b in zip(seq, par):
+                assert a[:5] == b[:5] and np.array_equal(a[5], b[5])
+    for e in ests:
+        e.close()

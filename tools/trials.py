@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--bases", type=int, default=100)
     ap.add_argument("--max-sets", type=int, default=200)
+    ap.add_argument("--streams", type=int, default=1, help="trial streams in flight per GPU (one context + HIP stream + host thread each)")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     rehearsal = os.environ.get("STOCS_BENCH_REHEARSAL") == "1"
@@ -50,17 +51,36 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    est = StocsEstimator(*cloud, build_index=True, device=local_rank)
+    n_streams = max(1, min(args.streams, hi - lo))
+    ests = [StocsEstimator(*cloud, build_index=True, device=local_rank) for _ in range(n_streams)]
     if mode:
-        est.set_edge_map(d["edge_map"])
-    for t in range(lo, hi):
-        est.reset_trial()                                                    # fresh class prior per trial (instance mode decays it)
-        est.sample_bases(args.seed + t, args.bases, mode=mode, dispersion=0.9)
-        est.find_congruent_all()
-        n_cand += est.make_transforms(args.max_sets, args.seed + t)
-        lcp, idx, pose = est.compute_best_transform()
-        if idx >= 0 and lcp > best[0]:
-            best = (lcp, (t << 16) | idx, pose.copy())
+        for est in ests:
+            est.set_edge_map(d["edge_map"])
+
+    def run_trials(k):
+        # stream k of this rank takes trials lo+k, lo+k+S, ...; the library calls release the GIL
+        est, b, nc = ests[k], (0.0, -1, None), 0
+        for t in range(lo + k, hi, n_streams):
+            est.reset_trial()                                                # fresh class prior per trial (instance mode decays it)
+            est.sample_bases(args.seed + t, args.bases, mode=mode, dispersion=0.9)
+            est.find_congruent_all()
+            nc += est.make_transforms(args.max_sets, args.seed + t)
+            lcp, idx, pose = est.compute_best_transform()
+            gid = (t << 16) | idx
+            if idx >= 0 and (lcp > b[0] or (lcp == b[0] and gid < b[1])):
+                b = (lcp, gid, pose.copy())
+        return b, nc
+
+    if n_streams == 1:
+        results = [run_trials(0)]
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(n_streams) as ex:
+            results = list(ex.map(run_trials, range(n_streams)))
+    for b, nc in results:                                                    # lowest (trial, candidate) id wins ties
+        n_cand += nc
+        if b[1] >= 0 and (b[0] > best[0] or (b[0] == best[0] and b[1] < best[1])):
+            best = b
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -80,7 +100,7 @@ def main():
         n_cand = int(cc.item())
     pose = sd.broadcast_pose(best[2] if (rank == owner and best[2] is not None) else np.zeros(16, np.float32), owner, device=dev)
     if rank == 0:
-        print(json.dumps({"example": args.example, "mode": "instance" if mode else "class", "trials": args.trials, "n_gpus": world, "rehearsal": rehearsal,
+        print(json.dumps({"example": args.example, "mode": "instance" if mode else "class", "trials": args.trials, "streams_per_gpu": n_streams, "n_gpus": world, "rehearsal": rehearsal,
                           "seconds": dt, "trials_per_s": args.trials / dt, "candidates_verified": n_cand, "candidates_per_s": n_cand / dt,
                           "best_lcp": g_lcp, "best_trial": (g_id >> 16) if g_id >= 0 else -1, "best_candidate": (g_id & 0xFFFF) if g_id >= 0 else -1,
                           "best_pose_row_major_3x4": [float(pose.reshape(4, 4).T[r, c]) for r in range(3) for c in range(4)]}), flush=True)
