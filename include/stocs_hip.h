@@ -117,9 +117,13 @@ int stocs_try_sampled_base(stocs_ctx* ctx, int32_t* ids4_inout, float* inv2, int
 int stocs_draw(stocs_ctx* ctx, const float* w, int n, uint64_t r64, int* index);
 
 /* ---- congruent sets: find_congruent_sets_on_model (stocs.cpp:753-869) for every base of the base
- * set at once; then per-base read-back.  Quads are sorted as the reference's std::set orders them. ---- */
+ * set at once (per-base COUNTS; quads are produced on demand); then per-base read-back:
+ * stocs_get_quads -- all quads of a base, sorted as the reference's std::set orders them (stocs.cpp:860-866);
+ * stocs_get_quads_at -- the quads at given ranks of the base's emission order (the order in which the loop of
+ * stocs.cpp:827-858 finds them), which is what stocs_make_transforms samples from for a base with >= max quads. ---- */
 int stocs_find_congruent_all(stocs_ctx* ctx, int64_t* total_quads);
 int stocs_get_quads(stocs_ctx* ctx, int base_slot, int32_t* quads4, int64_t cap, int64_t* n);
+int stocs_get_quads_at(stocs_ctx* ctx, int base_slot, const int64_t* ranks, int n, int32_t* quads4);
 
 /* ---- candidate transforms: the loop stocs_match_one_object.cpp:120-147 over
  * get_rigid_transform_from_congruent_pair (stocs.cpp:871-941 -> ComputeRigidTransformation :270-361):

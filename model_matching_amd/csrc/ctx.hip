@@ -380,7 +380,7 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     c->d_scratch = NULL; c->scratch_bytes = 0;
     c->index.built = false;
     c->index.d_bucket_start = NULL; c->index.d_pairs = NULL; c->index.d_exists = NULL;
-    c->d_quads = NULL; c->d_quad_off = NULL; c->quad_id_bits = 16;
+    c->cong = NULL; c->quad_id_bits = 16;
     c->d_best = NULL;
     c->best_lcp = 0; c->best_index = -1;
     c->has_edge = false;
@@ -500,7 +500,8 @@ int stocs_ctx_destroy(stocs_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_spos, c->d_snrmw, c->d_spix, c->d_mpos, c->d_mnrm, c->d_munit, c->d_mpos_raw, c->d_mpos_s,
                     c->d_mnrm_s, c->d_mperm, c->grid.d_top, c->grid.d_cells, c->grid.d_list, c->grid.d_chunk_r, c->index.d_bucket_start,
-                    c->index.d_pairs, c->index.d_exists, c->d_scratch, c->d_quads, c->d_quad_off, c->d_best};
+                    c->index.d_pairs, c->index.d_exists, c->d_scratch, c->d_best};
+    stocs_internal_free_congruent(c);
     for (void* p : ptrs) if (p) hipFree(p);
     hipEventDestroy(c->ev0);
     hipEventDestroy(c->ev1);
@@ -538,6 +539,7 @@ int stocs_sync(stocs_ctx* c) {
 void* stocs_stream(stocs_ctx* c) { return c ? (void*)c->stream : NULL; }
 int stocs_set_stream(stocs_ctx* c, void* hip_stream) {
     if (!c) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));   // nothing of the old stream may still be in flight
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return STOCS_OK;

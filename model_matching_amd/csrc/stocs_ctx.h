@@ -137,10 +137,10 @@ struct stocs_ctx {
 
     // run state
     std::vector<stocs::BaseRec> bases;
-    // congruent quads of all bases: device-resident, sorted by (base, a, b, c, d); packed with
-    // quad_id_bits bits per model id below the base id; quad_off[b] .. quad_off[b+1] is base b's run
-    uint64_t* d_quads;
-    unsigned long long* d_quad_off;
+    // congruent quads: only their per-base counts live here (quad_off[b+1] - quad_off[b]); `cong` (congruent.hip,
+    // CongruentState) keeps what is needed to produce the quads of a base on demand, packed with quad_id_bits
+    // bits per model id below the base id
+    void* cong;
     std::vector<unsigned long long> quad_off;
     int quad_id_bits;
     std::vector<stocs::Candidate> cands;
@@ -158,7 +158,8 @@ namespace stocs {
 int ensure_scratch(stocs_ctx* c, size_t bytes);
 int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d_hit, uint8_t* d_counted);
 int build_ppf_index(stocs_ctx* c);
-extern "C" int stocs_internal_make_jobs(stocs_ctx* c, const int32_t* picks2_host, int n, void* d_jobs_out);
+extern "C" int stocs_internal_make_jobs(stocs_ctx* c, const int32_t* picks4_host, int n, void* d_jobs_out);
+extern "C" void stocs_internal_free_congruent(stocs_ctx* c);
 int plan_lookup(const PpfIndex& ix, const int* K, std::vector<std::pair<uint32_t, uint32_t> >* ranges);
 void compute_thresholds(const stocs_params& prm, Thresholds* t);
 }  // namespace stocs

@@ -153,17 +153,25 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
     if (!c || max_per_base <= 0) return STOCS_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
     if (c->quad_off.size() != c->bases.size() + 1) { set_error("stocs_make_transforms: call stocs_find_congruent_all first"); return STOCS_ERR_STATE; }
-    // picks = (base, rank in the base's sorted quad run); the quads themselves stay on the device
+    // picks = (base, rank, job slot, sorted?) records; the quads themselves are produced on the device
     std::vector<int32_t> picks;
     std::vector<int> job_base;
+    auto add_pick = [&](size_t b, int rank, int sorted) {
+        picks.push_back((int32_t)b); picks.push_back((int32_t)rank); picks.push_back((int32_t)job_base.size()); picks.push_back(sorted);
+        job_base.push_back((int)b);
+    };
     for (size_t b = 0; b < c->bases.size(); ++b) {
-        const long long nq = (long long)(c->quad_off[b + 1] - c->quad_off[b]);
-        if (nq < max_per_base) {  // stocs_match_one_object.cpp:126: strictly fewer -> all
-            for (long long i = 0; i < nq; ++i) { picks.push_back((int32_t)b); picks.push_back((int32_t)i); job_base.push_back((int)b); }
+        const unsigned long long nq64 = c->quad_off[b + 1] - c->quad_off[b];
+        if (nq64 > 0x7FFFFFFFull) { set_error("base %zu has %llu congruent quads (more than 2^31 - 1)", b, nq64); return STOCS_ERR_CAPACITY; }
+        const long long nq = (long long)nq64;
+        if (nq < max_per_base) {  // stocs_match_one_object.cpp:126: strictly fewer -> all, in the std::set order of stocs.cpp:860-866
+            for (long long i = 0; i < nq; ++i) add_pick(b, (int)i, 1);
         } else {
-            // seeded sample without replacement (divergence Q5 from the biased 2N-vector shuffle,
-            // stocs_match_one_object.cpp:134-142): partial Fisher-Yates over the sorted quad list,
-            // kept sparse (only the touched entries of the identity permutation are stored)
+            // seeded sample without replacement (divergence Q5 from the biased 2N-vector shuffle of
+            // stocs_match_one_object.cpp:134-142, whose result depends on the C library's unseeded generator):
+            // partial Fisher-Yates over the base's quads in EMISSION order (the order the loop of
+            // stocs.cpp:827-858 finds them), kept sparse (only the touched entries of the identity
+            // permutation are stored).  Any fixed enumeration serves a uniform draw; this one needs no sort.
             std::unordered_map<int, int> perm;
             auto at = [&](int i) { auto it = perm.find(i); return it == perm.end() ? i : it->second; };
             for (int j = 0; j < max_per_base; ++j) {
@@ -171,7 +179,7 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
                 const int k = j + (int)mulhi64(r, (uint64_t)(nq - j));
                 const int vj = at(j), vk = at(k);
                 perm[j] = vk; perm[k] = vj;
-                picks.push_back((int32_t)b); picks.push_back((int32_t)vk); job_base.push_back((int)b);
+                add_pick(b, vk, 0);
             }
         }
     }

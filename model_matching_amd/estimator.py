@@ -138,6 +138,18 @@ class StocsEstimator:
             capi.check(self.L.stocs_get_quads(self.h, slot, out.ctypes.data_as(capi._ip), n.value, C.byref(n)))
         return out
 
+    def num_quads(self, slot):
+        n = C.c_int64(0)
+        capi.check(self.L.stocs_get_quads(self.h, slot, None, 0, C.byref(n)))
+        return n.value
+
+    def get_quads_at(self, slot, ranks):
+        """Quads of base `slot` at ranks of its emission order (stocs_get_quads_at)."""
+        r = np.ascontiguousarray(ranks, np.int64)
+        out = np.zeros((len(r), 4), np.int32)
+        capi.check(self.L.stocs_get_quads_at(self.h, slot, r.ctypes.data_as(capi._i64p), len(r), out.ctypes.data_as(capi._ip)))
+        return out
+
     def find_congruent_sets_on_model(self, base_indices, invariant1, invariant2):
         self.set_bases(np.asarray(base_indices).reshape(1, 4), np.array([[invariant1, invariant2]], np.float32))
         self.find_congruent_all()

@@ -88,6 +88,8 @@ def lib():
         L.orc_try_sampled_base.restype = C.c_int
         L.orc_find_congruent.argtypes = [vp, ip, C.c_float, C.c_float, ip, C.c_int64]
         L.orc_find_congruent.restype = C.c_int64
+        L.orc_find_congruent_seq.argtypes = [vp, ip, C.c_float, C.c_float, ip, C.c_int64]
+        L.orc_find_congruent_seq.restype = C.c_int64
         L.orc_normalset_params.argtypes = [C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int), fp]
         L.orc_cone_samples.argtypes = [C.c_float]
         L.orc_cone_samples.restype = C.c_int
@@ -301,6 +303,14 @@ class Oracle:
         out = np.zeros((n, 4), np.int32)
         if n:
             lib().orc_find_congruent(self.h, pi, inv1, inv2, out.ctypes.data_as(C.POINTER(C.c_int32)), n)
+        return out
+
+    def find_congruent_seq(self, ids, inv1, inv2):
+        ids, pi = _i(ids)
+        n = lib().orc_find_congruent_seq(self.h, pi, inv1, inv2, None, 0)
+        out = np.zeros((n, 4), np.int32)
+        if n:
+            lib().orc_find_congruent_seq(self.h, pi, inv1, inv2, out.ctypes.data_as(C.POINTER(C.c_int32)), n)
         return out
 
     def rigid_transform(self, ids, quad):

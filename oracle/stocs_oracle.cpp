@@ -694,8 +694,11 @@ struct NormalSet {
 };
 
 // row 8: find_congruent_sets_on_model -- stocs.cpp:753-869
+// `seq` (optional) receives the same quads in INSERTION order -- the order in which the loop below finds
+// them (Q pairs in list order; for one Q pair the coloured direction cells ascending, each cell's P
+// entries in insertion order).  The seeded subset rule of orc_run draws from that sequence.
 bool find_congruent(orc_ctx* c, const int ids[4], float invariant1, float invariant2,
-                    std::vector<std::array<int, 4> >* quads) {
+                    std::vector<std::array<int, 4> >* quads, std::vector<std::array<int, 4> >* seq = NULL) {
     const Pt* B[4] = {&c->scene[ids[0]], &c->scene[ids[1]], &c->scene[ids[2]], &c->scene[ids[3]]};
     int ppf_1[4], ppf_2[4];
     ppf_of(*B[0], *B[1], c->prm, ppf_1);
@@ -704,6 +707,7 @@ bool find_congruent(orc_ctx* c, const int ids[4], float invariant1, float invari
     index_lookup(c->index, ppf_1, &P_pairs);
     index_lookup(c->index, ppf_2, &Q_pairs);
     quads->clear();  // (the reference clears after the early return; callers start empty anyway)
+    if (seq) seq->clear();
     if (P_pairs.size() == 0 || Q_pairs.size() == 0) return false;
 
     const float alpha = dot(normalized(B[1]->pos - B[0]->pos), normalized(B[3]->pos - B[2]->pos));
@@ -733,7 +737,13 @@ bool find_congruent(orc_ctx* c, const int ids[4], float invariant1, float invari
             const V3 pp2 = c->model[P_pairs[id].second].pos;
             const V3 invPoint = pp1 + (pp2 - pp1) * invariant1;
             // squared metres compared with metres (Q1), reproduced
-            if (sqn(queryQ - invPoint) <= c->prm.distance_threshold) comb.insert(std::make_pair((unsigned)id, i));
+            if (sqn(queryQ - invPoint) <= c->prm.distance_threshold) {
+                const bool fresh = comb.insert(std::make_pair((unsigned)id, i)).second;
+                if (seq && fresh) {
+                    std::array<int, 4> q = {{P_pairs[id].first, P_pairs[id].second, Q_pairs[i].first, Q_pairs[i].second}};
+                    seq->push_back(q);
+                }
+            }
         }
     }
     for (auto it = comb.begin(); it != comb.end(); ++it) {
@@ -1220,6 +1230,14 @@ int64_t orc_find_congruent(orc_ctx* c, const int32_t* ids4, float inv1, float in
         for (int k = 0; k < 4; ++k) quads4[4 * i + k] = quads[i][k];
     return (int64_t)quads.size();
 }
+int64_t orc_find_congruent_seq(orc_ctx* c, const int32_t* ids4, float inv1, float inv2, int32_t* quads4, int64_t cap) {
+    int ids[4] = {ids4[0], ids4[1], ids4[2], ids4[3]};
+    std::vector<std::array<int, 4> > quads, seq;
+    find_congruent(c, ids, inv1, inv2, &quads, &seq);
+    for (size_t i = 0; i < seq.size() && (int64_t)i < cap; ++i)
+        for (int k = 0; k < 4; ++k) quads4[4 * i + k] = seq[i][k];
+    return (int64_t)seq.size();
+}
 int orc_normalset_params(float eps_unit, int* gridDepth, int* egSize, float* cell) {
     NormalSet ns(eps_unit);
     if (gridDepth) *gridDepth = (int)(-log2f(eps_unit));
@@ -1306,10 +1324,11 @@ int orc_greedy_clustering(const float* poses16, const float* lcp, int n, float a
 
 // row 19: run_stocs_estimation -- stocs_match_one_object.cpp:51-185, class mode, with the seeded
 // divergences Q5 (subset choice) and Q6 (draws).  Subset rule when a base has >= max quads:
-// partial Fisher-Yates over the sorted quad list with rng64(seed, 0x5E1EC7 + base_number, j).
+// partial Fisher-Yates over the base's quads in insertion order (find_congruent's `seq`) with
+// rng64(seed, 0x5E1EC7 + base_number, j); a base with fewer uses all of them in std::set order.
 int orc_run(orc_ctx* c, uint64_t seed, int number_of_bases, int maximum_congruent_sets, orc_run_result* out) {
     typedef std::chrono::high_resolution_clock clk;
-    struct Base { int ids[4]; float i1, i2; std::vector<std::array<int, 4> > quads; };
+    struct Base { int ids[4]; float i1, i2; std::vector<std::array<int, 4> > quads, seq; };
     std::vector<Base> base_set;
     c->all_transforms.clear(); c->all_pose.clear(); c->all_base_index.clear();
     auto t0 = clk::now();
@@ -1325,7 +1344,7 @@ int orc_run(orc_ctx* c, uint64_t seed, int number_of_bases, int maximum_congruen
     }
     auto t1 = clk::now();
     int total_quads = 0;
-    for (size_t b = 0; b < base_set.size(); ++b) find_congruent(c, base_set[b].ids, base_set[b].i1, base_set[b].i2, &base_set[b].quads);
+    for (size_t b = 0; b < base_set.size(); ++b) find_congruent(c, base_set[b].ids, base_set[b].i1, base_set[b].i2, &base_set[b].quads, &base_set[b].seq);
     for (size_t b = 0; b < base_set.size(); ++b) {
         const int nq = (int)base_set[b].quads.size();
         std::vector<int> pick;
@@ -1343,7 +1362,8 @@ int orc_run(orc_ctx* c, uint64_t seed, int number_of_bases, int maximum_congruen
         }
         for (size_t i = 0; i < pick.size(); ++i) {
             std::array<float, 16> T, P;
-            int q[4] = {base_set[b].quads[pick[i]][0], base_set[b].quads[pick[i]][1], base_set[b].quads[pick[i]][2], base_set[b].quads[pick[i]][3]};
+            const std::array<int, 4>& qq = (nq < maximum_congruent_sets) ? base_set[b].quads[pick[i]] : base_set[b].seq[pick[i]];
+            int q[4] = {qq[0], qq[1], qq[2], qq[3]};
             if (rigid_transform(c, base_set[b].ids, q, T.data(), P.data())) {
                 c->all_transforms.push_back(T);
                 c->all_pose.push_back(P);

@@ -94,6 +94,9 @@ int  orc_try_sampled_base(orc_ctx*, int32_t* ids4 /*in/out*/, float* inv2);
 /* ---- rows 8-10: congruent sets ---- */
 int64_t orc_find_congruent(orc_ctx*, const int32_t* ids4, float inv1, float inv2,
                            int32_t* quads4, int64_t cap);
+/* the same quads in the order the loop of stocs.cpp:827-858 inserts them (what the seeded subset rule draws from) */
+int64_t orc_find_congruent_seq(orc_ctx*, const int32_t* ids4, float inv1, float inv2,
+                               int32_t* quads4, int64_t cap);
 /* introspection for KATs */
 int  orc_normalset_params(float eps_unit, int* gridDepth, int* egSize, float* cell);
 int  orc_cone_samples(float cos_alpha);

@@ -118,6 +118,12 @@ def test_congruent_sets_and_transforms_equal_oracle(setup):
         assert qo.shape == qg.shape and np.array_equal(qo, qg), (a, qo.shape, qg.shape)
         tot_o += len(qo)
         n_nonempty += len(qo) > 0
+        # emission order (what the subset rule samples from): every rank, resolved without materialising
+        so = orc.find_congruent_seq(ids[a], float(inv[a][0]), float(inv[a][1]))
+        assert len(so) == len(qo) == est.num_quads(slot)
+        if len(so):
+            ranks = np.arange(len(so), dtype=np.int64)[::-1]
+            assert np.array_equal(est.get_quads_at(slot, ranks), so[::-1])
         # rows 11-12: transforms of the first quads, bit-exact
         for q in qo[:5]:
             oko, To, Po = orc.rigid_transform(ids[a], q)
@@ -281,3 +287,33 @@ def test_concurrent_contexts_on_threads_equal_sequential():
                 assert a[:5] == b[:5] and np.array_equal(a[5], b[5])
     for e in ests:
         e.close()
+
+
+def test_repeated_trials_on_one_context_equal_fresh_contexts():
+    """The congruent-set buffers are arena memory reused from trial to trial: a context that has already run
+    other trials must give exactly what a fresh context gives for the same seed."""
+    from model_matching_amd import synth
+    from model_matching_amd.estimator import StocsEstimator
+    m, s, k = synth.workload("small")
+    args = (s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm)
+
+    def trial(est, seed):
+        est.L.stocs_clear_bases(est.h)
+        valid, ids, inv = est.sample_bases(seed, 100)
+        tot = est.find_congruent_all()
+        nc = est.make_transforms(200, seed)
+        lcp, idx, pose = est.compute_best_transform()
+        return int(valid.sum()), int(tot), int(nc), float(lcp), int(idx), pose.copy()
+
+    est = StocsEstimator(*args, build_index=True)
+    reused = [trial(est, 1234 + r) for r in range(8)]
+    # a big trial in between (different sizes -> different arena layout), then the first seeds again
+    again = [trial(est, 1234 + r) for r in (7, 0, 3)]
+    for r, got in zip((7, 0, 3), again):
+        assert got[:5] == reused[r][:5] and np.array_equal(got[5], reused[r][5])
+    for r in (1, 3, 6):
+        fresh = StocsEstimator(*args, build_index=True)
+        ref = trial(fresh, 1234 + r)
+        fresh.close()
+        assert ref[:5] == reused[r][:5] and np.array_equal(ref[5], reused[r][5]), r
+    est.close()
