@@ -119,12 +119,20 @@ __global__ __launch_bounds__(256) void pkey_kernel(const BaseJob* __restrict__ j
 // P entries.  Replaces the pointer grid _grid[pId] -> AngularGrid of normalset.h:87-88.
 __global__ __launch_bounds__(256) void cell_ranges_kernel(const uint64_t* __restrict__ keys, uint32_t totalP, const uint32_t* __restrict__ p_off,
                                                           long long NC, uint16_t* __restrict__ pdir, uint32_t* __restrict__ cfirst,
-                                                          uint32_t* __restrict__ cend) {
+                                                          uint32_t* __restrict__ cend, const BaseJob* __restrict__ jobs,
+                                                          const uint32_t* __restrict__ pvals, const float4* __restrict__ mpos,
+                                                          float4* __restrict__ pinv) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= totalP) return;
     const uint64_t key = keys[e];
     const uint64_t kk = key & 0xFFFFFFFFFFull;
     const uint32_t b = (uint32_t)(key >> 40);
+    {   // invPoint of stocs.cpp:845-849, once per P entry instead of once per (Q, P) test
+        const uint32_t pr = pvals[e];
+        const V3 pp1 = ld3c(mpos, pr >> 16), pp2 = ld3c(mpos, pr & 0xFFFF);
+        const V3 ip = pp1 + (pp2 - pp1) * jobs[b].inv1;
+        pinv[e] = make_float4(ip.x, ip.y, ip.z, 0.f);
+    }
     if (kk == 0xFFFFFFFFFFull) { pdir[e] = 0xFFFF; return; }
     const uint64_t pc = kk / 343ull;
     pdir[e] = (uint16_t)(kk - pc * 343ull);
@@ -168,7 +176,7 @@ struct JoinArgs {
     const BaseJob* jobs; const uint32_t* q_off; int nB;
     const float4* munit; const float4* mpos;
     const uint64_t* Q; uint32_t totQ;   // (base << 32 | pair), each base's run in lexicographic pair order
-    const uint64_t* pkeys; const uint32_t* pvals; const uint16_t* pdir;
+    const uint64_t* pkeys; const uint32_t* pvals; const uint16_t* pdir; const float4* pinv;
     const uint32_t* cfirst; const uint32_t* cend; long long NC;
     float nepsilon, dist_thr;
     int id_bits;
@@ -227,12 +235,11 @@ __device__ __forceinline__ unsigned long long join_one(const JoinArgs& A, uint32
     for (uint32_t k = lo; k < hi; ++k) {
         const uint32_t dc = A.pdir[k];
         if (dc >= 343u || !((my[dc >> 5] >> (dc & 31)) & 1u)) continue;
-        const uint32_t pr = A.pvals[k];
-        const int pa = pr >> 16, pb = pr & 0xFFFF;
-        const V3 pp1 = ld3c(A.mpos, pa), pp2 = ld3c(A.mpos, pb);
-        const V3 invPoint = pp1 + (pp2 - pp1) * J.inv1;
+        const V3 invPoint = ld3c(A.pinv, k);
         if (sqn3(queryQ - invPoint) <= A.dist_thr) {  // squared metres vs metres (Q1), reproduced
             if (MODE != 0) {   // sort key: base, then (P.first, P.second, Q.first, Q.second) == the std::set order
+                const uint32_t pr = A.pvals[k];
+                const int pa = pr >> 16, pb = pr & 0xFFFF;
                 const uint64_t key = ((uint64_t)b << (4 * id_bits)) | ((uint64_t)pa << (3 * id_bits)) | ((uint64_t)pb << (2 * id_bits)) |
                                      ((uint64_t)qa << id_bits) | (uint64_t)qb;
                 if (MODE == 1) out[local] = key;
@@ -244,12 +251,27 @@ __device__ __forceinline__ unsigned long long join_one(const JoinArgs& A, uint32
     return local;
 }
 
-// count pass, one lane per Q pair
-__global__ __launch_bounds__(256) void join_count_kernel(JoinArgs A, unsigned long long* __restrict__ qcnt) {
-    __shared__ uint32_t seen[256][11];  // 343-bit set per lane
+// (base, position cell) of every Q pair: the count pass walks the Q pairs in this order, so that the lanes of a
+// wavefront share one P run (same loop length, broadcast loads) instead of 64 unrelated ones
+__global__ __launch_bounds__(256) void qcell_kernel(JoinArgs A, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= A.totQ) return;
-    if (e == 0) qcnt[A.totQ] = 0;   // the scan runs over totQ + 1 entries so that its last output is the total
+    const int b = find_base(A.q_off, A.nB, e);
+    const BaseJob& J = A.jobs[b];
+    const uint32_t qr = (uint32_t)A.Q[e];
+    const V3 p1 = ld3c(A.munit, qr >> 16), p2 = ld3c(A.munit, qr & 0xFFFF);
+    const int64_t pc = index_pos(p1 + J.inv2 * (p2 - p1), J.cell, J.egSize);
+    keys[e] = ((uint64_t)b << 32) | (uint64_t)((pc < 0 || pc >= ((int64_t)1 << 31)) ? 0xFFFFFFFFu : (uint32_t)pc);
+    vals[e] = e;
+}
+
+// count pass, one lane per Q pair, in (base, position cell) order; counts land at the pair's list position
+__global__ __launch_bounds__(256) void join_count_kernel(JoinArgs A, const uint32_t* __restrict__ qperm, unsigned long long* __restrict__ qcnt) {
+    __shared__ uint32_t seen[256][11];  // 343-bit set per lane
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.totQ) return;
+    if (i == 0) qcnt[A.totQ] = 0;   // the scan runs over totQ + 1 entries so that its last output is the total
+    const uint32_t e = qperm[i];
     const int b = find_base(A.q_off, A.nB, e);
     qcnt[e] = join_one<0>(A, e, b, seen[threadIdx.x], 0ull, NULL);
 }
@@ -357,9 +379,7 @@ __global__ __launch_bounds__(256) void resolve_picks_kernel(JoinArgs A, const un
                 if (dc < 343u && ((seen[dc >> 5] >> (dc & 31)) & 1u)) {
                     const uint32_t pr = A.pvals[k];
                     pa = pr >> 16; pb = pr & 0xFFFF;
-                    const V3 pp1 = ld3c(A.mpos, pa), pp2 = ld3c(A.mpos, pb);
-                    const V3 invPoint = pp1 + (pp2 - pp1) * J.inv1;
-                    hit = sqn3(queryQ - invPoint) <= A.dist_thr;
+                    hit = sqn3(queryQ - ld3c(A.pinv, k)) <= A.dist_thr;
                 }
             }
             const unsigned long long m = __ballot(hit);
@@ -401,6 +421,7 @@ struct Arena {
             size_t tot = 0;
             for (size_t i = 0; i < slabs.size(); ++i) { tot += slabs[i].cap; (void)hipFree(slabs[i].p); }
             slabs.clear();
+            tot += tot / 4;   // slack: trials of one scene differ in size by tens of percent
             Slab sl = {NULL, tot, 0};
             STOCS_HIP_CHECK(hipMalloc((void**)&sl.p, tot));
             slabs.push_back(sl);
@@ -448,6 +469,7 @@ struct CongruentState {
     DevBuf<BaseJob> d_jobs;
     DevBuf<uint32_t> d_qoff, d_Ps, d_cfirst, d_cend;
     DevBuf<uint64_t> d_keys_s, d_Q;
+    DevBuf<float4> d_pinv;
     DevBuf<uint16_t> d_pdir;
     DevBuf<unsigned long long> d_qoffe;
     DevBuf<int32_t> d_bids;
@@ -455,7 +477,7 @@ struct CongruentState {
     JoinArgs args(const stocs_ctx* c) const {
         JoinArgs A;
         A.jobs = d_jobs.p; A.q_off = d_qoff.p; A.nB = nB; A.munit = c->d_munit; A.mpos = c->d_mpos; A.Q = d_Q.p; A.totQ = totQ;
-        A.pkeys = d_keys_s.p; A.pvals = d_Ps.p; A.pdir = d_pdir.p;
+        A.pkeys = d_keys_s.p; A.pvals = d_Ps.p; A.pdir = d_pdir.p; A.pinv = d_pinv.p;
         A.cfirst = use_table ? d_cfirst.p : NULL; A.cend = use_table ? d_cend.p : NULL; A.NC = NC;
         A.nepsilon = nepsilon; A.dist_thr = c->prm.distance_threshold; A.id_bits = id_bits;
         return A;
@@ -633,13 +655,13 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     const long long NC = (long long)egSize * egSize * egSize;
     const bool use_table = NC > 0 && NC * (long long)nB <= (long long)32 * 1024 * 1024;
     S->NC = NC; S->use_table = use_table;
-    if ((rc = S->d_pdir.alloc(totP))) return rc;
+    if ((rc = S->d_pdir.alloc(totP)) || (rc = S->d_pinv.alloc(totP))) return rc;
     if (use_table) {
         if ((rc = S->d_cfirst.alloc((size_t)(NC * nB))) || (rc = S->d_cend.alloc((size_t)(NC * nB)))) return rc;
         hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)(((size_t)(NC * nB) + 255) / 256)), dim3(256), 0, st, S->d_cfirst.p, (size_t)(NC * nB), S->d_cend.p);
     }
     hipLaunchKernelGGL(cell_ranges_kernel, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, S->d_keys_s.p, (uint32_t)totP, d_poff.p, NC, S->d_pdir.p,
-                       use_table ? S->d_cfirst.p : (uint32_t*)NULL, use_table ? S->d_cend.p : (uint32_t*)NULL);
+                       use_table ? S->d_cfirst.p : (uint32_t*)NULL, use_table ? S->d_cend.p : (uint32_t*)NULL, S->d_jobs.p, S->d_Ps.p, c->d_mpos, S->d_pinv.p);
     STOCS_HIP_CHECK(hipGetLastError());
     STOCS_TICK("gather+keys+sort")
     // ---- 4. join: count pass + exclusive scan.  The quads themselves are produced on demand (materialise / resolve_picks_kernel) ----
@@ -648,8 +670,20 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     if (4 * id_bits + base_bits > 64) { set_error("|M| = %d with %d bases does not fit the 64-bit quad key", c->nM, nB); return STOCS_ERR_CAPACITY; }
     S->id_bits = id_bits; S->base_bits = base_bits;
     DevBuf<unsigned long long> d_qcnt;   // 64-bit: the total can exceed 2^32
+    DevBuf<uint32_t> d_qperm;
     if ((rc = d_qcnt.alloc(totQ + 1)) || (rc = S->d_qoffe.alloc(totQ + 1))) return rc;
-    hipLaunchKernelGGL(join_count_kernel, dim3((unsigned)((totQ + 255) / 256)), dim3(256), 0, st, S->args(c), d_qcnt.p);
+    {   // walk order of the count pass: Q pairs by (base, position cell)
+        DevBuf<uint64_t> d_qk, d_qk_s; DevBuf<uint32_t> d_qv;
+        if ((rc = d_qk.alloc(totQ)) || (rc = d_qk_s.alloc(totQ)) || (rc = d_qv.alloc(totQ)) || (rc = d_qperm.alloc(totQ))) return rc;
+        hipLaunchKernelGGL(qcell_kernel, dim3((unsigned)((totQ + 255) / 256)), dim3(256), 0, st, S->args(c), d_qk.p, d_qv.p);
+        STOCS_HIP_CHECK(hipGetLastError());
+        size_t tq = 0;
+        STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tq, d_qk.p, d_qk_s.p, d_qv.p, d_qperm.p, (size_t)totQ, 0, 32 + base_bits, st));
+        DevBuf<char> d_tq;
+        if ((rc = d_tq.alloc(tq))) return rc;
+        STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_tq.p, tq, d_qk.p, d_qk_s.p, d_qv.p, d_qperm.p, (size_t)totQ, 0, 32 + base_bits, st));
+    }
+    hipLaunchKernelGGL(join_count_kernel, dim3((unsigned)((totQ + 255) / 256)), dim3(256), 0, st, S->args(c), d_qperm.p, d_qcnt.p);
     STOCS_HIP_CHECK(hipGetLastError());
     size_t tmp_scan = 0;
     STOCS_HIP_CHECK(rocprim::exclusive_scan(NULL, tmp_scan, d_qcnt.p, S->d_qoffe.p, 0ull, (size_t)totQ + 1, rocprim::plus<unsigned long long>(), st));
