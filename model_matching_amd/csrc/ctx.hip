@@ -381,6 +381,7 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     c->index.built = false;
     c->index.d_bucket_start = NULL; c->index.d_pairs = NULL; c->index.d_exists = NULL;
     c->cong = NULL; c->quad_id_bits = 16;
+    c->d_cand = NULL; c->cand_bytes = 0; c->n_cands = 0; c->cand_cap = 0; c->cands_stale = false;
     c->d_best = NULL;
     c->best_lcp = 0; c->best_index = -1;
     c->has_edge = false;
@@ -500,7 +501,7 @@ int stocs_ctx_destroy(stocs_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_spos, c->d_snrmw, c->d_spix, c->d_mpos, c->d_mnrm, c->d_munit, c->d_mpos_raw, c->d_mpos_s,
                     c->d_mnrm_s, c->d_mperm, c->grid.d_top, c->grid.d_cells, c->grid.d_list, c->grid.d_chunk_r, c->index.d_bucket_start,
-                    c->index.d_pairs, c->index.d_exists, c->d_scratch, c->d_best};
+                    c->index.d_pairs, c->index.d_exists, c->d_scratch, c->d_best, c->d_cand};
     stocs_internal_free_congruent(c);
     for (void* p : ptrs) if (p) hipFree(p);
     hipEventDestroy(c->ev0);

@@ -430,7 +430,7 @@ int stocs_reset_trial(stocs_ctx* c) {
     std::fill(c->previous_segment.begin(), c->previous_segment.end(), 0);
     std::fill(c->segmentation_buffer.begin(), c->segmentation_buffer.end(), 0);
     c->seg_masks.clear();
-    c->bases.clear(); c->quad_off.clear(); c->cands.clear();
+    c->bases.clear(); c->quad_off.clear(); clear_candidates(c);
     c->best_lcp = 0; c->best_index = -1;
     return refresh_class_prob_on_device(c);
 }
@@ -451,7 +451,7 @@ int stocs_set_bases(stocs_ctx* c, int n, const int32_t* ids, const float* inv) {
 }
 int stocs_clear_bases(stocs_ctx* c) {
     if (!c) return STOCS_ERR_INVALID;
-    c->bases.clear(); c->quad_off.clear(); c->cands.clear();
+    c->bases.clear(); c->quad_off.clear(); clear_candidates(c);
     c->best_lcp = 0; c->best_index = -1;
     return STOCS_OK;
 }

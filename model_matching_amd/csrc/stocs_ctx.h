@@ -143,7 +143,13 @@ struct stocs_ctx {
     void* cong;
     std::vector<unsigned long long> quad_off;
     int quad_id_bits;
+    // candidates of the last stocs_make_transforms: device-resident (compacted, in pick order) as
+    // T[n][16] | pose[n][16] | lcp[n] | base[n] inside d_cand; `cands` is the host mirror, filled on demand
     std::vector<stocs::Candidate> cands;
+    char* d_cand;
+    size_t cand_bytes;
+    int n_cands, cand_cap;
+    bool cands_stale;   // the device copy is newer than `cands`
     float best_lcp;
     int best_index;
 
@@ -155,6 +161,11 @@ struct stocs_ctx {
 };
 
 namespace stocs {
+inline void clear_candidates(stocs_ctx* c) { c->cands.clear(); c->n_cands = 0; c->cands_stale = false; }
+inline float* cand_T(stocs_ctx* c) { return (float*)c->d_cand; }
+inline float* cand_P(stocs_ctx* c) { return (float*)c->d_cand + (size_t)c->cand_cap * 16; }
+inline float* cand_lcp(stocs_ctx* c) { return (float*)c->d_cand + (size_t)c->cand_cap * 32; }
+inline int32_t* cand_base(stocs_ctx* c) { return (int32_t*)((float*)c->d_cand + (size_t)c->cand_cap * 33); }
 int ensure_scratch(stocs_ctx* c, size_t bytes);
 int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d_hit, uint8_t* d_counted);
 int build_ppf_index(stocs_ctx* c);

@@ -7,7 +7,13 @@
 // One thread per (base, quad): three-point frame alignment (no SVD, no MFMA: a 3x3*3x3 product per
 // candidate is not a dense contraction).  Pure IEEE float arithmetic in the order fixed by
 // stocs_math.h, so the result is bit-identical to the CPU restatement.
+#include <stdlib.h>
 #include <string.h>
+#include <time.h>
+
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <unordered_map>
@@ -102,6 +108,20 @@ __global__ __launch_bounds__(256) void rigid_transform_kernel(const float4* __re
     ok_out[j] = ok;
 }
 
+// accepted candidates (ok != 0) keep their pick order: destination = exclusive scan of the flags
+__global__ __launch_bounds__(256) void compact_candidates_kernel(const float4* __restrict__ T, const float4* __restrict__ P, const int32_t* __restrict__ ok,
+                                                                 const int32_t* __restrict__ pos, const int32_t* __restrict__ job_base, int n,
+                                                                 float4* __restrict__ To, float4* __restrict__ Po, float* __restrict__ lcp,
+                                                                 int32_t* __restrict__ base_out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n || !ok[j]) return;
+    const int d = pos[j];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { To[(size_t)d * 4 + k] = T[(size_t)j * 4 + k]; Po[(size_t)d * 4 + k] = P[(size_t)j * 4 + k]; }
+    lcp[d] = 0.0f;   // "score is not computed at this time" (stocs.cpp:935-936)
+    base_out[d] = job_base[j];
+}
+
 static int run_jobs(stocs_ctx* c, const std::vector<XformJob>& jobs, std::vector<float>& T, std::vector<float>& P,
                     std::vector<int32_t>& ok) {
     const size_t n = jobs.size();
@@ -153,9 +173,23 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
     if (!c || max_per_base <= 0) return STOCS_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
     if (c->quad_off.size() != c->bases.size() + 1) { set_error("stocs_make_transforms: call stocs_find_congruent_all first"); return STOCS_ERR_STATE; }
+    const bool dbg = getenv("STOCS_DEBUG_TIMING") != NULL;
+    struct timespec ts0; clock_gettime(CLOCK_MONOTONIC, &ts0);
+    auto tick = [&](const char* label) {
+        if (!dbg) return;
+        (void)hipStreamSynchronize(c->stream);
+        struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+        fprintf(stderr, "[stocs transforms] %-18s %8.3f ms\n", label, (t1.tv_sec - ts0.tv_sec) * 1e3 + (t1.tv_nsec - ts0.tv_nsec) * 1e-6);
+        ts0 = t1;
+    };
     // picks = (base, rank, job slot, sorted?) records; the quads themselves are produced on the device
     std::vector<int32_t> picks;
     std::vector<int> job_base;
+    if (max_per_base > (1 << 24)) { set_error("stocs_make_transforms: max_per_base %d exceeds 2^24", max_per_base); return STOCS_ERR_INVALID; }
+    uint32_t hsize = 64;
+    while (hsize < 4u * (uint32_t)max_per_base) hsize <<= 1;
+    const uint32_t hmask = hsize - 1;
+    std::vector<int> hkeys(hsize), hvals(hsize);
     auto add_pick = [&](size_t b, int rank, int sorted) {
         picks.push_back((int32_t)b); picks.push_back((int32_t)rank); picks.push_back((int32_t)job_base.size()); picks.push_back(sorted);
         job_base.push_back((int)b);
@@ -172,92 +206,138 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
             // partial Fisher-Yates over the base's quads in EMISSION order (the order the loop of
             // stocs.cpp:827-858 finds them), kept sparse (only the touched entries of the identity
             // permutation are stored).  Any fixed enumeration serves a uniform draw; this one needs no sort.
-            std::unordered_map<int, int> perm;
-            auto at = [&](int i) { auto it = perm.find(i); return it == perm.end() ? i : it->second; };
+            // sparse identity permutation: open-addressing table, reset per base (<= 2 * max_per_base live keys)
+            std::fill(hkeys.begin(), hkeys.end(), -1);
+            auto slot_of = [&](int i) {
+                uint32_t h = ((uint32_t)i * 2654435761u) & hmask;
+                while (hkeys[h] != -1 && hkeys[h] != i) h = (h + 1) & hmask;
+                return h;
+            };
+            auto at = [&](int i) { const uint32_t h = slot_of(i); return hkeys[h] == i ? hvals[h] : i; };
+            auto put = [&](int i, int v) { const uint32_t h = slot_of(i); hkeys[h] = i; hvals[h] = v; };
             for (int j = 0; j < max_per_base; ++j) {
                 const uint64_t r = rng64(seed, 0x5E1EC7ull + b, (uint64_t)j);
                 const int k = j + (int)mulhi64(r, (uint64_t)(nq - j));
                 const int vj = at(j), vk = at(k);
-                perm[j] = vk; perm[k] = vj;
+                put(j, vk); put(k, vj);
                 add_pick(b, vk, 0);
             }
         }
     }
     const size_t n = job_base.size();
-    std::vector<float> T(n * 16), P(n * 16);
-    std::vector<int32_t> ok(n);
+    tick("host picks");
+    clear_candidates(c);
+    c->best_lcp = 0; c->best_index = -1;
     if (n) {
-        const size_t jb = ((n * sizeof(XformJob) + 255) / 256) * 256, tb = n * 64, ob = ((n * 4 + 255) / 256) * 256;
-        int rc = ensure_scratch(c, jb + 2 * tb + ob);
+        // candidates stay on the device: jobs -> transforms -> order-preserving compaction of the accepted ones
+        const size_t jb = ((n * sizeof(XformJob) + 255) / 256) * 256, tb = n * 64, ob = (((n + 1) * 4 + 255) / 256) * 256;
+        size_t scan_tmp = 0;
+        STOCS_HIP_CHECK(rocprim::exclusive_scan(NULL, scan_tmp, (int32_t*)NULL, (int32_t*)NULL, 0, n + 1, rocprim::plus<int32_t>(), c->stream));
+        scan_tmp = ((scan_tmp + 255) / 256) * 256;
+        int rc = ensure_scratch(c, jb + 2 * tb + 3 * ob + scan_tmp);
         if (rc) return rc;
+        if ((size_t)c->cand_cap < n) {
+            if (c->d_cand) { STOCS_HIP_CHECK(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_cand); c->d_cand = NULL; }
+            c->cand_cap = (int)(n + n / 4 + 1024);
+            c->cand_bytes = (size_t)c->cand_cap * (16 + 16 + 1 + 1) * 4;
+            STOCS_HIP_CHECK(hipMalloc((void**)&c->d_cand, c->cand_bytes));
+        }
         char* base = (char*)c->d_scratch;
         XformJob* dJ = (XformJob*)base;
         float* dT = (float*)(base + jb);
         float* dP = (float*)(base + jb + tb);
-        int32_t* dO = (int32_t*)(base + jb + 2 * tb);
+        int32_t* dO = (int32_t*)(base + jb + 2 * tb);          // n + 1 flags (the last one is 0)
+        int32_t* dPos = (int32_t*)(base + jb + 2 * tb + ob);   // their exclusive scan; dPos[n] = accepted count
+        int32_t* dB = (int32_t*)(base + jb + 2 * tb + 2 * ob);
+        void* dTmp = base + jb + 2 * tb + 3 * ob;
         rc = stocs_internal_make_jobs(c, picks.data(), (int)n, dJ);
         if (rc) return rc;
+        tick("resolve picks");
+        STOCS_HIP_CHECK(hipMemcpyAsync(dB, job_base.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+        STOCS_HIP_CHECK(hipMemsetAsync(dO + n, 0, 4, c->stream));
         hipLaunchKernelGGL(rigid_transform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_spos, c->d_mpos, dJ, (int)n,
                            c->centroid_scene, c->centroid_model, dT, dP, dO);
         STOCS_HIP_CHECK(hipGetLastError());
-        STOCS_HIP_CHECK(hipMemcpyAsync(T.data(), dT, tb, hipMemcpyDeviceToHost, c->stream));
-        STOCS_HIP_CHECK(hipMemcpyAsync(P.data(), dP, tb, hipMemcpyDeviceToHost, c->stream));
-        STOCS_HIP_CHECK(hipMemcpyAsync(ok.data(), dO, n * 4, hipMemcpyDeviceToHost, c->stream));
+        STOCS_HIP_CHECK(rocprim::exclusive_scan(dTmp, scan_tmp, dO, dPos, 0, n + 1, rocprim::plus<int32_t>(), c->stream));
+        hipLaunchKernelGGL(compact_candidates_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float4*)dT, (const float4*)dP, dO, dPos, dB,
+                           (int)n, (float4*)cand_T(c), (float4*)cand_P(c), cand_lcp(c), cand_base(c));
+        STOCS_HIP_CHECK(hipGetLastError());
+        int32_t n_ok = 0;
+        STOCS_HIP_CHECK(hipMemcpyAsync(&n_ok, dPos + n, 4, hipMemcpyDeviceToHost, c->stream));
         STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->n_cands = n_ok;
+        c->cands_stale = n_ok > 0;
+        tick("transform+compact");
     }
-    c->cands.clear();
-    c->best_lcp = 0; c->best_index = -1;
+    if (n_candidates) *n_candidates = c->n_cands;
+    return STOCS_OK;
+}
+
+// host mirror of the device-resident candidates (T, pose, lcp, base index), downloaded when somebody asks
+static int ensure_host_candidates(stocs_ctx* c) {
+    if (!c->cands_stale) return STOCS_OK;
+    const size_t n = (size_t)c->n_cands;
+    std::vector<float> T(n * 16), P(n * 16), l(n);
+    std::vector<int32_t> b(n);
+    STOCS_HIP_CHECK(hipMemcpyAsync(T.data(), cand_T(c), n * 64, hipMemcpyDeviceToHost, c->stream));
+    STOCS_HIP_CHECK(hipMemcpyAsync(P.data(), cand_P(c), n * 64, hipMemcpyDeviceToHost, c->stream));
+    STOCS_HIP_CHECK(hipMemcpyAsync(l.data(), cand_lcp(c), n * 4, hipMemcpyDeviceToHost, c->stream));
+    STOCS_HIP_CHECK(hipMemcpyAsync(b.data(), cand_base(c), n * 4, hipMemcpyDeviceToHost, c->stream));
+    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->cands.resize(n);
     for (size_t j = 0; j < n; ++j) {
-        if (!ok[j]) continue;
-        Candidate cd;
-        memcpy(cd.T, &T[j * 16], 64);
-        memcpy(cd.pose, &P[j * 16], 64);
-        cd.lcp = 0;                 // "score is not computed at this time" stocs.cpp:935-936
-        cd.base_index = job_base[j];
-        c->cands.push_back(cd);
+        memcpy(c->cands[j].T, &T[j * 16], 64);
+        memcpy(c->cands[j].pose, &P[j * 16], 64);
+        c->cands[j].lcp = l[j];   // 0 until stocs_verify_all ("score is not computed at this time", stocs.cpp:935-936)
+        c->cands[j].base_index = b[j];
     }
-    if (n_candidates) *n_candidates = (int)c->cands.size();
+    c->cands_stale = false;
     return STOCS_OK;
 }
 
 int stocs_get_candidates(stocs_ctx* c, float* T16, float* pose16, float* lcp, int32_t* base_index, int cap, int* n) {
     if (!c || !n) return STOCS_ERR_INVALID;
-    *n = (int)c->cands.size();
+    DeviceGuard dev_guard(c->device);
+    *n = c->n_cands;
+    if (!(T16 || pose16 || lcp || base_index)) return STOCS_OK;
+    int rc = ensure_host_candidates(c);
+    if (rc) return rc;
     for (int i = 0; i < *n && i < cap; ++i) {
         if (T16) memcpy(T16 + (size_t)i * 16, c->cands[i].T, 64);
         if (pose16) memcpy(pose16 + (size_t)i * 16, c->cands[i].pose, 64);
         if (lcp) lcp[i] = c->cands[i].lcp;
         if (base_index) base_index[i] = c->cands[i].base_index;
     }
-    return (*n > cap && (T16 || pose16 || lcp || base_index)) ? STOCS_ERR_CAPACITY : STOCS_OK;
+    return (*n > cap) ? STOCS_ERR_CAPACITY : STOCS_OK;
 }
 
 int stocs_verify_all(stocs_ctx* c, float* best_lcp, int* best_idx, float* best_pose16) {
     if (!c) return STOCS_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
-    const int n = (int)c->cands.size();
+    const int n = c->n_cands;
     c->best_lcp = 0; c->best_index = -1;
+    float pose[16];
+    memset(pose, 0, sizeof(pose));
     if (n > 0) {
-        std::vector<float> T((size_t)n * 16), l(n);
-        for (int i = 0; i < n; ++i) memcpy(&T[(size_t)i * 16], c->cands[i].T, 64);
-        int rc = stocs_score_transforms(c, T.data(), n, l.data());
+        // scores and the arg-max stay on the device: one LCP launch over the resident transforms, then
+        // compute_best_transform (stocs.cpp:987-998: strict > from 0 => first maximum wins, Q18) as an integer max
+        int rc = launch_lcp(c, cand_T(c), n, cand_lcp(c), NULL, NULL);
         if (rc) return rc;
-        // compute_best_transform, stocs.cpp:987-998: strict > from 0 => first maximum wins (Q18)
-        float max_score = 0;
-        int index = -1;
-        for (int i = 0; i < n; ++i) {
-            c->cands[i].lcp = l[i];
-            if (l[i] > max_score) { max_score = l[i]; index = i; }
+        uint64_t key = 0;
+        rc = stocs_best_device(c, cand_lcp(c), n, 0, &key);
+        if (rc) return rc;
+        c->cands_stale = true;   // the host mirror (if any) lacks the new scores
+        if (key) {
+            uint32_t id = 0;
+            stocs_unpack_best(key, &c->best_lcp, &id);
+            c->best_index = (int)id;
+            STOCS_HIP_CHECK(hipMemcpyAsync(pose, cand_P(c) + (size_t)id * 16, 64, hipMemcpyDeviceToHost, c->stream));
+            STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
         }
-        c->best_lcp = max_score;
-        c->best_index = index;
     }
     if (best_lcp) *best_lcp = c->best_lcp;
     if (best_idx) *best_idx = c->best_index;
-    if (best_pose16) {
-        if (c->best_index >= 0) memcpy(best_pose16, c->cands[c->best_index].pose, 64);
-        else memset(best_pose16, 0, 64);
-    }
+    if (best_pose16) memcpy(best_pose16, pose, 64);
     return STOCS_OK;
 }
 
