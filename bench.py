@@ -168,7 +168,10 @@ def main():
         pe.sync()
         t_idx = time.perf_counter() - t
         runs = []
-        for r in range(3):
+        from scipy.spatial import cKDTree
+        gt_pts = model.pos.astype(np.float64) @ np.asarray(scene.T_gt, np.float64)[:3, :3].T + np.asarray(scene.T_gt, np.float64)[:3, 3]
+        gt_tree = cKDTree(gt_pts)
+        for r in range(5):
             pe.L.stocs_clear_bases(pe.h)
             t0 = time.perf_counter(); valid, _, _ = pe.sample_bases(1234 + r, 100)
             t1 = time.perf_counter(); nq = pe.find_congruent_all()
@@ -182,12 +185,17 @@ def main():
             rot_err = float(np.degrees(np.arccos(np.clip((np.trace(dR) - 1.0) / 2.0, -1.0, 1.0))))
             c0 = model.pos.astype(np.float64).mean(0)
             tr_err = float(np.linalg.norm((Pm[:3, :3] @ c0 + Pm[:3, 3]) - (np.asarray(scene.T_gt)[:3, :3] @ c0 + np.asarray(scene.T_gt)[:3, 3])) * 1e3)
-            runs.append({"bases": int(valid.sum()), "congruent_quads": int(nq), "candidates": int(nc), "best_lcp": float(bl),
-                         "winner_rot_err_deg_vs_gt": rot_err, "winner_centroid_err_mm_vs_gt": tr_err,
+            est_pts = model.pos.astype(np.float64) @ Pm[:3, :3].T + Pm[:3, 3]
+            add_s = float(gt_tree.query(est_pts)[0].mean() * 1e3)   # symmetry-aware: mean closest-point distance (ADD-S)
+            runs.append({"warmup": r < 2, "bases": int(valid.sum()), "congruent_quads": int(nq), "candidates": int(nc), "best_lcp": float(bl),
+                         "winner_rot_err_deg_vs_gt": rot_err, "winner_centroid_err_mm_vs_gt": tr_err, "winner_add_s_mm_vs_gt": add_s,
                          "sample_ms": (t1 - t0) * 1e3, "congruent_ms": (t2 - t1) * 1e3, "transforms_ms": (t3 - t2) * 1e3,
                          "verify_ms": (t4 - t3) * 1e3, "poses_per_s_phases_2_4": nc / max(t4 - t1, 1e-9)})
-        out["pipeline"] = {"note": "one StoCS trial stream of 100 base attempts, <=200 quads per base, host wall clock incl. launches "
-                                   "and copies; first run includes one-time allocations", "context_plus_index_build_s": t_idx, "runs": runs}
+        out["pipeline"] = {"note": "StoCS trial streams of 100 base attempts, <=200 quads per base, host wall clock incl. launches "
+                                   "and copies; the first two runs grow the context's arenas (one-time hipMalloc) and are marked warmup. "
+                                   "The synthetic model is a near-symmetric ellipsoid of revolution (SURVEY 8d): the rotation about its "
+                                   "axis is barely observable, so the rotation error is reported next to the symmetry-aware ADD-S", "context_plus_index_build_s": t_idx, "runs": runs,
+                           "steady_state_poses_per_s_phases_2_4": float(np.mean([x["poses_per_s_phases_2_4"] for x in runs if not x["warmup"]]))}
         pe.close()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

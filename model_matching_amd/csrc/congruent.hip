@@ -429,6 +429,15 @@ struct Arena {
         for (size_t i = 0; i < slabs.size(); ++i) slabs[i].used = 0;
         return STOCS_OK;
     }
+    // right after reset(): make sure ONE slab can hold `bytes` (a good estimate up front avoids growing in pieces)
+    int reserve(size_t bytes) {
+        if (slabs.size() == 1 && slabs[0].cap >= bytes) return STOCS_OK;
+        destroy();
+        Slab sl = {NULL, bytes + bytes / 4, 0};
+        STOCS_HIP_CHECK(hipMalloc((void**)&sl.p, sl.cap));
+        slabs.push_back(sl);
+        return STOCS_OK;
+    }
     int take(size_t bytes, void** out) {
         bytes = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
         for (size_t i = 0; i < slabs.size(); ++i)
@@ -612,6 +621,12 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     if (totP == 0 || totQ == 0) return STOCS_OK;
 
     // ---- 2-3. gather + keys + sort ----
+    {   // everything this call allocates, estimated up front: one slab, one hipMalloc in a context's lifetime (if sizes stay put)
+        const long long NCe = (long long)egSize * egSize * egSize;
+        const size_t tables = (NCe > 0 && NCe * (long long)nB <= (long long)32 * 1024 * 1024) ? (size_t)(NCe * nB) * 8 : 0;
+        int rc0 = S->arena_state.reserve((size_t)totP * 64 + (size_t)totQ * 64 + tables + ((size_t)48 << 20));
+        if (rc0) return rc0;
+    }
     S->nB = nB; S->totP = (uint32_t)totP; S->totQ = (uint32_t)totQ; S->nepsilon = nepsilon; S->q_off = q_off;
     DevBuf<Segment> d_psegs, d_qsegs; DevBuf<uint32_t> d_poff, d_P32;
     DevBuf<uint64_t> d_keys, d_Pg, d_Pl, d_Qg; DevBuf<char> d_tmp;
