@@ -488,7 +488,7 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     if (!rc && build_index) rc = build_ppf_index(c);
     const size_t px = (size_t)prm->image_width * prm->image_height;
     c->edge_map.assign(px, 0);
-    c->previous_segment.assign(px, 0);
+    c->previous_segment.reset();
     c->segmentation_buffer.assign(px, 0);
     if (rc) { stocs_ctx_destroy(c); return rc; }
     *out = c;

@@ -20,6 +20,7 @@
 // reference, the PPF passes and draws run on the device.
 #include <math.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <limits>
@@ -59,14 +60,9 @@ __global__ __launch_bounds__(256) void init_weights_kernel(const float* __restri
 }
 
 // PASS = 1: stocs.cpp:395-407   PASS = 2: stocs.cpp:424-442   PASS = 3: stocs.cpp:456-497
+// whether pass PASS zeroes the weight of scene point i for the base points b1, b2, b3 chosen so far
 template <int PASS>
-__global__ __launch_bounds__(256) void pass_kernel(PassArgs a, const int32_t* __restrict__ bidx, const int32_t* __restrict__ fail,
-                                                   float* __restrict__ w) {
-    const int b = blockIdx.y;
-    if (fail[b]) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.S) return;
-    const int b1 = bidx[b * 4 + 0], b2 = bidx[b * 4 + 1], b3 = bidx[b * 4 + 2];
+__device__ __forceinline__ bool pass_zeroes(const PassArgs& a, int b1, int b2, int b3, int i) {
     const int cur = PASS == 1 ? b1 : (PASS == 2 ? b2 : b3);
     const float4 pc4 = a.spos[cur], nc4 = a.snrm[cur];
     const float4 pi4 = a.spos[i], ni4 = a.snrm[i];
@@ -102,18 +98,22 @@ __global__ __launch_bounds__(256) void pass_kernel(PassArgs a, const int32_t* __
         zero = zero || planar_distance > a.plane_threshold || norm3(pi - p1) < a.min_distance_base ||
                norm3(pi - p2) < a.min_distance_base || norm3(pi - pc) < a.min_distance_base;
     }
-    if (zero) w[(size_t)b * a.S + i] = 0.0f;
+    return zero;
 }
 
-// seeded weighted draw: one workgroup per attempt
-__global__ __launch_bounds__(1024) void draw_kernel(const float* __restrict__ w, size_t stride, int S, uint64_t seed,
-                                                    uint64_t first_attempt, uint64_t k, const uint64_t* __restrict__ r_explicit,
-                                                    int slot, int32_t* __restrict__ bidx, int32_t* __restrict__ fail) {
-    __shared__ uint64_t sh[1024];
-    __shared__ uint64_t sh_total;
-    const int b = blockIdx.x;
+template <int PASS>
+__global__ __launch_bounds__(256) void pass_kernel(PassArgs a, const int32_t* __restrict__ bidx, const int32_t* __restrict__ fail,
+                                                   float* __restrict__ w) {
+    const int b = blockIdx.y;
     if (fail[b]) return;
-    const float* wb = w + (size_t)b * stride;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.S) return;
+    if (pass_zeroes<PASS>(a, bidx[b * 4 + 0], bidx[b * 4 + 1], bidx[b * 4 + 2], i)) w[(size_t)b * a.S + i] = 0.0f;
+}
+
+// seeded weighted draw by one workgroup of 1024 threads: index into wb, or -1 when every weight is zero
+// ("FAILED SAMPLING:: Zero probability returned", stocs.cpp:386-389).  Every thread returns the same value.
+__device__ __forceinline__ int draw_block(const float* __restrict__ wb, int S, uint64_t r64, uint64_t* sh /*1024*/, uint64_t* sh_total, int* sh_pick) {
     const int t = threadIdx.x;
     const int chunk = (S + 1023) / 1024;
     const int lo = min(S, t * chunk), hi = min(S, lo + chunk);
@@ -128,25 +128,75 @@ __global__ __launch_bounds__(1024) void draw_kernel(const float* __restrict__ w,
         sh[t] += v;
         __syncthreads();
     }
-    if (t == 1023) sh_total = sh[t];
+    if (t == 1023) { *sh_total = sh[t]; *sh_pick = -1; }
     __syncthreads();
-    const uint64_t total = sh_total;
-    if (total == 0) {  // "FAILED SAMPLING:: Zero probability returned" (stocs.cpp:386-389)
-        if (t == 0) { fail[b] = 1; bidx[b * 4 + slot] = -1; }
+    const uint64_t total = *sh_total;
+    if (total != 0) {
+        const uint64_t r = mulhi64(r64, total);
+        const uint64_t incl = sh[t], excl = incl - local;
+        if (r >= excl && r < incl) {  // exactly one thread (local > 0)
+            uint64_t c = excl;
+            int pick = -1;
+            for (int i = lo; i < hi; ++i) {
+                c += weight_fix(wb[i]);
+                if (c > r) { pick = i; break; }
+            }
+            *sh_pick = pick;
+        }
+    }
+    __syncthreads();
+    const int pick = *sh_pick;
+    __syncthreads();   // sh / sh_pick may be reused by the next draw
+    return pick;
+}
+
+// one workgroup per attempt
+__global__ __launch_bounds__(1024) void draw_kernel(const float* __restrict__ w, size_t stride, int S, uint64_t seed,
+                                                    uint64_t first_attempt, uint64_t k, const uint64_t* __restrict__ r_explicit,
+                                                    int slot, int32_t* __restrict__ bidx, int32_t* __restrict__ fail) {
+    __shared__ uint64_t sh[1024];
+    __shared__ uint64_t sh_total;
+    __shared__ int sh_pick;
+    const int b = blockIdx.x;
+    if (fail[b]) return;
+    const uint64_t r64 = r_explicit ? r_explicit[b] : rng64(seed, first_attempt + (uint64_t)b, k);
+    const int pick = draw_block(w + (size_t)b * stride, S, r64, sh, &sh_total, &sh_pick);
+    if (threadIdx.x == 0) {
+        bidx[b * 4 + slot] = pick;
+        if (pick < 0) fail[b] = 1;
+    }
+}
+
+// Instance mode runs its attempts one after the other (the class prior decays between them), so launch count is
+// what matters: ONE workgroup does "draw point 1, pass 1" (FIRST) or "draw 2, pass 2, draw 3, pass 3, draw 4" in
+// a single launch.  hdr = {bidx[4], fail} directly behind the weights, so one copy moves weights + result.
+template <bool FIRST>
+__global__ __launch_bounds__(1024) void instance_steps_kernel(PassArgs a, uint64_t seed, uint64_t attempt, float* __restrict__ w, int32_t* __restrict__ bidx,
+                                                              int32_t* __restrict__ fail) {
+    __shared__ uint64_t sh[1024];
+    __shared__ uint64_t sh_total;
+    __shared__ int sh_pick;
+    const int t = threadIdx.x;
+    int b1, b2 = -1, b3 = -1;
+    if (FIRST) {
+        b1 = draw_block(w, a.S, rng64(seed, attempt, 0), sh, &sh_total, &sh_pick);
+        if (t == 0) { bidx[0] = b1; bidx[1] = bidx[2] = bidx[3] = -1; fail[0] = b1 < 0 ? 1 : 0; }
+        if (b1 < 0) return;
+        for (int i = t; i < a.S; i += 1024) if (pass_zeroes<1>(a, b1, -1, -1, i)) w[i] = 0.0f;
         return;
     }
-    const uint64_t r64 = r_explicit ? r_explicit[b] : rng64(seed, first_attempt + (uint64_t)b, k);
-    const uint64_t r = mulhi64(r64, total);
-    const uint64_t incl = sh[t], excl = incl - local;
-    if (r >= excl && r < incl) {  // exactly one thread (local > 0)
-        uint64_t c = excl;
-        int pick = -1;
-        for (int i = lo; i < hi; ++i) {
-            c += weight_fix(wb[i]);
-            if (c > r) { pick = i; break; }
-        }
-        bidx[b * 4 + slot] = pick;
-    }
+    b1 = bidx[0];
+    __syncthreads();
+    b2 = draw_block(w, a.S, rng64(seed, attempt, 1), sh, &sh_total, &sh_pick);
+    if (b2 < 0) { if (t == 0) { bidx[1] = -1; fail[0] = 1; } return; }
+    for (int i = t; i < a.S; i += 1024) if (pass_zeroes<2>(a, b1, b2, -1, i)) w[i] = 0.0f;
+    __syncthreads();
+    b3 = draw_block(w, a.S, rng64(seed, attempt, 2), sh, &sh_total, &sh_pick);
+    if (b3 < 0) { if (t == 0) { bidx[1] = b2; bidx[2] = -1; fail[0] = 1; } return; }
+    for (int i = t; i < a.S; i += 1024) if (pass_zeroes<3>(a, b1, b2, b3, i)) w[i] = 0.0f;
+    __syncthreads();
+    const int b4 = draw_block(w, a.S, rng64(seed, attempt, 3), sh, &sh_total, &sh_pick);
+    if (t == 0) { bidx[1] = b2; bidx[2] = b3; bidx[3] = b4; if (b4 < 0) fail[0] = 1; }
 }
 
 // ---- host helpers ------------------------------------------------------------------------------
@@ -224,10 +274,10 @@ static int carve(stocs_ctx* c, int nB, SampleBuffers* sb) {
     int rc = ensure_scratch(c, bw + bc + bi + bf + br);
     if (rc) return rc;
     char* p = (char*)c->d_scratch;
-    sb->w = (float*)p; p += bw;
-    sb->cls = (float*)p; p += bc;
+    sb->w = (float*)p; p += bw;          // weights, then bidx, then fail: one copy moves all three when nB == 1
     sb->bidx = (int32_t*)p; p += bi;
     sb->fail = (int32_t*)p; p += bf;
+    sb->cls = (float*)p; p += bc;
     sb->rexp = (uint64_t*)p;
     return STOCS_OK;
 }
@@ -304,13 +354,12 @@ static int sample_class(stocs_ctx* c, uint64_t seed, int first_attempt, int nB, 
 }
 
 // rgbd.cpp:314-367 with the PNG round trip through dbg/seg_mask_<n>.png replaced by seg_masks (Q14)
-static void generate_segmentation_mask(stocs_ctx* c, int prow, int pcol, float max_distance, std::vector<uint8_t>& closed_list, int base_num) {
+static std::shared_ptr<const std::vector<uint8_t> > generate_segmentation_mask(stocs_ctx* c, int prow, int pcol, float max_distance, int base_num) {
     const int W = c->prm.image_width, H = c->prm.image_height;
     const int segment_index = c->segmentation_buffer[(size_t)prow * W + pcol];
-    if (segment_index != 0) {
-        closed_list = c->seg_masks[segment_index];
-        return;
-    }
+    if (segment_index != 0) return c->seg_masks[segment_index];   // the mask file of that attempt is read back (rgbd.cpp:322-326)
+    std::shared_ptr<std::vector<uint8_t> > closed(new std::vector<uint8_t>((size_t)W * H, 0));
+    std::vector<uint8_t>& closed_list = *closed;
     std::queue<std::pair<int, int> > open_list;
     open_list.push(std::make_pair(prow, pcol));
     while (!open_list.empty()) {
@@ -331,6 +380,7 @@ static void generate_segmentation_mask(stocs_ctx* c, int prow, int pcol, float m
                 }
             }
     }
+    return closed;
 }
 
 static int refresh_class_prob_on_device(stocs_ctx* c) {
@@ -346,29 +396,38 @@ static int refresh_class_prob_on_device(stocs_ctx* c) {
     return STOCS_OK;
 }
 
+static double g_t_inst[6];
+static inline double now_s_() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+#define TSEC(k) { const double t_ = now_s_(); g_t_inst[k] += t_ - tprev_; tprev_ = t_; }
 static int sample_instance_one(stocs_ctx* c, uint64_t seed, int attempt, float dispersion, int base_num, int32_t* ids, float* inv, int32_t* valid) {
     const int S = c->nS, W = c->prm.image_width;
+    double tprev_ = now_s_();
     SampleBuffers sb;
     int rc = carve(c, 1, &sb);
     if (rc) return rc;
     std::vector<float> w(S);
     for (int i = 0; i < S; ++i) {  // stocs.cpp:572-580 (compounding decay) + prune_edge_pixels :521-535
         const size_t px = (size_t)c->h_spix[2 * i] * W + c->h_spix[2 * i + 1];
-        if (c->previous_segment[px]) c->h_sprob[i] = dispersion * c->h_sprob[i];
+        if (c->previous_segment && (*c->previous_segment)[px]) c->h_sprob[i] = dispersion * c->h_sprob[i];
         w[i] = c->h_sprob[i];
         const float edge_probability = (float)(255.0 - c->edge_map[px]) / 255.0;
         if (edge_probability == 1) w[i] = 0;
     }
+    TSEC(0)
+    // round trip 1: weights up, "draw point 1 + pass 1" in one launch, weights + (bidx, fail) back in one copy
+    const PassArgs pa = pass_args(c);
+    const size_t span = (size_t)((char*)sb.fail - (char*)sb.w) + 4;   // w .. fail, contiguous (carve)
+    std::vector<char> stage(span);
     STOCS_HIP_CHECK(hipMemcpyAsync(sb.w, w.data(), (size_t)S * 4, hipMemcpyHostToDevice, c->stream));
-    STOCS_HIP_CHECK(hipMemsetAsync(sb.fail, 0, 4, c->stream));
-    STOCS_HIP_CHECK(hipMemsetAsync(sb.bidx, 0xFF, 16, c->stream));
-    launch_draw(c, 1, sb, seed, (uint64_t)attempt, 0);
-    launch_pass(c, 1, 1, sb);
-    int32_t bidx[4], fail = 0;
-    STOCS_HIP_CHECK(hipMemcpyAsync(w.data(), sb.w, (size_t)S * 4, hipMemcpyDeviceToHost, c->stream));
-    STOCS_HIP_CHECK(hipMemcpyAsync(bidx, sb.bidx, 16, hipMemcpyDeviceToHost, c->stream));
-    STOCS_HIP_CHECK(hipMemcpyAsync(&fail, sb.fail, 4, hipMemcpyDeviceToHost, c->stream));
+    hipLaunchKernelGGL(instance_steps_kernel<true>, dim3(1), dim3(1024), 0, c->stream, pa, seed, (uint64_t)attempt, sb.w, sb.bidx, sb.fail);
+    STOCS_HIP_CHECK(hipGetLastError());
+    STOCS_HIP_CHECK(hipMemcpyAsync(stage.data(), sb.w, span, hipMemcpyDeviceToHost, c->stream));
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    int32_t bidx[4], fail = 0;
+    memcpy(w.data(), stage.data(), (size_t)S * 4);
+    memcpy(bidx, stage.data() + ((char*)sb.bidx - (char*)sb.w), 16);
+    memcpy(&fail, stage.data() + ((char*)sb.fail - (char*)sb.w), 4);
+    TSEC(1)
     std::vector<int32_t> vb(4, -1), vf(1, 1);
     if (fail || bidx[0] < 0) return finalize_bases(c, 1, vb, vf, ids, inv, valid);
     const int b1 = bidx[0];
@@ -378,22 +437,26 @@ static int sample_instance_one(stocs_ctx* c, uint64_t seed, int attempt, float d
             const float dist = (float)sqrt(pow((double)(c->h_spix[2 * b1] - c->h_spix[2 * i]), 2) + pow((double)(c->h_spix[2 * b1 + 1] - c->h_spix[2 * i + 1]), 2));
             if (dist > max_pixel_distance) max_pixel_distance = dist;
         }
-    std::vector<uint8_t> mask((size_t)W * c->prm.image_height, 0);
-    generate_segmentation_mask(c, c->h_spix[2 * b1], c->h_spix[2 * b1 + 1], max_pixel_distance, mask, base_num);
+    TSEC(2)
+    const std::shared_ptr<const std::vector<uint8_t> > mask_p = generate_segmentation_mask(c, c->h_spix[2 * b1], c->h_spix[2 * b1 + 1], max_pixel_distance, base_num);
+    const std::vector<uint8_t>& mask = *mask_p;
+    TSEC(3)
     if ((int)c->seg_masks.size() <= base_num) c->seg_masks.resize(base_num + 1);
-    c->seg_masks[base_num] = mask;      // cv::imwrite(seg_mask_<n>.png), stocs.cpp:625
-    c->previous_segment = mask;         // stocs.cpp:626
+    c->seg_masks[base_num] = mask_p;    // cv::imwrite(seg_mask_<n>.png), stocs.cpp:625
+    c->previous_segment = mask_p;       // stocs.cpp:626
     for (int i = 0; i < S; ++i)         // stocs.cpp:628-638
         if (w[i] != 0 && !mask[(size_t)c->h_spix[2 * i] * W + c->h_spix[2 * i + 1]]) w[i] = 0;
+    TSEC(4)
+    // round trip 2: filtered weights up, "draw 2, pass 2, draw 3, pass 3, draw 4" in one launch, (bidx, fail) back
     STOCS_HIP_CHECK(hipMemcpyAsync(sb.w, w.data(), (size_t)S * 4, hipMemcpyHostToDevice, c->stream));
-    for (int k = 1; k < 4; ++k) {
-        launch_draw(c, 1, sb, seed, (uint64_t)attempt, k);
-        if (k < 3) launch_pass(c, k + 1, 1, sb);
-    }
+    hipLaunchKernelGGL(instance_steps_kernel<false>, dim3(1), dim3(1024), 0, c->stream, pa, seed, (uint64_t)attempt, sb.w, sb.bidx, sb.fail);
     STOCS_HIP_CHECK(hipGetLastError());
-    STOCS_HIP_CHECK(hipMemcpyAsync(vb.data(), sb.bidx, 16, hipMemcpyDeviceToHost, c->stream));
-    STOCS_HIP_CHECK(hipMemcpyAsync(vf.data(), sb.fail, 4, hipMemcpyDeviceToHost, c->stream));
+    const size_t tail = (size_t)((char*)sb.fail - (char*)sb.bidx) + 4;
+    STOCS_HIP_CHECK(hipMemcpyAsync(stage.data(), sb.bidx, tail, hipMemcpyDeviceToHost, c->stream));
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    memcpy(vb.data(), stage.data(), 16);
+    memcpy(vf.data(), stage.data() + ((char*)sb.fail - (char*)sb.bidx), 4);
+    TSEC(5)
     return finalize_bases(c, 1, vb, vf, ids, inv, valid);
 }
 
@@ -420,6 +483,9 @@ int stocs_sample_bases(stocs_ctx* c, int mode, uint64_t seed, int first_attempt,
                                      inv2 ? inv2 + 2 * b : NULL, valid ? valid + b : NULL);
         if (rc) return rc;
     }
+    if (getenv("STOCS_DEBUG_TIMING"))
+        fprintf(stderr, "[stocs instance] cumulative ms: weights %.2f | draw0+pass1+sync %.2f | maxdist %.2f | flood fill %.2f | mask copies+filter %.2f | draws 1-3 + sync %.2f\n",
+                g_t_inst[0] * 1e3, g_t_inst[1] * 1e3, g_t_inst[2] * 1e3, g_t_inst[3] * 1e3, g_t_inst[4] * 1e3, g_t_inst[5] * 1e3);
     return refresh_class_prob_on_device(c);
 }
 
@@ -427,7 +493,7 @@ int stocs_reset_trial(stocs_ctx* c) {
     if (!c) return STOCS_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
     c->h_sprob = c->h_sprob0;
-    std::fill(c->previous_segment.begin(), c->previous_segment.end(), 0);
+    c->previous_segment.reset();
     std::fill(c->segmentation_buffer.begin(), c->segmentation_buffer.end(), 0);
     c->seg_masks.clear();
     c->bases.clear(); c->quad_off.clear(); clear_candidates(c);

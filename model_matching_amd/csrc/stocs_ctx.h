@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -132,8 +133,11 @@ struct stocs_ctx {
 
     // image-space state of instance mode (stocs.hpp:153-155)
     bool has_edge;
-    std::vector<uint8_t> edge_map, previous_segment, segmentation_buffer;
-    std::vector<std::vector<uint8_t> > seg_masks;
+    std::vector<uint8_t> edge_map, segmentation_buffer;
+    // masks are shared, never copied: seg_masks[n] is attempt n's mask (possibly the very mask of an earlier
+    // attempt), previous_segment the last one (null = all zero)
+    std::shared_ptr<const std::vector<uint8_t> > previous_segment;
+    std::vector<std::shared_ptr<const std::vector<uint8_t> > > seg_masks;
 
     // run state
     std::vector<stocs::BaseRec> bases;

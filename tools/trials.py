@@ -57,15 +57,24 @@ def main():
         for est in ests:
             est.set_edge_map(d["edge_map"])
 
+    phase_s = [[0.0] * 4 for _ in range(n_streams)]
+
     def run_trials(k):
         # stream k of this rank takes trials lo+k, lo+k+S, ...; the library calls release the GIL
         est, b, nc = ests[k], (0.0, -1, None), 0
         for t in range(lo + k, hi, n_streams):
+            t0 = time.perf_counter()
             est.reset_trial()                                                # fresh class prior per trial (instance mode decays it)
             est.sample_bases(args.seed + t, args.bases, mode=mode, dispersion=0.9)
+            t1 = time.perf_counter()
             est.find_congruent_all()
+            t2 = time.perf_counter()
             nc += est.make_transforms(args.max_sets, args.seed + t)
+            t3 = time.perf_counter()
             lcp, idx, pose = est.compute_best_transform()
+            t4 = time.perf_counter()
+            for i, d_ in enumerate((t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                phase_s[k][i] += d_
             gid = (t << 16) | idx
             if idx >= 0 and (lcp > b[0] or (lcp == b[0] and gid < b[1])):
                 b = (lcp, gid, pose.copy())
@@ -101,7 +110,8 @@ def main():
     pose = sd.broadcast_pose(best[2] if (rank == owner and best[2] is not None) else np.zeros(16, np.float32), owner, device=dev)
     if rank == 0:
         print(json.dumps({"example": args.example, "mode": "instance" if mode else "class", "trials": args.trials, "streams_per_gpu": n_streams, "n_gpus": world, "rehearsal": rehearsal,
-                          "seconds": dt, "trials_per_s": args.trials / dt, "candidates_verified": n_cand, "candidates_per_s": n_cand / dt,
+                          "seconds": dt, "trials_per_s": args.trials / dt,
+                          "rank0_phase_seconds_sample_congruent_transforms_verify": [sum(p[i] for p in phase_s) for i in range(4)], "candidates_verified": n_cand, "candidates_per_s": n_cand / dt,
                           "best_lcp": g_lcp, "best_trial": (g_id >> 16) if g_id >= 0 else -1, "best_candidate": (g_id & 0xFFFF) if g_id >= 0 else -1,
                           "best_pose_row_major_3x4": [float(pose.reshape(4, 4).T[r, c]) for r in range(3) for c in range(4)]}), flush=True)
     if world > 1:
