@@ -4,11 +4,26 @@ over the C ABI of libstocs_hip.so.  Same method names and argument meaning as th
 computed in Python."""
 from __future__ import annotations
 
+import atexit
 import ctypes as C
+import weakref
 
 import numpy as np
 
 from . import capi
+
+# contexts still open when the interpreter exits are destroyed before module teardown, i.e. while the HIP runtime
+# (possibly shared with PyTorch) is still up; a __del__ that runs after the runtime's own shutdown would free twice
+_LIVE = weakref.WeakSet()
+
+
+@atexit.register
+def _close_all():
+    for est in list(_LIVE):
+        try:
+            est.close()
+        except Exception:
+            pass
 
 
 class StocsEstimator:
@@ -28,8 +43,10 @@ class StocsEstimator:
         self.h = C.c_void_p()
         capi.check(self.L.stocs_ctx_create(C.byref(self.prm), psp, psn, pspr, ppx, self.nS, pmp, pmn, self.nM,
                                            1 if build_index else 0, device, C.byref(self.h)))
+        _LIVE.add(self)
 
     def close(self):
+        _LIVE.discard(self)
         if getattr(self, "h", None) and self.h.value:
             self.L.stocs_ctx_destroy(self.h)
             self.h = C.c_void_p()

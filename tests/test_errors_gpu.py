@@ -126,3 +126,47 @@ def test_native_rccl_allreduce_single_rank():
     assert L.stocs_allreduce_best(comm, None, C.byref(key), p2.ctypes.data_as(capi._fp), 65536) == -1
     assert L.stocs_comm_destroy(comm) == 0
     assert L.stocs_comm_create(uid, 2, 5, 0, C.byref(comm)) == -1   # rank out of range
+
+
+def test_on_demand_quads_edge_cases(oracle_lib):
+    """stocs_get_quads_at range checks; per-base maximum of 1 (every non-empty base is sampled, none materialised)
+    and a huge maximum (every base is materialised and used whole) against the oracle; stream switch keeps state."""
+    from model_matching_amd import capi
+    m, s, est = _mk()
+    orc = oracle_lib.Oracle(s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm, build_index=True)
+    seed = 5
+    valid, ids, inv = est.sample_bases(seed, 30)
+    assert est.find_congruent_all() > 0
+    slot = next(i for i in range(int(valid.sum())) if est.num_quads(i) > 3)
+    nq = est.num_quads(slot)
+    for bad in ([-1], [nq], [0, nq + 5]):
+        with pytest.raises(capi.StocsError) as e:
+            est.get_quads_at(slot, bad)
+        assert e.value.code == -1
+    with pytest.raises(capi.StocsError):
+        est.get_quads_at(10 ** 6, [0])
+    assert est.get_quads_at(slot, []).shape == (0, 4)
+    # same rank twice is allowed, and equals the oracle's insertion sequence
+    a = int(np.nonzero(valid)[0][slot])
+    so = orc.find_congruent_seq(ids[a], float(inv[a][0]), float(inv[a][1]))
+    assert np.array_equal(est.get_quads_at(slot, [2, 2, 0]), so[[2, 2, 0]])
+    for max_sets in (1, 10 ** 6):
+        r = orc.run(seed, 30, max_sets)
+        assert est.make_transforms(max_sets, seed) == r.n_candidates
+        To, Po, bo = orc.candidates()
+        Tg, Pg, lg, bg = est.get_pose_candidates()
+        assert np.array_equal(To, Tg) and np.array_equal(bo, bg)
+        lcp, idx, pose = est.compute_best_transform()
+        assert abs(lcp - r.best_lcp) <= 1e-5
+    with pytest.raises(capi.StocsError):
+        est.make_transforms((1 << 24) + 1, seed)
+    # switching the stream keeps the counted state usable
+    hip = C.CDLL("libamdhip64.so")
+    st = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(st)) == 0
+    est.set_stream(st.value)
+    assert np.array_equal(est.get_quads_at(slot, [1]), so[[1]])
+    est.set_stream(None)
+    assert hip.hipStreamDestroy(st) == 0
+    assert np.array_equal(est.get_quads(slot), orc.find_congruent(ids[a], float(inv[a][0]), float(inv[a][1])))
+    est.close()
