@@ -306,20 +306,50 @@ static int build_grid_div(stocs_ctx* c, int div_in) {
 }
 
 // Cell edge = epsilon unless the scene is so dense that the candidate lists get long (C5: 200k points,
-// 1.6 mm spacing -> 61 candidates per list): then epsilon/2 (39 per list, 2.4x faster verification,
-// 4x the list memory).  STOCS_GRID_DIV overrides.
+// 1.6 mm spacing -> 61 candidates per list): then epsilon/2 (39 per list) and, if the lists are still long,
+// epsilon/4 -- every halving multiplies the list memory by ~4 and the cell count by 8, and pays as long as
+// the centre-sorted early exit still has chunks to skip (C5: 50.5 -> 16.5 -> 13.2 ms).  STOCS_GRID_DIV overrides.
+static void free_grid(stocs_ctx* c) {
+    if (c->grid.d_top) (void)hipFree(c->grid.d_top);
+    if (c->grid.d_cells) (void)hipFree(c->grid.d_cells);
+    if (c->grid.d_list) (void)hipFree(c->grid.d_list);
+    if (c->grid.d_chunk_r) (void)hipFree(c->grid.d_chunk_r);
+    c->grid.d_top = NULL; c->grid.d_cells = NULL; c->grid.d_list = NULL; c->grid.d_chunk_r = NULL;
+}
+
+// one build at cell edge eps / div; lists longer than 16 on average get the centre-sorted layout + chunk bounds
+static int build_grid_once(stocs_ctx* c, int div) {
+    if (getenv("STOCS_GRID_HOST")) return build_grid_div(c, div);   // the host build, kept for A/B parity tests
+    int rc = build_grid_gpu(c, div, 0);
+    if (rc || c->grid.avg_list_len <= 16.0) return rc;
+    free_grid(c);
+    return build_grid_gpu(c, div, 1);
+}
+
 static int build_grid(stocs_ctx* c) {
     int div = c->grid_div;
     const char* e = getenv("STOCS_GRID_DIV");
     if (e) div = atoi(e);
-    int rc = build_grid_div(c, div);
-    if (rc) return rc;
-    if (!e && c->grid_div == 1 && c->grid.avg_list_len > 16.0 && c->grid.n_entries * 4 < (int64_t)1 << 30) {
-        (void)hipFree(c->grid.d_top); (void)hipFree(c->grid.d_cells); (void)hipFree(c->grid.d_list);
-        if (c->grid.d_chunk_r) (void)hipFree(c->grid.d_chunk_r);
-        c->grid.d_top = NULL; c->grid.d_cells = NULL; c->grid.d_list = NULL; c->grid.d_chunk_r = NULL;
-        rc = build_grid_div(c, 2);
+    int rc = build_grid_once(c, div);
+    if (rc || e || c->grid_div != 1) return rc;
+    for (int next = 2; next <= 4; next *= 2) {
+        // stop when the lists are short, or when the finer grid would not fit comfortably (entries x ~8, 16 B each)
+        // (measured, profiles/r01_sweep.json: 100k points, 20 per list at eps/2 -> eps/4 is 10 % slower; 200k points, 39 per
+        // list -> eps/4 is 20 % faster: the second halving needs lists well beyond the first threshold)
+        if (c->grid.avg_list_len <= (next == 2 ? 16.0 : 28.0) || c->grid.n_entries * 8 >= ((int64_t)1 << 29)) break;
+        const int prev = next / 2;
+        free_grid(c);
+        rc = build_grid_once(c, next);
+        if (rc == STOCS_ERR_INVALID) {   // the finer grid does not fit the 32-bit list offsets: stay with the coarser one
+            free_grid(c);
+            rc = build_grid_once(c, prev);
+            break;
+        }
+        if (rc) return rc;
     }
+    if (getenv("STOCS_DEBUG_TIMING"))
+        fprintf(stderr, "[stocs grid] cell edge eps/%d, %d bricks, %lld list entries (%.1f per non-empty cell)\n", (int)lround((double)c->prm.distance_threshold / c->grid.h),
+                c->grid.n_bricks, (long long)c->grid.n_entries, c->grid.avg_list_len);
     return rc;
 }
 

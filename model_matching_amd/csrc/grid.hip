@@ -1,0 +1,380 @@
+// grid.hip -- the scene brick grid (SceneGrid, stocs_ctx.h) built on the GPU.
+// Replaces the kd-tree construction of the reference (Super4PCS::KdTree, include/super4pcs/accelerators/
+// kdtree.h:191-330, built by stocs_estimator::kdtree_initialize, stocs.cpp:966-980) as the spatial index of the
+// verification pass; the restricted-radius query it has to answer is kdtree.h:387-442.
+//
+// A new scene arrives with every camera frame, so the build is part of the per-frame latency: every step is
+// a kernel or a rocPRIM primitive on the context's stream (the host only sizes buffers):
+//   1. count / fill the (cell, point) incidences: a point belongs to every cell whose box is within
+//      r = 1.001 eps of it (double arithmetic, the same predicate for count and fill);
+//   2. one stable radix sort by cell key (brick << 9 | local cell) -- incidences are generated in ascending
+//      point order, so a cell's list comes out in ascending scene index (the tie rule of the scan kernels
+//      relies on it); dense scenes append a 16-bit quantised distance to the cell centre to the key;
+//   3. run boundaries -> non-empty cells -> bricks (prefix sums), padded list offsets (multiples of 8
+//      entries = whole 128-byte lines, sentinel-filled);
+//   4. cell words (offset, count, 64-bit sub-cell mask), the top-level brick table, the lists;
+//   5. dense scenes: per 8-entry chunk a lower bound of the distance to the cell centre (suffix minimum of
+//      the exact distances, so the quantised order only affects how early the scan stops, never the result).
+// HBM-bound integer/byte work; no MFMA.
+#include <math.h>
+#include <string.h>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <vector>
+
+#include "stocs_ctx.h"
+
+namespace stocs {
+
+struct GridGeom {
+    double of[3];     // origin (the float origin the scan kernels use, widened)
+    double h, r;      // cell edge, inclusion radius
+    int n[3];         // cells per axis
+    int nbx, nby;
+    int dense;        // 1: key carries the quantised centre distance
+    double qscale;    // quantisation of the centre distance to 16 bits
+};
+
+__device__ __forceinline__ void cell_range(const GridGeom& G, const double p[3], int lo[3], int hi[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = max(0, (int)floor((p[k] - G.r - G.of[k]) / G.h));
+        hi[k] = min(G.n[k] - 1, (int)floor((p[k] + G.r - G.of[k]) / G.h));
+    }
+}
+
+__device__ __forceinline__ double box_dist2(const GridGeom& G, const double p[3], int cx, int cy, int cz) {
+    const int cc[3] = {cx, cy, cz};
+    double d2 = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double b0 = G.of[k] + cc[k] * G.h, b1 = b0 + G.h;
+        const double d = p[k] < b0 ? b0 - p[k] : (p[k] > b1 ? p[k] - b1 : 0.0);
+        d2 += d * d;
+    }
+    return d2;
+}
+
+// FILL = false: number of cells within r of every point; FILL = true: their (key, point) records
+template <bool FILL>
+__global__ __launch_bounds__(256) void incidence_kernel(GridGeom G, const float4* __restrict__ spos, int nS, uint32_t* __restrict__ cnt,
+                                                        const unsigned long long* __restrict__ off, uint64_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ vals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nS) return;
+    const float4 pf = spos[i];
+    const double p[3] = {pf.x, pf.y, pf.z};
+    int lo[3], hi[3];
+    cell_range(G, p, lo, hi);
+    uint32_t c = 0;
+    unsigned long long o = FILL ? off[i] : 0ull;
+    for (int cz = lo[2]; cz <= hi[2]; ++cz)
+        for (int cy = lo[1]; cy <= hi[1]; ++cy)
+            for (int cx = lo[0]; cx <= hi[0]; ++cx) {
+                if (box_dist2(G, p, cx, cy, cz) > G.r * G.r) continue;
+                if (FILL) {
+                    const uint64_t brick = ((uint64_t)(cz >> 3) * G.nby + (uint64_t)(cy >> 3)) * G.nbx + (uint64_t)(cx >> 3);
+                    uint64_t key = (brick << 9) | (uint64_t)(((cz & 7) << 6) | ((cy & 7) << 3) | (cx & 7));
+                    if (G.dense) {
+                        const double dx = p[0] - (G.of[0] + (cx + 0.5) * G.h), dy = p[1] - (G.of[1] + (cy + 0.5) * G.h),
+                                     dz = p[2] - (G.of[2] + (cz + 0.5) * G.h);
+                        const double q = sqrt(dx * dx + dy * dy + dz * dz) * G.qscale;
+                        key = (key << 16) | (uint64_t)(q < 65535.0 ? (unsigned)q : 65535u);
+                    }
+                    keys[o + c] = key;
+                    vals[o + c] = (uint32_t)i;
+                }
+                c++;
+            }
+    if (!FILL) cnt[i] = c;
+}
+
+// first incidence of every cell (keys sorted; the low `qbits` bits are not part of the cell)
+__global__ __launch_bounds__(256) void cell_flags_kernel(const uint64_t* __restrict__ keys, size_t n, int qbits, uint32_t* __restrict__ cflag,
+                                                         uint32_t* __restrict__ bflag) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const uint64_t ck = keys[e] >> qbits;
+    const uint64_t pk = e ? (keys[e - 1] >> qbits) : ~0ull;
+    cflag[e] = (e == 0 || ck != pk) ? 1u : 0u;
+    bflag[e] = (e == 0 || (ck >> 9) != (pk >> 9)) ? 1u : 0u;   // first incidence of a brick
+}
+
+// per non-empty cell: first incidence, cell key, brick ordinal
+__global__ __launch_bounds__(256) void cell_records_kernel(const uint64_t* __restrict__ keys, size_t n, int qbits, const uint32_t* __restrict__ cflag,
+                                                           const uint32_t* __restrict__ cidx, const uint32_t* __restrict__ bflag,
+                                                           const uint32_t* __restrict__ bidx, uint32_t* __restrict__ cell_first, uint64_t* __restrict__ cell_key,
+                                                           uint32_t* __restrict__ cell_brick) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n || !cflag[e]) return;
+    const uint32_t c = cidx[e];        // exclusive scan of cflag = ordinal of this cell
+    cell_first[c] = (uint32_t)e;
+    cell_key[c] = keys[e] >> qbits;
+    // bidx = exclusive scan of the brick-start flags: the bricks that start strictly before e.  The cell's own brick
+    // is that many if e opens it, one less otherwise
+    cell_brick[c] = bidx[e] + bflag[e] - 1u;
+}
+
+// padded length of every cell's list
+__global__ __launch_bounds__(256) void cell_padded_kernel(const uint32_t* __restrict__ cell_first, uint32_t n_cells, uint32_t n_inc,
+                                                          uint32_t* __restrict__ padded, uint32_t* __restrict__ max_count) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cells) return;
+    const uint32_t cnt = (c + 1 < n_cells ? cell_first[c + 1] : n_inc) - cell_first[c];
+    padded[c] = (cnt + 7u) & ~7u;
+    atomicMax(max_count, cnt);
+}
+
+__global__ __launch_bounds__(256) void fill_i32_kernel(int32_t* __restrict__ a, size_t n, int32_t v) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = v;
+}
+__global__ __launch_bounds__(256) void fill_list_kernel(float4* __restrict__ a, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = make_float4(1.0e30f, 1.0e30f, 1.0e30f, __int_as_float(-1));   // sentinel: far away, index -1
+}
+__global__ __launch_bounds__(256) void zero_cells_kernel(uint4* __restrict__ a, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// cell word + top table; one thread per non-empty cell.  Sub-cell masks (cell edge = eps only): bit s is set when
+// some point of the cell's list lies within r of sub-cell s (any point that close to a sub-cell is that close
+// to the cell, hence in its list).
+__global__ __launch_bounds__(256) void cell_words_kernel(GridGeom G, int div, const uint32_t* __restrict__ cell_first, const uint64_t* __restrict__ cell_key,
+                                                         const uint32_t* __restrict__ cell_brick, const uint32_t* __restrict__ list_off,
+                                                         uint32_t n_cells, uint32_t n_inc, const uint32_t* __restrict__ vals,
+                                                         const float4* __restrict__ spos, int32_t* __restrict__ top, uint4* __restrict__ cells) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cells) return;
+    const uint32_t first = cell_first[c];
+    const uint32_t cnt = (c + 1 < n_cells ? cell_first[c + 1] : n_inc) - first;
+    const uint64_t key = cell_key[c];
+    const uint64_t brick = key >> 9;
+    const uint32_t local = (uint32_t)(key & 511);
+    const uint32_t b = cell_brick[c];
+    top[brick] = (int32_t)b;   // every cell of the brick writes the same value
+    uint32_t mlo = 0xFFFFFFFFu, mhi = 0xFFFFFFFFu;
+    if (div == 1) {
+        mlo = 0; mhi = 0;
+        const int bx = (int)(brick % (uint64_t)G.nbx), by = (int)((brick / (uint64_t)G.nbx) % (uint64_t)G.nby),
+                  bz = (int)(brick / ((uint64_t)G.nbx * (uint64_t)G.nby));
+        const int cx = bx * 8 + (int)(local & 7), cy = by * 8 + (int)((local >> 3) & 7), cz = bz * 8 + (int)(local >> 6);
+        const double hs = G.h / 4.0;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            const float4 pf = spos[vals[first + k]];
+            const double p[3] = {pf.x, pf.y, pf.z};
+            for (int s = 0; s < 64; ++s) {
+                const int sc[3] = {4 * cx + (s & 3), 4 * cy + ((s >> 2) & 3), 4 * cz + (s >> 4)};
+                double d2 = 0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const double b0 = G.of[a] + sc[a] * hs, b1 = b0 + hs;
+                    const double d = p[a] < b0 ? b0 - p[a] : (p[a] > b1 ? p[a] - b1 : 0.0);
+                    d2 += d * d;
+                }
+                if (d2 <= G.r * G.r) { if (s < 32) mlo |= 1u << s; else mhi |= 1u << (s - 32); }
+            }
+        }
+    }
+    cells[(size_t)b * 512 + local] = make_uint4(list_off[c], cnt, mlo, mhi);
+}
+
+// list entries: incidence e of cell c goes to list_off[c] + (e - first[c])
+__global__ __launch_bounds__(256) void list_fill_kernel(const uint32_t* __restrict__ cflag, const uint32_t* __restrict__ cidx,
+                                                        const uint32_t* __restrict__ cell_first, const uint32_t* __restrict__ list_off,
+                                                        const uint32_t* __restrict__ vals, size_t n, const float4* __restrict__ spos,
+                                                        float4* __restrict__ list) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    // cidx = exclusive scan of the cell-start flags: the cells that start strictly before e; the own cell is that
+    // many if e opens it, one less otherwise
+    const uint32_t c = cidx[e] + cflag[e] - 1u;
+    const uint32_t pt = vals[e];
+    const float4 p = spos[pt];
+    list[(size_t)list_off[c] + (e - cell_first[c])] = make_float4(p.x, p.y, p.z, __int_as_float((int)pt));
+}
+
+// dense scenes: chunk_r[j] = (minimum exact distance to the cell centre over chunks >= j) - 2e-6
+__global__ __launch_bounds__(256) void chunk_bounds_kernel(GridGeom G, const uint32_t* __restrict__ cell_first, const uint64_t* __restrict__ cell_key,
+                                                           const uint32_t* __restrict__ list_off, uint32_t n_cells, uint32_t n_inc,
+                                                           const float4* __restrict__ list, float* __restrict__ chunk_r) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cells) return;
+    const uint32_t cnt = (c + 1 < n_cells ? cell_first[c + 1] : n_inc) - cell_first[c];
+    const uint64_t key = cell_key[c];
+    const uint64_t brick = key >> 9;
+    const uint32_t local = (uint32_t)(key & 511);
+    const int bx = (int)(brick % (uint64_t)G.nbx), by = (int)((brick / (uint64_t)G.nbx) % (uint64_t)G.nby),
+              bz = (int)(brick / ((uint64_t)G.nbx * (uint64_t)G.nby));
+    const int cx = bx * 8 + (int)(local & 7), cy = by * 8 + (int)((local >> 3) & 7), cz = bz * 8 + (int)(local >> 6);
+    const double ccx = G.of[0] + (cx + 0.5) * G.h, ccy = G.of[1] + (cy + 0.5) * G.h, ccz = G.of[2] + (cz + 0.5) * G.h;
+    const uint32_t o = list_off[c];
+    double run = 1e300;
+    for (int k = (int)cnt - 1; k >= 0; --k) {
+        const float4 e = list[(size_t)o + k];
+        const double dx = e.x - ccx, dy = e.y - ccy, dz = e.z - ccz;
+        run = fmin(run, sqrt(dx * dx + dy * dy + dz * dz));
+        if ((k & 7) == 0) chunk_r[(o + (uint32_t)k) >> 3] = (float)(run - 2e-6);
+    }
+}
+
+struct Tmp {   // plain device temporaries of one build, released together
+    std::vector<void*> ptrs;
+    ~Tmp() { for (size_t i = 0; i < ptrs.size(); ++i) (void)hipFree(ptrs[i]); }
+    template <class T>
+    int get(T** p, size_t n) {
+        *p = NULL;
+        STOCS_HIP_CHECK(hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)));
+        ptrs.push_back(*p);
+        return STOCS_OK;
+    }
+};
+
+static inline unsigned grid_of(size_t n) { return (unsigned)((n + 255) / 256); }
+
+// Builds c->grid for cell edge eps / div from c->d_spos (device) and c->h_spos (bounding box only).
+// dense != 0: lists ordered by distance to the cell centre + chunk bounds (scan kernels with early exit).
+int build_grid_gpu(stocs_ctx* c, int div, int dense) {
+    SceneGrid& g = c->grid;
+    const int nS = c->nS;
+    const double eps = (double)c->prm.distance_threshold;
+    if (div < 1 || div > 4) div = 1;
+    const double h = eps / div;
+    const double r = eps * 1.001;  // safety margin >> float rounding of the device cell computation
+    double mn[3] = {1e30, 1e30, 1e30}, mx[3] = {-1e30, -1e30, -1e30};
+    for (int i = 0; i < nS; ++i) {
+        const V3 p = c->h_spos[i];
+        const double v[3] = {p.x, p.y, p.z};
+        for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], v[k]); mx[k] = std::max(mx[k], v[k]); }
+    }
+    if (nS == 0) { for (int k = 0; k < 3; ++k) { mn[k] = 0; mx[k] = 0; } }
+    const double pad = r + 2 * h;  // a query outside the grid is farther than epsilon from every point
+    const double o[3] = {mn[0] - pad, mn[1] - pad, mn[2] - pad};
+    int n[3];
+    for (int k = 0; k < 3; ++k) n[k] = (int)floor((mx[k] + pad - o[k]) / h) + 1;
+    g.ox = (float)o[0]; g.oy = (float)o[1]; g.oz = (float)o[2];
+    g.inv_h = (float)(1.0 / h);
+    g.nx = n[0]; g.ny = n[1]; g.nz = n[2];
+    g.nbx = (n[0] + 7) / 8; g.nby = (n[1] + 7) / 8; g.nbz = (n[2] + 7) / 8;
+    g.h = (float)h;
+    g.n_bricks = 0; g.n_entries = 0; g.avg_list_len = 0;
+    g.d_top = NULL; g.d_cells = NULL; g.d_list = NULL; g.d_chunk_r = NULL;
+    const int64_t n_top = (int64_t)g.nbx * g.nby * g.nbz;
+    if (n_top > (int64_t)400 * 1000 * 1000) { set_error("scene extent too large for the brick grid"); return STOCS_ERR_INVALID; }
+    int cell_bits = 1;
+    while (((int64_t)1 << cell_bits) < n_top * 512) cell_bits++;
+
+    GridGeom G;
+    // the scan kernels compute the cell as floor((q - o_f) * inv_h) with the FLOAT origin: use exactly that origin
+    G.of[0] = g.ox; G.of[1] = g.oy; G.of[2] = g.oz;
+    G.h = h; G.r = r;
+    G.n[0] = n[0]; G.n[1] = n[1]; G.n[2] = n[2];
+    G.nbx = g.nbx; G.nby = g.nby;
+    G.dense = dense ? 1 : 0;
+    G.qscale = 65535.0 / (r + h * 0.8660254037844387 + 1e-9);   // a listed point is at most r + half a cell diagonal from the centre
+    const int qbits = dense ? 16 : 0;
+
+    hipStream_t st = c->stream;
+    Tmp T;
+    int rc;
+    STOCS_HIP_CHECK(hipMalloc((void**)&g.d_top, std::max<int64_t>(n_top, 1) * 4));
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(grid_of((size_t)n_top)), dim3(256), 0, st, g.d_top, (size_t)n_top, -1);
+    if (nS == 0) {
+        STOCS_HIP_CHECK(hipMalloc((void**)&g.d_cells, 16));
+        STOCS_HIP_CHECK(hipMalloc((void**)&g.d_list, 8 * 16));
+        STOCS_HIP_CHECK(hipStreamSynchronize(st));
+        return STOCS_OK;
+    }
+    // ---- 1. incidences ----
+    uint32_t* d_cnt; unsigned long long* d_off;
+    if ((rc = T.get(&d_cnt, (size_t)nS + 1)) || (rc = T.get(&d_off, (size_t)nS + 1))) return rc;
+    hipLaunchKernelGGL(incidence_kernel<false>, dim3(grid_of(nS)), dim3(256), 0, st, G, c->d_spos, nS, d_cnt, (const unsigned long long*)NULL,
+                       (uint64_t*)NULL, (uint32_t*)NULL);
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(256), 0, st, (int32_t*)(d_cnt + nS), (size_t)1, 0);
+    size_t tb = 0;
+    auto plus64 = rocprim::plus<unsigned long long>();
+    STOCS_HIP_CHECK(rocprim::exclusive_scan(NULL, tb, d_cnt, d_off, 0ull, (size_t)nS + 1, plus64, st));
+    char* d_tmp;
+    if ((rc = T.get(&d_tmp, tb))) return rc;
+    STOCS_HIP_CHECK(rocprim::exclusive_scan(d_tmp, tb, d_cnt, d_off, 0ull, (size_t)nS + 1, plus64, st));
+    unsigned long long n_inc64 = 0;
+    STOCS_HIP_CHECK(hipMemcpyAsync(&n_inc64, d_off + nS, 8, hipMemcpyDeviceToHost, st));
+    STOCS_HIP_CHECK(hipStreamSynchronize(st));
+    // padded lists stay below 2^31 entries (32-bit offsets in the cell words)
+    if (n_inc64 >= (1ull << 28)) { set_error("scene grid lists too large (%llu incidences)", n_inc64); return STOCS_ERR_INVALID; }
+    const size_t n_inc = (size_t)n_inc64;
+    uint64_t *d_keys, *d_keys_s; uint32_t *d_vals, *d_vals_s;
+    if ((rc = T.get(&d_keys, n_inc)) || (rc = T.get(&d_keys_s, n_inc)) || (rc = T.get(&d_vals, n_inc)) || (rc = T.get(&d_vals_s, n_inc))) return rc;
+    hipLaunchKernelGGL(incidence_kernel<true>, dim3(grid_of(nS)), dim3(256), 0, st, G, c->d_spos, nS, (uint32_t*)NULL, d_off, d_keys, d_vals);
+    STOCS_HIP_CHECK(hipGetLastError());
+    // ---- 2. stable sort by cell (and quantised centre distance) ----
+    size_t ts = 0;
+    const unsigned end_bit = (unsigned)std::min(64, cell_bits + qbits);
+    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, ts, d_keys, d_keys_s, d_vals, d_vals_s, n_inc, 0, end_bit, st));
+    char* d_ts;
+    if ((rc = T.get(&d_ts, ts))) return rc;
+    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_ts, ts, d_keys, d_keys_s, d_vals, d_vals_s, n_inc, 0, end_bit, st));
+    // ---- 3. cells and bricks ----
+    uint32_t *d_cflag, *d_bflag, *d_cidx, *d_bidx;
+    if ((rc = T.get(&d_cflag, n_inc + 1)) || (rc = T.get(&d_bflag, n_inc + 1)) || (rc = T.get(&d_cidx, n_inc + 1)) || (rc = T.get(&d_bidx, n_inc + 1))) return rc;
+    hipLaunchKernelGGL(cell_flags_kernel, dim3(grid_of(n_inc)), dim3(256), 0, st, d_keys_s, n_inc, qbits, d_cflag, d_bflag);
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(256), 0, st, (int32_t*)(d_cflag + n_inc), (size_t)1, 0);
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(256), 0, st, (int32_t*)(d_bflag + n_inc), (size_t)1, 0);
+    size_t t32 = 0;
+    auto plus32 = rocprim::plus<uint32_t>();
+    STOCS_HIP_CHECK(rocprim::exclusive_scan(NULL, t32, d_cflag, d_cidx, 0u, n_inc + 1, plus32, st));
+    char* d_t32;
+    if ((rc = T.get(&d_t32, t32))) return rc;
+    STOCS_HIP_CHECK(rocprim::exclusive_scan(d_t32, t32, d_cflag, d_cidx, 0u, n_inc + 1, plus32, st));
+    STOCS_HIP_CHECK(rocprim::exclusive_scan(d_t32, t32, d_bflag, d_bidx, 0u, n_inc + 1, plus32, st));
+    uint32_t counts[2] = {0, 0};
+    STOCS_HIP_CHECK(hipMemcpyAsync(&counts[0], d_cidx + n_inc, 4, hipMemcpyDeviceToHost, st));
+    STOCS_HIP_CHECK(hipMemcpyAsync(&counts[1], d_bidx + n_inc, 4, hipMemcpyDeviceToHost, st));
+    STOCS_HIP_CHECK(hipStreamSynchronize(st));
+    const uint32_t n_cells = counts[0], n_bricks = counts[1];
+    uint32_t *d_cell_first, *d_cell_brick, *d_padded, *d_list_off, *d_max;
+    uint64_t* d_cell_key;
+    if ((rc = T.get(&d_cell_first, (size_t)n_cells + 1)) || (rc = T.get(&d_cell_brick, (size_t)n_cells + 1)) || (rc = T.get(&d_padded, (size_t)n_cells + 1)) ||
+        (rc = T.get(&d_list_off, (size_t)n_cells + 1)) || (rc = T.get(&d_cell_key, (size_t)n_cells + 1)) || (rc = T.get(&d_max, 1)))
+        return rc;
+    hipLaunchKernelGGL(cell_records_kernel, dim3(grid_of(n_inc)), dim3(256), 0, st, d_keys_s, n_inc, qbits, d_cflag, d_cidx, d_bflag, d_bidx, d_cell_first,
+                       d_cell_key, d_cell_brick);
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(256), 0, st, (int32_t*)d_max, (size_t)1, 0);
+    hipLaunchKernelGGL(cell_padded_kernel, dim3(grid_of(n_cells)), dim3(256), 0, st, d_cell_first, n_cells, (uint32_t)n_inc, d_padded, d_max);
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(256), 0, st, (int32_t*)(d_padded + n_cells), (size_t)1, 0);
+    STOCS_HIP_CHECK(rocprim::exclusive_scan(d_t32, t32, d_padded, d_list_off, 0u, (size_t)n_cells + 1, plus32, st));
+    uint32_t tail[2] = {0, 0};
+    STOCS_HIP_CHECK(hipMemcpyAsync(&tail[0], d_list_off + n_cells, 4, hipMemcpyDeviceToHost, st));
+    STOCS_HIP_CHECK(hipMemcpyAsync(&tail[1], d_max, 4, hipMemcpyDeviceToHost, st));
+    STOCS_HIP_CHECK(hipStreamSynchronize(st));
+    const size_t n_list = tail[0];
+    if (tail[1] > 65535u) { set_error("more than 65535 scene points within epsilon of one grid cell"); return STOCS_ERR_INVALID; }
+    // ---- 4. cell words, top table, lists ----
+    STOCS_HIP_CHECK(hipMalloc((void**)&g.d_cells, std::max<size_t>((size_t)n_bricks * 512, 1) * sizeof(uint4)));
+    STOCS_HIP_CHECK(hipMalloc((void**)&g.d_list, std::max<size_t>(n_list, 8) * sizeof(float4)));
+    hipLaunchKernelGGL(zero_cells_kernel, dim3(grid_of((size_t)n_bricks * 512)), dim3(256), 0, st, g.d_cells, (size_t)n_bricks * 512);
+    hipLaunchKernelGGL(fill_list_kernel, dim3(grid_of(std::max<size_t>(n_list, 8))), dim3(256), 0, st, g.d_list, std::max<size_t>(n_list, 8));
+    hipLaunchKernelGGL(cell_words_kernel, dim3(grid_of(n_cells)), dim3(256), 0, st, G, div, d_cell_first, d_cell_key, d_cell_brick, d_list_off, n_cells,
+                       (uint32_t)n_inc, d_vals_s, c->d_spos, g.d_top, g.d_cells);
+    hipLaunchKernelGGL(list_fill_kernel, dim3(grid_of(n_inc)), dim3(256), 0, st, d_cflag, d_cidx, d_cell_first, d_list_off, d_vals_s, n_inc, c->d_spos, g.d_list);
+    STOCS_HIP_CHECK(hipGetLastError());
+    // ---- 5. dense scenes: chunk bounds ----
+    if (dense) {
+        STOCS_HIP_CHECK(hipMalloc((void**)&g.d_chunk_r, std::max<size_t>(n_list / 8, 1) * sizeof(float)));
+        hipLaunchKernelGGL(fill_i32_kernel, dim3(grid_of(n_list / 8)), dim3(256), 0, st, (int32_t*)g.d_chunk_r, n_list / 8, 0);
+        hipLaunchKernelGGL(chunk_bounds_kernel, dim3(grid_of(n_cells)), dim3(256), 0, st, G, d_cell_first, d_cell_key, d_list_off, n_cells, (uint32_t)n_inc,
+                           g.d_list, g.d_chunk_r);
+        STOCS_HIP_CHECK(hipGetLastError());
+    }
+    STOCS_HIP_CHECK(hipStreamSynchronize(st));   // the temporaries are released by ~Tmp
+    g.n_bricks = (int)n_bricks;
+    g.n_entries = (int64_t)n_list;
+    g.avg_list_len = n_cells ? (double)n_inc / (double)n_cells : 0.0;
+    return STOCS_OK;
+}
+
+}  // namespace stocs
