@@ -69,6 +69,12 @@ int stocs_ctx_create(const stocs_params* prm,
                      const float* model_pos3, const float* model_nrm3, int nM,
                      int build_index, int device, stocs_ctx** out);
 int stocs_ctx_destroy(stocs_ctx* ctx);
+/* A new scene (the next camera frame) against the same model: load_scene_info + centroid_shift +
+ * kdtree_initialize (stocs.hpp:36-60, stocs.cpp:943-980) for the scene only.  The model clouds and the PPF
+ * index are kept; bases, candidates, edge map and instance-mode segments of the old scene are dropped.
+ * Equivalent to destroying the context and creating it again with the same model, minus the index build. */
+int stocs_ctx_set_scene(stocs_ctx* ctx, const float* scene_pos3, const float* scene_nrm3, const float* scene_prob,
+                        const int32_t* scene_pixel2, int nS);
 
 /* getters: stocs.hpp:115-116 get_scene_centroid (+ model centroid) */
 int stocs_get_centroids(const stocs_ctx* ctx, float* scene3, float* model3);

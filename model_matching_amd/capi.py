@@ -43,6 +43,7 @@ SIGNATURES = {
     "stocs_version": (C.c_char_p, []),
     "stocs_ctx_create": (C.c_int, [C.POINTER(Params), _fp, _fp, _fp, _ip, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "stocs_ctx_destroy": (C.c_int, [_vp]),
+    "stocs_ctx_set_scene": (C.c_int, [_vp, _fp, _fp, _fp, _ip, C.c_int]),
     "stocs_get_centroids": (C.c_int, [_vp, _fp, _fp]),
     "stocs_get_sizes": (C.c_int, [_vp, _intp, _intp]),
     "stocs_set_edge_map": (C.c_int, [_vp, _u8p]),

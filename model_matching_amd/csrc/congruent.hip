@@ -546,6 +546,10 @@ void stocs_internal_free_congruent(stocs_ctx* c) {   // stocs_ctx_destroy: nothi
     }
 }
 
+void stocs_internal_invalidate_congruent(stocs_ctx* c) {   // the counted state refers to bases of another scene
+    if (c && c->cong) ((CongruentState*)c->cong)->valid = false;
+}
+
 int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     if (!c) return STOCS_ERR_INVALID;
     DeviceGuard dev_guard(c->device);

@@ -353,6 +353,54 @@ static int build_grid(stocs_ctx* c) {
     return rc;
 }
 
+// Everything that depends on the scene cloud: host copies (kdtree_initialize / centroid_shift of the scene,
+// stocs.cpp:943-980), device clouds, the brick grid; per-trial state is reset.  Used by stocs_ctx_create and
+// stocs_ctx_set_scene (a new camera frame against the same model keeps the model clouds and the PPF index).
+static int load_scene(stocs_ctx* c, const float* sp, const float* sn, const float* sprob, const int32_t* spix, int nS) {
+    c->nS = nS;
+    c->h_spos.resize(nS); c->h_snrm.resize(nS); c->h_sprob.assign(sprob, sprob + nS); c->h_sprob0 = c->h_sprob; c->h_spix.assign((size_t)2 * nS, 0);
+    for (int i = 0; i < nS; ++i) {
+        c->h_spos[i] = mk3(sp[3 * i], sp[3 * i + 1], sp[3 * i + 2]);
+        c->h_snrm[i] = normalized3(mk3(sn[3 * i], sn[3 * i + 1], sn[3 * i + 2]));  // set_normal, point3d.hpp:43-45
+        if (spix) { c->h_spix[2 * i] = spix[2 * i]; c->h_spix[2 * i + 1] = spix[2 * i + 1]; }
+    }
+    // centroid_shift -- stocs.cpp:943-964 (sequential float sums, then divide, then subtract)
+    V3 cs = mk3(0, 0, 0);
+    for (int i = 0; i < nS; ++i) cs = cs + c->h_spos[i];
+    cs = cs / (float)nS;
+    for (int i = 0; i < nS; ++i) c->h_spos[i] = c->h_spos[i] - cs;
+    c->centroid_scene = cs;
+    if (c->d_spos) { (void)hipFree(c->d_spos); c->d_spos = NULL; }
+    if (c->d_snrmw) { (void)hipFree(c->d_snrmw); c->d_snrmw = NULL; }
+    if (c->d_spix) { (void)hipFree(c->d_spix); c->d_spix = NULL; }
+    free_grid(c);
+    int rc = STOCS_OK;
+    {
+        std::vector<float4> a(std::max(nS, 1)), b(std::max(nS, 1));
+        std::vector<int2> px(std::max(nS, 1));
+        for (int i = 0; i < nS; ++i) {
+            a[i] = make_float4(c->h_spos[i].x, c->h_spos[i].y, c->h_spos[i].z, c->h_sprob[i]);
+            b[i] = make_float4(c->h_snrm[i].x, c->h_snrm[i].y, c->h_snrm[i].z, c->h_sprob[i]);
+            px[i] = make_int2(c->h_spix[2 * i], c->h_spix[2 * i + 1]);
+        }
+        if (!rc) rc = upload(&c->d_spos, a.data(), a.size());
+        if (!rc) rc = upload(&c->d_snrmw, b.data(), b.size());
+        if (!rc) rc = upload(&c->d_spix, px.data(), px.size());
+    }
+    if (!rc) rc = build_grid(c);
+    // per-trial state belongs to the old scene
+    c->bases.clear(); c->quad_off.clear(); clear_candidates(c);
+    c->best_lcp = 0; c->best_index = -1;
+    stocs_internal_invalidate_congruent(c);
+    const size_t npx = (size_t)c->prm.image_width * c->prm.image_height;
+    c->has_edge = false;
+    c->edge_map.assign(npx, 0);
+    c->previous_segment.reset();
+    c->segmentation_buffer.assign(npx, 0);
+    c->seg_masks.clear();
+    return rc;
+}
+
 }  // namespace stocs
 
 using namespace stocs;
@@ -429,26 +477,17 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     c->stream = c->own_stream;
     compute_thresholds(c->prm, &c->thr);
 
-    c->h_spos.resize(nS); c->h_snrm.resize(nS); c->h_sprob.assign(sprob, sprob + nS); c->h_sprob0 = c->h_sprob; c->h_spix.assign((size_t)2 * nS, 0);
-    for (int i = 0; i < nS; ++i) {
-        c->h_spos[i] = mk3(sp[3 * i], sp[3 * i + 1], sp[3 * i + 2]);
-        c->h_snrm[i] = normalized3(mk3(sn[3 * i], sn[3 * i + 1], sn[3 * i + 2]));  // set_normal, point3d.hpp:43-45
-        if (spix) { c->h_spix[2 * i] = spix[2 * i]; c->h_spix[2 * i + 1] = spix[2 * i + 1]; }
-    }
     c->h_mpos.resize(nM); c->h_mnrm.resize(nM); c->h_mpos_raw.resize(nM);
     for (int i = 0; i < nM; ++i) {
         c->h_mpos_raw[i] = c->h_mpos[i] = mk3(mp[3 * i], mp[3 * i + 1], mp[3 * i + 2]);
         c->h_mnrm[i] = normalized3(mk3(mn[3 * i], mn[3 * i + 1], mn[3 * i + 2]));
     }
     // centroid_shift -- stocs.cpp:943-964 (sequential float sums, then divide, then subtract)
-    V3 cs = mk3(0, 0, 0), cm = mk3(0, 0, 0);
-    for (int i = 0; i < nS; ++i) cs = cs + c->h_spos[i];
+    V3 cm = mk3(0, 0, 0);
     for (int i = 0; i < nM; ++i) cm = cm + c->h_mpos[i];
-    cs = cs / (float)nS;
     cm = cm / (float)nM;
-    for (int i = 0; i < nS; ++i) c->h_spos[i] = c->h_spos[i] - cs;
     for (int i = 0; i < nM; ++i) c->h_mpos[i] = c->h_mpos[i] - cm;
-    c->centroid_scene = cs; c->centroid_model = cm;
+    c->centroid_model = cm;
 
     // PairCreationFunctor::synch3DContent -- pairCreationFunctor.h:96-132 (once, not per base)
     {
@@ -485,18 +524,6 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
 
     int rc = STOCS_OK;
     {
-        std::vector<float4> a(std::max(nS, 1)), b(std::max(nS, 1));
-        std::vector<int2> px(std::max(nS, 1));
-        for (int i = 0; i < nS; ++i) {
-            a[i] = make_float4(c->h_spos[i].x, c->h_spos[i].y, c->h_spos[i].z, c->h_sprob[i]);
-            b[i] = make_float4(c->h_snrm[i].x, c->h_snrm[i].y, c->h_snrm[i].z, c->h_sprob[i]);
-            px[i] = make_int2(c->h_spix[2 * i], c->h_spix[2 * i + 1]);
-        }
-        if (!rc) rc = upload(&c->d_spos, a.data(), a.size());
-        if (!rc) rc = upload(&c->d_snrmw, b.data(), b.size());
-        if (!rc) rc = upload(&c->d_spix, px.data(), px.size());
-    }
-    {
         const int n = std::max(nM, 1);
         std::vector<float4> a(n), b(n), u(n), raw(n), as(n), bs(n);
         for (int i = 0; i < nM; ++i) {
@@ -514,12 +541,8 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
         if (!rc) rc = upload(&c->d_mnrm_s, bs.data(), bs.size());
         if (!rc) rc = upload(&c->d_mperm, c->h_mperm.data(), c->h_mperm.size());
     }
-    if (!rc) rc = build_grid(c);
+    if (!rc) rc = load_scene(c, sp, sn, sprob, spix, nS);
     if (!rc && build_index) rc = build_ppf_index(c);
-    const size_t px = (size_t)prm->image_width * prm->image_height;
-    c->edge_map.assign(px, 0);
-    c->previous_segment.reset();
-    c->segmentation_buffer.assign(px, 0);
     if (rc) { stocs_ctx_destroy(c); return rc; }
     *out = c;
     return STOCS_OK;
@@ -539,6 +562,13 @@ int stocs_ctx_destroy(stocs_ctx* c) {
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
     return STOCS_OK;
+}
+
+int stocs_ctx_set_scene(stocs_ctx* c, const float* sp, const float* sn, const float* sprob, const int32_t* spix, int nS) {
+    if (!c || nS <= 0 || !sp || !sn || !sprob) { set_error("stocs_ctx_set_scene: invalid argument"); return STOCS_ERR_INVALID; }
+    DeviceGuard dev_guard(c->device);
+    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));   // nothing of the old scene may still be in flight
+    return load_scene(c, sp, sn, sprob, spix, nS);
 }
 
 int stocs_get_centroids(const stocs_ctx* c, float* s, float* m) {

@@ -45,6 +45,17 @@ class StocsEstimator:
                                            1 if build_index else 0, device, C.byref(self.h)))
         _LIVE.add(self)
 
+    def set_scene(self, scene_pos, scene_nrm, scene_prob, scene_pixel=None):
+        """The next camera frame against the same model (stocs_ctx_set_scene): keeps the model and its PPF index."""
+        self._sp, psp = capi.f32(scene_pos)
+        self._sn, psn = capi.f32(scene_nrm)
+        self._spr, pspr = capi.f32(scene_prob)
+        ppx = None
+        if scene_pixel is not None:
+            self._spx, ppx = capi.i32(scene_pixel)
+        capi.check(self.L.stocs_ctx_set_scene(self.h, psp, psn, pspr, ppx, len(self._sp)))
+        self.nS = len(self._sp)
+
     def close(self):
         _LIVE.discard(self)
         if getattr(self, "h", None) and self.h.value:

@@ -317,3 +317,33 @@ def test_repeated_trials_on_one_context_equal_fresh_contexts():
         fresh.close()
         assert ref[:5] == reused[r][:5] and np.array_equal(ref[5], reused[r][5]), r
     est.close()
+
+
+def test_set_scene_equals_fresh_context():
+    """stocs_ctx_set_scene (next frame, same model): the whole trial on the updated context equals the trial on a
+    context created from scratch with the new scene; switching back reproduces the first scene's result."""
+    from model_matching_amd import synth
+    from model_matching_amd.estimator import StocsEstimator
+    m = synth.make_model(1000, seed=77)
+    s1 = synth.make_scene(m, 5000, seed=78)
+    s2 = synth.make_scene(m, 4200, seed=79, T_gt=synth.gt_pose(seed=5))
+
+    def trial(est, seed):
+        est.L.stocs_clear_bases(est.h)
+        valid, ids, inv = est.sample_bases(seed, 60)
+        tot = est.find_congruent_all()
+        nc = est.make_transforms(200, seed)
+        lcp, idx, pose = est.compute_best_transform()
+        return int(valid.sum()), ids[valid].tolist(), int(tot), int(nc), float(lcp), int(idx), pose.tolist(), est.get_scene_centroid().tolist()
+
+    est = StocsEstimator(s1.pos, s1.nrm, s1.prob, s1.pixel, m.pos, m.nrm, build_index=True)
+    r1 = trial(est, 9)
+    est.set_scene(s2.pos, s2.nrm, s2.prob, s2.pixel)
+    assert est.get_pose_candidates()[0].shape[0] == 0          # candidates of the old scene are gone
+    r2 = trial(est, 9)
+    fresh = StocsEstimator(s2.pos, s2.nrm, s2.prob, s2.pixel, m.pos, m.nrm, build_index=True)
+    assert trial(fresh, 9) == r2
+    est.set_scene(s1.pos, s1.nrm, s1.prob, s1.pixel)
+    assert trial(est, 9) == r1
+    assert r1 != r2
+    est.close(); fresh.close()
