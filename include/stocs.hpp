@@ -104,6 +104,17 @@ public:
     stocs_estimator& operator=(const stocs_estimator&) = delete;
 
     void set_seed(uint64_t seed) { seed_ = seed; attempt_ = 0; }
+    // not in the reference (one estimator per scene there): the next frame against the same model; the model
+    // clouds and the PPF index are kept, everything derived from the old scene is dropped
+    void set_scene(const SceneCloud& scene) {
+        const int rc = stocs_ctx_set_scene(ctx_, scene.pos.data(), scene.nrm.data(), scene.class_probability.data(),
+                                           scene.pixel.empty() ? NULL : scene.pixel.data(), scene.size());
+        if (rc != STOCS_OK) throw std::runtime_error(std::string("stocs_ctx_set_scene: ") + stocs_last_error());
+        if (!scene.edge_map.empty()) stocs_set_edge_map(ctx_, scene.edge_map.data());
+        has_edge_ = !scene.edge_map.empty();
+        scene_ = &scene;
+        attempt_ = 0; best_lcp = 0; best_index = -1;
+    }
     bool has_edge_map() const { return has_edge_; }
     stocs_ctx* context() { return ctx_; }
 
