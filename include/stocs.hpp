@@ -114,6 +114,7 @@ public:
         has_edge_ = !scene.edge_map.empty();
         scene_ = &scene;
         attempt_ = 0; best_lcp = 0; best_index = -1;
+        all_transforms.clear(); all_pose_store_.clear();
     }
     bool has_edge_map() const { return has_edge_; }
     stocs_ctx* context() { return ctx_; }
