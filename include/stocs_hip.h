@@ -194,6 +194,9 @@ int stocs_ingest_scene(const stocs_camera* cam, const uint16_t* depth, const uin
  * from the model origin -> voxel grid (positions and normals averaged per leaf) -> scale */
 int stocs_preprocess_model(const float* raw_pos3, int n_raw, float normal_radius, float voxel_size, float model_scale,
                            int device, float* pos3, float* nrm3, int cap, int* n_out);
+/* stocs_ingest_scene / stocs_preprocess_model keep their device workspace cached per calling thread and device
+ * (a stream of frames does no hipMalloc / hipFree after the first one); this gives the calling thread's cache back. */
+int stocs_trim(void);
 
 /* clustering::point_to_plane_icp (pose_clustering.cpp:123-140: PCL IterativeClosestPointWithNormals, 5
  * iterations, 3.5 cm): own linearised point-to-plane ICP; T16_out maps the source cloud onto the target

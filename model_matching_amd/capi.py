@@ -82,6 +82,7 @@ SIGNATURES = {
     "stocs_cluster_poses": (C.c_int, [_fp, _fp, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, _fp, _ip, C.c_int, _intp]),
     "stocs_ingest_scene": (C.c_int, [C.POINTER(Camera), C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.c_float, C.c_float, C.c_int, _fp, _fp, _fp, _ip, C.c_int, _intp]),
     "stocs_preprocess_model": (C.c_int, [_fp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, _fp, _fp, C.c_int, _intp]),
+    "stocs_trim": (C.c_int, []),
     "stocs_icp_point_to_plane": (C.c_int, [_fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_float, C.c_int, _fp, _intp]),
     "stocs_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "stocs_set_stream": (C.c_int, [_vp, _vp]),

@@ -407,50 +407,9 @@ __global__ __launch_bounds__(256) void resolve_picks_kernel(JoinArgs A, const un
     }
 }
 
-// Device memory of this file comes from two arenas owned by the context: slabs of plain hipMalloc memory handed out
-// by bumping an offset, reset (not freed) at the start of the entry point that owns the arena.  After the first
-// trial a call does no hipMalloc / hipFree at all; a slab that turned out too small is joined by a bigger one and
-// the slabs are merged at the next reset.  (hipMallocAsync pools were tried first and returned stale data under
-// reuse on this ROCm build -- see DESIGN.md.)
-struct Slab { char* p; size_t cap, used; };
-struct Arena {
-    std::vector<Slab> slabs;
-    // nothing that lives in the arena may still be in flight on the device
-    int reset() {
-        if (slabs.size() > 1) {
-            size_t tot = 0;
-            for (size_t i = 0; i < slabs.size(); ++i) { tot += slabs[i].cap; (void)hipFree(slabs[i].p); }
-            slabs.clear();
-            tot += tot / 4;   // slack: trials of one scene differ in size by tens of percent
-            Slab sl = {NULL, tot, 0};
-            STOCS_HIP_CHECK(hipMalloc((void**)&sl.p, tot));
-            slabs.push_back(sl);
-        }
-        for (size_t i = 0; i < slabs.size(); ++i) slabs[i].used = 0;
-        return STOCS_OK;
-    }
-    // right after reset(): make sure ONE slab can hold `bytes` (a good estimate up front avoids growing in pieces)
-    int reserve(size_t bytes) {
-        if (slabs.size() == 1 && slabs[0].cap >= bytes) return STOCS_OK;
-        destroy();
-        Slab sl = {NULL, bytes + bytes / 4, 0};
-        STOCS_HIP_CHECK(hipMalloc((void**)&sl.p, sl.cap));
-        slabs.push_back(sl);
-        return STOCS_OK;
-    }
-    int take(size_t bytes, void** out) {
-        bytes = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
-        for (size_t i = 0; i < slabs.size(); ++i)
-            if (slabs[i].cap - slabs[i].used >= bytes) { *out = slabs[i].p + slabs[i].used; slabs[i].used += bytes; return STOCS_OK; }
-        Slab sl = {NULL, std::max<size_t>(bytes + bytes / 4, slabs.empty() ? ((size_t)64 << 20) : 2 * slabs.back().cap), 0};
-        STOCS_HIP_CHECK(hipMalloc((void**)&sl.p, sl.cap));
-        sl.used = bytes;
-        slabs.push_back(sl);
-        *out = sl.p;
-        return STOCS_OK;
-    }
-    void destroy() { for (size_t i = 0; i < slabs.size(); ++i) (void)hipFree(slabs[i].p); slabs.clear(); }
-};
+// Device memory of this file comes from two arenas (stocs_ctx.h) owned by the context, reset (not freed) at the start
+// of the entry point that owns the arena: after the first trial a call does no hipMalloc / hipFree at all.
+// (hipMallocAsync pools were tried first and returned stale data under reuse on this ROCm build -- see DESIGN.md.)
 static thread_local Arena* tl_arena = NULL;   // set by every entry point of this file before it allocates
 
 template <class T>

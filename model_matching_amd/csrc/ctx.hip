@@ -116,6 +116,8 @@ static int upload(T** dptr, const T* h, size_t n) {
 static int build_grid_div(stocs_ctx* c, int div_in) {
     SceneGrid& g = c->grid;
     const int nS = c->nS;
+    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    { int rc0 = c->grid_mem.reset(); if (rc0) return rc0; }
     const double eps = (double)c->prm.distance_threshold;
     // cell edge = epsilon / div: a finer grid gives shorter candidate lists (closer to the epsilon ball)
     // at the price of more cells and more list copies per point
@@ -297,11 +299,16 @@ static int build_grid_div(stocs_ctx* c, int div_in) {
                 }
             }
         }
-        if ((rc = upload(&g.d_chunk_r, chunk_r.data(), chunk_r.size()))) return rc;
+        if ((rc = c->grid_mem.take(std::max<size_t>(chunk_r.size(), 1) * sizeof(float), (void**)&g.d_chunk_r))) return rc;
+        STOCS_HIP_CHECK(hipMemcpy(g.d_chunk_r, chunk_r.data(), chunk_r.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    if ((rc = upload(&g.d_top, top.data(), top.size()))) return rc;
-    if ((rc = upload(&g.d_cells, cells.data(), cells.size()))) return rc;
-    if ((rc = upload(&g.d_list, list.data(), list.size()))) return rc;
+    if ((rc = c->grid_mem.take(std::max<size_t>(top.size(), 1) * 4, (void**)&g.d_top)) ||
+        (rc = c->grid_mem.take(std::max<size_t>(cells.size(), 1) * sizeof(uint4), (void**)&g.d_cells)) ||
+        (rc = c->grid_mem.take(std::max<size_t>(list.size(), 8) * sizeof(float4), (void**)&g.d_list)))
+        return rc;
+    STOCS_HIP_CHECK(hipMemcpy(g.d_top, top.data(), top.size() * 4, hipMemcpyHostToDevice));
+    STOCS_HIP_CHECK(hipMemcpy(g.d_cells, cells.data(), cells.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    STOCS_HIP_CHECK(hipMemcpy(g.d_list, list.data(), list.size() * sizeof(float4), hipMemcpyHostToDevice));
     return STOCS_OK;
 }
 
@@ -309,11 +316,7 @@ static int build_grid_div(stocs_ctx* c, int div_in) {
 // 1.6 mm spacing -> 61 candidates per list): then epsilon/2 (39 per list) and, if the lists are still long,
 // epsilon/4 -- every halving multiplies the list memory by ~4 and the cell count by 8, and pays as long as
 // the centre-sorted early exit still has chunks to skip (C5: 50.5 -> 16.5 -> 13.2 ms).  STOCS_GRID_DIV overrides.
-static void free_grid(stocs_ctx* c) {
-    if (c->grid.d_top) (void)hipFree(c->grid.d_top);
-    if (c->grid.d_cells) (void)hipFree(c->grid.d_cells);
-    if (c->grid.d_list) (void)hipFree(c->grid.d_list);
-    if (c->grid.d_chunk_r) (void)hipFree(c->grid.d_chunk_r);
+static void free_grid(stocs_ctx* c) {   // the grid lives in c->grid_mem, which the next build resets
     c->grid.d_top = NULL; c->grid.d_cells = NULL; c->grid.d_list = NULL; c->grid.d_chunk_r = NULL;
 }
 
@@ -553,9 +556,10 @@ int stocs_ctx_destroy(stocs_ctx* c) {
     DeviceGuard dev_guard(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_spos, c->d_snrmw, c->d_spix, c->d_mpos, c->d_mnrm, c->d_munit, c->d_mpos_raw, c->d_mpos_s,
-                    c->d_mnrm_s, c->d_mperm, c->grid.d_top, c->grid.d_cells, c->grid.d_list, c->grid.d_chunk_r, c->index.d_bucket_start,
+                    c->d_mnrm_s, c->d_mperm, c->index.d_bucket_start,
                     c->index.d_pairs, c->index.d_exists, c->d_scratch, c->d_best, c->d_cand};
     stocs_internal_free_congruent(c);
+    c->grid_mem.destroy(); c->grid_ws.destroy();
     for (void* p : ptrs) if (p) hipFree(p);
     hipEventDestroy(c->ev0);
     hipEventDestroy(c->ev1);

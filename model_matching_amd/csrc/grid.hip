@@ -222,16 +222,10 @@ __global__ __launch_bounds__(256) void chunk_bounds_kernel(GridGeom G, const uin
     }
 }
 
-struct Tmp {   // plain device temporaries of one build, released together
-    std::vector<void*> ptrs;
-    ~Tmp() { for (size_t i = 0; i < ptrs.size(); ++i) (void)hipFree(ptrs[i]); }
+struct Tmp {   // temporaries of one build: the context's workspace arena (no hipMalloc / hipFree in steady state)
+    Arena* ws;
     template <class T>
-    int get(T** p, size_t n) {
-        *p = NULL;
-        STOCS_HIP_CHECK(hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)));
-        ptrs.push_back(*p);
-        return STOCS_OK;
-    }
+    int get(T** p, size_t n) { return ws->take(std::max<size_t>(n, 1) * sizeof(T), (void**)p); }
 };
 
 static inline unsigned grid_of(size_t n) { return (unsigned)((n + 255) / 256); }
@@ -280,12 +274,14 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense) {
 
     hipStream_t st = c->stream;
     Tmp T;
+    T.ws = &c->grid_ws;
     int rc;
-    STOCS_HIP_CHECK(hipMalloc((void**)&g.d_top, std::max<int64_t>(n_top, 1) * 4));
+    STOCS_HIP_CHECK(hipStreamSynchronize(st));   // the previous grid and the previous build's temporaries are recycled
+    if ((rc = c->grid_ws.reset()) || (rc = c->grid_mem.reset())) return rc;
+    if ((rc = c->grid_mem.take((size_t)std::max<int64_t>(n_top, 1) * 4, (void**)&g.d_top))) return rc;
     hipLaunchKernelGGL(fill_i32_kernel, dim3(grid_of((size_t)n_top)), dim3(256), 0, st, g.d_top, (size_t)n_top, -1);
     if (nS == 0) {
-        STOCS_HIP_CHECK(hipMalloc((void**)&g.d_cells, 16));
-        STOCS_HIP_CHECK(hipMalloc((void**)&g.d_list, 8 * 16));
+        if ((rc = c->grid_mem.take(16, (void**)&g.d_cells)) || (rc = c->grid_mem.take(8 * 16, (void**)&g.d_list))) return rc;
         STOCS_HIP_CHECK(hipStreamSynchronize(st));
         return STOCS_OK;
     }
@@ -354,8 +350,9 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense) {
     const size_t n_list = tail[0];
     if (tail[1] > 65535u) { set_error("more than 65535 scene points within epsilon of one grid cell"); return STOCS_ERR_INVALID; }
     // ---- 4. cell words, top table, lists ----
-    STOCS_HIP_CHECK(hipMalloc((void**)&g.d_cells, std::max<size_t>((size_t)n_bricks * 512, 1) * sizeof(uint4)));
-    STOCS_HIP_CHECK(hipMalloc((void**)&g.d_list, std::max<size_t>(n_list, 8) * sizeof(float4)));
+    if ((rc = c->grid_mem.take(std::max<size_t>((size_t)n_bricks * 512, 1) * sizeof(uint4), (void**)&g.d_cells)) ||
+        (rc = c->grid_mem.take(std::max<size_t>(n_list, 8) * sizeof(float4), (void**)&g.d_list)))
+        return rc;
     hipLaunchKernelGGL(zero_cells_kernel, dim3(grid_of((size_t)n_bricks * 512)), dim3(256), 0, st, g.d_cells, (size_t)n_bricks * 512);
     hipLaunchKernelGGL(fill_list_kernel, dim3(grid_of(std::max<size_t>(n_list, 8))), dim3(256), 0, st, g.d_list, std::max<size_t>(n_list, 8));
     hipLaunchKernelGGL(cell_words_kernel, dim3(grid_of(n_cells)), dim3(256), 0, st, G, div, d_cell_first, d_cell_key, d_cell_brick, d_list_off, n_cells,
@@ -364,13 +361,13 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense) {
     STOCS_HIP_CHECK(hipGetLastError());
     // ---- 5. dense scenes: chunk bounds ----
     if (dense) {
-        STOCS_HIP_CHECK(hipMalloc((void**)&g.d_chunk_r, std::max<size_t>(n_list / 8, 1) * sizeof(float)));
+        if ((rc = c->grid_mem.take(std::max<size_t>(n_list / 8, 1) * sizeof(float), (void**)&g.d_chunk_r))) return rc;
         hipLaunchKernelGGL(fill_i32_kernel, dim3(grid_of(n_list / 8)), dim3(256), 0, st, (int32_t*)g.d_chunk_r, n_list / 8, 0);
         hipLaunchKernelGGL(chunk_bounds_kernel, dim3(grid_of(n_cells)), dim3(256), 0, st, G, d_cell_first, d_cell_key, d_list_off, n_cells, (uint32_t)n_inc,
                            g.d_list, g.d_chunk_r);
         STOCS_HIP_CHECK(hipGetLastError());
     }
-    STOCS_HIP_CHECK(hipStreamSynchronize(st));   // the temporaries are released by ~Tmp
+    STOCS_HIP_CHECK(hipStreamSynchronize(st));
     g.n_bricks = (int)n_bricks;
     g.n_entries = (int64_t)n_list;
     g.avg_list_len = n_cells ? (double)n_inc / (double)n_cells : 0.0;

@@ -17,7 +17,10 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <limits.h>
+
 #include <algorithm>
+#include <map>
 #include <vector>
 
 #include "stocs_ctx.h"
@@ -119,24 +122,63 @@ __global__ __launch_bounds__(256) void seg_heads_kernel(const uint64_t* __restri
     if (idx >= n) return;
     head[idx] = (idx == 0 || keys[idx] != keys[idx - 1]) ? 1u : 0u;
 }
-// one thread per leaf: sequential double sums over the leaf's points in original order (stable sort)
-__global__ __launch_bounds__(256) void centroid_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ head,
-                                                       const uint32_t* __restrict__ seg_of, int n, const float4* __restrict__ P,
-                                                       const float4* __restrict__ extra, float4* __restrict__ cen, float4* __restrict__ ext) {
+// first sorted position of every leaf (+ the end sentinel)
+__global__ __launch_bounds__(256) void seg_start_kernel(const uint32_t* __restrict__ head, const uint32_t* __restrict__ seg_of, int n, int nv,
+                                                        uint32_t* __restrict__ seg_start) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n || !head[idx]) return;
+    if (idx >= n) return;
+    if (head[idx]) seg_start[seg_of[idx]] = (uint32_t)idx;
+    if (idx == 0) seg_start[nv] = (uint32_t)n;
+}
+// Leaf centroids in double.  One thread per leaf sums a short leaf in sorted (= original, the sort is stable) order;
+// a long leaf -- e.g. the one that collects every zero-depth pixel at the origin, > 10^5 points -- is queued for
+// centroid_long_kernel instead of serialising one thread for milliseconds.
+#define STOCS_LONG_LEAF 192
+__global__ __launch_bounds__(256) void centroid_kernel(const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ ids, int nv,
+                                                       const float4* __restrict__ P, const float4* __restrict__ extra, float4* __restrict__ cen,
+                                                       float4* __restrict__ ext, uint32_t* __restrict__ long_list, uint32_t* __restrict__ n_long) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nv) return;
+    const uint32_t e0 = seg_start[s], e1 = seg_start[s + 1];
+    if (e1 - e0 > STOCS_LONG_LEAF) { long_list[atomicAdd(n_long, 1u)] = (uint32_t)s; return; }
     double sx = 0, sy = 0, sz = 0, ex = 0, ey = 0, ez = 0;
-    int cnt = 0;
-    const uint64_t k = keys[idx];
-    for (int e = idx; e < n && keys[e] == k; ++e) {
+    for (uint32_t e = e0; e < e1; ++e) {
         const float4 p = P[ids[e]];
         sx += p.x; sy += p.y; sz += p.z;
         if (extra) { const float4 q = extra[ids[e]]; ex += q.x; ey += q.y; ez += q.z; }
-        cnt++;
     }
-    const uint32_t s = seg_of[idx];
+    const double cnt = (double)(e1 - e0);
     cen[s] = make_float4((float)(sx / cnt), (float)(sy / cnt), (float)(sz / cnt), 0.f);
     if (extra) ext[s] = make_float4((float)(ex / cnt), (float)(ey / cnt), (float)(ez / cnt), 0.f);
+}
+// one workgroup per queued leaf: strided partial sums, then a fixed tree (deterministic, whatever order the queue has)
+__global__ __launch_bounds__(256) void centroid_long_kernel(const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ ids,
+                                                            const float4* __restrict__ P, const float4* __restrict__ extra, float4* __restrict__ cen,
+                                                            float4* __restrict__ ext, const uint32_t* __restrict__ long_list,
+                                                            const uint32_t* __restrict__ n_long) {
+    __shared__ double sh[6][256];
+    for (uint32_t j = blockIdx.x; j < *n_long; j += gridDim.x) {
+        const uint32_t s = long_list[j];
+        const uint32_t e0 = seg_start[s], e1 = seg_start[s + 1];
+        double v[6] = {0, 0, 0, 0, 0, 0};
+        for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) {
+            const float4 p = P[ids[e]];
+            v[0] += p.x; v[1] += p.y; v[2] += p.z;
+            if (extra) { const float4 q = extra[ids[e]]; v[3] += q.x; v[4] += q.y; v[5] += q.z; }
+        }
+        for (int k = 0; k < 6; ++k) sh[k][threadIdx.x] = v[k];
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) for (int k = 0; k < 6; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const double cnt = (double)(e1 - e0);
+            cen[s] = make_float4((float)(sh[0][0] / cnt), (float)(sh[1][0] / cnt), (float)(sh[2][0] / cnt), 0.f);
+            if (extra) ext[s] = make_float4((float)(sh[3][0] / cnt), (float)(sh[4][0] / cnt), (float)(sh[5][0] / cnt), 0.f);
+        }
+        __syncthreads();
+    }
 }
 
 // pcl::RadiusOutlierRemoval (rgbd.cpp:233-237): number of points (itself included) within radius
@@ -238,53 +280,132 @@ __global__ __launch_bounds__(256) void model_normals_kernel(const float4* __rest
     N[idx] = out;
 }
 
+// ---- workspace: every temporary of a call comes out of a grow-only arena cached per host thread and device, so a
+// caller that ingests one frame after the other does no hipMalloc / hipFree after the first frame.
+// stocs_trim() gives the calling thread's cached memory back.
+static thread_local std::map<int, Arena>* tl_ws = NULL;
+static thread_local Arena* tl_cur = NULL;
+
+static int workspace_begin(int device) {
+    if (!tl_ws) tl_ws = new std::map<int, Arena>();
+    int dev = device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+    tl_cur = &(*tl_ws)[dev];
+    return tl_cur->reset();   // the previous call synchronised before it returned
+}
+
 template <class T>
-struct Buf {
+struct Buf {   // typed view of workspace memory
     T* p;
     Buf() : p(NULL) {}
-    ~Buf() { if (p) (void)hipFree(p); }
-    int alloc(size_t n) { STOCS_HIP_CHECK(hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T))); return STOCS_OK; }
+    int alloc(size_t n) { return tl_cur->take(n * sizeof(T), (void**)&p); }
 };
 
-// voxel grid on device points dP[n] (+ optional extra field); outputs device centroid arrays (allocated here)
+// min / max of int3 or of the xyz of float4 over n elements -> out[0..5] (single workgroup; n is a few 10^5)
+__global__ __launch_bounds__(1024) void minmax_i3_kernel(const int3* __restrict__ v, int n, int* __restrict__ out) {
+    __shared__ int sh[6][1024];
+    int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const int3 c = v[i];
+        mn[0] = min(mn[0], c.x); mn[1] = min(mn[1], c.y); mn[2] = min(mn[2], c.z);
+        mx[0] = max(mx[0], c.x); mx[1] = max(mx[1], c.y); mx[2] = max(mx[2], c.z);
+    }
+    for (int k = 0; k < 3; ++k) { sh[k][threadIdx.x] = mn[k]; sh[3 + k][threadIdx.x] = mx[k]; }
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            for (int k = 0; k < 3; ++k) {
+                sh[k][threadIdx.x] = min(sh[k][threadIdx.x], sh[k][threadIdx.x + off]);
+                sh[3 + k][threadIdx.x] = max(sh[3 + k][threadIdx.x], sh[3 + k][threadIdx.x + off]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) out[threadIdx.x] = sh[threadIdx.x][0];
+}
+__global__ __launch_bounds__(1024) void minmax_f4_kernel(const float4* __restrict__ v, int n, float* __restrict__ out) {
+    __shared__ float sh[6][1024];
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float4 c = v[i];
+        // (a < b ? a : b) keeps the host loop's std::min semantics: a NaN never replaces the running value
+        mn[0] = c.x < mn[0] ? c.x : mn[0]; mn[1] = c.y < mn[1] ? c.y : mn[1]; mn[2] = c.z < mn[2] ? c.z : mn[2];
+        mx[0] = c.x > mx[0] ? c.x : mx[0]; mx[1] = c.y > mx[1] ? c.y : mx[1]; mx[2] = c.z > mx[2] ? c.z : mx[2];
+    }
+    for (int k = 0; k < 3; ++k) { sh[k][threadIdx.x] = mn[k]; sh[3 + k][threadIdx.x] = mx[k]; }
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            for (int k = 0; k < 3; ++k) {
+                sh[k][threadIdx.x] = fminf(sh[k][threadIdx.x], sh[k][threadIdx.x + off]);
+                sh[3 + k][threadIdx.x] = fmaxf(sh[3 + k][threadIdx.x], sh[3 + k][threadIdx.x + off]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) out[threadIdx.x] = sh[threadIdx.x][0];
+}
+__global__ __launch_bounds__(256) void iota_kernel(uint32_t* __restrict__ a, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = (uint32_t)i;
+}
+__global__ __launch_bounds__(256) void zero_u32x2_kernel(uint32_t* __restrict__ a, uint32_t* __restrict__ b, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { a[i] = 0; b[i] = 0; }
+}
+// survivors, in voxel order (stable): pos | nrm | prob | pixel packed for one copy per field
+__global__ __launch_bounds__(256) void scene_pack_kernel(const float4* __restrict__ cen, const float4* __restrict__ nn, const float* __restrict__ pp,
+                                                         const int2* __restrict__ px, const uint32_t* __restrict__ keep, const uint32_t* __restrict__ pos,
+                                                         int n, float* __restrict__ o_pos, float* __restrict__ o_nrm, float* __restrict__ o_prob,
+                                                         int32_t* __restrict__ o_px) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !keep[i]) return;
+    const uint32_t m = pos[i];
+    o_pos[3 * m] = cen[i].x; o_pos[3 * m + 1] = cen[i].y; o_pos[3 * m + 2] = cen[i].z;
+    o_nrm[3 * m] = nn[i].x; o_nrm[3 * m + 1] = nn[i].y; o_nrm[3 * m + 2] = nn[i].z;
+    o_prob[m] = pp[i];
+    o_px[2 * m] = px[i].x; o_px[2 * m + 1] = px[i].y;
+}
+
+// voxel grid on device points dP[n] (+ optional extra field); outputs device centroid arrays (workspace memory)
 static int voxel_grid_device(const float4* dP, const float4* dExtra, int n, double leaf, Buf<float4>& cen, Buf<float4>& ext, int* n_out, hipStream_t st) {
     *n_out = 0;
     if (n == 0) return STOCS_OK;
-    Buf<int3> ijk; Buf<uint64_t> keys, keys_s; Buf<uint32_t> ids, ids_s, head, seg; Buf<char> tmp;
+    Buf<int3> ijk; Buf<uint64_t> keys, keys_s; Buf<uint32_t> ids, ids_s, head, seg; Buf<char> tmp; Buf<int> mm;
     int rc;
-    if ((rc = ijk.alloc(n)) || (rc = keys.alloc(n)) || (rc = keys_s.alloc(n)) || (rc = ids.alloc(n)) || (rc = ids_s.alloc(n)) || (rc = head.alloc(n)) || (rc = seg.alloc(n))) return rc;
+    if ((rc = ijk.alloc(n)) || (rc = keys.alloc(n)) || (rc = keys_s.alloc(n)) || (rc = ids.alloc(n)) || (rc = ids_s.alloc(n)) || (rc = head.alloc(n)) ||
+        (rc = seg.alloc(n)) || (rc = mm.alloc(8)))
+        return rc;
     const dim3 g((unsigned)((n + 255) / 256));
     hipLaunchKernelGGL(leaf_coords_kernel, g, dim3(256), 0, st, dP, n, 1.0 / leaf, ijk.p);
-    std::vector<int3> h((size_t)n);
-    STOCS_HIP_CHECK(hipMemcpyAsync(h.data(), ijk.p, sizeof(int3) * (size_t)n, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(minmax_i3_kernel, dim3(1), dim3(1024), 0, st, ijk.p, n, mm.p);
+    int h6[6];
+    STOCS_HIP_CHECK(hipMemcpyAsync(h6, mm.p, sizeof(h6), hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
-    int3 mn = h[0], mx = h[0];
-    for (int i = 1; i < n; ++i) {
-        mn.x = std::min(mn.x, h[i].x); mn.y = std::min(mn.y, h[i].y); mn.z = std::min(mn.z, h[i].z);
-        mx.x = std::max(mx.x, h[i].x); mx.y = std::max(mx.y, h[i].y); mx.z = std::max(mx.z, h[i].z);
-    }
+    const int3 mn = make_int3(h6[0], h6[1], h6[2]), mx = make_int3(h6[3], h6[4], h6[5]);
     const int3 dims = make_int3(mx.x - mn.x + 1, mx.y - mn.y + 1, mx.z - mn.z + 1);
     if ((double)dims.x * dims.y * dims.z > 9.0e18) { set_error("voxel grid: leaf size too small for the cloud extent"); return STOCS_ERR_INVALID; }
     hipLaunchKernelGGL(leaf_keys_kernel, g, dim3(256), 0, st, ijk.p, n, mn, dims, keys.p, ids.p);
-    size_t tb = 0;
+    size_t tb = 0, tb2 = 0;
     STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb, keys.p, keys_s.p, ids.p, ids_s.p, (size_t)n, 0, 64, st));   // stable
-    if ((rc = tmp.alloc(tb))) return rc;
-    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, tb, keys.p, keys_s.p, ids.p, ids_s.p, (size_t)n, 0, 64, st));
-    hipLaunchKernelGGL(seg_heads_kernel, g, dim3(256), 0, st, keys_s.p, n, head.p);
-    size_t tb2 = 0;
-    Buf<char> tmp2;
     STOCS_HIP_CHECK(rocprim::exclusive_scan(NULL, tb2, head.p, seg.p, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
-    if ((rc = tmp2.alloc(tb2))) return rc;
-    STOCS_HIP_CHECK(rocprim::exclusive_scan(tmp2.p, tb2, head.p, seg.p, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
+    if ((rc = tmp.alloc(std::max(tb, tb2)))) return rc;
+    int key_bits = 1;   // sort only the bits the keys can have
+    while (key_bits < 64 && (double)(1ull << key_bits) < (double)dims.x * dims.y * dims.z) key_bits++;
+    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, tb, keys.p, keys_s.p, ids.p, ids_s.p, (size_t)n, 0, (unsigned)key_bits, st));
+    hipLaunchKernelGGL(seg_heads_kernel, g, dim3(256), 0, st, keys_s.p, n, head.p);
+    STOCS_HIP_CHECK(rocprim::exclusive_scan(tmp.p, tb2, head.p, seg.p, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
     uint32_t last_seg = 0, last_head = 0;
     STOCS_HIP_CHECK(hipMemcpyAsync(&last_seg, seg.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipMemcpyAsync(&last_head, head.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
     const int nv = (int)(last_seg + last_head);
-    if ((rc = cen.alloc(nv)) || (rc = ext.alloc(nv))) return rc;
-    hipLaunchKernelGGL(centroid_kernel, g, dim3(256), 0, st, keys_s.p, ids_s.p, head.p, seg.p, n, dP, dExtra, cen.p, ext.p);
+    Buf<uint32_t> seg_start, long_list, n_long;
+    if ((rc = cen.alloc(nv)) || (rc = ext.alloc(nv)) || (rc = seg_start.alloc((size_t)nv + 1)) || (rc = long_list.alloc(nv)) || (rc = n_long.alloc(2))) return rc;
+    hipLaunchKernelGGL(seg_start_kernel, g, dim3(256), 0, st, head.p, seg.p, n, nv, seg_start.p);
+    hipLaunchKernelGGL(zero_u32x2_kernel, dim3(1), dim3(256), 0, st, n_long.p, n_long.p + 1, (size_t)1);
+    hipLaunchKernelGGL(centroid_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, seg_start.p, ids_s.p, nv, dP, dExtra, cen.p, ext.p, long_list.p,
+                       n_long.p);
+    hipLaunchKernelGGL(centroid_long_kernel, dim3(256), dim3(256), 0, st, seg_start.p, ids_s.p, dP, dExtra, cen.p, ext.p, long_list.p, n_long.p);
     STOCS_HIP_CHECK(hipGetLastError());
-    STOCS_HIP_CHECK(hipStreamSynchronize(st));
     *n_out = nv;
     return STOCS_OK;
 }
@@ -295,16 +416,28 @@ using namespace stocs;
 
 extern "C" {
 
+int stocs_trim(void) {
+    if (tl_ws) {
+        (void)hipDeviceSynchronize();
+        for (std::map<int, Arena>::iterator it = tl_ws->begin(); it != tl_ws->end(); ++it) it->second.destroy();
+        delete tl_ws;
+        tl_ws = NULL;
+        tl_cur = NULL;
+    }
+    return STOCS_OK;
+}
+
 int stocs_ingest_scene(const stocs_camera* cam, const uint16_t* depth, const uint16_t* class_prob, float voxel_size,
                        float class_threshold, int device, float* pos3, float* nrm3, float* prob, int32_t* pixel2, int cap, int* n_out) {
     if (!cam || !depth || !class_prob || !n_out || cam->width <= 0 || cam->height <= 0 || !(voxel_size > 0)) return STOCS_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available: this library has no CPU fallback"); return STOCS_ERR_NO_DEVICE; }
     if (device >= 0) STOCS_HIP_CHECK(hipSetDevice(device));
+    int rc = workspace_begin(device);
+    if (rc) return rc;
     hipStream_t st = NULL;
     const int W = cam->width, H = cam->height, npx = W * H;
     Buf<uint16_t> dD, dC; Buf<float4> dP, dN;
-    int rc;
     if ((rc = dD.alloc(npx)) || (rc = dC.alloc(npx)) || (rc = dP.alloc(npx)) || (rc = dN.alloc(npx))) return rc;
     STOCS_HIP_CHECK(hipMemcpyAsync(dD.p, depth, 2 * (size_t)npx, hipMemcpyHostToDevice, st));
     STOCS_HIP_CHECK(hipMemcpyAsync(dC.p, class_prob, 2 * (size_t)npx, hipMemcpyHostToDevice, st));
@@ -314,15 +447,17 @@ int stocs_ingest_scene(const stocs_camera* cam, const uint16_t* depth, const uin
     Buf<float4> cen, ext;
     int nv = 0;
     if ((rc = voxel_grid_device(dP.p, NULL, npx, (double)voxel_size, cen, ext, &nv, st))) return rc;   // rgbd.cpp:228-231
+    *n_out = 0;
+    if (nv == 0) { STOCS_HIP_CHECK(hipStreamSynchronize(st)); return STOCS_OK; }
     // radius outlier removal: radius 2*voxel + 5 mm, more than 10 points (itself included)   rgbd.cpp:233-237
     const double radius = 2.0 * (double)voxel_size + 0.005;
-    std::vector<float4> hc((size_t)std::max(nv, 1));
-    STOCS_HIP_CHECK(hipMemcpy(hc.data(), cen.p, sizeof(float4) * (size_t)nv, hipMemcpyDeviceToHost));
-    double3 mn = make_double3(1e30, 1e30, 1e30), mx = make_double3(-1e30, -1e30, -1e30);
-    for (int i = 0; i < nv; ++i) {
-        mn.x = std::min(mn.x, (double)hc[i].x); mn.y = std::min(mn.y, (double)hc[i].y); mn.z = std::min(mn.z, (double)hc[i].z);
-        mx.x = std::max(mx.x, (double)hc[i].x); mx.y = std::max(mx.y, (double)hc[i].y); mx.z = std::max(mx.z, (double)hc[i].z);
-    }
+    Buf<float> bb;
+    if ((rc = bb.alloc(8))) return rc;
+    hipLaunchKernelGGL(minmax_f4_kernel, dim3(1), dim3(1024), 0, st, cen.p, nv, bb.p);
+    float hbb[6];
+    STOCS_HIP_CHECK(hipMemcpyAsync(hbb, bb.p, sizeof(hbb), hipMemcpyDeviceToHost, st));
+    STOCS_HIP_CHECK(hipStreamSynchronize(st));
+    const double3 mn = make_double3(hbb[0], hbb[1], hbb[2]), mx = make_double3(hbb[3], hbb[4], hbb[5]);
     const int3 dims = make_int3((int)floor((mx.x - mn.x) / radius) + 1, (int)floor((mx.y - mn.y) / radius) + 1, (int)floor((mx.z - mn.z) / radius) + 1);
     const size_t ncell = (size_t)dims.x * dims.y * dims.z;
     if (ncell > ((size_t)1 << 28)) { set_error("scene extent too large for the outlier-removal grid"); return STOCS_ERR_INVALID; }
@@ -331,46 +466,41 @@ int stocs_ingest_scene(const stocs_camera* cam, const uint16_t* depth, const uin
         (rc = count.alloc(nv)) || (rc = keep.alloc(nv + 1)) || (rc = kpos.alloc(nv + 1))) return rc;
     const dim3 gv((unsigned)((nv + 255) / 256));
     hipLaunchKernelGGL(ror_cell_kernel, gv, dim3(256), 0, st, cen.p, nv, mn, 1.0 / radius, dims, cell.p);
-    {
-        std::vector<uint32_t> iota((size_t)nv);
-        for (int i = 0; i < nv; ++i) iota[i] = (uint32_t)i;
-        STOCS_HIP_CHECK(hipMemcpy(ids.p, iota.data(), 4 * (size_t)nv, hipMemcpyHostToDevice));
-    }
-    size_t tb = 0;
-    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb, cell.p, cell_s.p, ids.p, ids_s.p, (size_t)nv, 0, 32, st));
-    if ((rc = tmp.alloc(tb))) return rc;
-    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, tb, cell.p, cell_s.p, ids.p, ids_s.p, (size_t)nv, 0, 32, st));
-    STOCS_HIP_CHECK(hipMemsetAsync(cstart.p, 0, 4 * ncell, st));
-    STOCS_HIP_CHECK(hipMemsetAsync(cend.p, 0, 4 * ncell, st));
+    hipLaunchKernelGGL(iota_kernel, gv, dim3(256), 0, st, ids.p, nv);
+    size_t tb = 0, tb2 = 0;
+    int cell_bits = 1;
+    while (cell_bits < 32 && ((size_t)1 << cell_bits) < ncell) cell_bits++;
+    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb, cell.p, cell_s.p, ids.p, ids_s.p, (size_t)nv, 0, (unsigned)cell_bits, st));
+    STOCS_HIP_CHECK(rocprim::exclusive_scan(NULL, tb2, keep.p, kpos.p, 0u, (size_t)nv + 1, rocprim::plus<uint32_t>(), st));
+    if ((rc = tmp.alloc(std::max(tb, tb2)))) return rc;
+    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, tb, cell.p, cell_s.p, ids.p, ids_s.p, (size_t)nv, 0, (unsigned)cell_bits, st));
+    hipLaunchKernelGGL(zero_u32x2_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, cstart.p, cend.p, ncell);
     hipLaunchKernelGGL(cell_start_kernel, gv, dim3(256), 0, st, cell_s.p, nv, cstart.p, cend.p);
     hipLaunchKernelGGL(ror_count_kernel, gv, dim3(256), 0, st, cen.p, nv, mn, 1.0 / radius, dims, radius, cstart.p, cend.p, ids_s.p, count.p);
     Buf<float4> on; Buf<float> op; Buf<int2> opx;
     if ((rc = on.alloc(nv)) || (rc = op.alloc(nv)) || (rc = opx.alloc(nv))) return rc;
     hipLaunchKernelGGL(scene_select_kernel, gv, dim3(256), 0, st, cen.p, count.p, nv, 10u, cam->fx, cam->cx, cam->fy, cam->cy, W, H, dC.p, class_threshold, dN.p,
                        keep.p, on.p, op.p, opx.p);
+    // stable compaction on the device: destination = exclusive scan of the keep flags
+    hipLaunchKernelGGL(zero_u32x2_kernel, dim3(1), dim3(256), 0, st, keep.p + nv, kpos.p + nv, (size_t)1);
+    STOCS_HIP_CHECK(rocprim::exclusive_scan(tmp.p, tb2, keep.p, kpos.p, 0u, (size_t)nv + 1, rocprim::plus<uint32_t>(), st));
+    Buf<float> o_pos, o_nrm, o_prob; Buf<int32_t> o_px;
+    if ((rc = o_pos.alloc((size_t)nv * 3)) || (rc = o_nrm.alloc((size_t)nv * 3)) || (rc = o_prob.alloc(nv)) || (rc = o_px.alloc((size_t)nv * 2))) return rc;
+    hipLaunchKernelGGL(scene_pack_kernel, gv, dim3(256), 0, st, cen.p, on.p, op.p, opx.p, keep.p, kpos.p, nv, o_pos.p, o_nrm.p, o_prob.p, o_px.p);
     STOCS_HIP_CHECK(hipGetLastError());
-    // stable compaction on the host side of the boundary (a few 10^4 records)
-    std::vector<uint32_t> hk((size_t)nv);
-    std::vector<float4> hn((size_t)nv);
-    std::vector<float> hp((size_t)nv);
-    std::vector<int2> hpx((size_t)nv);
-    STOCS_HIP_CHECK(hipMemcpy(hk.data(), keep.p, 4 * (size_t)nv, hipMemcpyDeviceToHost));
-    STOCS_HIP_CHECK(hipMemcpy(hn.data(), on.p, sizeof(float4) * (size_t)nv, hipMemcpyDeviceToHost));
-    STOCS_HIP_CHECK(hipMemcpy(hp.data(), op.p, 4 * (size_t)nv, hipMemcpyDeviceToHost));
-    STOCS_HIP_CHECK(hipMemcpy(hpx.data(), opx.p, sizeof(int2) * (size_t)nv, hipMemcpyDeviceToHost));
-    int m = 0;
-    for (int i = 0; i < nv; ++i) {
-        if (!hk[i]) continue;
-        if (m < cap) {
-            if (pos3) { pos3[3 * m] = hc[i].x; pos3[3 * m + 1] = hc[i].y; pos3[3 * m + 2] = hc[i].z; }
-            if (nrm3) { nrm3[3 * m] = hn[i].x; nrm3[3 * m + 1] = hn[i].y; nrm3[3 * m + 2] = hn[i].z; }
-            if (prob) prob[m] = hp[i];
-            if (pixel2) { pixel2[2 * m] = hpx[i].x; pixel2[2 * m + 1] = hpx[i].y; }
-        }
-        m++;
+    uint32_t m = 0;
+    STOCS_HIP_CHECK(hipMemcpyAsync(&m, kpos.p + nv, 4, hipMemcpyDeviceToHost, st));
+    STOCS_HIP_CHECK(hipStreamSynchronize(st));
+    const size_t mc = std::min<size_t>(m, (size_t)std::max(cap, 0));
+    if (mc) {
+        if (pos3) STOCS_HIP_CHECK(hipMemcpyAsync(pos3, o_pos.p, 12 * mc, hipMemcpyDeviceToHost, st));
+        if (nrm3) STOCS_HIP_CHECK(hipMemcpyAsync(nrm3, o_nrm.p, 12 * mc, hipMemcpyDeviceToHost, st));
+        if (prob) STOCS_HIP_CHECK(hipMemcpyAsync(prob, o_prob.p, 4 * mc, hipMemcpyDeviceToHost, st));
+        if (pixel2) STOCS_HIP_CHECK(hipMemcpyAsync(pixel2, o_px.p, 8 * mc, hipMemcpyDeviceToHost, st));
     }
-    *n_out = m;
-    return m > cap ? STOCS_ERR_CAPACITY : STOCS_OK;
+    STOCS_HIP_CHECK(hipStreamSynchronize(st));
+    *n_out = (int)m;
+    return (int)m > cap ? STOCS_ERR_CAPACITY : STOCS_OK;
 }
 
 int stocs_preprocess_model(const float* raw_pos3, int n_raw, float normal_radius, float voxel_size, float model_scale, int device,
@@ -379,6 +509,7 @@ int stocs_preprocess_model(const float* raw_pos3, int n_raw, float normal_radius
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available: this library has no CPU fallback"); return STOCS_ERR_NO_DEVICE; }
     if (device >= 0) STOCS_HIP_CHECK(hipSetDevice(device));
+    { int rc0 = workspace_begin(device); if (rc0) return rc0; }
     hipStream_t st = NULL;
     std::vector<float4> hp((size_t)n_raw);
     for (int i = 0; i < n_raw; ++i) hp[i] = make_float4(raw_pos3[3 * i], raw_pos3[3 * i + 1], raw_pos3[3 * i + 2], 0.f);
@@ -404,6 +535,7 @@ int stocs_preprocess_model(const float* raw_pos3, int n_raw, float normal_radius
     STOCS_HIP_CHECK(hipMemcpy(dN2.p, kn.data(), sizeof(float4) * (size_t)nk, hipMemcpyHostToDevice));
     int nv = 0;
     if ((rc = voxel_grid_device(dP2.p, dN2.p, nk, (double)voxel_size, cen, ext, &nv, st))) return rc;   // stocs.cpp:54-57
+    STOCS_HIP_CHECK(hipStreamSynchronize(st));
     std::vector<float4> hc((size_t)std::max(nv, 1)), he((size_t)std::max(nv, 1));
     STOCS_HIP_CHECK(hipMemcpy(hc.data(), cen.p, sizeof(float4) * (size_t)nv, hipMemcpyDeviceToHost));
     STOCS_HIP_CHECK(hipMemcpy(he.data(), ext.p, sizeof(float4) * (size_t)nv, hipMemcpyDeviceToHost));

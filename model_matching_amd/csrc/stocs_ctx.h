@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <algorithm>
 #include <memory>
 #include <string>
 #include <utility>
@@ -38,6 +39,49 @@ struct DeviceGuard {
     ~DeviceGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
     DeviceGuard(const DeviceGuard&) = delete;
     DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+// Grow-only device workspace: slabs of plain hipMalloc memory handed out by bumping an offset.  reset() recycles
+// everything (nothing of it may still be in flight); a slab that turned out too small is joined by a bigger one
+// and the slabs are merged at the next reset, so a steady-state caller never calls hipMalloc / hipFree.
+struct Slab { char* p; size_t cap, used; };
+struct Arena {
+    std::vector<Slab> slabs;
+    // nothing that lives in the arena may still be in flight on the device
+    int reset() {
+        if (slabs.size() > 1) {
+            size_t tot = 0;
+            for (size_t i = 0; i < slabs.size(); ++i) { tot += slabs[i].cap; (void)hipFree(slabs[i].p); }
+            slabs.clear();
+            tot += tot / 4;   // slack: trials of one scene differ in size by tens of percent
+            Slab sl = {NULL, tot, 0};
+            STOCS_HIP_CHECK(hipMalloc((void**)&sl.p, tot));
+            slabs.push_back(sl);
+        }
+        for (size_t i = 0; i < slabs.size(); ++i) slabs[i].used = 0;
+        return STOCS_OK;
+    }
+    // right after reset(): make sure ONE slab can hold `bytes` (a good estimate up front avoids growing in pieces)
+    int reserve(size_t bytes) {
+        if (slabs.size() == 1 && slabs[0].cap >= bytes) return STOCS_OK;
+        destroy();
+        Slab sl = {NULL, bytes + bytes / 4, 0};
+        STOCS_HIP_CHECK(hipMalloc((void**)&sl.p, sl.cap));
+        slabs.push_back(sl);
+        return STOCS_OK;
+    }
+    int take(size_t bytes, void** out) {
+        bytes = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+        for (size_t i = 0; i < slabs.size(); ++i)
+            if (slabs[i].cap - slabs[i].used >= bytes) { *out = slabs[i].p + slabs[i].used; slabs[i].used += bytes; return STOCS_OK; }
+        Slab sl = {NULL, std::max<size_t>(bytes + bytes / 4, slabs.empty() ? ((size_t)64 << 20) : 2 * slabs.back().cap), 0};
+        STOCS_HIP_CHECK(hipMalloc((void**)&sl.p, sl.cap));
+        sl.used = bytes;
+        slabs.push_back(sl);
+        *out = sl.p;
+        return STOCS_OK;
+    }
+    void destroy() { for (size_t i = 0; i < slabs.size(); ++i) (void)hipFree(slabs[i].p); slabs.clear(); }
 };
 
 // Brick grid over the centred scene (replaces the kd-tree of kdtree.h for the restricted-radius
@@ -127,6 +171,8 @@ struct stocs_ctx {
     int32_t* d_mperm;
 
     stocs::SceneGrid grid;
+    stocs::Arena grid_mem;   // top / cells / list / chunk_r of the current grid (reset by every build)
+    stocs::Arena grid_ws;    // temporaries of a grid build
     int grid_div;   // cell edge = epsilon / grid_div
     int lcp_variant;   // -1: STOCS_LCP_VARIANT or automatic; else stocs_set_option("lcp_variant")
     stocs::PpfIndex index;

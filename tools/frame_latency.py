@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Per-frame latency of the whole path on the reference's three example frames (raw data fixtures under
+tests/golden/): uint16 depth + class-probability image -> scene cloud (stocs_ingest_scene) -> stocs_ctx_set_scene
+(upload, centroid shift, GPU brick grid; the model and its PPF index stay) -> one StoCS trial of 100 base
+attempts (sampling, congruent sets, <= 200 transforms per base, verification) -> best pose.
+usage: python tools/frame_latency.py [frames]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from model_matching_amd.estimator import StocsEstimator, ingest_scene, preprocess_model  # noqa: E402
+
+
+def main():
+    frames = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+    out = {}
+    for name in ("ycb_024_bowl", "linemod_obj_06", "packed_dove"):
+        raw = np.load(os.path.join(ROOT, "tests", "golden", "example_%s_raw.npz" % name))
+        fix = np.load(os.path.join(ROOT, "tests", "golden", "example_%s.npz" % name))
+        K = [float(x) for x in raw["K"]]
+        mpos, mnrm = preprocess_model(raw["model_raw"], float(raw["normal_radius"]), float(raw["model_voxel"]), float(raw["model_scale"]))
+        pos, nrm, prob, pix = ingest_scene(raw["depth"], raw["prob"], K, float(raw["depth_scale"]))
+        mode = 1 if "edge_map" in fix.files else 0
+        t = time.perf_counter()
+        est = StocsEstimator(pos, nrm, prob, pix, mpos, mnrm, build_index=True)
+        est.sync()
+        t_ctx = (time.perf_counter() - t) * 1e3
+        rows = []
+        for f in range(frames):
+            t0 = time.perf_counter()
+            pos, nrm, prob, pix = ingest_scene(raw["depth"], raw["prob"], K, float(raw["depth_scale"]))
+            t1 = time.perf_counter()
+            est.set_scene(pos, nrm, prob, pix)
+            if mode:
+                est.set_edge_map(fix["edge_map"])
+            t2 = time.perf_counter()
+            est.sample_bases(100 + f, 100, mode=mode, dispersion=0.9)
+            t3 = time.perf_counter()
+            nq = est.find_congruent_all()
+            nc = est.make_transforms(200, 100 + f)
+            lcp, idx, pose = est.compute_best_transform()
+            t4 = time.perf_counter()
+            rows.append([(t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (t4 - t0) * 1e3, int(nq), int(nc), float(lcp)])
+        r = np.array(rows[1:])   # the first frame warms the arenas up
+        out[name] = {"mode": "instance" if mode else "class", "scene_points": int(len(pos)), "model_points": int(len(mpos)),
+                     "context_create_incl_index_ms": t_ctx,
+                     "median_ms": {"ingest": float(np.median(r[:, 0])), "set_scene": float(np.median(r[:, 1])), "sample_100_bases": float(np.median(r[:, 2])),
+                                   "congruent+transforms+verify": float(np.median(r[:, 3])), "frame_total": float(np.median(r[:, 4]))},
+                     "quads": [int(x) for x in r[:, 5]], "candidates": [int(x) for x in r[:, 6]], "best_lcp": [float(x) for x in r[:, 7]]}
+        est.close()
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
