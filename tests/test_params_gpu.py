@@ -111,3 +111,42 @@ def test_phases_1_to_3_at_metric_size():
         if checked == 2:
             break
     assert checked == 2
+
+
+def test_on_demand_quads_at_metric_size():
+    """Cm: the count-only congruent pass against its own materialisation (size-independent properties, no oracle):
+    per-base counts add up; for a mid-size base the emission order is a permutation of the sorted std::set order;
+    for a big base, sampled ranks resolve to distinct members of the materialised set; the candidates of
+    make_transforms come from exactly those quads."""
+    m, s, est, orc = _pair("Cm")
+    seed = 4321
+    valid, ids, inv = est.sample_bases(seed, 24)
+    nb = int(valid.sum())
+    total = est.find_congruent_all()
+    sizes = np.array([est.num_quads(b) for b in range(nb)])
+    assert sizes.sum() == total and total > 10 ** 6
+
+    def pack(q):
+        q = q.astype(np.int64)
+        return ((q[:, 0] * 65536 + q[:, 1]) * 65536 + q[:, 2]) * 65536 + q[:, 3]
+
+    mid = [b for b in range(nb) if 1000 <= sizes[b] <= 300000]
+    assert mid
+    b = mid[0]
+    full = est.get_quads(b)
+    assert len(full) == sizes[b] and np.all(np.diff(pack(full)) > 0)           # sorted, no duplicates
+    emitted = est.get_quads_at(b, np.arange(sizes[b]))
+    assert np.array_equal(np.sort(pack(emitted)), pack(full))                   # same set, other order
+    big = int(np.argmax(sizes))
+    if sizes[big] <= 4 * 10 ** 6:
+        fullb = pack(est.get_quads(big))
+        rng = np.random.default_rng(1)
+        ranks = rng.choice(sizes[big], size=2000, replace=False)
+        got = pack(est.get_quads_at(big, ranks))
+        assert np.isin(got, fullb).all() and len(np.unique(got)) == len(got)
+    # every candidate is the transform of (its base, one of that base's quads): check through the quad counts
+    nc = est.make_transforms(200, seed)
+    T, P, l, bidx = est.get_pose_candidates()
+    assert nc == len(T) and nc <= np.minimum(sizes, 200).sum()
+    per_base = np.bincount(bidx, minlength=nb)
+    assert np.all(per_base <= np.minimum(sizes, 200))
