@@ -12,7 +12,9 @@
 // uniform-grid neighbour count, stable compaction of the survivors.  All integer/byte-heavy and
 // HBM/L2-bound; no MFMA.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -433,8 +435,18 @@ int stocs_ingest_scene(const stocs_camera* cam, const uint16_t* depth, const uin
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available: this library has no CPU fallback"); return STOCS_ERR_NO_DEVICE; }
     if (device >= 0) STOCS_HIP_CHECK(hipSetDevice(device));
+    const bool dbg = getenv("STOCS_DEBUG_TIMING") != NULL;
+    struct timespec ts0; clock_gettime(CLOCK_MONOTONIC, &ts0);
+    auto tick = [&](const char* label) {
+        if (!dbg) return;
+        (void)hipDeviceSynchronize();
+        struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+        fprintf(stderr, "[stocs ingest] %-22s %8.3f ms\n", label, (t1.tv_sec - ts0.tv_sec) * 1e3 + (t1.tv_nsec - ts0.tv_nsec) * 1e-6);
+        ts0 = t1;
+    };
     int rc = workspace_begin(device);
     if (rc) return rc;
+    tick("workspace");
     hipStream_t st = NULL;
     const int W = cam->width, H = cam->height, npx = W * H;
     Buf<uint16_t> dD, dC; Buf<float4> dP, dN;
@@ -444,10 +456,12 @@ int stocs_ingest_scene(const stocs_camera* cam, const uint16_t* depth, const uin
     const dim3 g((unsigned)((npx + 255) / 256));
     hipLaunchKernelGGL(backproject_kernel, g, dim3(256), 0, st, dD.p, W, H, cam->fx, cam->cx, cam->fy, cam->cy, cam->depth_scale, dP.p);
     hipLaunchKernelGGL(depth_normals_kernel, g, dim3(256), 0, st, dP.p, W, H, dN.p);
+    tick("upload+backproject+normals");
     Buf<float4> cen, ext;
     int nv = 0;
     if ((rc = voxel_grid_device(dP.p, NULL, npx, (double)voxel_size, cen, ext, &nv, st))) return rc;   // rgbd.cpp:228-231
     *n_out = 0;
+    tick("voxel grid");
     if (nv == 0) { STOCS_HIP_CHECK(hipStreamSynchronize(st)); return STOCS_OK; }
     // radius outlier removal: radius 2*voxel + 5 mm, more than 10 points (itself included)   rgbd.cpp:233-237
     const double radius = 2.0 * (double)voxel_size + 0.005;
@@ -488,6 +502,7 @@ int stocs_ingest_scene(const stocs_camera* cam, const uint16_t* depth, const uin
     if ((rc = o_pos.alloc((size_t)nv * 3)) || (rc = o_nrm.alloc((size_t)nv * 3)) || (rc = o_prob.alloc(nv)) || (rc = o_px.alloc((size_t)nv * 2))) return rc;
     hipLaunchKernelGGL(scene_pack_kernel, gv, dim3(256), 0, st, cen.p, on.p, op.p, opx.p, keep.p, kpos.p, nv, o_pos.p, o_nrm.p, o_prob.p, o_px.p);
     STOCS_HIP_CHECK(hipGetLastError());
+    tick("outlier removal+select");
     uint32_t m = 0;
     STOCS_HIP_CHECK(hipMemcpyAsync(&m, kpos.p + nv, 4, hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
@@ -499,6 +514,7 @@ int stocs_ingest_scene(const stocs_camera* cam, const uint16_t* depth, const uin
         if (pixel2) STOCS_HIP_CHECK(hipMemcpyAsync(pixel2, o_px.p, 8 * mc, hipMemcpyDeviceToHost, st));
     }
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
+    tick("download");
     *n_out = (int)m;
     return (int)m > cap ? STOCS_ERR_CAPACITY : STOCS_OK;
 }

@@ -23,9 +23,11 @@ def main():
         raw = np.load(os.path.join(ROOT, "tests", "golden", "example_%s_raw.npz" % name))
         fix = np.load(os.path.join(ROOT, "tests", "golden", "example_%s.npz" % name))
         K = [float(x) for x in raw["K"]]
+        depth, cprob, dscale = np.ascontiguousarray(raw["depth"]), np.ascontiguousarray(raw["prob"]), float(raw["depth_scale"])   # npz entries decompress on access
         mpos, mnrm = preprocess_model(raw["model_raw"], float(raw["normal_radius"]), float(raw["model_voxel"]), float(raw["model_scale"]))
-        pos, nrm, prob, pix = ingest_scene(raw["depth"], raw["prob"], K, float(raw["depth_scale"]))
+        pos, nrm, prob, pix = ingest_scene(depth, cprob, K, dscale)
         mode = 1 if "edge_map" in fix.files else 0
+        edge = np.ascontiguousarray(fix["edge_map"]) if mode else None
         t = time.perf_counter()
         est = StocsEstimator(pos, nrm, prob, pix, mpos, mnrm, build_index=True)
         est.sync()
@@ -33,11 +35,11 @@ def main():
         rows = []
         for f in range(frames):
             t0 = time.perf_counter()
-            pos, nrm, prob, pix = ingest_scene(raw["depth"], raw["prob"], K, float(raw["depth_scale"]))
+            pos, nrm, prob, pix = ingest_scene(depth, cprob, K, dscale)
             t1 = time.perf_counter()
             est.set_scene(pos, nrm, prob, pix)
             if mode:
-                est.set_edge_map(fix["edge_map"])
+                est.set_edge_map(edge)
             t2 = time.perf_counter()
             est.sample_bases(100 + f, 100, mode=mode, dispersion=0.9)
             t3 = time.perf_counter()
