@@ -141,46 +141,49 @@ __global__ __launch_bounds__(256) void zero_cells_kernel(uint4* __restrict__ a, 
     if (i < n) a[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
-// cell word + top table; one thread per non-empty cell.  Sub-cell masks (cell edge = eps only): bit s is set when
-// some point of the cell's list lies within r of sub-cell s (any point that close to a sub-cell is that close
-// to the cell, hence in its list).
+// cell word + top table; one wavefront per non-empty cell, lane = sub-cell.  Sub-cell masks (cell edge = eps
+// only): bit s is set when some point of the cell's list lies within r of sub-cell s (any point that close to a
+// sub-cell is that close to the cell, hence in its list); the 64 lanes ballot the mask.
 __global__ __launch_bounds__(256) void cell_words_kernel(GridGeom G, int div, const uint32_t* __restrict__ cell_first, const uint64_t* __restrict__ cell_key,
                                                          const uint32_t* __restrict__ cell_brick, const uint32_t* __restrict__ list_off,
                                                          uint32_t n_cells, uint32_t n_inc, const uint32_t* __restrict__ vals,
                                                          const float4* __restrict__ spos, int32_t* __restrict__ top, uint4* __restrict__ cells) {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_cells) return;
+    const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int s = threadIdx.x & 63;
+    if (c >= n_cells) return;   // whole wavefront
     const uint32_t first = cell_first[c];
     const uint32_t cnt = (c + 1 < n_cells ? cell_first[c + 1] : n_inc) - first;
     const uint64_t key = cell_key[c];
     const uint64_t brick = key >> 9;
     const uint32_t local = (uint32_t)(key & 511);
     const uint32_t b = cell_brick[c];
-    top[brick] = (int32_t)b;   // every cell of the brick writes the same value
     uint32_t mlo = 0xFFFFFFFFu, mhi = 0xFFFFFFFFu;
     if (div == 1) {
-        mlo = 0; mhi = 0;
         const int bx = (int)(brick % (uint64_t)G.nbx), by = (int)((brick / (uint64_t)G.nbx) % (uint64_t)G.nby),
                   bz = (int)(brick / ((uint64_t)G.nbx * (uint64_t)G.nby));
         const int cx = bx * 8 + (int)(local & 7), cy = by * 8 + (int)((local >> 3) & 7), cz = bz * 8 + (int)(local >> 6);
         const double hs = G.h / 4.0;
-        for (uint32_t k = 0; k < cnt; ++k) {
-            const float4 pf = spos[vals[first + k]];
+        const int sc[3] = {4 * cx + (s & 3), 4 * cy + ((s >> 2) & 3), 4 * cz + (s >> 4)};
+        bool any = false;
+        for (uint32_t k = 0; k < cnt && !any; ++k) {
+            const float4 pf = spos[vals[first + k]];   // same address in every lane: one broadcast load
             const double p[3] = {pf.x, pf.y, pf.z};
-            for (int s = 0; s < 64; ++s) {
-                const int sc[3] = {4 * cx + (s & 3), 4 * cy + ((s >> 2) & 3), 4 * cz + (s >> 4)};
-                double d2 = 0;
+            double d2 = 0;
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const double b0 = G.of[a] + sc[a] * hs, b1 = b0 + hs;
-                    const double d = p[a] < b0 ? b0 - p[a] : (p[a] > b1 ? p[a] - b1 : 0.0);
-                    d2 += d * d;
-                }
-                if (d2 <= G.r * G.r) { if (s < 32) mlo |= 1u << s; else mhi |= 1u << (s - 32); }
+            for (int a = 0; a < 3; ++a) {
+                const double b0 = G.of[a] + sc[a] * hs, b1 = b0 + hs;
+                const double d = p[a] < b0 ? b0 - p[a] : (p[a] > b1 ? p[a] - b1 : 0.0);
+                d2 += d * d;
             }
+            any = d2 <= G.r * G.r;
         }
+        const unsigned long long m = __ballot(any);
+        mlo = (uint32_t)(m & 0xFFFFFFFFull); mhi = (uint32_t)(m >> 32);
     }
-    cells[(size_t)b * 512 + local] = make_uint4(list_off[c], cnt, mlo, mhi);
+    if (s == 0) {
+        top[brick] = (int32_t)b;   // every cell of the brick writes the same value
+        cells[(size_t)b * 512 + local] = make_uint4(list_off[c], cnt, mlo, mhi);
+    }
 }
 
 // list entries: incidence e of cell c goes to list_off[c] + (e - first[c])
@@ -355,7 +358,7 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense) {
         return rc;
     hipLaunchKernelGGL(zero_cells_kernel, dim3(grid_of((size_t)n_bricks * 512)), dim3(256), 0, st, g.d_cells, (size_t)n_bricks * 512);
     hipLaunchKernelGGL(fill_list_kernel, dim3(grid_of(std::max<size_t>(n_list, 8))), dim3(256), 0, st, g.d_list, std::max<size_t>(n_list, 8));
-    hipLaunchKernelGGL(cell_words_kernel, dim3(grid_of(n_cells)), dim3(256), 0, st, G, div, d_cell_first, d_cell_key, d_cell_brick, d_list_off, n_cells,
+    hipLaunchKernelGGL(cell_words_kernel, dim3((unsigned)((n_cells + 3) / 4)), dim3(256), 0, st, G, div, d_cell_first, d_cell_key, d_cell_brick, d_list_off, n_cells,
                        (uint32_t)n_inc, d_vals_s, c->d_spos, g.d_top, g.d_cells);
     hipLaunchKernelGGL(list_fill_kernel, dim3(grid_of(n_inc)), dim3(256), 0, st, d_cflag, d_cidx, d_cell_first, d_list_off, d_vals_s, n_inc, c->d_spos, g.d_list);
     STOCS_HIP_CHECK(hipGetLastError());

@@ -12,16 +12,21 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def newest(pattern):
+    """gpurun_out/ accumulates one sub-directory per profiler run: take the most recent match."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
-    shutil.copy(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, "%s_final_bench_kernel_stats.csv" % tag))
-    shutil.copy(glob.glob(os.path.join(src, "pipe", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, "%s_pipeline_Cm_kernel_stats.csv" % tag))
+    shutil.copy(newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), os.path.join(dst, "%s_final_bench_kernel_stats.csv" % tag))
+    shutil.copy(newest(os.path.join(src, "pipe", "*", "*_kernel_stats.csv")), os.path.join(dst, "%s_pipeline_Cm_kernel_stats.csv" % tag))
     shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "%s_final_bench.json" % tag))
     out = {}
     for d in ("fetch", "write", "sq", "tcp", "ta"):
-        f = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))[0]
+        f = newest(os.path.join(src, d, "*", "*_counter_collection.csv"))
         acc = collections.defaultdict(list)
         kern = None
         for r in csv.DictReader(open(f)):
