@@ -265,6 +265,13 @@ __global__ __launch_bounds__(256) void qcell_kernel(JoinArgs A, uint64_t* __rest
     vals[e] = e;
 }
 
+// per-base totals: the scanned count at the first Q pair of every base (one small copy instead of one per base)
+__global__ __launch_bounds__(256) void base_offsets_kernel(const unsigned long long* __restrict__ qoffe, const uint32_t* __restrict__ q_off, int n,
+                                                           unsigned long long* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n) out[b] = qoffe[q_off[b]];
+}
+
 // count pass, one lane per Q pair, in (base, position cell) order; counts land at the pair's list position
 __global__ __launch_bounds__(256) void join_count_kernel(JoinArgs A, const uint32_t* __restrict__ qperm, unsigned long long* __restrict__ qcnt) {
     __shared__ uint32_t seen[256][11];  // 343-bit set per lane
@@ -670,8 +677,11 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     STOCS_HIP_CHECK(rocprim::exclusive_scan(d_tmp_scan.p, tmp_scan, d_qcnt.p, S->d_qoffe.p, 0ull, (size_t)totQ + 1, rocprim::plus<unsigned long long>(), st));
     // per-base offsets = scan value at the first Q entry of each base
     std::vector<unsigned long long> qoff_at(nB + 1);
-    for (int b = 0; b <= nB; ++b)
-        STOCS_HIP_CHECK(hipMemcpyAsync(&qoff_at[b], S->d_qoffe.p + q_off[b], 8, hipMemcpyDeviceToHost, st));
+    DevBuf<unsigned long long> d_boff;
+    if ((rc = d_boff.alloc(nB + 1))) return rc;
+    hipLaunchKernelGGL(base_offsets_kernel, dim3((unsigned)((nB + 1 + 255) / 256)), dim3(256), 0, st, S->d_qoffe.p, S->d_qoff.p, nB + 1, d_boff.p);
+    STOCS_HIP_CHECK(hipGetLastError());
+    STOCS_HIP_CHECK(hipMemcpyAsync(qoff_at.data(), d_boff.p, 8 * (size_t)(nB + 1), hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
     STOCS_TICK("join count+scan")
     for (int b = 0; b <= nB; ++b) c->quad_off[b] = qoff_at[b];

@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--example", default="packed_dove")
+    ap.add_argument("--example", default="packed_dove", help="reference example fixture, or synth:<workload> (e.g. synth:Cm)")
     ap.add_argument("--trials", type=int, default=64)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--bases", type=int, default=100)
@@ -41,9 +41,16 @@ def main():
         dist.init_process_group("gloo") if rehearsal else dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from model_matching_amd import dist as sd
     from model_matching_amd.estimator import StocsEstimator
-    d = np.load(os.path.join(ROOT, "tests", "golden", "example_%s.npz" % args.example))
-    cloud = (d["scene_pos"], d["scene_nrm"], d["scene_prob"], d["scene_pixel"], d["model_pos"], d["model_nrm"])
-    mode = 1 if "edge_map" in d.files else 0
+    if args.example.startswith("synth:"):
+        from model_matching_amd import synth
+        m_, s_, _ = synth.workload(args.example.split(":", 1)[1])
+        d = None
+        cloud = (s_.pos, s_.nrm, s_.prob, s_.pixel, m_.pos, m_.nrm)
+        mode = 0
+    else:
+        d = np.load(os.path.join(ROOT, "tests", "golden", "example_%s.npz" % args.example))
+        cloud = (d["scene_pos"], d["scene_nrm"], d["scene_prob"], d["scene_pixel"], d["model_pos"], d["model_nrm"])
+        mode = 1 if "edge_map" in d.files else 0
     lo, hi = sd.shard_range(args.trials, rank, world)
     best = (0.0, -1, None)
     n_cand = 0
