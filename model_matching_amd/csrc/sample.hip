@@ -396,7 +396,7 @@ static int refresh_class_prob_on_device(stocs_ctx* c) {
     return STOCS_OK;
 }
 
-static double g_t_inst[6];
+static thread_local double g_t_inst[6];   // STOCS_DEBUG_TIMING accumulators
 static inline double now_s_() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 #define TSEC(k) { const double t_ = now_s_(); g_t_inst[k] += t_ - tprev_; tprev_ = t_; }
 static int sample_instance_one(stocs_ctx* c, uint64_t seed, int attempt, float dispersion, int base_num, int32_t* ids, float* inv, int32_t* valid) {
