@@ -112,217 +112,12 @@ static int upload(T** dptr, const T* h, size_t n) {
     return STOCS_OK;
 }
 
-// ---- scene grid build (host) -------------------------------------------------------------------
-static int build_grid_div(stocs_ctx* c, int div_in) {
-    SceneGrid& g = c->grid;
-    const int nS = c->nS;
-    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
-    { int rc0 = c->grid_mem.reset(); if (rc0) return rc0; }
-    const double eps = (double)c->prm.distance_threshold;
-    // cell edge = epsilon / div: a finer grid gives shorter candidate lists (closer to the epsilon ball)
-    // at the price of more cells and more list copies per point
-    int div = div_in;
-    if (div < 1 || div > 4) div = 1;
-    const double h = eps / div;
-    const double r = eps * 1.001;  // safety margin >> float rounding of the device cell computation
-    double mn[3] = {1e30, 1e30, 1e30}, mx[3] = {-1e30, -1e30, -1e30};
-    for (int i = 0; i < nS; ++i) {
-        const V3 p = c->h_spos[i];
-        const double v[3] = {p.x, p.y, p.z};
-        for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], v[k]); mx[k] = std::max(mx[k], v[k]); }
-    }
-    if (nS == 0) { for (int k = 0; k < 3; ++k) { mn[k] = 0; mx[k] = 0; } }
-    const double pad = r + 2 * h;  // a query outside the grid is farther than epsilon from every point
-    const double o[3] = {mn[0] - pad, mn[1] - pad, mn[2] - pad};
-    int n[3];
-    for (int k = 0; k < 3; ++k) n[k] = (int)floor((mx[k] + pad - o[k]) / h) + 1;
-    g.ox = (float)o[0]; g.oy = (float)o[1]; g.oz = (float)o[2];
-    // the device computes the cell as floor((q - o_f) * inv_h) with the float origin; re-derive the
-    // exact origin the host uses from the float value so both agree
-    const double of[3] = {g.ox, g.oy, g.oz};
-    g.inv_h = (float)(1.0 / h);
-    g.nx = n[0]; g.ny = n[1]; g.nz = n[2];
-    g.nbx = (n[0] + 7) / 8; g.nby = (n[1] + 7) / 8; g.nbz = (n[2] + 7) / 8;
-    const int64_t n_top = (int64_t)g.nbx * g.nby * g.nbz;
-    if (n_top > (int64_t)400 * 1000 * 1000) { set_error("scene extent too large for the brick grid"); return STOCS_ERR_INVALID; }
-
-    // (cell key, point) incidences: cell box [o + c*h, o + (c+1)*h]
-    struct Inc { uint64_t key; int32_t pt; };
-    std::vector<Inc> inc;
-    inc.reserve((size_t)nS * 24);
-    for (int i = 0; i < nS; ++i) {
-        const V3 pf = c->h_spos[i];
-        const double p[3] = {pf.x, pf.y, pf.z};
-        int lo[3], hi[3];
-        for (int k = 0; k < 3; ++k) {
-            lo[k] = std::max(0, (int)floor((p[k] - r - of[k]) / h));
-            hi[k] = std::min(n[k] - 1, (int)floor((p[k] + r - of[k]) / h));
-        }
-        for (int cz = lo[2]; cz <= hi[2]; ++cz)
-            for (int cy = lo[1]; cy <= hi[1]; ++cy)
-                for (int cx = lo[0]; cx <= hi[0]; ++cx) {
-                    const int cc[3] = {cx, cy, cz};
-                    double d2 = 0;
-                    for (int k = 0; k < 3; ++k) {
-                        const double b0 = of[k] + cc[k] * h, b1 = b0 + h;
-                        const double d = p[k] < b0 ? b0 - p[k] : (p[k] > b1 ? p[k] - b1 : 0.0);
-                        d2 += d * d;
-                    }
-                    if (d2 > r * r) continue;
-                    const uint64_t brick = ((uint64_t)(cz >> 3) * g.nby + (uint64_t)(cy >> 3)) * g.nbx + (uint64_t)(cx >> 3);
-                    const uint32_t local = (uint32_t)(((cz & 7) << 6) | ((cy & 7) << 3) | (cx & 7));
-                    Inc e;
-                    e.key = (brick << 9) | local;
-                    e.pt = i;
-                    inc.push_back(e);
-                }
-    }
-    std::sort(inc.begin(), inc.end(), [](const Inc& a, const Inc& b) { return a.key != b.key ? a.key < b.key : a.pt < b.pt; });
-
-    // Lists are padded to multiples of 8 entries (one 128-byte line per 8 candidates) with sentinel
-    // entries far away, so that 8 lanes can scan one query's list with whole-line loads.
-    std::vector<int32_t> top((size_t)n_top, -1);
-    std::vector<uint4> cells;
-    std::vector<float4> list;
-    list.reserve(inc.size() + inc.size() / 2 + 8);
-    float4 sentinel; sentinel.x = sentinel.y = sentinel.z = 1.0e30f;
-    { const int32_t m1 = -1; memcpy(&sentinel.w, &m1, 4); }
-    int n_bricks = 0;
-    std::vector<uint64_t> brick_lin;   // brick id -> linear brick index
-    uint64_t cur_brick = ~0ull, cur_key = ~0ull;
-    for (size_t e = 0; e < inc.size(); ++e) {
-        const uint64_t brick = inc[e].key >> 9;
-        const uint32_t local = (uint32_t)(inc[e].key & 511);
-        if (brick != cur_brick) {
-            cur_brick = brick;
-            top[(size_t)brick] = n_bricks++;
-            brick_lin.push_back(brick);
-            uint4 z; z.x = 0; z.y = 0; z.z = 0; z.w = 0;
-            cells.resize((size_t)n_bricks * 512, z);
-        }
-        if (inc[e].key != cur_key) {
-            cur_key = inc[e].key;
-            while (list.size() % 8) list.push_back(sentinel);
-            cells[(size_t)(n_bricks - 1) * 512 + local].x = (uint32_t)list.size();
-        }
-        if (++cells[(size_t)(n_bricks - 1) * 512 + local].y > 65535u) { set_error("more than 65535 scene points within epsilon of one grid cell"); return STOCS_ERR_INVALID; }
-        const V3 p = c->h_spos[inc[e].pt];
-        float4 v; v.x = p.x; v.y = p.y; v.z = p.z;
-        memcpy(&v.w, &inc[e].pt, 4);
-        list.push_back(v);
-    }
-    while (list.size() % 8) list.push_back(sentinel);
-    if (list.size() >= 0xFFFFFFF0ull) { set_error("scene grid lists too large"); return STOCS_ERR_INVALID; }
-    if (getenv("STOCS_DEBUG_GRID")) {
-        size_t hist[12] = {0}, ncell = 0, tot = 0, mx = 0;
-        for (size_t i = 0; i < cells.size(); ++i) if (cells[i].y) {
-            ncell++; tot += cells[i].y; mx = std::max<size_t>(mx, cells[i].y);
-            int b = 0; while ((1u << b) < cells[i].y && b < 11) b++;
-            hist[b]++;
-        }
-        fprintf(stderr, "[stocs grid] dims %dx%dx%d bricks %d nonempty cells %zu entries %zu (padded %zu) avg %.2f max %zu\n[stocs grid] len<=1,2,4,8,16,32,..:", g.nx, g.ny, g.nz, n_bricks, ncell, tot, list.size(), (double)tot / std::max<size_t>(ncell, 1), mx);
-        for (int b = 0; b < 12; ++b) fprintf(stderr, " %zu", hist[b]);
-        fprintf(stderr, "\n");
-    }
-    // sub-cell masks: a query can only have a neighbour within epsilon if its sub-cell's bit is set.
-    // Only for cell edge = epsilon; finer grids get all-ones masks.
-    if (div == 1) {
-        const double hs = h / 4.0;
-        for (int i = 0; i < nS; ++i) {
-            const V3 pf = c->h_spos[i];
-            const double p[3] = {pf.x, pf.y, pf.z};
-            int lo[3], hi[3];
-            for (int k = 0; k < 3; ++k) {
-                lo[k] = std::max(0, (int)floor((p[k] - r - of[k]) / hs));
-                hi[k] = std::min(4 * n[k] - 1, (int)floor((p[k] + r - of[k]) / hs));
-            }
-            for (int sz = lo[2]; sz <= hi[2]; ++sz) {
-                const double bz0 = of[2] + sz * hs, bz1 = bz0 + hs;
-                const double dz = p[2] < bz0 ? bz0 - p[2] : (p[2] > bz1 ? p[2] - bz1 : 0.0);
-                for (int sy = lo[1]; sy <= hi[1]; ++sy) {
-                    const double by0 = of[1] + sy * hs, by1 = by0 + hs;
-                    const double dy = p[1] < by0 ? by0 - p[1] : (p[1] > by1 ? p[1] - by1 : 0.0);
-                    const double dyz = dy * dy + dz * dz;
-                    if (dyz > r * r) continue;
-                    for (int sx = lo[0]; sx <= hi[0]; ++sx) {
-                        const double bx0 = of[0] + sx * hs, bx1 = bx0 + hs;
-                        const double dx = p[0] < bx0 ? bx0 - p[0] : (p[0] > bx1 ? p[0] - bx1 : 0.0);
-                        if (dx * dx + dyz > r * r) continue;
-                        const int cx = sx >> 2, cy = sy >> 2, cz = sz >> 2;
-                        const int64_t brick = ((int64_t)(cz >> 3) * g.nby + (cy >> 3)) * g.nbx + (cx >> 3);
-                        const int32_t bid = top[(size_t)brick];
-                        if (bid < 0) continue;  // cannot happen: the cell is within r of the point
-                        uint4& cw = cells[(size_t)bid * 512 + (((cz & 7) << 6) | ((cy & 7) << 3) | (cx & 7))];
-                        const int bit = ((sz & 3) << 4) | ((sy & 3) << 2) | (sx & 3);
-                        if (bit < 32) cw.z |= 1u << bit; else cw.w |= 1u << (bit - 32);
-                    }
-                }
-            }
-        }
-    } else {
-        for (size_t i = 0; i < cells.size(); ++i) if (cells[i].y) { cells[i].z = 0xFFFFFFFFu; cells[i].w = 0xFFFFFFFFu; }
-    }
-    {
-        size_t ncell = 0, tot = 0;
-        for (size_t i = 0; i < cells.size(); ++i) if (cells[i].y) { ncell++; tot += cells[i].y; }
-        g.avg_list_len = ncell ? (double)tot / (double)ncell : 0.0;
-    }
-    g.n_bricks = n_bricks;
-    g.n_entries = (int64_t)list.size();
-    g.h = (float)h;
-    g.d_chunk_r = NULL;
-    int rc;
-    // Dense scenes (long lists): order every list by distance from its cell centre and keep, per 8-entry
-    // chunk, a lower bound of that distance.  For a query q of the cell, |q - p| >= |p - c| - |q - c|, so the
-    // scan may stop at the first chunk whose bound exceeds sqrt(best d^2) + |q - c|.
-    if (g.avg_list_len > 16.0) {
-        std::vector<float> chunk_r(list.size() / 8, 0.0f);
-        std::vector<std::pair<double, float4> > tmp;
-        for (int bidx = 0; bidx < n_bricks; ++bidx) {
-            const uint64_t bl = brick_lin[bidx];
-            const int bx = (int)(bl % g.nbx), by = (int)((bl / g.nbx) % g.nby), bz = (int)(bl / ((uint64_t)g.nbx * g.nby));
-            for (int local = 0; local < 512; ++local) {
-                const uint4 cw = cells[(size_t)bidx * 512 + local];
-                if (!cw.y) continue;
-                const int cx = bx * 8 + (local & 7), cy = by * 8 + ((local >> 3) & 7), cz = bz * 8 + (local >> 6);
-                const double ccx = of[0] + (cx + 0.5) * h, ccy = of[1] + (cy + 0.5) * h, ccz = of[2] + (cz + 0.5) * h;
-                tmp.clear();
-                for (uint32_t k = 0; k < cw.y; ++k) {
-                    const float4 e = list[cw.x + k];
-                    const double dx = e.x - ccx, dy = e.y - ccy, dz = e.z - ccz;
-                    tmp.push_back(std::make_pair(sqrt(dx * dx + dy * dy + dz * dz), e));
-                }
-                std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<double, float4>& a, const std::pair<double, float4>& b) { return a.first < b.first; });
-                for (uint32_t k = 0; k < cw.y; ++k) {
-                    list[cw.x + k] = tmp[k].second;
-                    if ((k & 7) == 0) chunk_r[(cw.x + k) >> 3] = (float)(tmp[k].first - 2e-6);
-                }
-            }
-        }
-        if ((rc = c->grid_mem.take(std::max<size_t>(chunk_r.size(), 1) * sizeof(float), (void**)&g.d_chunk_r))) return rc;
-        STOCS_HIP_CHECK(hipMemcpy(g.d_chunk_r, chunk_r.data(), chunk_r.size() * sizeof(float), hipMemcpyHostToDevice));
-    }
-    if ((rc = c->grid_mem.take(std::max<size_t>(top.size(), 1) * 4, (void**)&g.d_top)) ||
-        (rc = c->grid_mem.take(std::max<size_t>(cells.size(), 1) * sizeof(uint4), (void**)&g.d_cells)) ||
-        (rc = c->grid_mem.take(std::max<size_t>(list.size(), 8) * sizeof(float4), (void**)&g.d_list)))
-        return rc;
-    STOCS_HIP_CHECK(hipMemcpy(g.d_top, top.data(), top.size() * 4, hipMemcpyHostToDevice));
-    STOCS_HIP_CHECK(hipMemcpy(g.d_cells, cells.data(), cells.size() * sizeof(uint4), hipMemcpyHostToDevice));
-    STOCS_HIP_CHECK(hipMemcpy(g.d_list, list.data(), list.size() * sizeof(float4), hipMemcpyHostToDevice));
-    return STOCS_OK;
-}
-
-// Cell edge = epsilon unless the scene is so dense that the candidate lists get long (C5: 200k points,
-// 1.6 mm spacing -> 61 candidates per list): then epsilon/2 (39 per list) and, if the lists are still long,
-// epsilon/4 -- every halving multiplies the list memory by ~4 and the cell count by 8, and pays as long as
-// the centre-sorted early exit still has chunks to skip (C5: 50.5 -> 16.5 -> 13.2 ms).  STOCS_GRID_DIV overrides.
 static void free_grid(stocs_ctx* c) {   // the grid lives in c->grid_mem, which the next build resets
     c->grid.d_top = NULL; c->grid.d_cells = NULL; c->grid.d_list = NULL; c->grid.d_chunk_r = NULL;
 }
 
 // one build at cell edge eps / div; lists longer than 16 on average get the centre-sorted layout + chunk bounds
 static int build_grid_once(stocs_ctx* c, int div) {
-    if (getenv("STOCS_GRID_HOST")) return build_grid_div(c, div);   // the host build, kept for A/B parity tests
     int rc = build_grid_gpu(c, div, 0);
     if (rc || c->grid.avg_list_len <= 16.0) return rc;
     free_grid(c);

@@ -165,26 +165,3 @@ def test_dense_scene_and_all_scan_variants(oracle_lib):
         assert same.mean() > 0.999, v                  # only exact-distance ties may differ (Q11)
         assert np.array_equal(cg[same], co[same]), v
     est.set_option("lcp_variant", 99)
-
-
-@pytest.mark.parametrize("name", ["small", "dense"])
-def test_gpu_built_grid_equals_host_built_grid(name, monkeypatch):
-    """The scene grid is built on the GPU (grid.hip); the host build it replaced is kept behind STOCS_GRID_HOST for
-    exactly this check: same nearest neighbour for every (candidate, model point), same scores bit for bit."""
-    from model_matching_amd import synth
-    from model_matching_amd.estimator import StocsEstimator
-    m, s, k = synth.workload(name)
-    args = (s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm)
-    est_gpu = StocsEstimator(*args, build_index=False)
-    monkeypatch.setenv("STOCS_GRID_HOST", "1")
-    est_host = StocsEstimator(*args, build_index=False)
-    monkeypatch.delenv("STOCS_GRID_HOST")
-    cs, cm = est_gpu.get_scene_centroid().astype(np.float64), est_gpu.get_model_centroid().astype(np.float64)
-    T = synth.make_candidates(synth.centred_gt(s.T_gt, cs, cm), 512)
-    a, b = est_gpu.score_transforms(T), est_host.score_transforms(T)
-    assert np.array_equal(a, b)
-    for t in T[:6]:
-        ha, ca = est_gpu.lcp_detail(t)
-        hb, cb = est_host.lcp_detail(t)
-        assert np.array_equal(ha, hb) and np.array_equal(ca, cb)
-    est_gpu.close(); est_host.close()
