@@ -167,42 +167,10 @@ __global__ __launch_bounds__(1024) void draw_kernel(const float* __restrict__ w,
     }
 }
 
-// Instance mode runs its attempts one after the other (the class prior decays between them), so launch count is
-// what matters: ONE workgroup does "draw point 1, pass 1" (FIRST) or "draw 2, pass 2, draw 3, pass 3, draw 4" in
-// a single launch.  hdr = {bidx[4], fail} directly behind the weights, so one copy moves weights + result.
-template <bool FIRST>
-__global__ __launch_bounds__(1024) void instance_steps_kernel(PassArgs a, uint64_t seed, uint64_t attempt, float* __restrict__ w, int32_t* __restrict__ bidx,
-                                                              int32_t* __restrict__ fail) {
-    __shared__ uint64_t sh[1024];
-    __shared__ uint64_t sh_total;
-    __shared__ int sh_pick;
-    const int t = threadIdx.x;
-    int b1, b2 = -1, b3 = -1;
-    if (FIRST) {
-        b1 = draw_block(w, a.S, rng64(seed, attempt, 0), sh, &sh_total, &sh_pick);
-        if (t == 0) { bidx[0] = b1; bidx[1] = bidx[2] = bidx[3] = -1; fail[0] = b1 < 0 ? 1 : 0; }
-        if (b1 < 0) return;
-        for (int i = t; i < a.S; i += 1024) if (pass_zeroes<1>(a, b1, -1, -1, i)) w[i] = 0.0f;
-        return;
-    }
-    b1 = bidx[0];
-    __syncthreads();
-    b2 = draw_block(w, a.S, rng64(seed, attempt, 1), sh, &sh_total, &sh_pick);
-    if (b2 < 0) { if (t == 0) { bidx[1] = -1; fail[0] = 1; } return; }
-    for (int i = t; i < a.S; i += 1024) if (pass_zeroes<2>(a, b1, b2, -1, i)) w[i] = 0.0f;
-    __syncthreads();
-    b3 = draw_block(w, a.S, rng64(seed, attempt, 2), sh, &sh_total, &sh_pick);
-    if (b3 < 0) { if (t == 0) { bidx[1] = b2; bidx[2] = -1; fail[0] = 1; } return; }
-    for (int i = t; i < a.S; i += 1024) if (pass_zeroes<3>(a, b1, b2, b3, i)) w[i] = 0.0f;
-    __syncthreads();
-    const int b4 = draw_block(w, a.S, rng64(seed, attempt, 3), sh, &sh_total, &sh_pick);
-    if (t == 0) { bidx[1] = b2; bidx[2] = b3; bidx[3] = b4; if (b4 < 0) fail[0] = 1; }
-}
-
 // ---- host helpers ------------------------------------------------------------------------------
 
 // stocs.cpp:155-222 with VectorType = float vector, Scalar = double (deduced at the call :237-244)
-static double seg_dist_inv(V3 p1, V3 p2, V3 q1, V3 q2, double& invariant1, double& invariant2) {
+__host__ __device__ static double seg_dist_inv(V3 p1, V3 p2, V3 q1, V3 q2, double& invariant1, double& invariant2) {
     const double kSmallNumber = 0.0001;
     const V3 u = p2 - p1, v = q2 - q1, w = p1 - q1;
     const double a = dot3(u, u), b = dot3(u, v), c = dot3(v, v), d = dot3(u, w), e = dot3(v, w);
@@ -234,8 +202,8 @@ static double seg_dist_inv(V3 p1, V3 p2, V3 q1, V3 q2, double& invariant1, doubl
 }
 
 // stocs.cpp:224-268
-static bool try_sampled_base(const V3 base[4], float& invariant1, float& invariant2, int ids[4]) {
-    float min_distance = std::numeric_limits<float>::max();
+__host__ __device__ static bool try_sampled_base(const V3 base[4], float& invariant1, float& invariant2, int ids[4]) {
+    float min_distance = 3.402823466e+38f;   // std::numeric_limits<float>::max()
     int best1 = -1, best2 = -1, best3 = -1, best4 = -1;
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) {
@@ -259,7 +227,70 @@ static bool try_sampled_base(const V3 base[4], float& invariant1, float& invaria
     return true;
 }
 
+// rows 6-7 on the device: ordered base + invariants of one attempt (try_sampled_base, stocs.cpp:224-268)
+struct BaseOut { int32_t ids[4]; float inv[2]; int32_t valid; int32_t pad; };
+
+__device__ __forceinline__ void finalize_one(const float4* __restrict__ spos, const int32_t* bidx4, int fail, BaseOut* o) {
+    int ids[4] = {bidx4[0], bidx4[1], bidx4[2], bidx4[3]};
+    float i1 = 0, i2 = 0;
+    bool ok = !fail && ids[0] >= 0 && ids[1] >= 0 && ids[2] >= 0 && ids[3] >= 0;
+    if (ok) {
+        V3 base[4];
+        for (int k = 0; k < 4; ++k) { const float4 p = spos[ids[k]]; base[k] = mk3(p.x, p.y, p.z); }
+        ok = try_sampled_base(base, i1, i2, ids);
+    }
+    for (int k = 0; k < 4; ++k) o->ids[k] = ids[k];
+    o->inv[0] = i1; o->inv[1] = i2;
+    o->valid = ok ? 1 : 0;
+    o->pad = 0;
+}
+
+__global__ __launch_bounds__(64) void finalize_bases_kernel(const float4* __restrict__ spos, const int32_t* __restrict__ bidx,
+                                                            const int32_t* __restrict__ fail, int nB, BaseOut* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nB) finalize_one(spos, bidx + 4 * b, fail[b], out + b);
+}
+
+// Instance mode runs its attempts one after the other (the class prior decays between them), so launch count is
+// what matters: ONE workgroup does "draw point 1, pass 1" (FIRST) or "draw 2, pass 2, draw 3, pass 3, draw 4" in
+// a single launch.  hdr = {bidx[4], fail} directly behind the weights, so one copy moves weights + result.
+template <bool FIRST>
+__global__ __launch_bounds__(1024) void instance_steps_kernel(PassArgs a, uint64_t seed, uint64_t attempt, float* __restrict__ w, int32_t* __restrict__ bidx,
+                                                              int32_t* __restrict__ fail, BaseOut* __restrict__ res) {
+    __shared__ uint64_t sh[1024];
+    __shared__ uint64_t sh_total;
+    __shared__ int sh_pick;
+    const int t = threadIdx.x;
+    int b1, b2 = -1, b3 = -1;
+    if (FIRST) {
+        b1 = draw_block(w, a.S, rng64(seed, attempt, 0), sh, &sh_total, &sh_pick);
+        if (t == 0) { bidx[0] = b1; bidx[1] = bidx[2] = bidx[3] = -1; fail[0] = b1 < 0 ? 1 : 0; }
+        if (b1 < 0) return;
+        for (int i = t; i < a.S; i += 1024) if (pass_zeroes<1>(a, b1, -1, -1, i)) w[i] = 0.0f;
+        return;
+    }
+    b1 = bidx[0];
+    __syncthreads();
+    bool go = true;
+    b2 = draw_block(w, a.S, rng64(seed, attempt, 1), sh, &sh_total, &sh_pick);
+    if (b2 < 0) { if (t == 0) { bidx[1] = -1; fail[0] = 1; } go = false; }
+    if (go) {
+        for (int i = t; i < a.S; i += 1024) if (pass_zeroes<2>(a, b1, b2, -1, i)) w[i] = 0.0f;
+        __syncthreads();
+        b3 = draw_block(w, a.S, rng64(seed, attempt, 2), sh, &sh_total, &sh_pick);
+        if (b3 < 0) { if (t == 0) { bidx[1] = b2; bidx[2] = -1; fail[0] = 1; } go = false; }
+    }
+    if (go) {
+        for (int i = t; i < a.S; i += 1024) if (pass_zeroes<3>(a, b1, b2, b3, i)) w[i] = 0.0f;
+        __syncthreads();
+        const int b4 = draw_block(w, a.S, rng64(seed, attempt, 3), sh, &sh_total, &sh_pick);
+        if (t == 0) { bidx[1] = b2; bidx[2] = b3; bidx[3] = b4; if (b4 < 0) fail[0] = 1; }
+    }
+    if (t == 0) finalize_one(a.spos, bidx, fail[0], res);   // thread 0 reads back its own writes
+}
+
 struct SampleBuffers {
+    BaseOut* res;    // nB
     float* w;        // nB * S
     float* cls;      // S (class probabilities)
     int32_t* bidx;   // nB * 4
@@ -270,15 +301,17 @@ struct SampleBuffers {
 static int carve(stocs_ctx* c, int nB, SampleBuffers* sb) {
     const size_t S = (size_t)std::max(c->nS, 1);
     auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-    const size_t bw = al((size_t)nB * S * 4), bc = al(S * 4), bi = al((size_t)nB * 16), bf = al((size_t)nB * 4), br = al((size_t)nB * 8);
-    int rc = ensure_scratch(c, bw + bc + bi + bf + br);
+    const size_t bw = al((size_t)nB * S * 4), bc = al(S * 4), bi = al((size_t)nB * 16), bf = al((size_t)nB * 4), br = al((size_t)nB * 8),
+                 bo = al((size_t)nB * sizeof(BaseOut));
+    int rc = ensure_scratch(c, bw + bc + bi + bf + br + bo);
     if (rc) return rc;
     char* p = (char*)c->d_scratch;
     sb->w = (float*)p; p += bw;          // weights, then bidx, then fail: one copy moves all three when nB == 1
     sb->bidx = (int32_t*)p; p += bi;
     sb->fail = (int32_t*)p; p += bf;
     sb->cls = (float*)p; p += bc;
-    sb->rexp = (uint64_t*)p;
+    sb->rexp = (uint64_t*)p; p += br;
+    sb->res = (BaseOut*)p;
     return STOCS_OK;
 }
 
@@ -304,23 +337,16 @@ static void launch_draw(stocs_ctx* c, int nB, const SampleBuffers& sb, uint64_t 
                        (uint64_t)k, (const uint64_t*)NULL, k, sb.bidx, sb.fail);
 }
 
-static int finalize_bases(stocs_ctx* c, int nB, const std::vector<int32_t>& bidx, const std::vector<int32_t>& fail, int32_t* ids_out,
-                          float* inv_out, int32_t* valid_out) {
+// host bookkeeping of the attempts the device has finalised (finalize_one): outputs + the context's base set
+static int record_bases(stocs_ctx* c, int nB, const BaseOut* res, int32_t* ids_out, float* inv_out, int32_t* valid_out) {
     for (int b = 0; b < nB; ++b) {
-        int ids[4] = {bidx[b * 4], bidx[b * 4 + 1], bidx[b * 4 + 2], bidx[b * 4 + 3]};
-        float i1 = 0, i2 = 0;
-        bool ok = !fail[b] && ids[0] >= 0 && ids[1] >= 0 && ids[2] >= 0 && ids[3] >= 0;
-        if (ok) {
-            const V3 base[4] = {c->h_spos[ids[0]], c->h_spos[ids[1]], c->h_spos[ids[2]], c->h_spos[ids[3]]};
-            ok = try_sampled_base(base, i1, i2, ids);
-        }
-        if (ids_out) for (int k = 0; k < 4; ++k) ids_out[b * 4 + k] = ids[k];
-        if (inv_out) { inv_out[b * 2] = i1; inv_out[b * 2 + 1] = i2; }
-        if (valid_out) valid_out[b] = ok ? 1 : 0;
-        if (ok) {
+        if (ids_out) for (int k = 0; k < 4; ++k) ids_out[b * 4 + k] = res[b].ids[k];
+        if (inv_out) { inv_out[b * 2] = res[b].inv[0]; inv_out[b * 2 + 1] = res[b].inv[1]; }
+        if (valid_out) valid_out[b] = res[b].valid;
+        if (res[b].valid) {
             BaseRec r;
-            for (int k = 0; k < 4; ++k) r.ids[k] = ids[k];
-            r.inv1 = i1; r.inv2 = i2;
+            for (int k = 0; k < 4; ++k) r.ids[k] = res[b].ids[k];
+            r.inv1 = res[b].inv[0]; r.inv2 = res[b].inv[1];
             c->bases.push_back(r);
         }
     }
@@ -346,11 +372,12 @@ static int sample_class(stocs_ctx* c, uint64_t seed, int first_attempt, int nB, 
         if (k < 3) launch_pass(c, k + 1, nB, sb);
     }
     STOCS_HIP_CHECK(hipGetLastError());
-    std::vector<int32_t> bidx((size_t)nB * 4), fail(nB);
-    STOCS_HIP_CHECK(hipMemcpyAsync(bidx.data(), sb.bidx, (size_t)nB * 16, hipMemcpyDeviceToHost, c->stream));
-    STOCS_HIP_CHECK(hipMemcpyAsync(fail.data(), sb.fail, (size_t)nB * 4, hipMemcpyDeviceToHost, c->stream));
+    hipLaunchKernelGGL(finalize_bases_kernel, dim3((unsigned)((nB + 63) / 64)), dim3(64), 0, c->stream, c->d_spos, sb.bidx, sb.fail, nB, sb.res);
+    STOCS_HIP_CHECK(hipGetLastError());
+    std::vector<BaseOut> res((size_t)nB);
+    STOCS_HIP_CHECK(hipMemcpyAsync(res.data(), sb.res, (size_t)nB * sizeof(BaseOut), hipMemcpyDeviceToHost, c->stream));
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
-    return finalize_bases(c, nB, bidx, fail, ids, inv, valid);
+    return record_bases(c, nB, res.data(), ids, inv, valid);
 }
 
 // rgbd.cpp:314-367 with the PNG round trip through dbg/seg_mask_<n>.png replaced by seg_masks (Q14)
@@ -419,7 +446,7 @@ static int sample_instance_one(stocs_ctx* c, uint64_t seed, int attempt, float d
     const size_t span = (size_t)((char*)sb.fail - (char*)sb.w) + 4;   // w .. fail, contiguous (carve)
     std::vector<char> stage(span);
     STOCS_HIP_CHECK(hipMemcpyAsync(sb.w, w.data(), (size_t)S * 4, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(instance_steps_kernel<true>, dim3(1), dim3(1024), 0, c->stream, pa, seed, (uint64_t)attempt, sb.w, sb.bidx, sb.fail);
+    hipLaunchKernelGGL(instance_steps_kernel<true>, dim3(1), dim3(1024), 0, c->stream, pa, seed, (uint64_t)attempt, sb.w, sb.bidx, sb.fail, sb.res);
     STOCS_HIP_CHECK(hipGetLastError());
     STOCS_HIP_CHECK(hipMemcpyAsync(stage.data(), sb.w, span, hipMemcpyDeviceToHost, c->stream));
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -428,8 +455,10 @@ static int sample_instance_one(stocs_ctx* c, uint64_t seed, int attempt, float d
     memcpy(bidx, stage.data() + ((char*)sb.bidx - (char*)sb.w), 16);
     memcpy(&fail, stage.data() + ((char*)sb.fail - (char*)sb.w), 4);
     TSEC(1)
-    std::vector<int32_t> vb(4, -1), vf(1, 1);
-    if (fail || bidx[0] < 0) return finalize_bases(c, 1, vb, vf, ids, inv, valid);
+    BaseOut res;
+    memset(&res, 0, sizeof(res));
+    res.ids[0] = res.ids[1] = res.ids[2] = res.ids[3] = -1;   // "FAILED SAMPLING": no base, nothing to compute
+    if (fail || bidx[0] < 0) return record_bases(c, 1, &res, ids, inv, valid);
     const int b1 = bidx[0];
     float max_pixel_distance = 0;  // stocs.cpp:610-618
     for (int i = 0; i < S; ++i)
@@ -449,15 +478,12 @@ static int sample_instance_one(stocs_ctx* c, uint64_t seed, int attempt, float d
     TSEC(4)
     // round trip 2: filtered weights up, "draw 2, pass 2, draw 3, pass 3, draw 4" in one launch, (bidx, fail) back
     STOCS_HIP_CHECK(hipMemcpyAsync(sb.w, w.data(), (size_t)S * 4, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(instance_steps_kernel<false>, dim3(1), dim3(1024), 0, c->stream, pa, seed, (uint64_t)attempt, sb.w, sb.bidx, sb.fail);
+    hipLaunchKernelGGL(instance_steps_kernel<false>, dim3(1), dim3(1024), 0, c->stream, pa, seed, (uint64_t)attempt, sb.w, sb.bidx, sb.fail, sb.res);
     STOCS_HIP_CHECK(hipGetLastError());
-    const size_t tail = (size_t)((char*)sb.fail - (char*)sb.bidx) + 4;
-    STOCS_HIP_CHECK(hipMemcpyAsync(stage.data(), sb.bidx, tail, hipMemcpyDeviceToHost, c->stream));
+    STOCS_HIP_CHECK(hipMemcpyAsync(&res, sb.res, sizeof(res), hipMemcpyDeviceToHost, c->stream));   // ordered base + invariants, finalised on the device
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
-    memcpy(vb.data(), stage.data(), 16);
-    memcpy(vf.data(), stage.data() + ((char*)sb.fail - (char*)sb.bidx), 4);
     TSEC(5)
-    return finalize_bases(c, 1, vb, vf, ids, inv, valid);
+    return record_bases(c, 1, &res, ids, inv, valid);
 }
 
 }  // namespace stocs
@@ -546,12 +572,19 @@ int stocs_try_sampled_base(stocs_ctx* c, int32_t* ids4, float* inv2, int* valid)
     if (!c || !ids4 || !inv2 || !valid) return STOCS_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
     for (int k = 0; k < 4; ++k) if (ids4[k] < 0 || ids4[k] >= c->nS) return STOCS_ERR_INVALID;
-    int ids[4] = {ids4[0], ids4[1], ids4[2], ids4[3]};
-    const V3 base[4] = {c->h_spos[ids[0]], c->h_spos[ids[1]], c->h_spos[ids[2]], c->h_spos[ids[3]]};
-    float i1 = 0, i2 = 0;
-    *valid = try_sampled_base(base, i1, i2, ids) ? 1 : 0;
-    for (int k = 0; k < 4; ++k) ids4[k] = ids[k];
-    inv2[0] = i1; inv2[1] = i2;
+    SampleBuffers sb;
+    int rc = carve(c, 1, &sb);
+    if (rc) return rc;
+    STOCS_HIP_CHECK(hipMemcpyAsync(sb.bidx, ids4, 16, hipMemcpyHostToDevice, c->stream));
+    STOCS_HIP_CHECK(hipMemsetAsync(sb.fail, 0, 4, c->stream));
+    hipLaunchKernelGGL(finalize_bases_kernel, dim3(1), dim3(64), 0, c->stream, c->d_spos, sb.bidx, sb.fail, 1, sb.res);
+    STOCS_HIP_CHECK(hipGetLastError());
+    BaseOut res;
+    STOCS_HIP_CHECK(hipMemcpyAsync(&res, sb.res, sizeof(res), hipMemcpyDeviceToHost, c->stream));
+    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *valid = res.valid;
+    for (int k = 0; k < 4; ++k) ids4[k] = res.ids[k];
+    inv2[0] = res.inv[0]; inv2[1] = res.inv[1];
     return STOCS_OK;
 }
 
