@@ -253,7 +253,7 @@ __device__ __forceinline__ unsigned long long join_one(const JoinArgs& A, uint32
 
 // (base, position cell) of every Q pair: the count pass walks the Q pairs in this order, so that the lanes of a
 // wavefront share one P run (same loop length, broadcast loads) instead of 64 unrelated ones
-__global__ __launch_bounds__(256) void qcell_kernel(JoinArgs A, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+__global__ __launch_bounds__(256) void qcell_kernel(JoinArgs A, int pc_bits, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= A.totQ) return;
     const int b = find_base(A.q_off, A.nB, e);
@@ -261,7 +261,9 @@ __global__ __launch_bounds__(256) void qcell_kernel(JoinArgs A, uint64_t* __rest
     const uint32_t qr = (uint32_t)A.Q[e];
     const V3 p1 = ld3c(A.munit, qr >> 16), p2 = ld3c(A.munit, qr & 0xFFFF);
     const int64_t pc = index_pos(p1 + J.inv2 * (p2 - p1), J.cell, J.egSize);
-    keys[e] = ((uint64_t)b << 32) | (uint64_t)((pc < 0 || pc >= ((int64_t)1 << 31)) ? 0xFFFFFFFFu : (uint32_t)pc);
+    // compact key (base, cell): only the bits that can be set are sorted; an unusable cell sorts behind the base's real ones
+    const uint64_t inval = ((uint64_t)1 << pc_bits) - 1ull;
+    keys[e] = ((uint64_t)b << pc_bits) | ((pc < 0 || (uint64_t)pc >= inval) ? inval : (uint64_t)pc);
     vals[e] = e;
 }
 
@@ -660,13 +662,16 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     {   // walk order of the count pass: Q pairs by (base, position cell)
         DevBuf<uint64_t> d_qk, d_qk_s; DevBuf<uint32_t> d_qv;
         if ((rc = d_qk.alloc(totQ)) || (rc = d_qk_s.alloc(totQ)) || (rc = d_qv.alloc(totQ)) || (rc = d_qperm.alloc(totQ))) return rc;
-        hipLaunchKernelGGL(qcell_kernel, dim3((unsigned)((totQ + 255) / 256)), dim3(256), 0, st, S->args(c), d_qk.p, d_qv.p);
+        int pc_bits = 1;   // cells of the table path are < NC; without the table any cell below 2^31 may occur
+        const long long pc_lim = use_table ? NC + 1 : ((long long)1 << 31) + 1;
+        while (((long long)1 << pc_bits) < pc_lim + 1) pc_bits++;
+        hipLaunchKernelGGL(qcell_kernel, dim3((unsigned)((totQ + 255) / 256)), dim3(256), 0, st, S->args(c), pc_bits, d_qk.p, d_qv.p);
         STOCS_HIP_CHECK(hipGetLastError());
         size_t tq = 0;
-        STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tq, d_qk.p, d_qk_s.p, d_qv.p, d_qperm.p, (size_t)totQ, 0, 32 + base_bits, st));
+        STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tq, d_qk.p, d_qk_s.p, d_qv.p, d_qperm.p, (size_t)totQ, 0, pc_bits + base_bits, st));
         DevBuf<char> d_tq;
         if ((rc = d_tq.alloc(tq))) return rc;
-        STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_tq.p, tq, d_qk.p, d_qk_s.p, d_qv.p, d_qperm.p, (size_t)totQ, 0, 32 + base_bits, st));
+        STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_tq.p, tq, d_qk.p, d_qk_s.p, d_qv.p, d_qperm.p, (size_t)totQ, 0, pc_bits + base_bits, st));
     }
     hipLaunchKernelGGL(join_count_kernel, dim3((unsigned)((totQ + 255) / 256)), dim3(256), 0, st, S->args(c), d_qperm.p, d_qcnt.p);
     STOCS_HIP_CHECK(hipGetLastError());
