@@ -115,6 +115,39 @@ __global__ __launch_bounds__(256) void pkey_kernel(const BaseJob* __restrict__ j
     keys[e] = key;
 }
 
+// One-sort form of the two steps above when (base, cell, pair) fits 64 bits: the merged key orders a base's P
+// entries by cell and, inside a cell, by the list order (lexicographic pair) -- what the list-order sort followed
+// by the stable cell sort produces, in 8 instead of 11 radix passes and without a value array.
+__global__ __launch_bounds__(256) void pkey_merged_kernel(const BaseJob* __restrict__ jobs, const float4* __restrict__ munit,
+                                                          const uint64_t* __restrict__ P, uint32_t totalP, float nepsilon, int cell_bits, int id_bits,
+                                                          uint64_t* __restrict__ keys) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= totalP) return;
+    const uint64_t g = P[e];
+    const uint32_t b = (uint32_t)(g >> 32), pr = (uint32_t)g;
+    const BaseJob& J = jobs[b];
+    const uint32_t ia = pr >> 16, ib = pr & 0xFFFF;
+    const V3 p1 = ld3c(munit, ia), p2 = ld3c(munit, ib);
+    const V3 n = normalized3(p2 - p1);
+    const V3 pos = p1 + J.inv1 * (p2 - p1);
+    const int64_t pc = index_pos(pos, J.cell, J.egSize);
+    const int nc = index_normal(n, nepsilon);
+    const uint64_t cmask = ((uint64_t)1 << cell_bits) - 1ull;
+    uint64_t cell = cmask;   // unreachable by queries
+    if (!(nc < 0 || nc >= 343 || pc < 0 || pc >= ((int64_t)1 << 31))) { cell = (uint64_t)pc * 343ull + (uint64_t)nc; if (cell >= cmask) cell = cmask; }
+    keys[e] = ((uint64_t)b << (cell_bits + 2 * id_bits)) | (cell << (2 * id_bits)) | ((uint64_t)ia << id_bits) | (uint64_t)ib;
+}
+__global__ __launch_bounds__(256) void punpack_kernel(const uint64_t* __restrict__ mk, uint32_t totalP, int cell_bits, int id_bits,
+                                                      uint64_t* __restrict__ keys, uint32_t* __restrict__ P32) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= totalP) return;
+    const uint64_t k = mk[e];
+    const uint64_t cmask = ((uint64_t)1 << cell_bits) - 1ull, imask = ((uint64_t)1 << id_bits) - 1ull;
+    const uint64_t b = k >> (cell_bits + 2 * id_bits), cell = (k >> (2 * id_bits)) & cmask;
+    keys[e] = (b << 40) | (cell == cmask ? 0xFFFFFFFFFFull : cell);
+    P32[e] = (uint32_t)((((k >> id_bits) & imask) << 16) | (k & imask));
+}
+
 // After the sort: direction cell of every P entry, and for every (base, position cell) the run of its
 // P entries.  Replaces the pointer grid _grid[pId] -> AngularGrid of normalset.h:87-88.
 __global__ __launch_bounds__(256) void cell_ranges_kernel(const uint64_t* __restrict__ keys, uint32_t totalP, const uint32_t* __restrict__ p_off,
@@ -142,6 +175,7 @@ __global__ __launch_bounds__(256) void cell_ranges_kernel(const uint64_t* __rest
     if (!first) { const uint64_t pk = keys[e - 1]; const uint64_t pkk = pk & 0xFFFFFFFFFFull; first = (pk - (pkk - (pkk / 343ull) * 343ull)) != grp || pkk == 0xFFFFFFFFFFull; }
     bool last = (e + 1 == p_off[b + 1]);
     if (!last) { const uint64_t nk = keys[e + 1]; const uint64_t nkk = nk & 0xFFFFFFFFFFull; last = nkk == 0xFFFFFFFFFFull || (nk - (nkk - (nkk / 343ull) * 343ull)) != grp; }
+    if ((long long)pc >= NC) return;   // outside the table (cannot happen for points of the unit cube): never queried
     if (first) cfirst[(long long)b * NC + (long long)pc] = e;
     if (last) cend[(long long)b * NC + (long long)pc] = e + 1;
 }
@@ -623,24 +657,42 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, ix.d_pairs, d_psegs.p, (int)psegs.size(), (uint32_t)totP, d_Pg.p);
     hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((totQ + 255) / 256)), dim3(256), 0, st, ix.d_pairs, d_qsegs.p, (int)qsegs.size(), (uint32_t)totQ, d_Qg.p);
     STOCS_HIP_CHECK(hipGetLastError());
+    // direction cells + per-(base, position cell) runs
+    const long long NC = (long long)egSize * egSize * egSize;
+    const bool use_table = NC > 0 && NC * (long long)nB <= (long long)32 * 1024 * 1024;
+    int id_bits = 1;
+    while ((1 << id_bits) < c->nM) id_bits++;
     // each base's P and Q list into the reference's list order (lexicographic pairs); bases stay contiguous
+    int cell_bits = 1;   // valid P cells of the table path are < NC * 343 (a P entry outside the table is never looked at)
+    {
+        const unsigned long long cell_lim = use_table ? (unsigned long long)NC * 343ull : (((unsigned long long)1 << 31) * 343ull);
+        while (cell_bits < 41 && ((unsigned long long)1 << cell_bits) < cell_lim + 2ull) cell_bits++;
+    }
+    const bool merged = base_bits + cell_bits + 2 * id_bits <= 64 && cell_bits <= 40 && !getenv("STOCS_P_TWO_SORTS");   // env: keeps the general path testable
     size_t tmp_bytes = 0, tb2 = 0, tb3 = 0;
-    STOCS_HIP_CHECK(rocprim::radix_sort_keys(NULL, tmp_bytes, d_Pg.p, d_Pl.p, (size_t)totP, 0, 32 + base_bits, st));
+    STOCS_HIP_CHECK(rocprim::radix_sort_keys(NULL, tmp_bytes, d_Pg.p, d_Pl.p, (size_t)totP, 0, 64, st));
     STOCS_HIP_CHECK(rocprim::radix_sort_keys(NULL, tb2, d_Qg.p, S->d_Q.p, (size_t)totQ, 0, 32 + base_bits, st));
     STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb3, d_keys.p, S->d_keys_s.p, d_P32.p, S->d_Ps.p, (size_t)totP, 0, 40 + base_bits, st));
     tmp_bytes = std::max(tmp_bytes, std::max(tb2, tb3));
     if ((rc = d_tmp.alloc(tmp_bytes))) return rc;
-    STOCS_HIP_CHECK(rocprim::radix_sort_keys(d_tmp.p, tmp_bytes, d_Pg.p, d_Pl.p, (size_t)totP, 0, 32 + base_bits, st));
     STOCS_HIP_CHECK(rocprim::radix_sort_keys(d_tmp.p, tmp_bytes, d_Qg.p, S->d_Q.p, (size_t)totQ, 0, 32 + base_bits, st));
-    // (base, position cell, direction cell) keys; the stable sort keeps the list order inside a cell
-    hipLaunchKernelGGL(pkey_kernel, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, S->d_jobs.p, d_poff.p, nB, c->d_munit, d_Pl.p, (uint32_t)totP, nepsilon,
-                       d_keys.p, d_P32.p);
+    if (merged) {
+        hipLaunchKernelGGL(pkey_merged_kernel, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, S->d_jobs.p, c->d_munit, d_Pg.p, (uint32_t)totP, nepsilon,
+                           cell_bits, id_bits, d_keys.p);
+        STOCS_HIP_CHECK(hipGetLastError());
+        STOCS_HIP_CHECK(rocprim::radix_sort_keys(d_tmp.p, tmp_bytes, d_keys.p, d_Pl.p, (size_t)totP, 0, (unsigned)(base_bits + cell_bits + 2 * id_bits), st));
+        hipLaunchKernelGGL(punpack_kernel, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, d_Pl.p, (uint32_t)totP, cell_bits, id_bits, S->d_keys_s.p,
+                           S->d_Ps.p);
+    } else {
+        STOCS_HIP_CHECK(rocprim::radix_sort_keys(d_tmp.p, tmp_bytes, d_Pg.p, d_Pl.p, (size_t)totP, 0, 32 + base_bits, st));
+        // (base, position cell, direction cell) keys; the stable sort keeps the list order inside a cell
+        hipLaunchKernelGGL(pkey_kernel, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, S->d_jobs.p, d_poff.p, nB, c->d_munit, d_Pl.p, (uint32_t)totP,
+                           nepsilon, d_keys.p, d_P32.p);
+        STOCS_HIP_CHECK(hipGetLastError());
+        STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_keys.p, S->d_keys_s.p, d_P32.p, S->d_Ps.p, (size_t)totP, 0, 40 + base_bits, st));
+    }
     STOCS_HIP_CHECK(hipGetLastError());
-    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_keys.p, S->d_keys_s.p, d_P32.p, S->d_Ps.p, (size_t)totP, 0, 40 + base_bits, st));
 
-    // direction cells + per-(base, position cell) runs
-    const long long NC = (long long)egSize * egSize * egSize;
-    const bool use_table = NC > 0 && NC * (long long)nB <= (long long)32 * 1024 * 1024;
     S->NC = NC; S->use_table = use_table;
     if ((rc = S->d_pdir.alloc(totP)) || (rc = S->d_pinv.alloc(totP))) return rc;
     if (use_table) {
@@ -652,8 +704,6 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     STOCS_HIP_CHECK(hipGetLastError());
     STOCS_TICK("gather+keys+sort")
     // ---- 4. join: count pass + exclusive scan.  The quads themselves are produced on demand (materialise / resolve_picks_kernel) ----
-    int id_bits = 1;
-    while ((1 << id_bits) < c->nM) id_bits++;
     if (4 * id_bits + base_bits > 64) { set_error("|M| = %d with %d bases does not fit the 64-bit quad key", c->nM, nB); return STOCS_ERR_CAPACITY; }
     S->id_bits = id_bits; S->base_bits = base_bits;
     DevBuf<unsigned long long> d_qcnt;   // 64-bit: the total can exceed 2^32

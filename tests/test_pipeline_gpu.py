@@ -143,6 +143,26 @@ def test_congruent_sets_and_transforms_equal_oracle(setup):
     assert okg == oko == False
 
 
+def test_two_sort_path_of_the_p_entries(setup, monkeypatch):
+    """Big position grids do not fit the one-sort key of the P entries; the general path (list-order sort, then a
+    stable cell sort) must give the same quads in the same orders."""
+    m, s, est, orc = setup
+    monkeypatch.setenv("STOCS_P_TWO_SORTS", "1")
+    est.L.stocs_clear_bases(est.h)
+    valid, ids, inv = est.sample_bases(99, 24)
+    est.find_congruent_all()
+    slot = 0
+    for a in range(24):
+        if not valid[a]:
+            continue
+        qo = orc.find_congruent(ids[a], float(inv[a][0]), float(inv[a][1]))
+        assert np.array_equal(est.get_quads(slot), qo)
+        if len(qo):
+            so = orc.find_congruent_seq(ids[a], float(inv[a][0]), float(inv[a][1]))
+            assert np.array_equal(est.get_quads_at(slot, np.arange(len(so))), so)
+        slot += 1
+
+
 def test_full_run_equals_oracle_and_recovers_pose(setup, oracle_lib):
     """run_stocs_estimation (stocs_match_one_object.cpp:51-185), class mode, seeded."""
     m, s, est, orc = setup
