@@ -251,44 +251,6 @@ __global__ __launch_bounds__(64) void finalize_bases_kernel(const float4* __rest
     if (b < nB) finalize_one(spos, bidx + 4 * b, fail[b], out + b);
 }
 
-// Instance mode runs its attempts one after the other (the class prior decays between them), so launch count is
-// what matters: ONE workgroup does "draw point 1, pass 1" (FIRST) or "draw 2, pass 2, draw 3, pass 3, draw 4" in
-// a single launch.  hdr = {bidx[4], fail} directly behind the weights, so one copy moves weights + result.
-template <bool FIRST>
-__global__ __launch_bounds__(1024) void instance_steps_kernel(PassArgs a, uint64_t seed, uint64_t attempt, float* __restrict__ w, int32_t* __restrict__ bidx,
-                                                              int32_t* __restrict__ fail, BaseOut* __restrict__ res) {
-    __shared__ uint64_t sh[1024];
-    __shared__ uint64_t sh_total;
-    __shared__ int sh_pick;
-    const int t = threadIdx.x;
-    int b1, b2 = -1, b3 = -1;
-    if (FIRST) {
-        b1 = draw_block(w, a.S, rng64(seed, attempt, 0), sh, &sh_total, &sh_pick);
-        if (t == 0) { bidx[0] = b1; bidx[1] = bidx[2] = bidx[3] = -1; fail[0] = b1 < 0 ? 1 : 0; }
-        if (b1 < 0) return;
-        for (int i = t; i < a.S; i += 1024) if (pass_zeroes<1>(a, b1, -1, -1, i)) w[i] = 0.0f;
-        return;
-    }
-    b1 = bidx[0];
-    __syncthreads();
-    bool go = true;
-    b2 = draw_block(w, a.S, rng64(seed, attempt, 1), sh, &sh_total, &sh_pick);
-    if (b2 < 0) { if (t == 0) { bidx[1] = -1; fail[0] = 1; } go = false; }
-    if (go) {
-        for (int i = t; i < a.S; i += 1024) if (pass_zeroes<2>(a, b1, b2, -1, i)) w[i] = 0.0f;
-        __syncthreads();
-        b3 = draw_block(w, a.S, rng64(seed, attempt, 2), sh, &sh_total, &sh_pick);
-        if (b3 < 0) { if (t == 0) { bidx[1] = b2; bidx[2] = -1; fail[0] = 1; } go = false; }
-    }
-    if (go) {
-        for (int i = t; i < a.S; i += 1024) if (pass_zeroes<3>(a, b1, b2, b3, i)) w[i] = 0.0f;
-        __syncthreads();
-        const int b4 = draw_block(w, a.S, rng64(seed, attempt, 3), sh, &sh_total, &sh_pick);
-        if (t == 0) { bidx[1] = b2; bidx[2] = b3; bidx[3] = b4; if (b4 < 0) fail[0] = 1; }
-    }
-    if (t == 0) finalize_one(a.spos, bidx, fail[0], res);   // thread 0 reads back its own writes
-}
-
 struct SampleBuffers {
     BaseOut* res;    // nB
     float* w;        // nB * S
@@ -441,12 +403,20 @@ static int sample_instance_one(stocs_ctx* c, uint64_t seed, int attempt, float d
         if (edge_probability == 1) w[i] = 0;
     }
     TSEC(0)
-    // round trip 1: weights up, "draw point 1 + pass 1" in one launch, weights + (bidx, fail) back in one copy
-    const PassArgs pa = pass_args(c);
+    // round trip 1: weights up, draw point 1, pass 1, weights + (bidx, fail) back in one copy
     const size_t span = (size_t)((char*)sb.fail - (char*)sb.w) + 4;   // w .. fail, contiguous (carve)
     std::vector<char> stage(span);
-    STOCS_HIP_CHECK(hipMemcpyAsync(sb.w, w.data(), (size_t)S * 4, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(instance_steps_kernel<true>, dim3(1), dim3(1024), 0, c->stream, pa, seed, (uint64_t)attempt, sb.w, sb.bidx, sb.fail, sb.res);
+    {
+        // weights + (bidx = -1, fail = 0) go up in ONE copy (they are contiguous, carve); draw and pass are separate
+        // launches so that the double-precision pass runs on the whole chip (a fused one-workgroup kernel was 25 % slower)
+        memcpy(stage.data(), w.data(), (size_t)S * 4);
+        const int32_t init_bidx[4] = {-1, -1, -1, -1}, init_fail = 0;
+        memcpy(stage.data() + ((char*)sb.bidx - (char*)sb.w), init_bidx, 16);
+        memcpy(stage.data() + ((char*)sb.fail - (char*)sb.w), &init_fail, 4);
+        STOCS_HIP_CHECK(hipMemcpyAsync(sb.w, stage.data(), span, hipMemcpyHostToDevice, c->stream));
+        launch_draw(c, 1, sb, seed, (uint64_t)attempt, 0);
+        launch_pass(c, 1, 1, sb);
+    }
     STOCS_HIP_CHECK(hipGetLastError());
     STOCS_HIP_CHECK(hipMemcpyAsync(stage.data(), sb.w, span, hipMemcpyDeviceToHost, c->stream));
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -476,9 +446,13 @@ static int sample_instance_one(stocs_ctx* c, uint64_t seed, int attempt, float d
     for (int i = 0; i < S; ++i)         // stocs.cpp:628-638
         if (w[i] != 0 && !mask[(size_t)c->h_spix[2 * i] * W + c->h_spix[2 * i + 1]]) w[i] = 0;
     TSEC(4)
-    // round trip 2: filtered weights up, "draw 2, pass 2, draw 3, pass 3, draw 4" in one launch, (bidx, fail) back
+    // round trip 2: filtered weights up, draw 2, pass 2, draw 3, pass 3, draw 4, base finalised on the device, result back
     STOCS_HIP_CHECK(hipMemcpyAsync(sb.w, w.data(), (size_t)S * 4, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(instance_steps_kernel<false>, dim3(1), dim3(1024), 0, c->stream, pa, seed, (uint64_t)attempt, sb.w, sb.bidx, sb.fail, sb.res);
+    for (int k = 1; k < 4; ++k) {
+        launch_draw(c, 1, sb, seed, (uint64_t)attempt, k);
+        if (k < 3) launch_pass(c, k + 1, 1, sb);
+    }
+    hipLaunchKernelGGL(finalize_bases_kernel, dim3(1), dim3(64), 0, c->stream, c->d_spos, sb.bidx, sb.fail, 1, sb.res);
     STOCS_HIP_CHECK(hipGetLastError());
     STOCS_HIP_CHECK(hipMemcpyAsync(&res, sb.res, sizeof(res), hipMemcpyDeviceToHost, c->stream));   // ordered base + invariants, finalised on the device
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
