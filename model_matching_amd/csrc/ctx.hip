@@ -254,6 +254,7 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     c->device = device;
     c->nS = nS; c->nM = nM;
     c->d_scratch = NULL; c->scratch_bytes = 0;
+    c->h_pin = NULL; c->pin_bytes = 0;
     c->index.built = false;
     c->index.d_bucket_start = NULL; c->index.d_pairs = NULL; c->index.d_exists = NULL;
     c->cong = NULL; c->quad_id_bits = 16;
@@ -355,6 +356,7 @@ int stocs_ctx_destroy(stocs_ctx* c) {
                     c->index.d_pairs, c->index.d_exists, c->d_scratch, c->d_best, c->d_cand};
     stocs_internal_free_congruent(c);
     c->grid_mem.destroy(); c->grid_ws.destroy();
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (void* p : ptrs) if (p) hipFree(p);
     hipEventDestroy(c->ev0);
     hipEventDestroy(c->ev1);

@@ -405,7 +405,13 @@ static int sample_instance_one(stocs_ctx* c, uint64_t seed, int attempt, float d
     TSEC(0)
     // round trip 1: weights up, draw point 1, pass 1, weights + (bidx, fail) back in one copy
     const size_t span = (size_t)((char*)sb.fail - (char*)sb.w) + 4;   // w .. fail, contiguous (carve)
-    std::vector<char> stage(span);
+    // pinned staging (grown on demand, owned by the context): the small copies of every attempt go straight over DMA
+    if (c->pin_bytes < span + 64) {
+        if (c->h_pin) { (void)hipHostFree(c->h_pin); c->h_pin = NULL; c->pin_bytes = 0; }
+        STOCS_HIP_CHECK(hipHostMalloc(&c->h_pin, span + 4096, hipHostMallocDefault));
+        c->pin_bytes = span + 4096;
+    }
+    struct { char* p; char* data() { return p; } } stage = {(char*)c->h_pin};
     {
         // weights + (bidx = -1, fail = 0) go up in ONE copy (they are contiguous, carve); draw and pass are separate
         // launches so that the double-precision pass runs on the whole chip (a fused one-workgroup kernel was 25 % slower)
@@ -447,15 +453,18 @@ static int sample_instance_one(stocs_ctx* c, uint64_t seed, int attempt, float d
         if (w[i] != 0 && !mask[(size_t)c->h_spix[2 * i] * W + c->h_spix[2 * i + 1]]) w[i] = 0;
     TSEC(4)
     // round trip 2: filtered weights up, draw 2, pass 2, draw 3, pass 3, draw 4, base finalised on the device, result back
-    STOCS_HIP_CHECK(hipMemcpyAsync(sb.w, w.data(), (size_t)S * 4, hipMemcpyHostToDevice, c->stream));
+    memcpy(stage.data(), w.data(), (size_t)S * 4);
+    STOCS_HIP_CHECK(hipMemcpyAsync(sb.w, stage.data(), (size_t)S * 4, hipMemcpyHostToDevice, c->stream));
     for (int k = 1; k < 4; ++k) {
         launch_draw(c, 1, sb, seed, (uint64_t)attempt, k);
         if (k < 3) launch_pass(c, k + 1, 1, sb);
     }
     hipLaunchKernelGGL(finalize_bases_kernel, dim3(1), dim3(64), 0, c->stream, c->d_spos, sb.bidx, sb.fail, 1, sb.res);
     STOCS_HIP_CHECK(hipGetLastError());
-    STOCS_HIP_CHECK(hipMemcpyAsync(&res, sb.res, sizeof(res), hipMemcpyDeviceToHost, c->stream));   // ordered base + invariants, finalised on the device
+    BaseOut* pres = (BaseOut*)(stage.data() + (((size_t)S * 4 + 63) & ~(size_t)63));
+    STOCS_HIP_CHECK(hipMemcpyAsync(pres, sb.res, sizeof(res), hipMemcpyDeviceToHost, c->stream));   // ordered base + invariants, finalised on the device
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    res = *pres;
     TSEC(5)
     return record_bases(c, 1, &res, ids, inv, valid);
 }

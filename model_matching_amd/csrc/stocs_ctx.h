@@ -205,6 +205,10 @@ struct stocs_ctx {
 
     unsigned long long* d_best;   // 8-byte arg-max key
 
+    // pinned host staging of instance-mode sampling
+    void* h_pin;
+    size_t pin_bytes;
+
     // scratch
     void* d_scratch;
     size_t scratch_bytes;
