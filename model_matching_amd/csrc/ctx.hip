@@ -264,6 +264,8 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     c->has_edge = false;
     c->grid_div = 1;
     c->lcp_variant = -1;
+    c->lcp_order = getenv("STOCS_LCP_ORDER") ? atoi(getenv("STOCS_LCP_ORDER")) : 1;
+    c->d_order = NULL; c->order_bytes = 0;
     memset(&c->grid, 0, sizeof(c->grid));
     c->d_spos = c->d_snrmw = c->d_mpos = c->d_mnrm = c->d_munit = c->d_mpos_raw = c->d_mpos_s = c->d_mnrm_s = NULL;
     c->d_spix = NULL; c->d_mperm = NULL;
@@ -353,7 +355,7 @@ int stocs_ctx_destroy(stocs_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_spos, c->d_snrmw, c->d_spix, c->d_mpos, c->d_mnrm, c->d_munit, c->d_mpos_raw, c->d_mpos_s,
                     c->d_mnrm_s, c->d_mperm, c->index.d_bucket_start,
-                    c->index.d_pairs, c->index.d_exists, c->d_scratch, c->d_best, c->d_cand};
+                    c->index.d_pairs, c->index.d_exists, c->d_scratch, c->d_best, c->d_cand, c->d_order};
     stocs_internal_free_congruent(c);
     c->grid_mem.destroy(); c->grid_ws.destroy();
     if (c->h_pin) (void)hipHostFree(c->h_pin);

@@ -17,6 +17,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
 #include <algorithm>
 
 #include "stocs_ctx.h"
@@ -36,7 +40,23 @@ struct LcpArgs {
     float ox, oy, oz, inv_h, inv_h4, h;
     int nx, ny, nz, nbx, nby;
     float sq_eps, dot_lo;
+    const int32_t* order;   // processing slot -> candidate (NULL: identity): candidates that land in the same part of the scene run together
+    int xcd_blocks;         // != 0: workgroups of one XCD take a contiguous run of slots (each XCD has its own L2)
 };
+
+// workgroup -> first processing slot.  The hardware hands consecutive workgroups to the 8 XCDs round-robin; with
+// xcd_blocks the workgroups that land on one XCD take consecutive slot blocks, so an XCD's L2 sees one
+// contiguous part of the (spatially ordered) candidate list.  Then slot -> candidate through the order array.
+__device__ __forceinline__ int lcp_candidate(const LcpArgs& a, int n, int w) {
+    int blk = blockIdx.x;
+    if (a.xcd_blocks) {
+        const int nb = gridDim.x, per = nb >> 3, rem = nb & 7, xcd = blk & 7;
+        blk = xcd * per + (xcd < rem ? xcd : rem) + (blk >> 3);
+    }
+    const int slot = __builtin_amdgcn_readfirstlane(blk * 4 + w);
+    if (slot >= n) return -1;
+    return a.order ? __builtin_amdgcn_readfirstlane(a.order[slot]) : slot;
+}
 
 // ABL > 0 are timing-only ablations (results wrong): 1 = transform only, 2 = + brick lookup,
 // 3 = + cell word, 4 = + list scan without the normal test
@@ -57,8 +77,8 @@ template <bool DETAIL, int ABL = 0, bool IDX = true>
 __global__ __launch_bounds__(256) void lcp_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
                                                   int n, int32_t* __restrict__ hit_out, uint8_t* __restrict__ cnt_out) {
     const int lane = threadIdx.x & 63;
-    const int cand = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (cand >= n) return;
+    const int cand = lcp_candidate(a, n, threadIdx.x >> 6);
+    if (cand < 0) return;
     const float* T = T16 + (size_t)cand * 16;
     const float t0 = T[0], t1 = T[1], t2 = T[2], t4 = T[4], t5 = T[5], t6 = T[6], t8 = T[8], t9 = T[9], t10 = T[10],
                 t12 = T[12], t13 = T[13], t14 = T[14];
@@ -148,8 +168,8 @@ __global__ __launch_bounds__(256) void lcp_coop_kernel(LcpArgs a, const float* _
     const int lane = threadIdx.x & 63;
     const int sub = lane & 7, grp = lane >> 3;
     const int w = threadIdx.x >> 6;
-    const int cand = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w);
-    if (cand >= n) return;
+    const int cand = lcp_candidate(a, n, w);
+    if (cand < 0) return;
     const float* T = T16 + (size_t)cand * 16;
     const float t0 = T[0], t1 = T[1], t2 = T[2], t4 = T[4], t5 = T[5], t6 = T[6], t8 = T[8], t9 = T[9], t10 = T[10],
                 t12 = T[12], t13 = T[13], t14 = T[14];
@@ -298,8 +318,8 @@ __global__ __launch_bounds__(256) void lcp_coopq_kernel(LcpArgs a, const float* 
     const int lane = threadIdx.x & 63;
     const int sub = lane & 7, grp = lane >> 3;
     const int w = threadIdx.x >> 6;
-    const int cand = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w);
-    if (cand >= n) return;
+    const int cand = lcp_candidate(a, n, w);
+    if (cand < 0) return;
     const float* T = T16 + (size_t)cand * 16;
     const float t0 = T[0], t1 = T[1], t2 = T[2], t4 = T[4], t5 = T[5], t6 = T[6], t8 = T[8], t9 = T[9], t10 = T[10],
                 t12 = T[12], t13 = T[13], t14 = T[14];
@@ -474,6 +494,25 @@ __global__ __launch_bounds__(256) void best_kernel(const float* __restrict__ lcp
     if ((threadIdx.x & 63) == 0 && k) atomicMax(best, k);
 }
 
+// processing order of a batch: Morton code of the candidate's translation (= where the model centroid lands) in the
+// scene grid's bounding box, 8 bits per axis (2 mm at a 0.5 m scene: candidate batches are concentrated around a few
+// hypotheses, coarse buckets of 1.5 cm lost a third of the gain).  Candidates that put the model in the same place read the same
+// bricks, cell words and lists; running them back to back raises the L1 / L2 hit rates (Cm: 1.67 -> 1.44 ms).
+__device__ __forceinline__ uint32_t spread10(uint32_t x) {
+    x &= 0x3ff; x = (x | (x << 16)) & 0x30000ff; x = (x | (x << 8)) & 0x300f00f; x = (x | (x << 4)) & 0x30c30c3; x = (x | (x << 2)) & 0x9249249;
+    return x;
+}
+__global__ __launch_bounds__(256) void order_keys_kernel(const float* __restrict__ T16, int n, float ox, float oy, float oz, float sx, float sy, float sz,
+                                                         uint32_t* __restrict__ keys, int32_t* __restrict__ vals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* T = T16 + (size_t)i * 16;
+    const float qx = fminf(fmaxf((T[12] - ox) * sx, 0.0f), 255.0f), qy = fminf(fmaxf((T[13] - oy) * sy, 0.0f), 255.0f),
+                qz = fminf(fmaxf((T[14] - oz) * sz, 0.0f), 255.0f);   // NaN -> 0 (fmaxf ignores it)
+    keys[i] = (spread10((uint32_t)qz) << 2) | (spread10((uint32_t)qy) << 1) | spread10((uint32_t)qx);
+    vals[i] = i;
+}
+
 static int lcp_variant() {
     static int v = -1;
     if (v < 0) {
@@ -493,6 +532,28 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
     a.sq_eps = c->prm.distance_threshold * c->prm.distance_threshold;  // sq_eps = epsilon*epsilon, stocs.cpp:1014
     a.dot_lo = c->thr.lcp_dot_lo;
     const int blocks = (n + 3) / 4;
+    a.order = NULL; a.xcd_blocks = 0;
+    if (!d_hit && n >= 32768 && c->lcp_order) {   // big batches (the ordering costs ~50 us): spatially ordered processing; scores do not depend on it
+        const size_t kb = (((size_t)n * 4 + 255) / 256) * 256;
+        size_t tb = 0;
+        STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb, (uint32_t*)NULL, (uint32_t*)NULL, (int32_t*)NULL, (int32_t*)NULL, (size_t)n, 0, 24, c->stream));
+        const size_t need = 4 * kb + tb;
+        if (c->order_bytes < need) {
+            if (c->d_order) { STOCS_HIP_CHECK(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_order); c->d_order = NULL; c->order_bytes = 0; }
+            STOCS_HIP_CHECK(hipMalloc(&c->d_order, need + need / 4));
+            c->order_bytes = need + need / 4;
+        }
+        char* p = (char*)c->d_order;
+        uint32_t* keys = (uint32_t*)p; uint32_t* keys_s = (uint32_t*)(p + kb);
+        int32_t* vals = (int32_t*)(p + 2 * kb); int32_t* order = (int32_t*)(p + 3 * kb);
+        void* tmp = p + 4 * kb;
+        const float sx = 256.0f / ((float)c->grid.nx * c->grid.h), sy = 256.0f / ((float)c->grid.ny * c->grid.h), sz = 256.0f / ((float)c->grid.nz * c->grid.h);
+        hipLaunchKernelGGL(order_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_T16, n, c->grid.ox, c->grid.oy, c->grid.oz, sx, sy, sz,
+                           keys, vals);
+        STOCS_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tb, keys, keys_s, vals, order, (size_t)n, 0, 24, c->stream));
+        a.order = order;
+        a.xcd_blocks = c->lcp_order >= 2 ? 1 : 0;
+    }
     int variant = c->lcp_variant >= 0 ? c->lcp_variant : lcp_variant();
     // dense grids keep their lists sorted by distance from the cell centre (not by index): only kernels
     // instantiated with the order-independent tie rule may scan them
@@ -625,6 +686,7 @@ int stocs_score_best_device(stocs_ctx* c, const void* d_T16, int n, void* d_lcp,
 int stocs_set_option(stocs_ctx* c, const char* key, int value) {
     if (!c || !key) return STOCS_ERR_INVALID;
     if (!strcmp(key, "lcp_variant") && value >= 0 && value <= 99) { c->lcp_variant = value; return STOCS_OK; }
+    if (!strcmp(key, "lcp_order") && value >= 0 && value <= 2) { c->lcp_order = value; return STOCS_OK; }   // 0 off, 1 spatial order, 2 + XCD-contiguous blocks
     set_error("stocs_set_option: unknown option or value");
     return STOCS_ERR_INVALID;
 }

@@ -175,6 +175,9 @@ struct stocs_ctx {
     stocs::Arena grid_ws;    // temporaries of a grid build
     int grid_div;   // cell edge = epsilon / grid_div
     int lcp_variant;   // -1: STOCS_LCP_VARIANT or automatic; else stocs_set_option("lcp_variant")
+    int lcp_order;     // 0: candidates in batch order; 1: spatially ordered processing of big batches; 2: + XCD-contiguous blocks
+    void* d_order;     // keys / permutation / sort scratch of the ordering
+    size_t order_bytes;
     stocs::PpfIndex index;
 
     // image-space state of instance mode (stocs.hpp:153-155)

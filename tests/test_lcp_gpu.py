@@ -165,3 +165,25 @@ def test_dense_scene_and_all_scan_variants(oracle_lib):
         assert same.mean() > 0.999, v                  # only exact-distance ties may differ (Q11)
         assert np.array_equal(cg[same], co[same]), v
     est.set_option("lcp_variant", 99)
+
+
+def test_processing_order_does_not_change_scores(oracle_lib):
+    """Big batches are processed in a spatial order of the candidates (and optionally in XCD-contiguous blocks):
+    every score must be bitwise identical to the plain batch order, and the device arg-max must pick the same
+    first maximum."""
+    from model_matching_amd import synth
+    from model_matching_amd.estimator import StocsEstimator
+    m, s, k = synth.workload("small")
+    est = StocsEstimator(s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm, build_index=False)
+    cs, cm = est.get_scene_centroid().astype(np.float64), est.get_model_centroid().astype(np.float64)
+    n = 40000
+    T = synth.make_candidates(synth.centred_gt(s.T_gt, cs, cm), n)
+    T[123, 12:15] = np.nan                      # a NaN translation sorts somewhere and still scores like in batch order
+    T[7] = T[5]                                 # duplicate candidates: equal scores, the lower index wins the arg-max
+    outs = []
+    for mode in (0, 1, 2):
+        est.set_option("lcp_order", mode)
+        outs.append(est.score_transforms(T))
+    assert np.array_equal(outs[0], outs[1], equal_nan=True) and np.array_equal(outs[0], outs[2], equal_nan=True)
+    assert outs[0][5] == outs[0][7]
+    est.close()
