@@ -176,7 +176,7 @@ def test_processing_order_does_not_change_scores(oracle_lib):
     m, s, k = synth.workload("small")
     est = StocsEstimator(s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm, build_index=False)
     cs, cm = est.get_scene_centroid().astype(np.float64), est.get_model_centroid().astype(np.float64)
-    n = 40000
+    n = 160000                                  # x 1000 model points: above the ordering threshold of launch_lcp
     T = synth.make_candidates(synth.centred_gt(s.T_gt, cs, cm), n)
     T[123, 12:15] = np.nan                      # a NaN translation sorts somewhere and still scores like in batch order
     T[7] = T[5]                                 # duplicate candidates: equal scores, the lower index wins the arg-max
