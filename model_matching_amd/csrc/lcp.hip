@@ -47,13 +47,13 @@ struct LcpArgs {
 // workgroup -> first processing slot.  The hardware hands consecutive workgroups to the 8 XCDs round-robin; with
 // xcd_blocks the workgroups that land on one XCD take consecutive slot blocks, so an XCD's L2 sees one
 // contiguous part of the (spatially ordered) candidate list.  Then slot -> candidate through the order array.
-__device__ __forceinline__ int lcp_candidate(const LcpArgs& a, int n, int w) {
+__device__ __forceinline__ int lcp_candidate(const LcpArgs& a, int n, int w, int wpb = 4) {
     int blk = blockIdx.x;
     if (a.xcd_blocks) {
         const int nb = gridDim.x, per = nb >> 3, rem = nb & 7, xcd = blk & 7;
         blk = xcd * per + (xcd < rem ? xcd : rem) + (blk >> 3);
     }
-    const int slot = __builtin_amdgcn_readfirstlane(blk * 4 + w);
+    const int slot = __builtin_amdgcn_readfirstlane(blk * wpb + w);
     if (slot >= n) return -1;
     return a.order ? __builtin_amdgcn_readfirstlane(a.order[slot]) : slot;
 }
@@ -156,19 +156,19 @@ __device__ __forceinline__ int dpp_i32(int v) {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
 
-template <bool DETAIL, int UNR, bool MASK = true, bool EARLY = false, bool IDX = true>
-__global__ __launch_bounds__(256) void lcp_coop_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
+template <bool DETAIL, int UNR, bool MASK = true, bool EARLY = false, bool IDX = true, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void lcp_coop_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
                                                        int n, int32_t* __restrict__ hit_out, uint8_t* __restrict__ cnt_out) {
-    __shared__ float4 qt[4][64];     // per lane: qx, qy, qz, bits(list offset)
-    __shared__ uint32_t qn[4][64];   // per lane: list length
-    __shared__ uint32_t hl[4][64];   // compacted hit list: r-th hit lane
-    __shared__ float rd[4][64];      // per lane: best d^2
-    __shared__ int ri[4][64];        // per lane: best scene index
-    __shared__ float qd[4][64];      // per lane: |query - cell centre| (EARLY)
+    __shared__ float4 qt[WPB][64];     // per lane: qx, qy, qz, bits(list offset)
+    __shared__ uint32_t qn[WPB][64];   // per lane: list length
+    __shared__ uint32_t hl[WPB][64];   // compacted hit list: r-th hit lane
+    __shared__ float rd[WPB][64];      // per lane: best d^2
+    __shared__ int ri[WPB][64];        // per lane: best scene index
+    __shared__ float qd[WPB][64];      // per lane: |query - cell centre| (EARLY)
     const int lane = threadIdx.x & 63;
     const int sub = lane & 7, grp = lane >> 3;
     const int w = threadIdx.x >> 6;
-    const int cand = lcp_candidate(a, n, w);
+    const int cand = lcp_candidate(a, n, w, WPB);
     if (cand < 0) return;
     const float* T = T16 + (size_t)cand * 16;
     const float t0 = T[0], t1 = T[1], t2 = T[2], t4 = T[4], t5 = T[5], t6 = T[6], t8 = T[8], t9 = T[9], t10 = T[10],
@@ -307,18 +307,18 @@ __global__ __launch_bounds__(256) void lcp_coop_kernel(LcpArgs a, const float* _
 // normal test runs on full wavefronts.  Lane <-> point assignment of the accumulation differs from v0,
 // so scores agree with v0 to rounding (1e-7), not bitwise; still run-to-run deterministic.
 // ---------------------------------------------------------------------------------------------
-template <bool DETAIL, int UNR, bool SORTQ = false, int PIPE = 4, bool IDX = true>
-__global__ __launch_bounds__(256) void lcp_coopq_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
+template <bool DETAIL, int UNR, bool SORTQ = false, int PIPE = 4, bool IDX = true, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
                                                         int n, int32_t* __restrict__ hit_out, uint8_t* __restrict__ cnt_out) {
-    __shared__ float4 qt[4][128];     // qx, qy, qz, bits(list offset)
-    __shared__ uint32_t qn[4][128];   // list length
-    __shared__ uint32_t qs[4][128];   // model slot (Morton order)
-    __shared__ int ri[4][128];        // best scene index
-    __shared__ uint8_t ord[4][64];    // batch order sorted by list length (SORTQ)
+    __shared__ float4 qt[WPB][128];     // qx, qy, qz, bits(list offset)
+    __shared__ uint32_t qn[WPB][128];   // list length
+    __shared__ uint32_t qs[WPB][128];   // model slot (Morton order)
+    __shared__ int ri[WPB][128];        // best scene index
+    __shared__ uint8_t ord[WPB][64];    // batch order sorted by list length (SORTQ)
     const int lane = threadIdx.x & 63;
     const int sub = lane & 7, grp = lane >> 3;
     const int w = threadIdx.x >> 6;
-    const int cand = lcp_candidate(a, n, w);
+    const int cand = lcp_candidate(a, n, w, WPB);
     if (cand < 0) return;
     const float* T = T16 + (size_t)cand * 16;
     const float t0 = T[0], t1 = T[1], t2 = T[2], t4 = T[4], t5 = T[5], t6 = T[6], t8 = T[8], t9 = T[9], t10 = T[10],
@@ -562,8 +562,8 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
     const bool dense = c->grid.d_chunk_r != NULL;
     if (variant == 99)   // automatic; must not depend on the batch size (a candidate's score is batch-invariant)
         variant = dense ? 31 : (c->grid.avg_list_len <= 10.0 ? 24 : 15);   // measured: tools/lcp_ab.py (Cm, C5)
-    if (dense && !(variant == 0 || variant == 16 || (variant >= 30 && variant <= 32))) variant = 31;
-    if (!dense && variant >= 30 && variant <= 32) variant = 24;
+    if (dense && !(variant == 0 || variant == 16 || (variant >= 30 && variant <= 33))) variant = 31;
+    if (!dense && variant >= 30 && variant <= 33) variant = 24;
 #define STOCS_LCP_LAUNCH(...) hipLaunchKernelGGL((__VA_ARGS__), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted)
     if (d_hit) {   // per-point detail (parity tests)
         if (dense) STOCS_LCP_LAUNCH(lcp_coop_kernel<true, 2, true, true, false>);
@@ -576,7 +576,8 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
             case 16: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 8, true, false, false>); break;
             case 30: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 1, true, true, false>); break;
             case 32: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 4, true, true, false>); break;
-            default: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 2, true, true, false>); break;   // 31
+            case 33: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 2, true, true, false>); break;   // 31 with four waves per workgroup
+            default: hipLaunchKernelGGL((lcp_coop_kernel<false, 2, true, true, false, 1>), dim3(n), dim3(64), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); break;   // 31
         }
     } else {
         switch (variant) {
@@ -596,7 +597,10 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
             case 27: STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 2, true>); break;
             case 28: STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 8, true>); break;
             case 25: STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 2, true, 4, true>); break;
-            default: STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 4, true>); break;       // 24
+            // waves per workgroup (the kernel has no workgroup-wide barrier): 16 / 8 / 4 / 2 / 1 -> 1.83 / 1.62 / 1.51 / 1.51 / 1.475 ms at Cm
+            case 40: hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 4, true, 8>), dim3((n + 7) / 8), dim3(512), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); break;
+            case 44: STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 4, true, 4>); break;
+            default: hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 4, true, 1>), dim3(n), dim3(64), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); break;   // 24
         }
     }
 #undef STOCS_LCP_LAUNCH
