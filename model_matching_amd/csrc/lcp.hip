@@ -49,9 +49,15 @@ struct LcpArgs {
 // contiguous part of the (spatially ordered) candidate list.  Then slot -> candidate through the order array.
 __device__ __forceinline__ int lcp_candidate(const LcpArgs& a, int n, int w, int wpb = 4) {
     int blk = blockIdx.x;
-    if (a.xcd_blocks) {
+    if (a.xcd_blocks == 1) {
         const int nb = gridDim.x, per = nb >> 3, rem = nb & 7, xcd = blk & 7;
         blk = xcd * per + (xcd < rem ? xcd : rem) + (blk >> 3);
+    } else if (a.xcd_blocks > 1) {   // chunks of xcd_blocks consecutive blocks per XCD, chunks dealt round-robin (balanced)
+        const int C = a.xcd_blocks, nb = gridDim.x, full = (nb / (8 * C)) * (8 * C);
+        if (blk < full) {
+            const int xcd = blk & 7, j = blk >> 3;
+            blk = ((j / C) * 8 + xcd) * C + (j % C);
+        }
     }
     const int slot = __builtin_amdgcn_readfirstlane(blk * wpb + w);
     if (slot >= n) return -1;
@@ -554,7 +560,7 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
                            keys, vals);
         STOCS_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tb, keys, keys_s, vals, order, (size_t)n, 0, 24, c->stream));
         a.order = order;
-        a.xcd_blocks = c->lcp_order >= 2 ? 1 : 0;
+        a.xcd_blocks = c->lcp_order >= 2 ? (c->lcp_order == 2 ? 1 : c->lcp_order) : 0;
     }
     int variant = c->lcp_variant >= 0 ? c->lcp_variant : lcp_variant();
     // dense grids keep their lists sorted by distance from the cell centre (not by index): only kernels
@@ -692,7 +698,8 @@ int stocs_score_best_device(stocs_ctx* c, const void* d_T16, int n, void* d_lcp,
 int stocs_set_option(stocs_ctx* c, const char* key, int value) {
     if (!c || !key) return STOCS_ERR_INVALID;
     if (!strcmp(key, "lcp_variant") && value >= 0 && value <= 99) { c->lcp_variant = value; return STOCS_OK; }
-    if (!strcmp(key, "lcp_order") && value >= 0 && value <= 2) { c->lcp_order = value; return STOCS_OK; }   // 0 off, 1 spatial order, 2 + XCD-contiguous blocks
+    // 0 off, 1 spatial order, 2 + XCD-contiguous halves of the list, k > 2 + chunks of k consecutive slots per XCD
+    if (!strcmp(key, "lcp_order") && value >= 0 && value <= 4096) { c->lcp_order = value; return STOCS_OK; }
     set_error("stocs_set_option: unknown option or value");
     return STOCS_ERR_INVALID;
 }
