@@ -170,3 +170,29 @@ def test_on_demand_quads_edge_cases(oracle_lib):
     assert hip.hipStreamDestroy(st) == 0
     assert np.array_equal(est.get_quads(slot), orc.find_congruent(ids[a], float(inv[a][0]), float(inv[a][1])))
     est.close()
+
+
+def test_set_scene_and_workspace_calls_reject_bad_arguments():
+    from model_matching_amd import capi
+    from model_matching_amd.estimator import ingest_scene
+    L = capi.load()
+    m, s, est = _mk()
+    pos, pp = capi.f32(s.pos); nrm, pn = capi.f32(s.nrm); pr, ppr = capi.f32(s.prob)
+    assert L.stocs_ctx_set_scene(None, pp, pn, ppr, None, len(pos)) == -1
+    assert L.stocs_ctx_set_scene(est.h, pp, pn, ppr, None, 0) == -1
+    assert L.stocs_ctx_set_scene(est.h, None, pn, ppr, None, len(pos)) == -1
+    assert b"set_scene" in L.stocs_last_error()
+    # a failed call leaves the context usable with its old scene
+    v, ids, inv = est.sample_bases(3, 10)
+    assert len(v) == 10
+    # pixels are optional (class mode never reads them)
+    assert L.stocs_ctx_set_scene(est.h, pp, pn, ppr, None, len(pos)) == 0
+    v2, ids2, inv2 = est.sample_bases(3, 10)
+    assert np.array_equal(v, v2) and np.array_equal(ids[v], ids2[v2])
+    # the ingest workspace of this thread can be given back at any time and is rebuilt on demand
+    depth = np.full((48, 64), 8000, np.uint16); prob = np.full((48, 64), 9000, np.uint16)
+    a = ingest_scene(depth, prob, (60.0, 32.0, 60.0, 24.0), 1e-4)
+    assert L.stocs_trim() == 0 and L.stocs_trim() == 0
+    b = ingest_scene(depth, prob, (60.0, 32.0, 60.0, 24.0), 1e-4)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    est.close()
