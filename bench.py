@@ -134,6 +134,21 @@ def main():
         except Exception:
             traffic = None
 
+    # what physically limits the kernel (the working set is cache resident, HBM is not it): VALU issue and the texture
+    # addresser, from the committed PMC passes of this command and the kernel time measured above
+    physical = None
+    if traffic is not None:
+        try:
+            pm = json.load(open(pmc))
+            clk, simds, cus = 2.4e9, 1024, 256
+            t = k_ms * 1e-3
+            physical = {"valu_issue_frac": pm["SQ_INSTS_VALU"]["per_launch_mean"] * 2.0 / (simds * clk * t),
+                        "texture_addresser_busy_frac": pm["TA_TA_BUSY_sum"]["per_launch_mean"] / (cus * clk * t),
+                        "l1_requests_per_clk_per_cu": pm["TCP_TOTAL_CACHE_ACCESSES_sum"]["per_launch_mean"] / (cus * clk * t),
+                        "assumed_clock_hz": clk, "source": traffic_src}
+        except Exception:
+            physical = None
+
     out = {
         "metric": "candidate poses verified/sec",
         "value": value,
@@ -155,10 +170,10 @@ def main():
         "final_lcp_percent": float(final_lcp) * 100.0,
         "best_global_candidate_id": int(final_gid),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-                     "traffic": traffic, "traffic_source": traffic_src, "kernel": "lcp_coopq_kernel (stocs_score_transforms_device)",
+                     "traffic": traffic, "traffic_source": traffic_src, "kernel": "lcp_coopq_kernel behind stocs_score_transforms_device (kernel_ms includes the ~50 us candidate ordering in front of it)",
                      "kernel_ms": k_ms,
                      "algorithmic_bytes_per_launch": b_pose * kcand,
-                     "kernel_poses_per_s": kcand / (k_ms * 1e-3)},
+                     "kernel_poses_per_s": kcand / (k_ms * 1e-3), "physical": physical},
     }
 
     if rank == 0 and world == 1 and not args.no_pipeline and est.nM <= 8192:
