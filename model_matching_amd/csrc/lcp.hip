@@ -500,6 +500,29 @@ __global__ __launch_bounds__(256) void best_kernel(const float* __restrict__ lcp
     if ((threadIdx.x & 63) == 0 && k) atomicMax(best, k);
 }
 
+// the same for one batch of moderate size in ONE workgroup: no zero fill in front, no atomics, the key is simply written
+__global__ __launch_bounds__(1024) void best_single_kernel(const float* __restrict__ lcp, int n, uint32_t id_offset, unsigned long long* __restrict__ best) {
+    __shared__ unsigned long long sh[16];
+    unsigned long long k = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float s = lcp[i];
+        if (s > 0.0f) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned long long)(0xFFFFFFFFu - (id_offset + (uint32_t)i));
+            k = key > k ? key : k;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(k, off, 64);
+        k = o > k ? o : k;
+    }
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = k;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) k = sh[w] > k ? sh[w] : k;
+        *best = k;
+    }
+}
+
 // processing order of a batch: Morton code of the candidate's translation (= where the model centroid lands) in the
 // scene grid's bounding box, 8 bits per axis (2 mm at a 0.5 m scene: candidate batches are concentrated around a few
 // hypotheses, coarse buckets of 1.5 cm lost a third of the gain).  Candidates that put the model in the same place read the same
@@ -669,9 +692,13 @@ int stocs_best_device(stocs_ctx* c, const void* d_lcp, int n, uint32_t id_offset
     *key = 0;
     if (n == 0) return STOCS_OK;
     if (!c->d_best) STOCS_HIP_CHECK(hipMalloc((void**)&c->d_best, 8));
-    STOCS_HIP_CHECK(hipMemsetAsync(c->d_best, 0, 8, c->stream));
-    const int blocks = std::min((n + 255) / 256, 1024);
-    hipLaunchKernelGGL(best_kernel, dim3(blocks), dim3(256), 0, c->stream, (const float*)d_lcp, n, id_offset, c->d_best);
+    if (n <= (1 << 18)) {
+        hipLaunchKernelGGL(best_single_kernel, dim3(1), dim3(1024), 0, c->stream, (const float*)d_lcp, n, id_offset, c->d_best);
+    } else {
+        STOCS_HIP_CHECK(hipMemsetAsync(c->d_best, 0, 8, c->stream));
+        const int blocks = std::min((n + 255) / 256, 1024);
+        hipLaunchKernelGGL(best_kernel, dim3(blocks), dim3(256), 0, c->stream, (const float*)d_lcp, n, id_offset, c->d_best);
+    }
     STOCS_HIP_CHECK(hipGetLastError());
     STOCS_HIP_CHECK(hipMemcpyAsync(key, c->d_best, 8, hipMemcpyDeviceToHost, c->stream));
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -681,10 +708,14 @@ int stocs_best_device(stocs_ctx* c, const void* d_lcp, int n, uint32_t id_offset
 int stocs_best_device_async(stocs_ctx* c, const void* d_lcp, int n, uint32_t id_offset, void* d_key8) {
     if (!c || !d_key8 || n < 0 || (n && !d_lcp)) return STOCS_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
-    STOCS_HIP_CHECK(hipMemsetAsync(d_key8, 0, 8, c->stream));
-    if (n == 0) return STOCS_OK;
-    const int blocks = std::min((n + 255) / 256, 1024);
-    hipLaunchKernelGGL(best_kernel, dim3(blocks), dim3(256), 0, c->stream, (const float*)d_lcp, n, id_offset, (unsigned long long*)d_key8);
+    if (n == 0) { STOCS_HIP_CHECK(hipMemsetAsync(d_key8, 0, 8, c->stream)); return STOCS_OK; }
+    if (n <= (1 << 18)) {
+        hipLaunchKernelGGL(best_single_kernel, dim3(1), dim3(1024), 0, c->stream, (const float*)d_lcp, n, id_offset, (unsigned long long*)d_key8);
+    } else {
+        STOCS_HIP_CHECK(hipMemsetAsync(d_key8, 0, 8, c->stream));
+        const int blocks = std::min((n + 255) / 256, 1024);
+        hipLaunchKernelGGL(best_kernel, dim3(blocks), dim3(256), 0, c->stream, (const float*)d_lcp, n, id_offset, (unsigned long long*)d_key8);
+    }
     STOCS_HIP_CHECK(hipGetLastError());
     return STOCS_OK;
 }
