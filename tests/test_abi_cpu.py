@@ -107,3 +107,14 @@ def test_cluster_poses_matches_oracle(capi, oracle_lib):
         a = cluster_poses(poses, lcp, 0.3, float(lcp.max()), 20, 0.03, 25.0, sym)
         b = oracle_lib.greedy_clustering(poses, lcp, 0.3, float(lcp.max()), 20, 0.03, 25.0, sym)
         assert a.tolist() == b.tolist() and len(a) > 3
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/stocs_hip.h is the FFI boundary: it must compile as C99 (no C++ types, extern "C" guards in place)."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "stocs_hip.h"\nint main(void){ stocs_params p; stocs_default_params(&p); return (int)sizeof(p) == 0; }\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and not r.stderr.strip(), r.stderr
