@@ -118,3 +118,14 @@ def test_header_is_plain_c(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0 and not r.stderr.strip(), r.stderr
+
+
+def test_facade_header_compiles_with_the_reference_language_level(tmp_path):
+    """include/stocs.hpp (the drop-in stocs::stocs_estimator) must build with a plain host compiler at the reference's
+    language level (-std=c++11, reference CMakeLists.txt:6-7); no HIP headers are needed on the caller's side."""
+    import subprocess
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "stocs.hpp"\nint main(){ return 0; }\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0 and not r.stderr.strip(), r.stderr
