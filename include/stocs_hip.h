@@ -158,7 +158,8 @@ int stocs_verify_all(stocs_ctx* ctx, float* best_lcp, int* best_idx, float* best
  * stocs_pack_best(lcp[i], id_offset + i), 0 when no score is positive (first maximum wins, as the
  * strict > of stocs.cpp:994).  Synchronises the context's stream; 8 bytes cross PCIe. */
 int stocs_best_device(stocs_ctx* ctx, const void* d_lcp, int n, uint32_t id_offset, uint64_t* key);
-/* order-preserving key for the cross-GPU arg-max (max wins; lowest global id wins ties) */
+/* order-preserving key for the cross-GPU arg-max (max wins; lowest global id wins ties); 0 = "no pose" when the score
+ * is not positive (stocs.cpp:987-998), so a rank whose candidates all scored 0 never wins */
 uint64_t stocs_pack_best(float lcp, uint32_t global_candidate_id);
 void stocs_unpack_best(uint64_t key, float* lcp, uint32_t* global_candidate_id);
 
@@ -169,7 +170,8 @@ int stocs_comm_unique_id(void* id128);                       /* rank 0: 128-byte
 int stocs_comm_create(const void* id128, int nranks, int rank, int device, stocs_comm** out);
 int stocs_comm_destroy(stocs_comm* comm);
 /* in: this rank's packed key (0 = none) and pose; out: the global maximum and the winner's pose.
- * Global ids must satisfy id / ids_per_rank == owning rank. */
+ * Global ids must satisfy id / ids_per_rank == owning rank.  Status: exercised with a one-rank communicator on a
+ * one-GPU box and by world-size-2 gloo tests of the same reduction; the 2+ rank RCCL path is unmeasured so far. */
 int stocs_allreduce_best(stocs_comm* comm, void* hip_stream, uint64_t* key_inout, float* pose16_inout, uint32_t ids_per_rank);
 
 /* ---- pose post-processing: clustering::greedy_clustering (pose_clustering.cpp:79-121), host ---- */
@@ -205,12 +207,13 @@ int stocs_icp_point_to_plane(const float* src_pos3, int nsrc, const float* tgt_p
                              int max_iterations, float max_correspondence_distance, int device, float* T16_out,
                              int* n_correspondences);
 
-/* ---- tuning knobs (never change results beyond float summation order): "lcp_variant"
- * 99 = automatic (default): cooperative 8-lane scan fed from an LDS queue for scenes with short
- * candidate lists (24), centre-sorted lists with triangle-inequality early exit for dense scenes (31);
- * 0 = lane-per-query scan (the first kernel of round 1); 1/9/15/16 = cooperative scan with 1/2/4/8 list
- * lines in flight; 20-28 = queue variants; 30-32 = early-exit variants (dense grids only);
- * 10-14 = timing-only ablations of the lane-per-query kernel (wrong results) ---- */
+/* ---- tuning knobs (never change results beyond float summation order).
+ * "lcp_variant": 99 = automatic (default): cooperative 8-lane scan fed from an LDS queue for scenes with short
+ *   candidate lists (24), cooperative scan with 4 list lines in flight for medium lists (15), centre-sorted lists with
+ *   triangle-inequality early exit for dense scenes (31); 0 = plain lane-per-query scan (independent cross-check).
+ *   Every selectable kernel returns the reference's scores; any other value is STOCS_ERR_INVALID.
+ * "lcp_order": 0 = candidates in batch order, 1 (default) = big batches are processed in a spatial order of their
+ *   translations (scores are bitwise independent of it), >= 2 = XCD-blocked variants of that order. ---- */
 int stocs_set_option(stocs_ctx* ctx, const char* key, int value);
 
 /* ---- stream / timing plumbing ---- */
@@ -227,6 +230,9 @@ void* stocs_stream(stocs_ctx* ctx);          /* hipStream_t */
  * events on the context's stream; returns the average milliseconds per launch */
 int stocs_time_score_kernel(stocs_ctx* ctx, const void* d_T16, int n, void* d_lcp, int reps,
                             float* avg_ms);
+/* number of device allocations (hipMalloc) the library has made in this process so far.  A warm context -- one that has
+ * run a trial of the current scene -- runs further trials without allocating: the difference across them is 0. */
+int64_t stocs_device_alloc_count(void);
 /* device memory helpers so that callers without a HIP binding (ctypes) can keep inputs resident */
 int stocs_dev_alloc(stocs_ctx* ctx, int64_t bytes, void** dptr);
 int stocs_dev_free(stocs_ctx* ctx, void* dptr);

@@ -93,7 +93,11 @@ int stocs_comm_create(const void* id128, int nranks, int rank, int device, stocs
     memcpy(&id, id128, sizeof(id));
     ncclResult_t r = R->CommInitRank(&c->comm, nranks, id, rank);
     if (r != ncclSuccess) { set_error("ncclCommInitRank failed: %s", R->GetErrorString ? R->GetErrorString(r) : "?"); delete c; return STOCS_ERR_HIP; }
-    if (hipMalloc((void**)&c->d_key, 8) != hipSuccess || hipMalloc((void**)&c->d_pose, 64) != hipSuccess) { set_error("hipMalloc failed"); delete c; return STOCS_ERR_HIP; }
+    if (dev_malloc((void**)&c->d_key, 8) != hipSuccess || dev_malloc((void**)&c->d_pose, 64) != hipSuccess) {
+        set_error("hipMalloc failed");
+        (void)stocs_comm_destroy(c);   // gives back the communicator and whichever buffer exists
+        return STOCS_ERR_HIP;
+    }
     *out = c;
     return STOCS_OK;
 }
@@ -120,6 +124,7 @@ int stocs_allreduce_best(stocs_comm* c, void* hip_stream, uint64_t* key_inout, f
     uint64_t best = 0;
     STOCS_HIP_CHECK(hipMemcpyAsync(&best, c->d_key, 8, hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
+    if ((best >> 32) == 0) best = 0;   // score bits 0: a key packed by hand from a zero score is "no pose" too (stocs.cpp:987-998)
     *key_inout = best;
     if (best == 0) { memset(pose16_inout, 0, 64); return STOCS_OK; }   // no pose anywhere (Q18)
     float lcp; uint32_t gid;

@@ -17,6 +17,7 @@
 namespace stocs {
 
 static thread_local char g_err[512] = "";
+unsigned long long g_dev_allocs = 0;
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -89,7 +90,7 @@ int ensure_scratch(stocs_ctx* c, size_t bytes) {
     c->d_scratch = NULL;
     c->scratch_bytes = 0;
     size_t want = bytes + bytes / 4 + (1 << 20);
-    STOCS_HIP_CHECK(hipMalloc(&c->d_scratch, want));
+    STOCS_HIP_CHECK(dev_malloc(&c->d_scratch, want));
     c->scratch_bytes = want;
     return STOCS_OK;
 }
@@ -107,7 +108,7 @@ template <class T>
 static int upload(T** dptr, const T* h, size_t n) {
     *dptr = NULL;
     if (n == 0) n = 1;
-    STOCS_HIP_CHECK(hipMalloc((void**)dptr, n * sizeof(T)));
+    STOCS_HIP_CHECK(dev_malloc((void**)dptr, n * sizeof(T)));
     if (h) STOCS_HIP_CHECK(hipMemcpy(*dptr, h, n * sizeof(T), hipMemcpyHostToDevice));
     return STOCS_OK;
 }
@@ -155,6 +156,14 @@ static int build_grid(stocs_ctx* c) {
 // stocs.cpp:943-980), device clouds, the brick grid; per-trial state is reset.  Used by stocs_ctx_create and
 // stocs_ctx_set_scene (a new camera frame against the same model keeps the model clouds and the PPF index).
 static int load_scene(stocs_ctx* c, const float* sp, const float* sn, const float* sprob, const int32_t* spix, int nS) {
+    if (spix) {   // instance-mode sampling indexes the 2-D maps with these (sample.hip); refuse what would land outside them
+        const int W = c->prm.image_width, H = c->prm.image_height;
+        for (int i = 0; i < nS; ++i)
+            if (spix[2 * i] < 0 || spix[2 * i] >= H || spix[2 * i + 1] < 0 || spix[2 * i + 1] >= W) {
+                set_error("scene point %d has pixel (row %d, col %d) outside the %dx%d image of stocs_params", i, spix[2 * i], spix[2 * i + 1], W, H);
+                return STOCS_ERR_INVALID;
+            }
+    }
     c->nS = nS;
     c->h_spos.resize(nS); c->h_snrm.resize(nS); c->h_sprob.assign(sprob, sprob + nS); c->h_sprob0 = c->h_sprob; c->h_spix.assign((size_t)2 * nS, 0);
     for (int i = 0; i < nS; ++i) {
@@ -412,7 +421,7 @@ int stocs_set_stream(stocs_ctx* c, void* hip_stream) {
 int stocs_dev_alloc(stocs_ctx* c, int64_t bytes, void** dptr) {
     if (!c || !dptr || bytes < 0) return STOCS_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
-    STOCS_HIP_CHECK(hipMalloc(dptr, (size_t)std::max<int64_t>(bytes, 16)));
+    STOCS_HIP_CHECK(dev_malloc(dptr, (size_t)std::max<int64_t>(bytes, 16)));
     return STOCS_OK;
 }
 int stocs_dev_free(stocs_ctx* c, void* dptr) {
@@ -436,10 +445,14 @@ int stocs_dev_download(stocs_ctx* c, void* host, const void* dptr, int64_t bytes
     return STOCS_OK;
 }
 
+int64_t stocs_device_alloc_count(void) { return (int64_t)__atomic_load_n(&g_dev_allocs, __ATOMIC_RELAXED); }
+
 uint64_t stocs_pack_best(float lcp, uint32_t id) {
+    // a score that is not positive never wins (stocs.cpp:987-998: strict > from 0, all-zero => no pose): its key is 0 =
+    // "none", the same value best_kernel produces, so a rank whose candidates all scored 0 cannot win the all-reduce
+    if (!(lcp > 0.0f)) return 0;
     uint32_t bits;
     memcpy(&bits, &lcp, 4);
-    if (!(lcp > 0.0f)) bits = 0;  // scores are >= 0; NaN/negative never win
     return ((uint64_t)bits << 32) | (uint64_t)(0xFFFFFFFFu - id);
 }
 void stocs_unpack_best(uint64_t key, float* lcp, uint32_t* id) {

@@ -116,11 +116,11 @@ extern "C" int stocs_icp_point_to_plane(const float* src_pos3, int nsrc, const f
     float4 *ds = NULL, *dt = NULL, *dn = NULL;
     double *dT = NULL, *dP = NULL;
     const int blocks = (nsrc + 255) / 256;
-    STOCS_HIP_CHECK(hipMalloc((void**)&ds, sizeof(float4) * (size_t)nsrc));
-    STOCS_HIP_CHECK(hipMalloc((void**)&dt, sizeof(float4) * (size_t)ntgt));
-    STOCS_HIP_CHECK(hipMalloc((void**)&dn, sizeof(float4) * (size_t)ntgt));
-    STOCS_HIP_CHECK(hipMalloc((void**)&dT, sizeof(double) * 12));
-    STOCS_HIP_CHECK(hipMalloc((void**)&dP, sizeof(double) * 28 * (size_t)blocks));
+    STOCS_HIP_CHECK(dev_malloc((void**)&ds, sizeof(float4) * (size_t)nsrc));
+    STOCS_HIP_CHECK(dev_malloc((void**)&dt, sizeof(float4) * (size_t)ntgt));
+    STOCS_HIP_CHECK(dev_malloc((void**)&dn, sizeof(float4) * (size_t)ntgt));
+    STOCS_HIP_CHECK(dev_malloc((void**)&dT, sizeof(double) * 12));
+    STOCS_HIP_CHECK(dev_malloc((void**)&dP, sizeof(double) * 28 * (size_t)blocks));
     STOCS_HIP_CHECK(hipMemcpy(ds, hs.data(), sizeof(float4) * (size_t)nsrc, hipMemcpyHostToDevice));
     STOCS_HIP_CHECK(hipMemcpy(dt, ht.data(), sizeof(float4) * (size_t)ntgt, hipMemcpyHostToDevice));
     STOCS_HIP_CHECK(hipMemcpy(dn, hn.data(), sizeof(float4) * (size_t)ntgt, hipMemcpyHostToDevice));

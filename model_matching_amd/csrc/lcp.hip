@@ -3,7 +3,8 @@
 // src/stocs.cpp:1006-1041) and the kd-tree query it calls per model point
 // (reference include/super4pcs/accelerators/kdtree.h:394-459).
 //
-// Mapping: one 64-lane wavefront per candidate transform, four candidates per 256-thread workgroup.
+// Mapping: one 64-lane wavefront per candidate transform; the shipped kernels run one wavefront per workgroup
+// (they have no workgroup-wide barrier; 1 / 2 / 4 / 8 / 16 waves per workgroup were measured).
 // The 3x4 transform is wave-uniform (scalar loads -> SGPRs).  Lane l walks the Morton-sorted model
 // points l, l+64, ...: coalesced 16-byte loads, and the 64 queries of one step fall into a handful
 // of neighbouring grid cells, so the brick/cell/list gathers of a wave share cache lines.
@@ -64,8 +65,6 @@ __device__ __forceinline__ int lcp_candidate(const LcpArgs& a, int n, int w, int
     return a.order ? __builtin_amdgcn_readfirstlane(a.order[slot]) : slot;
 }
 
-// ABL > 0 are timing-only ablations (results wrong): 1 = transform only, 2 = + brick lookup,
-// 3 = + cell word, 4 = + list scan without the normal test
 #define DPP_QUAD_XOR1 0xB1   /* quad_perm [1,0,3,2] */
 #define DPP_QUAD_XOR2 0x4E   /* quad_perm [2,3,0,1] */
 #define DPP_HALF_MIRROR 0x141 /* lane k <-> 7-k inside each group of 8 */
@@ -79,7 +78,7 @@ __device__ __forceinline__ void take_if_better(float d, int ei, float& gd, int& 
     else { if (d < gd || (d == gd && ei > gi)) { gd = d; gi = ei; } }
 }
 
-template <bool DETAIL, int ABL = 0, bool IDX = true>
+template <bool DETAIL, bool IDX = true>
 __global__ __launch_bounds__(256) void lcp_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
                                                   int n, int32_t* __restrict__ hit_out, uint8_t* __restrict__ cnt_out) {
     const int lane = threadIdx.x & 63;
@@ -99,18 +98,14 @@ __global__ __launch_bounds__(256) void lcp_kernel(LcpArgs a, const float* __rest
         const float fy = floorf((qy - a.oy) * a.inv_h);
         const float fz = floorf((qz - a.oz) * a.inv_h);
         int best = -1;
-        if (ABL == 1) { acc += fx + fy + fz; continue; }
         if (fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float)a.nx && fy < (float)a.ny && fz < (float)a.nz) {
             const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
             const int brick = a.top[((cz >> 3) * a.nby + (cy >> 3)) * a.nbx + (cx >> 3)];
-            if (ABL == 2) { acc += (float)brick; continue; }
             if (brick >= 0) {
                 const uint4 cw = a.cells[(size_t)brick * 512 + (((cz & 7) << 6) | ((cy & 7) << 3) | (cx & 7))];
-                if (ABL == 3) { acc += (float)(cw.x + cw.y); continue; }
                 float bd = a.sq_eps;
                 for (uint32_t k = 0; k < cw.y; ++k) {
-                    // ABL 5: timing-only, every lane reads the same few lines (cost of the gather itself)
-                    const float4 s = (ABL == 5) ? a.list[(cw.x & 8u) + k] : a.list[cw.x + k];
+                    const float4 s = a.list[cw.x + k];
                     const float dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
                     const float d = dx * dx + (dy * dy + dz * dz);
                     take_if_better<IDX>(d, __float_as_int(s.w), bd, best);
@@ -118,7 +113,6 @@ __global__ __launch_bounds__(256) void lcp_kernel(LcpArgs a, const float* __rest
             }
         }
         bool counted = false;
-        if (ABL == 4) { acc += (float)best; continue; }
         if (best >= 0) {
             const float4 nm = a.mnrm[i];
             // mat.block<3,3>(0,0) * normal
@@ -542,13 +536,30 @@ __global__ __launch_bounds__(256) void order_keys_kernel(const float* __restrict
     vals[i] = i;
 }
 
+// Kernel selection.  The product library ships the kernels the automatic choice uses (24: cooperative scan fed from an
+// LDS queue, sparse scenes; 15: cooperative scan, 4 lines in flight, medium lists; 31: centre-sorted lists with early
+// exit, dense scenes) plus the plain lane-per-query kernel (0) as an independent cross-check; every one of them returns
+// the reference's scores.  The other measured variants (profiles/r01_lcp_analysis.md) exist only in a tools build
+// (make tools -> libstocs_hip_tools.so, -DSTOCS_TOOLS_BUILD), which also honours the STOCS_LCP_VARIANT environment variable.
+static bool lcp_variant_selectable(int v) {
+    if (v == 99 || v == 0 || v == 15 || v == 24 || v == 31) return true;
+#ifdef STOCS_TOOLS_BUILD
+    static const int extra[] = {1, 9, 16, 17, 20, 25, 26, 27, 28, 30, 32, 33, 40, 44};
+    for (size_t i = 0; i < sizeof(extra) / sizeof(extra[0]); ++i) if (extra[i] == v) return true;
+#endif
+    return false;
+}
 static int lcp_variant() {
+#ifdef STOCS_TOOLS_BUILD
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("STOCS_LCP_VARIANT");
-        v = e ? atoi(e) : 99;
+        v = (e && lcp_variant_selectable(atoi(e))) ? atoi(e) : 99;
     }
     return v;
+#else
+    return 99;
+#endif
 }
 
 int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d_hit, uint8_t* d_counted) {
@@ -571,7 +582,7 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
         const size_t need = 4 * kb + tb;
         if (c->order_bytes < need) {
             if (c->d_order) { STOCS_HIP_CHECK(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_order); c->d_order = NULL; c->order_bytes = 0; }
-            STOCS_HIP_CHECK(hipMalloc(&c->d_order, need + need / 4));
+            STOCS_HIP_CHECK(dev_malloc(&c->d_order, need + need / 4));
             c->order_bytes = need + need / 4;
         }
         char* p = (char*)c->d_order;
@@ -596,29 +607,27 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
 #define STOCS_LCP_LAUNCH(...) hipLaunchKernelGGL((__VA_ARGS__), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted)
     if (d_hit) {   // per-point detail (parity tests)
         if (dense) STOCS_LCP_LAUNCH(lcp_coop_kernel<true, 2, true, true, false>);
-        else if (variant == 0) STOCS_LCP_LAUNCH(lcp_kernel<true, 0, true>);
+        else if (variant == 0) STOCS_LCP_LAUNCH(lcp_kernel<true, true>);
         else if (variant >= 20 && variant <= 28) STOCS_LCP_LAUNCH(lcp_coopq_kernel<true, 1, true, 4, true>);
         else STOCS_LCP_LAUNCH(lcp_coop_kernel<true, 1, true, false, true>);
     } else if (dense) {
         switch (variant) {
-            case 0: STOCS_LCP_LAUNCH(lcp_kernel<false, 0, false>); break;
+            case 0: STOCS_LCP_LAUNCH(lcp_kernel<false, false>); break;
+#ifdef STOCS_TOOLS_BUILD
             case 16: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 8, true, false, false>); break;
             case 30: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 1, true, true, false>); break;
             case 32: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 4, true, true, false>); break;
             case 33: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 2, true, true, false>); break;   // 31 with four waves per workgroup
+#endif
             default: hipLaunchKernelGGL((lcp_coop_kernel<false, 2, true, true, false, 1>), dim3(n), dim3(64), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); break;   // 31
         }
     } else {
         switch (variant) {
-            case 0: STOCS_LCP_LAUNCH(lcp_kernel<false, 0, true>); break;
-            case 10: STOCS_LCP_LAUNCH(lcp_kernel<false, 1, true>); break;   // 10-14: timing-only ablations
-            case 11: STOCS_LCP_LAUNCH(lcp_kernel<false, 2, true>); break;
-            case 12: STOCS_LCP_LAUNCH(lcp_kernel<false, 3, true>); break;
-            case 13: STOCS_LCP_LAUNCH(lcp_kernel<false, 4, true>); break;
-            case 14: STOCS_LCP_LAUNCH(lcp_kernel<false, 5, true>); break;
+            case 0: STOCS_LCP_LAUNCH(lcp_kernel<false, true>); break;
+            case 15: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 4, true, false, true>); break;
+#ifdef STOCS_TOOLS_BUILD
             case 1: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 1, true, false, true>); break;
             case 9: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 2, true, false, true>); break;
-            case 15: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 4, true, false, true>); break;
             case 16: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 8, true, false, true>); break;
             case 17: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 2, false, false, true>); break;   // no sub-cell mask
             case 20: STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, false, 4, true>); break;
@@ -629,6 +638,7 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
             // waves per workgroup (the kernel has no workgroup-wide barrier): 16 / 8 / 4 / 2 / 1 -> 1.83 / 1.62 / 1.51 / 1.51 / 1.475 ms at Cm
             case 40: hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 4, true, 8>), dim3((n + 7) / 8), dim3(512), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); break;
             case 44: STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 4, true, 4>); break;
+#endif
             default: hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 4, true, 1>), dim3(n), dim3(64), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); break;   // 24
         }
     }
@@ -691,7 +701,7 @@ int stocs_best_device(stocs_ctx* c, const void* d_lcp, int n, uint32_t id_offset
     DeviceGuard dev_guard(c->device);
     *key = 0;
     if (n == 0) return STOCS_OK;
-    if (!c->d_best) STOCS_HIP_CHECK(hipMalloc((void**)&c->d_best, 8));
+    if (!c->d_best) STOCS_HIP_CHECK(dev_malloc((void**)&c->d_best, 8));
     if (n <= (1 << 18)) {
         hipLaunchKernelGGL(best_single_kernel, dim3(1), dim3(1024), 0, c->stream, (const float*)d_lcp, n, id_offset, c->d_best);
     } else {
@@ -728,7 +738,11 @@ int stocs_score_best_device(stocs_ctx* c, const void* d_T16, int n, void* d_lcp,
 
 int stocs_set_option(stocs_ctx* c, const char* key, int value) {
     if (!c || !key) return STOCS_ERR_INVALID;
-    if (!strcmp(key, "lcp_variant") && value >= 0 && value <= 99) { c->lcp_variant = value; return STOCS_OK; }
+    if (!strcmp(key, "lcp_variant")) {
+        if (!lcp_variant_selectable(value)) { set_error("stocs_set_option: lcp_variant %d is not part of this build (99 automatic, 0, 15, 24, 31)", value); return STOCS_ERR_INVALID; }
+        c->lcp_variant = value;
+        return STOCS_OK;
+    }
     // 0 off, 1 spatial order, 2 + XCD-contiguous halves of the list, k > 2 + chunks of k consecutive slots per XCD
     if (!strcmp(key, "lcp_order") && value >= 0 && value <= 4096) { c->lcp_order = value; return STOCS_OK; }
     set_error("stocs_set_option: unknown option or value");

@@ -100,12 +100,17 @@ int build_ppf_index(stocs_ctx* c) {
     uint64_t *d_keys = NULL, *d_sorted = NULL;
     void* d_tmp = NULL;
     size_t tmp_bytes = 0;
+    // the temporaries are released on every exit path (the HIP checks below return early)
+    struct TmpGuard {
+        uint32_t** a; uint64_t** b; uint64_t** c; void** d;
+        ~TmpGuard() { if (*a) (void)hipFree(*a); if (*b) (void)hipFree(*b); if (*c) (void)hipFree(*c); if (*d) (void)hipFree(*d); }
+    } tmp_guard = {&d_hist, &d_keys, &d_sorted, &d_tmp};
     const size_t words = (size_t)((ix.n_keys + 31) / 32);
-    STOCS_HIP_CHECK(hipMalloc((void**)&d_hist, (size_t)(ix.n_keys + 1) * 4));
+    STOCS_HIP_CHECK(dev_malloc((void**)&d_hist, (size_t)(ix.n_keys + 1) * 4));
     STOCS_HIP_CHECK(hipMemsetAsync(d_hist, 0, (size_t)(ix.n_keys + 1) * 4, c->stream));
-    STOCS_HIP_CHECK(hipMalloc((void**)&d_keys, (size_t)std::max<int64_t>(total, 1) * 8));
-    STOCS_HIP_CHECK(hipMalloc((void**)&d_sorted, (size_t)std::max<int64_t>(total, 1) * 8));
-    STOCS_HIP_CHECK(hipMalloc((void**)&ix.d_exists, std::max<size_t>(words, 1) * 4));
+    STOCS_HIP_CHECK(dev_malloc((void**)&d_keys, (size_t)std::max<int64_t>(total, 1) * 8));
+    STOCS_HIP_CHECK(dev_malloc((void**)&d_sorted, (size_t)std::max<int64_t>(total, 1) * 8));
+    STOCS_HIP_CHECK(dev_malloc((void**)&ix.d_exists, std::max<size_t>(words, 1) * 4));
     STOCS_HIP_CHECK(hipMemsetAsync(ix.d_exists, 0, std::max<size_t>(words, 1) * 4, c->stream));
     if (total > 0) {
         const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 64);
@@ -117,7 +122,7 @@ int build_ppf_index(stocs_ctx* c) {
         const unsigned end_bit = 64;  // invalid entries (all ones) must sort last
         (void)key_bits;
         STOCS_HIP_CHECK(rocprim::radix_sort_keys(NULL, tmp_bytes, d_keys, d_sorted, (size_t)total, 0, end_bit, c->stream));
-        STOCS_HIP_CHECK(hipMalloc(&d_tmp, tmp_bytes));
+        STOCS_HIP_CHECK(dev_malloc(&d_tmp, tmp_bytes));
         STOCS_HIP_CHECK(rocprim::radix_sort_keys(d_tmp, tmp_bytes, d_keys, d_sorted, (size_t)total, 0, end_bit, c->stream));
         hipLaunchKernelGGL(ppf_exists_kernel, dim3((unsigned)ix.n_keys), dim3(128), 0, c->stream, d_hist, ix.n_keys, ix.tr, ix.rot,
                            ix.NA, ix.nD, ix.d_exists);
@@ -137,9 +142,9 @@ int build_ppf_index(stocs_ctx* c) {
     }
     ix.h_bucket_start[(size_t)ix.n_keys] = (uint32_t)run;
     ix.n_pairs = (int64_t)run;
-    STOCS_HIP_CHECK(hipMalloc((void**)&ix.d_bucket_start, (size_t)(ix.n_keys + 1) * 4));
+    STOCS_HIP_CHECK(dev_malloc((void**)&ix.d_bucket_start, (size_t)(ix.n_keys + 1) * 4));
     STOCS_HIP_CHECK(hipMemcpyAsync(ix.d_bucket_start, ix.h_bucket_start.data(), (size_t)(ix.n_keys + 1) * 4, hipMemcpyHostToDevice, c->stream));
-    STOCS_HIP_CHECK(hipMalloc((void**)&ix.d_pairs, (size_t)std::max<int64_t>(ix.n_pairs, 1) * 4));
+    STOCS_HIP_CHECK(dev_malloc((void**)&ix.d_pairs, (size_t)std::max<int64_t>(ix.n_pairs, 1) * 4));
     if (ix.n_pairs > 0) {
         hipLaunchKernelGGL(ppf_unpack_pairs_kernel, dim3((unsigned)((ix.n_pairs + 255) / 256)), dim3(256), 0, c->stream, d_sorted,
                            ix.n_pairs, ix.d_pairs);
@@ -151,8 +156,6 @@ int build_ppf_index(stocs_ctx* c) {
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
     ix.n_exist_keys = 0;
     for (size_t w = 0; w < ix.h_exists.size(); ++w) ix.n_exist_keys += __builtin_popcount(ix.h_exists[w]);
-    hipFree(d_hist); hipFree(d_keys); hipFree(d_sorted);
-    if (d_tmp) hipFree(d_tmp);
     ix.built = true;
     return STOCS_OK;
 }
@@ -294,15 +297,31 @@ int stocs_index_load(stocs_ctx* c, const char* path) {
         }
     }
     fclose(f);
-    if (rc) return rc;
+    if (!rc) {
+        // one O(n_keys + n_pairs) pass: a file that passes is safe to index with (offsets monotone and in range, every
+        // model id below nM, no existence bit beyond the key space)
+        const char* why = NULL;
+        for (int64_t k = 0; k < h.n_keys && !why; ++k)
+            if (ix.h_bucket_start[(size_t)k] > ix.h_bucket_start[(size_t)k + 1]) why = "bucket offsets are not monotone";
+        if (!why && ix.h_bucket_start[0] != 0) why = "first bucket offset is not 0";
+        const uint32_t nM = (uint32_t)c->nM;
+        for (int64_t e = 0; e < h.n_pairs && !why; ++e)
+            if ((pairs[(size_t)e] >> 16) >= nM || (pairs[(size_t)e] & 0xFFFFu) >= nM) why = "pair id outside the model";
+        if (!why && (h.n_keys & 31)) {
+            const uint32_t tail = ix.h_exists.back() >> (h.n_keys & 31);
+            if (tail) why = "existence bits beyond the key space";
+        }
+        if (why) { set_error("stocs_index_load: inconsistent file %s (%s)", path, why); rc = STOCS_ERR_INVALID; }
+    }
+    if (rc) { ix.h_bucket_start.clear(); ix.h_exists.clear(); return rc; }
     ix.tr = h.tr; ix.rot = h.rot; ix.NA = h.NA; ix.nD = h.nD; ix.n_keys = h.n_keys; ix.n_pairs = h.n_pairs;
     ix.n_nonempty_buckets = 0;
     for (int64_t k = 0; k < ix.n_keys; ++k) ix.n_nonempty_buckets += ix.h_bucket_start[(size_t)k + 1] != ix.h_bucket_start[(size_t)k];
     ix.n_exist_keys = 0;
     for (size_t w = 0; w < ix.h_exists.size(); ++w) ix.n_exist_keys += __builtin_popcount(ix.h_exists[w]);
-    STOCS_HIP_CHECK(hipMalloc((void**)&ix.d_bucket_start, (size_t)(ix.n_keys + 1) * 4));
-    STOCS_HIP_CHECK(hipMalloc((void**)&ix.d_pairs, (size_t)std::max<int64_t>(ix.n_pairs, 1) * 4));
-    STOCS_HIP_CHECK(hipMalloc((void**)&ix.d_exists, ix.h_exists.size() * 4));
+    STOCS_HIP_CHECK(dev_malloc((void**)&ix.d_bucket_start, (size_t)(ix.n_keys + 1) * 4));
+    STOCS_HIP_CHECK(dev_malloc((void**)&ix.d_pairs, (size_t)std::max<int64_t>(ix.n_pairs, 1) * 4));
+    STOCS_HIP_CHECK(dev_malloc((void**)&ix.d_exists, ix.h_exists.size() * 4));
     STOCS_HIP_CHECK(hipMemcpyAsync(ix.d_bucket_start, ix.h_bucket_start.data(), (size_t)(ix.n_keys + 1) * 4, hipMemcpyHostToDevice, c->stream));
     STOCS_HIP_CHECK(hipMemcpyAsync(ix.d_pairs, pairs.data(), (size_t)ix.n_pairs * 4, hipMemcpyHostToDevice, c->stream));
     STOCS_HIP_CHECK(hipMemcpyAsync(ix.d_exists, ix.h_exists.data(), ix.h_exists.size() * 4, hipMemcpyHostToDevice, c->stream));

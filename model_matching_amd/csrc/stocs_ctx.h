@@ -28,6 +28,15 @@ void set_error(const char* fmt, ...);
         }                                                                                      \
     } while (0)
 
+// Every device allocation of the library goes through here and is counted (stocs_device_alloc_count): a warm context
+// must run trial after trial without allocating, and the tests assert exactly that.
+extern unsigned long long g_dev_allocs;
+inline hipError_t dev_malloc(void** p, size_t bytes) {
+    __atomic_fetch_add(&g_dev_allocs, 1ull, __ATOMIC_RELAXED);
+    return hipMalloc(p, bytes);
+}
+template <class T> inline hipError_t dev_malloc(T** p, size_t bytes) { return dev_malloc((void**)p, bytes); }
+
 // Binds the calling thread to the context's device for the duration of an entry point and restores the
 // caller's device afterwards (a context may be driven from any thread, one thread at a time).
 struct DeviceGuard {
@@ -53,9 +62,9 @@ struct Arena {
             size_t tot = 0;
             for (size_t i = 0; i < slabs.size(); ++i) { tot += slabs[i].cap; (void)hipFree(slabs[i].p); }
             slabs.clear();
-            tot += tot / 4;   // slack: trials of one scene differ in size by tens of percent
+            tot += tot;       // slack: trials of one scene differ in size by tens of percent, and 288 GB of HBM make room cheap
             Slab sl = {NULL, tot, 0};
-            STOCS_HIP_CHECK(hipMalloc((void**)&sl.p, tot));
+            STOCS_HIP_CHECK(dev_malloc((void**)&sl.p, tot));
             slabs.push_back(sl);
         }
         for (size_t i = 0; i < slabs.size(); ++i) slabs[i].used = 0;
@@ -65,8 +74,10 @@ struct Arena {
     int reserve(size_t bytes) {
         if (slabs.size() == 1 && slabs[0].cap >= bytes) return STOCS_OK;
         destroy();
-        Slab sl = {NULL, bytes + bytes / 4, 0};
-        STOCS_HIP_CHECK(hipMalloc((void**)&sl.p, sl.cap));
+        // twice the need: a later trial of the same scene with more pair-list entries must not regrow the slab (a 0.6 GB
+        // hipFree + hipMalloc inside a trial was the 78 ms outlier of BENCH_r01's pipeline run 4)
+        Slab sl = {NULL, 2 * bytes, 0};
+        STOCS_HIP_CHECK(dev_malloc((void**)&sl.p, sl.cap));
         slabs.push_back(sl);
         return STOCS_OK;
     }
@@ -75,7 +86,7 @@ struct Arena {
         for (size_t i = 0; i < slabs.size(); ++i)
             if (slabs[i].cap - slabs[i].used >= bytes) { *out = slabs[i].p + slabs[i].used; slabs[i].used += bytes; return STOCS_OK; }
         Slab sl = {NULL, std::max<size_t>(bytes + bytes / 4, slabs.empty() ? ((size_t)64 << 20) : 2 * slabs.back().cap), 0};
-        STOCS_HIP_CHECK(hipMalloc((void**)&sl.p, sl.cap));
+        STOCS_HIP_CHECK(dev_malloc((void**)&sl.p, sl.cap));
         sl.used = bytes;
         slabs.push_back(sl);
         *out = sl.p;

@@ -240,7 +240,7 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
             if (c->d_cand) { STOCS_HIP_CHECK(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_cand); c->d_cand = NULL; }
             c->cand_cap = (int)(n + n / 4 + 1024);
             c->cand_bytes = (size_t)c->cand_cap * (16 + 16 + 1 + 1) * 4;
-            STOCS_HIP_CHECK(hipMalloc((void**)&c->d_cand, c->cand_bytes));
+            STOCS_HIP_CHECK(dev_malloc((void**)&c->d_cand, c->cand_bytes));
         }
         char* base = (char*)c->d_scratch;
         XformJob* dJ = (XformJob*)base;

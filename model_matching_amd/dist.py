@@ -27,7 +27,9 @@ def pack_best(lcp: float, global_id: int) -> int:
     """Same key as stocs_pack_best (include/stocs_hip.h): max wins, lowest id wins ties, scores <= 0
     never win.  Positive float bit patterns are order-preserving and below 2^31, so the key fits a
     signed 64-bit integer (what RCCL / gloo reduce)."""
-    bits = struct.unpack("<I", struct.pack("<f", lcp))[0] if lcp > 0 else 0
+    if not lcp > 0:
+        return 0    # "no pose" (stocs.cpp:987-998): a rank whose candidates all scored 0 must not win the reduction
+    bits = struct.unpack("<I", struct.pack("<f", lcp))[0]
     return (bits << 32) | (0xFFFFFFFF - (global_id & 0xFFFFFFFF))
 
 

@@ -21,7 +21,9 @@ def test_pack_best_matches_c_abi():
         s, i = dist.unpack_best(dist.pack_best(lcp, gid))
         assert s == np.float32(lcp) and i == gid
     assert dist.pack_best(0.5, 3) > dist.pack_best(0.5, 4) > dist.pack_best(0.4, 0)
-    assert dist.pack_best(0.0, 5) == dist.pack_best(-1.0, 5) & 0xFFFFFFFF  # zero score bits
+    # scores that are not positive pack to 0 = "no pose" on both sides (a rank whose candidates all scored 0 never wins)
+    for bad in (0.0, -1.0, float("nan")):
+        assert dist.pack_best(bad, 5) == 0 == L.stocs_pack_best(C.c_float(bad), 5)
 
 
 def test_sharding_covers_everything_once():

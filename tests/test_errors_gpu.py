@@ -122,6 +122,9 @@ def test_native_rccl_allreduce_single_rank():
     key = C.c_uint64(0)
     assert L.stocs_allreduce_best(comm, None, C.byref(key), p2.ctypes.data_as(capi._fp), 65536) == 0
     assert key.value == 0 and not p2.any()
+    # a rank whose candidates all scored 0 contributes "none", not a pose with lcp 0 (stocs.cpp:987-998)
+    assert L.stocs_pack_best(C.c_float(0.0), 17) == 0 and L.stocs_pack_best(C.c_float(-1.0), 17) == 0
+    assert L.stocs_pack_best(C.c_float(float("nan")), 17) == 0
     key = C.c_uint64(L.stocs_pack_best(C.c_float(0.5), 70000))      # id maps to rank 1 of a 1-rank job
     assert L.stocs_allreduce_best(comm, None, C.byref(key), p2.ctypes.data_as(capi._fp), 65536) == -1
     assert L.stocs_comm_destroy(comm) == 0
@@ -185,6 +188,19 @@ def test_set_scene_and_workspace_calls_reject_bad_arguments():
     # a failed call leaves the context usable with its old scene
     v, ids, inv = est.sample_bases(3, 10)
     assert len(v) == 10
+    # pixels outside the image of stocs_params are refused (instance mode indexes its 2-D maps with them), at creation and
+    # per frame; the refused call changes nothing
+    h = C.c_void_p()
+    prm = capi.default_params()
+    mp, pmp = capi.f32(m.pos); mn, pmn = capi.f32(m.nrm)
+    for bad_px in ((480, 0), (0, 640), (-1, 5), (5, -1)):
+        px = np.ascontiguousarray(s.pixel, np.int32).copy()
+        px[7] = bad_px
+        ppx = px.ctypes.data_as(capi._ip)
+        assert L.stocs_ctx_set_scene(est.h, pp, pn, ppr, ppx, len(pos)) == -1 and b"pixel" in L.stocs_last_error()
+        assert L.stocs_ctx_create(C.byref(prm), pp, pn, ppr, ppx, len(pos), pmp, pmn, len(mp), 0, -1, C.byref(h)) == -1 and not h.value
+    v1, ids1, inv1 = est.sample_bases(3, 10)
+    assert np.array_equal(v, v1) and np.array_equal(ids[v], ids1[v1])
     # pixels are optional (class mode never reads them)
     assert L.stocs_ctx_set_scene(est.h, pp, pn, ppr, None, len(pos)) == 0
     v2, ids2, inv2 = est.sample_bases(3, 10)

@@ -8,7 +8,11 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from model_matching_amd import synth  # noqa: E402
+from model_matching_amd import capi, synth  # noqa: E402
+# variants beyond 0 / 15 / 24 / 31 exist only in the measurement build (make -C model_matching_amd/csrc tools)
+_tools_lib = os.path.join(os.path.dirname(capi.LIB_PATH), "libstocs_hip_tools.so")
+if os.path.exists(_tools_lib):
+    capi.LIB_PATH = _tools_lib
 from model_matching_amd.estimator import StocsEstimator  # noqa: E402
 
 
