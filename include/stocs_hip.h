@@ -125,11 +125,19 @@ int stocs_draw(stocs_ctx* ctx, const float* w, int n, uint64_t r64, int* index);
 /* ---- congruent sets: find_congruent_sets_on_model (stocs.cpp:753-869) for every base of the base
  * set at once (per-base COUNTS; quads are produced on demand); then per-base read-back:
  * stocs_get_quads -- all quads of a base, sorted as the reference's std::set orders them (stocs.cpp:860-866);
- * stocs_get_quads_at -- the quads at given ranks of the base's emission order (the order in which the loop of
- * stocs.cpp:827-858 finds them), which is what stocs_make_transforms samples from for a base with >= max quads. ---- */
+ * stocs_get_quads_at -- the quads at given ranks of the base's WALK order: by position cell of the Q pair's query
+ * point, then index position of the Q pair, then index position of the P pair (index position of a model pair = its
+ * quantised feature, then (id1, id2)) -- the enumeration stocs_make_transforms samples from for a base with >= max
+ * quads (the reference shuffles with an unseeded generator there, so any fixed enumeration serves). ---- */
 int stocs_find_congruent_all(stocs_ctx* ctx, int64_t* total_quads);
 int stocs_get_quads(stocs_ctx* ctx, int base_slot, int32_t* quads4, int64_t cap, int64_t* n);
 int stocs_get_quads_at(stocs_ctx* ctx, int base_slot, const int64_t* ranks, int n, int32_t* quads4);
+
+/* one cone query of the normal set (normalset.hpp:166-214) evaluated on the host, for tests: the 343-bit direction-cell set
+ * from the reference's float arithmetic alone and the one the kernels build (a cheap filtered evaluation, the
+ * reference's arithmetic where the filter cannot decide; cone_cells.h); the two must be equal.  n3 = query direction. */
+int stocs_cone_cells_host(const float* n3, float cos_alpha, uint32_t* exact_bits11, uint32_t* kernel_bits11, int* n_samples,
+                          int* n_undecided);
 
 /* ---- candidate transforms: the loop stocs_match_one_object.cpp:120-147 over
  * get_rigid_transform_from_congruent_pair (stocs.cpp:871-941 -> ComputeRigidTransformation :270-361):

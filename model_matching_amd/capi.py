@@ -64,6 +64,7 @@ SIGNATURES = {
     "stocs_find_congruent_all": (C.c_int, [_vp, _i64p]),
     "stocs_get_quads": (C.c_int, [_vp, C.c_int, _ip, C.c_int64, _i64p]),
     "stocs_get_quads_at": (C.c_int, [_vp, C.c_int, _i64p, C.c_int, _ip]),
+    "stocs_cone_cells_host": (C.c_int, [_fp, C.c_float, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _intp, _intp]),
     "stocs_make_transforms": (C.c_int, [_vp, C.c_int, C.c_uint64, _intp]),
     "stocs_rigid_transform": (C.c_int, [_vp, _ip, _ip, _fp, _fp, _intp]),
     "stocs_get_candidates": (C.c_int, [_vp, _fp, _fp, _fp, _ip, C.c_int, _intp]),

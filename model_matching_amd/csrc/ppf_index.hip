@@ -160,7 +160,7 @@ int build_ppf_index(stocs_ctx* c) {
     return STOCS_OK;
 }
 
-// host-side planning shared with congruent.hip: the source buckets of lookup(K) in ascending key order
+// host-side planning shared with congruent.hip: the source buckets of lookup(K) as CSR ranges in ascending index position
 int plan_lookup(const PpfIndex& ix, const int* K, std::vector<std::pair<uint32_t, uint32_t> >* ranges) {
     ranges->clear();
     if (K[0] <= 5 || K[1] < 0 || K[2] < 0 || K[3] < 0) return 0;
@@ -179,6 +179,16 @@ int plan_lookup(const PpfIndex& ix, const int* K, std::vector<std::pair<uint32_t
                     const uint32_t s = ix.h_bucket_start[key], e = ix.h_bucket_start[key + 1];
                     if (e > s) { ranges->push_back(std::make_pair(s, e)); total += e - s; }
                 }
+    // ascending index position, adjacent buckets merged (the 4 consecutive a3 bins of a lookup are neighbours in the CSR
+    // array): the gathered list of a lookup is then in INDEX ORDER -- ascending quantised feature, then ascending
+    // (id1, id2) -- which is what the enumeration of congruent.hip is defined on
+    std::sort(ranges->begin(), ranges->end());
+    size_t w = 0;
+    for (size_t r = 0; r < ranges->size(); ++r) {
+        if (w && (*ranges)[w - 1].second == (*ranges)[r].first) (*ranges)[w - 1].second = (*ranges)[r].second;
+        else (*ranges)[w++] = (*ranges)[r];
+    }
+    ranges->resize(w);
     return (int)std::min<int64_t>(total, 0x7fffffff);
 }
 

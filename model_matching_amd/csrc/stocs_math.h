@@ -13,7 +13,7 @@
 // stocs_atan2() below -- plain + - * / on doubles, so host and device agree exactly, and it agrees
 // with glibc's double atan2 (<= 1 ulp each) unless the true angle is within ~1e-14 of an integer
 // degree.  The acos-based predicates (stocs.cpp:428-440, 1028-1032) are turned into exact float
-// thresholds on the dot product (see stocs_thresholds in stocs_host.cpp).
+// thresholds on the dot product (compute_thresholds in ctx.hip).
 #ifndef STOCS_MATH_H
 #define STOCS_MATH_H
 

@@ -172,7 +172,7 @@ class StocsEstimator:
         return n.value
 
     def get_quads_at(self, slot, ranks):
-        """Quads of base `slot` at ranks of its emission order (stocs_get_quads_at)."""
+        """Quads of base `slot` at ranks of its walk order (stocs_get_quads_at)."""
         r = np.ascontiguousarray(ranks, np.int64)
         out = np.zeros((len(r), 4), np.int32)
         capi.check(self.L.stocs_get_quads_at(self.h, slot, r.ctypes.data_as(capi._i64p), len(r), out.ctypes.data_as(capi._ip)))

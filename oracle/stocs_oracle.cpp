@@ -172,8 +172,12 @@ struct orc_index_lit {
 
 namespace {
 
-int64_t index_lookup(const orc_index* ix, const int* K, std::vector<IPair>* out) {
+// `feat` (optional) receives, parallel to `out`, the quantised feature F each pair is stored under: (F, pair) is the
+// pair's position in the product's index, which the walk-order enumeration of find_congruent sorts by.
+int64_t index_lookup(const orc_index* ix, const int* K, std::vector<IPair>* out, std::vector<std::array<int, 4> >* feat = NULL) {
     if (out) out->clear();
+    if (feat) feat->clear();
+    std::vector<std::pair<IPair, std::array<int, 4> > > both;
     const int tr = ix->tr, rot = ix->rot;
     // rgbd.cpp:136: keys with p1 <= 5 or any angle key < 0 are never stored
     if (K[0] <= 5 || K[1] < 0 || K[2] < 0 || K[3] < 0) return 0;
@@ -188,9 +192,14 @@ int64_t index_lookup(const orc_index* ix, const int* K, std::vector<IPair>* out)
                     auto it = ix->base.find(F);
                     if (it == ix->base.end()) continue;
                     total += (int64_t)it->second.size();
-                    if (out) out->insert(out->end(), it->second.begin(), it->second.end());
+                    if (out && !feat) out->insert(out->end(), it->second.begin(), it->second.end());
+                    if (out && feat) for (size_t k = 0; k < it->second.size(); ++k) both.push_back(std::make_pair(it->second[k], F));
                 }
-    if (out) std::sort(out->begin(), out->end());  // insertion order of the literal map
+    if (out && !feat) std::sort(out->begin(), out->end());  // insertion order of the literal map
+    if (out && feat) {   // same order (a pair occurs once: the pair alone decides), features alongside
+        std::sort(both.begin(), both.end());
+        for (size_t k = 0; k < both.size(); ++k) { out->push_back(both[k].first); feat->push_back(both[k].second); }
+    }
     return total;
 }
 
@@ -694,9 +703,11 @@ struct NormalSet {
 };
 
 // row 8: find_congruent_sets_on_model -- stocs.cpp:753-869
-// `seq` (optional) receives the same quads in INSERTION order -- the order in which the loop below finds
-// them (Q pairs in list order; for one Q pair the coloured direction cells ascending, each cell's P
-// entries in insertion order).  The seeded subset rule of orc_run draws from that sequence.
+// `seq` (optional) receives the same quads in WALK order: sorted by (position cell of the Q pair's query point, index
+// position of the Q pair, index position of the P pair), the index position of a model pair being (its own quantised
+// feature F, then (id1, id2)).  This enumeration exists only for the seeded subset rule of orc_run (divergence Q5: the
+// reference shuffles with the C library's unseeded generator, so any fixed enumeration serves); it is the order in
+// which the product's sort-based join meets the quads, so the product can resolve a drawn rank without writing them.
 bool find_congruent(orc_ctx* c, const int ids[4], float invariant1, float invariant2,
                     std::vector<std::array<int, 4> >* quads, std::vector<std::array<int, 4> >* seq = NULL) {
     const Pt* B[4] = {&c->scene[ids[0]], &c->scene[ids[1]], &c->scene[ids[2]], &c->scene[ids[3]]};
@@ -704,8 +715,9 @@ bool find_congruent(orc_ctx* c, const int ids[4], float invariant1, float invari
     ppf_of(*B[0], *B[1], c->prm, ppf_1);
     ppf_of(*B[2], *B[3], c->prm, ppf_2);
     std::vector<IPair> P_pairs, Q_pairs;
-    index_lookup(c->index, ppf_1, &P_pairs);
-    index_lookup(c->index, ppf_2, &Q_pairs);
+    std::vector<std::array<int, 4> > P_feat, Q_feat;
+    index_lookup(c->index, ppf_1, &P_pairs, seq ? &P_feat : NULL);
+    index_lookup(c->index, ppf_2, &Q_pairs, seq ? &Q_feat : NULL);
     quads->clear();  // (the reference clears after the early return; callers start empty anyway)
     if (seq) seq->clear();
     if (P_pairs.size() == 0 || Q_pairs.size() == 0) return false;
@@ -721,6 +733,8 @@ bool find_congruent(orc_ctx* c, const int ids[4], float invariant1, float invari
     }
     std::set<std::pair<unsigned, unsigned> > comb;
     std::vector<unsigned> nei;
+    typedef std::array<int, 13> WalkKey;   // query cell | Q feature, Q pair | P feature, P pair
+    std::vector<std::pair<WalkKey, std::array<int, 4> > > walk;
     for (unsigned i = 0; i < Q_pairs.size(); ++i) {
         const V3 p1 = c->unit_pts[Q_pairs[i].first];
         const V3 p2 = c->unit_pts[Q_pairs[i].second];
@@ -741,10 +755,16 @@ bool find_congruent(orc_ctx* c, const int ids[4], float invariant1, float invari
                 const bool fresh = comb.insert(std::make_pair((unsigned)id, i)).second;
                 if (seq && fresh) {
                     std::array<int, 4> q = {{P_pairs[id].first, P_pairs[id].second, Q_pairs[i].first, Q_pairs[i].second}};
-                    seq->push_back(q);
+                    WalkKey k = {{nset.indexPos(query), Q_feat[i][0], Q_feat[i][1], Q_feat[i][2], Q_feat[i][3], Q_pairs[i].first, Q_pairs[i].second,
+                                  P_feat[id][0], P_feat[id][1], P_feat[id][2], P_feat[id][3], P_pairs[id].first, P_pairs[id].second}};
+                    walk.push_back(std::make_pair(k, q));
                 }
             }
         }
+    }
+    if (seq) {
+        std::sort(walk.begin(), walk.end());
+        for (size_t k = 0; k < walk.size(); ++k) seq->push_back(walk[k].second);
     }
     for (auto it = comb.begin(); it != comb.end(); ++it) {
         std::array<int, 4> q = {{P_pairs[it->first].first, P_pairs[it->first].second,
@@ -1324,7 +1344,7 @@ int orc_greedy_clustering(const float* poses16, const float* lcp, int n, float a
 
 // row 19: run_stocs_estimation -- stocs_match_one_object.cpp:51-185, class mode, with the seeded
 // divergences Q5 (subset choice) and Q6 (draws).  Subset rule when a base has >= max quads:
-// partial Fisher-Yates over the base's quads in insertion order (find_congruent's `seq`) with
+// partial Fisher-Yates over the base's quads in walk order (find_congruent's `seq`) with
 // rng64(seed, 0x5E1EC7 + base_number, j); a base with fewer uses all of them in std::set order.
 int orc_run(orc_ctx* c, uint64_t seed, int number_of_bases, int maximum_congruent_sets, orc_run_result* out) {
     typedef std::chrono::high_resolution_clock clk;

@@ -129,3 +129,29 @@ def test_facade_header_compiles_with_the_reference_language_level(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)], capture_output=True, text=True)
     assert r.returncode == 0 and not r.stderr.strip(), r.stderr
+
+
+def test_cone_filter_never_disagrees_with_the_reference_arithmetic(capi):
+    """cone_cells.h: the join kernels colour direction cells with a cheap filtered evaluation and fall back to the
+    reference's float arithmetic (normalset.hpp:178-204) whenever a sample is within 5e-5 of a cell boundary.  Host
+    evaluation of both over random cone queries -- a quarter of them near the anti-parallel case, where the quaternion
+    of setFromTwoVectors is furthest from unit length: the bitsets must be identical, and the fallback must be rare."""
+    L = capi.load()
+    rng = np.random.default_rng(20261004)
+    ex, ke = (C.c_uint32 * 11)(), (C.c_uint32 * 11)()
+    ns, nu = C.c_int(), C.c_int()
+    tot = und = 0
+    for i in range(60000):
+        n = rng.normal(size=3).astype(np.float32)
+        if i % 4 == 0:
+            n[:2] *= np.float32(10.0 ** rng.uniform(-6, -1)); n[2] = -abs(n[2])
+        n /= np.linalg.norm(n)
+        assert L.stocs_cone_cells_host(n.ctypes.data_as(capi._fp), C.c_float(rng.uniform(-1, 1)), ex, ke, C.byref(ns), C.byref(nu)) == 0
+        assert list(ex) == list(ke), (n, i)
+        tot += ns.value; und += nu.value
+    assert tot > 2_000_000 and und < 1e-3 * tot
+    # alpha = 0 -> no samples (Q9); cos > 1 -> NaN alpha -> no samples
+    n = np.array([0, 0, 1], np.float32)
+    for ca in (1.0, 1.0000001):
+        assert L.stocs_cone_cells_host(n.ctypes.data_as(capi._fp), C.c_float(ca), ex, ke, C.byref(ns), C.byref(nu)) == 0
+        assert ns.value == 0 and not any(ex) and not any(ke)

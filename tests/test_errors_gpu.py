@@ -149,7 +149,7 @@ def test_on_demand_quads_edge_cases(oracle_lib):
     with pytest.raises(capi.StocsError):
         est.get_quads_at(10 ** 6, [0])
     assert est.get_quads_at(slot, []).shape == (0, 4)
-    # same rank twice is allowed, and equals the oracle's insertion sequence
+    # same rank twice is allowed, and equals the oracle's walk-order sequence
     a = int(np.nonzero(valid)[0][slot])
     so = orc.find_congruent_seq(ids[a], float(inv[a][0]), float(inv[a][1]))
     assert np.array_equal(est.get_quads_at(slot, [2, 2, 0]), so[[2, 2, 0]])

@@ -115,7 +115,7 @@ def test_phases_1_to_3_at_metric_size():
 
 def test_on_demand_quads_at_metric_size():
     """Cm: the count-only congruent pass against its own materialisation (size-independent properties, no oracle):
-    per-base counts add up; for a mid-size base the emission order is a permutation of the sorted std::set order;
+    per-base counts add up; for a mid-size base the walk order is a permutation of the sorted std::set order;
     for a big base, sampled ranks resolve to distinct members of the materialised set; the candidates of
     make_transforms come from exactly those quads."""
     m, s, est, orc = _pair("Cm")

@@ -118,7 +118,7 @@ def test_congruent_sets_and_transforms_equal_oracle(setup):
         assert qo.shape == qg.shape and np.array_equal(qo, qg), (a, qo.shape, qg.shape)
         tot_o += len(qo)
         n_nonempty += len(qo) > 0
-        # emission order (what the subset rule samples from): every rank, resolved without materialising
+        # walk order (what the subset rule samples from): every rank, resolved without materialising
         so = orc.find_congruent_seq(ids[a], float(inv[a][0]), float(inv[a][1]))
         assert len(so) == len(qo) == est.num_quads(slot)
         if len(so):
@@ -143,11 +143,11 @@ def test_congruent_sets_and_transforms_equal_oracle(setup):
     assert okg == oko == False
 
 
-def test_two_sort_path_of_the_p_entries(setup, monkeypatch):
-    """Big position grids do not fit the one-sort key of the P entries; the general path (list-order sort, then a
-    stable cell sort) must give the same quads in the same orders."""
+def test_wide_key_path_of_the_pair_lists(setup, monkeypatch):
+    """Position grids beyond 32 bits of (base, cell) take 64-bit sort keys; that path (forced here) must give the same
+    quads in the same orders."""
     m, s, est, orc = setup
-    monkeypatch.setenv("STOCS_P_TWO_SORTS", "1")
+    monkeypatch.setenv("STOCS_CONGRUENT_WIDE_KEYS", "1")
     est.L.stocs_clear_bases(est.h)
     valid, ids, inv = est.sample_bases(99, 24)
     est.find_congruent_all()
