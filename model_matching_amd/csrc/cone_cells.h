@@ -101,9 +101,10 @@ STOCS_HD int cone_cell_filtered(const ConeFilter& f, float dx, float dy) {
     const float fx = floorf(tx), fy = floorf(ty), fz = floorf(tz);
     const float rx = tx - fx, ry = ty - fy, rz = tz - fz;
     const float lo = fminf(rx, fminf(ry, rz)), hi = fmaxf(rx, fmaxf(ry, rz));
-    // every comparison is false for a NaN, so non-finite samples take the exact path
-    const bool certain = lo > STOCS_CONE_MARGIN && hi < 1.0f - STOCS_CONE_MARGIN && fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx <= 6.0f &&
-                         fy <= 6.0f && fz <= 6.0f;
+    // t = s (v/|v| + 1) lies in [-1e-6, 2 s + 1e-6] = [-1e-6, 6.99952]: a coordinate below 0 has a fractional part just under
+    // 1 and fails the `hi` test, so a certain sample has every cell coordinate in 0..6.  Every comparison is false for a
+    // NaN, so non-finite samples take the exact path.
+    const bool certain = lo > STOCS_CONE_MARGIN && hi < 1.0f - STOCS_CONE_MARGIN;
     return certain ? (int)fz * 49 + ((int)fy * 7 + (int)fx) : -1;
 }
 

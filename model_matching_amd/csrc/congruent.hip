@@ -59,8 +59,10 @@ struct Segment { uint32_t src, len, dst, base; };
 __device__ __forceinline__ V3 ld3c(const float4* a, int i) { const float4 v = a[i]; return mk3(v.x, v.y, v.z); }
 
 // normalset.h:97-104 + utils.h:139-148: int truncation of coord/epsilon, x fastest
+// (cell = 1 / eg with eg a power of two, normalset.h:117-119: dividing by it and multiplying by eg are the same float)
 __device__ __forceinline__ int64_t index_pos(V3 p, float cell, int eg) {
-    const V3 cp = p / cell;
+    (void)cell;
+    const V3 cp = p * (float)eg;
     return (int64_t)(int)cp.z * eg * eg + ((int64_t)(int)cp.y * eg + (int64_t)(int)cp.x);
 }
 
@@ -72,14 +74,19 @@ template <class KeyT>
 __global__ __launch_bounds__(256) void gather_key_kernel(const uint32_t* __restrict__ pairs, const Segment* __restrict__ segs, int nseg, uint32_t total,
                                                          const BaseJob* __restrict__ jobs, const float4* __restrict__ munit, int is_q, int cell_bits,
                                                          long long cell_limit, KeyT* __restrict__ keys, uint32_t* __restrict__ vals) {
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    int lo = 0, hi = nseg - 1;  // last segment with dst <= e
+    // segment of the workgroup's first entry: one uniform binary search (scalar loads); a segment holds thousands of
+    // entries, so the lanes then step forward zero or one segment
+    const uint32_t e0 = blockIdx.x * blockDim.x;
+    int lo = 0, hi = nseg - 1;  // last segment with dst <= e0
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (segs[mid].dst <= e) lo = mid; else hi = mid - 1;
+        if (segs[mid].dst <= e0) lo = mid; else hi = mid - 1;
     }
-    const Segment sg = segs[lo];
+    const uint32_t e = e0 + threadIdx.x;
+    if (e >= total) return;
+    int sgi = lo;
+    while (sgi + 1 < nseg && segs[sgi + 1].dst <= e) ++sgi;
+    const Segment sg = segs[sgi];
     const uint32_t pr = pairs[sg.src + (e - sg.dst)];
     const BaseJob& J = jobs[sg.base];
     const V3 p1 = ld3c(munit, pr >> 16), p2 = ld3c(munit, pr & 0xFFFF);
@@ -156,17 +163,29 @@ __device__ __forceinline__ void p_run(const JoinArgs<KeyT>& A, const BaseJob& J,
     *hi = J.p_off + l;
 }
 
+// Cone tables of the bases a workgroup's Q entries belong to, staged in LDS: the (x, y) components of a base's samples
+// (z = cos alpha is folded into the filter).  A workgroup's 256 consecutive entries of the (base, cell)-sorted list
+// belong to one base, seldom two; entries of a base beyond JOIN_LDS_BASES read the table from global memory.
+#define JOIN_LDS_BASES 2
+struct JoinLds {
+    uint32_t seen[256][11];                          // 343-bit direction-cell set per lane (11 is odd: no bank conflicts)
+    float2 dirs[JOIN_LDS_BASES][STOCS_MAX_CONE];
+};
+
 // The join of ONE Q entry against the P entries of its position cell: stocs.cpp:827-858 + normalset.hpp:166-214.
 //   MODE 0: count;  MODE 1: write every match to out[0..] (walk order).
+// b0 = base of the workgroup's first entry (its table is lds.dirs[0], the next base's lds.dirs[1]).
 template <int MODE, class KeyT>
-__device__ __forceinline__ uint32_t join_one(const JoinArgs<KeyT>& A, uint32_t i, uint32_t* my, uint64_t* __restrict__ out) {
+__device__ __forceinline__ uint32_t join_one(const JoinArgs<KeyT>& A, uint32_t i, JoinLds& lds, uint32_t b0, uint64_t* __restrict__ out) {
+    uint32_t* my = lds.seen[threadIdx.x];
     const KeyT key = A.qkeys[i];
     const KeyT cmask = ((KeyT)1 << A.cell_bits) - (KeyT)1;
     const KeyT pc = key & cmask;
     if (pc == cmask) return 0;
     const uint32_t b = (uint32_t)(key >> A.cell_bits);
     const BaseJob& J = A.jobs[b];
-    if (J.p_len == 0 || J.nb == 0) return 0;
+    const int nb = J.nb;
+    if (J.p_len == 0 || nb == 0) return 0;
     uint32_t lo, hi;
     p_run(A, J, b, key, pc, &lo, &hi);
     if (lo >= hi) return 0;
@@ -181,23 +200,34 @@ __device__ __forceinline__ uint32_t join_one(const JoinArgs<KeyT>& A, uint32_t i
     for (int k = 0; k < 11; ++k) my[k] = 0;
     float q[4];
     quat_from_z(queryn, q);
-    const ConeFilter cf = cone_filter_setup(q, J.cos_alpha, A.half_inv_neps);
-    for (int a = 0; a < J.nb; ++a) {
-        const float dx = J.dirs[a][0], dy = J.dirs[a][1];
+    const float dz = J.cos_alpha;
+    const ConeFilter cf = cone_filter_setup(q, dz, A.half_inv_neps);
+    auto colour = [&](float dx, float dy) {
         int id = cone_cell_filtered(cf, dx, dy);
         if (id < 0) {   // within 5e-5 of a cell boundary (or not finite): the reference's own arithmetic decides
-            id = cone_cell_exact(q, mk3(dx, dy, J.dirs[a][2]), A.nepsilon);
-            if (id < 0) continue;  // std::array::at would throw (NaN direction)
+            id = cone_cell_exact(q, mk3(dx, dy, dz), A.nepsilon);
+            if (id < 0) return;  // std::array::at would throw (NaN direction)
         }
-        my[id >> 5] |= 1u << (id & 31);
+        // this lane's own words; the no-return LDS atomic is one instruction and needs no wait
+        __hip_atomic_fetch_or(&my[id >> 5], 1u << (id & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    };
+    if (b - b0 < (uint32_t)JOIN_LDS_BASES) {   // the sample after this one is read while this one is evaluated
+        const float2* tab = lds.dirs[b - b0];
+        float2 d = tab[0];
+        for (int a = 0; a < nb; ++a) {
+            const float2 dn = tab[a + 1 < nb ? a + 1 : a];
+            colour(d.x, d.y);
+            d = dn;
+        }
+    } else {
+        for (int a = 0; a < nb; ++a) colour(J.dirs[a][0], J.dirs[a][1]);
     }
-    // one linear pass over the position cell's P entries against the direction bitset
+    // one linear pass over the position cell's P entries against the direction bitset, four records in flight
     uint32_t local = 0;
     const int id_bits = A.id_bits;
-    for (uint32_t k = lo; k < hi; ++k) {
-        const float4 r = A.prec[k];
+    auto test = [&](const float4& r, uint32_t k) {
         const uint32_t dc = (uint32_t)__float_as_int(r.w);
-        if (dc >= 343u || !((my[dc >> 5] >> (dc & 31)) & 1u)) continue;
+        if (dc >= 343u || !((my[dc >> 5] >> (dc & 31)) & 1u)) return;
         if (sqn3(queryQ - mk3(r.x, r.y, r.z)) <= A.dist_thr) {  // squared metres vs metres (Q1), reproduced
             if (MODE == 1) {   // sort key: base, then (P.first, P.second, Q.first, Q.second) == the std::set order
                 const uint32_t pr = A.pvals[k];
@@ -207,8 +237,28 @@ __device__ __forceinline__ uint32_t join_one(const JoinArgs<KeyT>& A, uint32_t i
             }
             local++;
         }
+    };
+    uint32_t k = lo;
+    for (; k + 4 <= hi; k += 4) {
+        const float4 r0 = A.prec[k], r1 = A.prec[k + 1], r2 = A.prec[k + 2], r3 = A.prec[k + 3];
+        test(r0, k); test(r1, k + 1); test(r2, k + 2); test(r3, k + 3);
     }
+    for (; k < hi; ++k) test(A.prec[k], k);
     return local;
+}
+
+// workgroup prologue of the join kernels: cone tables of the first JOIN_LDS_BASES bases of the workgroup's entries
+template <class KeyT>
+__device__ __forceinline__ uint32_t join_stage_tables(const JoinArgs<KeyT>& A, JoinLds& lds) {
+    const uint32_t i0 = blockIdx.x * blockDim.x;
+    const uint32_t b0 = (uint32_t)(A.qkeys[i0] >> A.cell_bits);   // i0 < totQ for every launched workgroup
+    for (int t = threadIdx.x; t < JOIN_LDS_BASES * STOCS_MAX_CONE; t += blockDim.x) {
+        const uint32_t b = b0 + (uint32_t)(t / STOCS_MAX_CONE);
+        const int a = t % STOCS_MAX_CONE;
+        lds.dirs[t / STOCS_MAX_CONE][a] = b < (uint32_t)A.nB ? make_float2(A.jobs[b].dirs[a][0], A.jobs[b].dirs[a][1]) : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    return b0;
 }
 
 // per-base totals: the scanned count at the first Q entry of every base (one small copy instead of one per base)
@@ -221,11 +271,12 @@ __global__ __launch_bounds__(256) void base_offsets_kernel(const unsigned long l
 // count pass, one lane per Q entry in (base, position cell) order
 template <class KeyT>
 __global__ __launch_bounds__(256) void join_count_kernel(JoinArgs<KeyT> A, unsigned long long* __restrict__ qcnt) {
-    __shared__ uint32_t seen[256][11];  // 343-bit set per lane
+    __shared__ JoinLds lds;
+    const uint32_t b0 = join_stage_tables(A, lds);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.totQ) return;
     if (i == 0) qcnt[A.totQ] = 0;   // the scan runs over totQ + 1 entries so that its last output is the total
-    qcnt[i] = join_one<0>(A, i, seen[threadIdx.x], (uint64_t*)NULL);
+    qcnt[i] = join_one<0>(A, i, lds, b0, (uint64_t*)NULL);
 }
 
 // fill pass for the bases whose out_base is not ~0: destinations from the exclusive scan of the counts (no atomics);
@@ -233,7 +284,8 @@ __global__ __launch_bounds__(256) void join_count_kernel(JoinArgs<KeyT> A, unsig
 template <class KeyT>
 __global__ __launch_bounds__(256) void join_fill_kernel(JoinArgs<KeyT> A, const unsigned long long* __restrict__ qoffe,
                                                         const unsigned long long* __restrict__ out_base, uint64_t* __restrict__ quads) {
-    __shared__ uint32_t seen[256][11];
+    __shared__ JoinLds lds;
+    const uint32_t b0 = join_stage_tables(A, lds);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.totQ) return;
     const uint32_t b = (uint32_t)(A.qkeys[i] >> A.cell_bits);
@@ -241,7 +293,7 @@ __global__ __launch_bounds__(256) void join_fill_kernel(JoinArgs<KeyT> A, const 
     if (ob == ~0ull) return;
     const unsigned long long o0 = qoffe[i];
     if (qoffe[i + 1] == o0) return;
-    join_one<1>(A, i, seen[threadIdx.x], quads + ob + (o0 - qoffe[A.q_off[b]]));
+    join_one<1>(A, i, lds, b0, quads + ob + (o0 - qoffe[A.q_off[b]]));
 }
 
 struct XformJobC { int32_t s[4]; int32_t q[4]; };
@@ -382,6 +434,11 @@ struct CongruentState {
     DevBuf<unsigned long long> d_qoffe;
     DevBuf<int32_t> d_bids;
     DevBuf<unsigned int> d_err;   // picks resolve_picks_kernel could not resolve (internal consistency check)
+    // host sources of asynchronous uploads issued by materialise / make_jobs: kept here so that they outlive the copy
+    // (those calls return without synchronising; the caller's own synchronisation point comes before the next reuse)
+    std::vector<unsigned long long> h_out_base, h_off;
+    void* h_stage = NULL;         // pinned staging of the per-trial tables (one upload per trial)
+    size_t stage_bytes = 0;
     template <class KeyT>
     JoinArgs<KeyT> args(const stocs_ctx* c) const {
         JoinArgs<KeyT> A;
@@ -399,7 +456,8 @@ struct CongruentState {
 template <class KeyT>
 static int materialise_t(stocs_ctx* c, CongruentState* S, const std::vector<char>& sel, DevBuf<uint64_t>* out, std::vector<unsigned long long>* off) {
     const int nB = S->nB;
-    std::vector<unsigned long long> out_base(nB, ~0ull);
+    std::vector<unsigned long long>& out_base = S->h_out_base;
+    out_base.assign(nB, ~0ull);
     off->assign(nB + 1, 0);
     unsigned long long tot = 0;
     for (int b = 0; b < nB; ++b) {
@@ -421,25 +479,37 @@ static int materialise_t(stocs_ctx* c, CongruentState* S, const std::vector<char
     STOCS_HIP_CHECK(rocprim::radix_sort_keys(NULL, tmp, d_raw.p, out->p, (size_t)tot, 0, end_bit, st));
     if ((rc = d_tmp.alloc(tmp))) return rc;
     STOCS_HIP_CHECK(rocprim::radix_sort_keys(d_tmp.p, tmp, d_raw.p, out->p, (size_t)tot, 0, end_bit, st));
-    STOCS_HIP_CHECK(hipStreamSynchronize(st));   // the temporaries die with this scope
+    // no synchronisation: the temporaries are arena memory, recycled only by a later call's reset, and every later use is
+    // ordered behind this work on the context's stream (out_base was copied from pageable memory: staged by the runtime
+    // before hipMemcpyAsync returned)
     return STOCS_OK;
 }
 static int materialise(stocs_ctx* c, CongruentState* S, const std::vector<char>& sel, DevBuf<uint64_t>* out, std::vector<unsigned long long>* off) {
     return S->wide ? materialise_t<uint64_t>(c, S, sel, out, off) : materialise_t<uint32_t>(c, S, sel, out, off);
 }
 
-// cone sample table of a base: normalset.hpp:178-190 (float libm calls on per-base scalars: exactly the reference's values)
+// cone sample table of a base: normalset.hpp:178-190 (float libm calls on per-base scalars: exactly the reference's values).
+// theta_a = a * angleStep depends on the sample count alone, so cosf / sinf of it are computed once per count.
 static void fill_cone_table(BaseJob* J) {
+    static thread_local float trig[STOCS_MAX_CONE + 1][STOCS_MAX_CONE][2];
+    static thread_local bool have[STOCS_MAX_CONE + 1] = {false};
     const float alpha = acosf(J->cos_alpha);
     const float perimeter = (float)((double)2.0f * M_PI * (double)atanf(alpha));  // sic (Q10)
     const unsigned nb = (unsigned)(2 * ceilf(perimeter * 7.0f / 2.0f));
-    const float angleStep = (float)((double)2.0f * M_PI / (double)(float)nb);
     const float sinAlpha = sinf(alpha);
     J->nb = (nb > STOCS_MAX_CONE || !(alpha == alpha)) ? 0 : (int)nb;  // nb <= 56 for any alpha in [0, pi]; NaN alpha -> no samples
+    if (J->nb && !have[J->nb]) {
+        const float angleStep = (float)((double)2.0f * M_PI / (double)(float)nb);
+        for (int a = 0; a < J->nb; ++a) {
+            const float theta = (float)a * angleStep;
+            trig[J->nb][a][0] = cosf(theta);
+            trig[J->nb][a][1] = sinf(theta);
+        }
+        have[J->nb] = true;
+    }
     for (int a = 0; a < J->nb; ++a) {
-        const float theta = (float)a * angleStep;
-        J->dirs[a][0] = sinAlpha * cosf(theta);
-        J->dirs[a][1] = sinAlpha * sinf(theta);
+        J->dirs[a][0] = sinAlpha * trig[J->nb][a][0];
+        J->dirs[a][1] = sinAlpha * trig[J->nb][a][1];
         J->dirs[a][2] = J->cos_alpha;
     }
 }
@@ -459,29 +529,48 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const std::vector<Segment
     const int nB = S->nB;
     const size_t totP = S->totP, totQ = S->totQ;
     hipStream_t st = c->stream;
-    DevBuf<Segment> d_psegs, d_qsegs;
     DevBuf<KeyT> d_pk_raw, d_qk_raw;
     DevBuf<uint32_t> d_pv_raw, d_qv_raw;
-    DevBuf<char> d_tmp;
+    DevBuf<char> d_tmp, d_up;
     int rc;
-    if ((rc = S->d_jobs.alloc(nB)) || (rc = d_psegs.alloc(psegs.size())) || (rc = d_qsegs.alloc(qsegs.size())) || (rc = S->d_qoff.alloc(nB + 1)) ||
+    // the per-trial tables travel in ONE copy from pinned memory: jobs | P segments | Q segments | q_off | base ids | error word
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_jobs = 0, o_pseg = o_jobs + al(sizeof(BaseJob) * nB), o_qseg = o_pseg + al(sizeof(Segment) * psegs.size()),
+                 o_qoff = o_qseg + al(sizeof(Segment) * qsegs.size()), o_bids = o_qoff + al(4 * (size_t)(nB + 1)), o_err = o_bids + al(16 * (size_t)nB),
+                 up_bytes = o_err + 256;
+    if (S->stage_bytes < up_bytes) {
+        if (S->h_stage) (void)hipHostFree(S->h_stage);
+        S->h_stage = NULL; S->stage_bytes = 0;
+        STOCS_HIP_CHECK(hipHostMalloc(&S->h_stage, 2 * up_bytes, hipHostMallocDefault));
+        S->stage_bytes = 2 * up_bytes;
+    }
+    if ((rc = d_up.alloc(up_bytes)) ||
         (rc = d_pk_raw.alloc(totP)) || (rc = d_pv_raw.alloc(totP)) || (rc = d_qk_raw.alloc(totQ)) || (rc = d_qv_raw.alloc(totQ)) ||
         (rc = S->d_pkeys.alloc(totP * sizeof(KeyT))) || (rc = S->d_pvals.alloc(totP)) || (rc = S->d_qkeys.alloc(totQ * sizeof(KeyT))) || (rc = S->d_qvals.alloc(totQ)) ||
-        (rc = S->d_prec.alloc(totP)) || (rc = S->d_bids.alloc((size_t)nB * 4)) || (rc = S->d_err.alloc(1)))
+        (rc = S->d_prec.alloc(totP)))
         return rc;
-    hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(256), 0, st, S->d_err.p, (size_t)1, (uint32_t*)NULL);
-    std::vector<int32_t> bids((size_t)nB * 4);
-    for (int b = 0; b < nB; ++b) for (int k = 0; k < 4; ++k) bids[4 * b + k] = c->bases[b].ids[k];
-    STOCS_HIP_CHECK(hipMemcpyAsync(S->d_bids.p, bids.data(), 16 * (size_t)nB, hipMemcpyHostToDevice, st));
-    STOCS_HIP_CHECK(hipMemcpyAsync(S->d_jobs.p, jobs.data(), sizeof(BaseJob) * nB, hipMemcpyHostToDevice, st));
-    STOCS_HIP_CHECK(hipMemcpyAsync(d_psegs.p, psegs.data(), sizeof(Segment) * psegs.size(), hipMemcpyHostToDevice, st));
-    STOCS_HIP_CHECK(hipMemcpyAsync(d_qsegs.p, qsegs.data(), sizeof(Segment) * qsegs.size(), hipMemcpyHostToDevice, st));
-    STOCS_HIP_CHECK(hipMemcpyAsync(S->d_qoff.p, q_off.data(), 4 * (nB + 1), hipMemcpyHostToDevice, st));
+    {
+        char* h = (char*)S->h_stage;
+        memcpy(h + o_jobs, jobs.data(), sizeof(BaseJob) * nB);
+        memcpy(h + o_pseg, psegs.data(), sizeof(Segment) * psegs.size());
+        memcpy(h + o_qseg, qsegs.data(), sizeof(Segment) * qsegs.size());
+        memcpy(h + o_qoff, q_off.data(), 4 * (size_t)(nB + 1));
+        int32_t* bids = (int32_t*)(h + o_bids);
+        for (int b = 0; b < nB; ++b) for (int k = 0; k < 4; ++k) bids[4 * b + k] = c->bases[b].ids[k];
+        memset(h + o_err, 0, 256);
+        STOCS_HIP_CHECK(hipMemcpyAsync(d_up.p, h, up_bytes, hipMemcpyHostToDevice, st));
+    }
+    S->d_jobs.p = (BaseJob*)(d_up.p + o_jobs);
+    const Segment* d_psegs = (const Segment*)(d_up.p + o_pseg);
+    const Segment* d_qsegs = (const Segment*)(d_up.p + o_qseg);
+    S->d_qoff.p = (uint32_t*)(d_up.p + o_qoff);
+    S->d_bids.p = (int32_t*)(d_up.p + o_bids);
+    S->d_err.p = (unsigned int*)(d_up.p + o_err);
     const PpfIndex& ix = c->index;
     const long long cell_limit = S->use_table ? S->NC : ((long long)1 << 31);
-    hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, ix.d_pairs, d_psegs.p, (int)psegs.size(), (uint32_t)totP,
+    hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, ix.d_pairs, d_psegs, (int)psegs.size(), (uint32_t)totP,
                        S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p);
-    hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totQ + 255) / 256)), dim3(256), 0, st, ix.d_pairs, d_qsegs.p, (int)qsegs.size(), (uint32_t)totQ,
+    hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totQ + 255) / 256)), dim3(256), 0, st, ix.d_pairs, d_qsegs, (int)qsegs.size(), (uint32_t)totQ,
                        S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p);
     STOCS_HIP_CHECK(hipGetLastError());
     // one stable sort per list: (base, position cell); inside a cell the entries keep the index order of the gather
@@ -536,6 +625,7 @@ void stocs_internal_free_congruent(stocs_ctx* c) {   // stocs_ctx_destroy: nothi
     if (c && c->cong) {
         CongruentState* S = (CongruentState*)c->cong;
         S->arena_state.destroy(); S->arena_tmp.destroy();
+        if (S->h_stage) (void)hipHostFree(S->h_stage);
         delete S;
         c->cong = NULL;
     }
@@ -605,15 +695,26 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     const float nepsilon = (float)((double)(1.0f / 7.0f) + 0.00001);  // normalset.h:86
     uint64_t totP = 0, totQ = 0;
     std::vector<std::pair<uint32_t, uint32_t> > pr, qr;
+    // the two PPF keys of every base first, touching the index's bucket table ahead of the planning loop: a lookup probes
+    // 32 lines of a ~10 MB host array, and the host would otherwise wait for them one after the other
+    std::vector<int> keys8((size_t)nB * 8);
+    for (int b = 0; b < nB; ++b) {
+        const BaseRec& B = c->bases[b];
+        int* K1 = &keys8[(size_t)b * 8];
+        int* K2 = K1 + 4;
+        ppf_compute(c->h_spos[B.ids[0]], c->h_snrm[B.ids[0]], c->h_spos[B.ids[1]], c->h_snrm[B.ids[1]], ix.tr, ix.rot, K1);  // stocs.cpp:771
+        ppf_compute(c->h_spos[B.ids[2]], c->h_snrm[B.ids[2]], c->h_spos[B.ids[3]], c->h_snrm[B.ids[3]], ix.tr, ix.rot, K2);  // stocs.cpp:772
+        prefetch_lookup(ix, K1);
+        prefetch_lookup(ix, K2);
+    }
     for (int b = 0; b < nB; ++b) {
         const BaseRec& B = c->bases[b];
         BaseJob& J = jobs[b];
         memset(&J, 0, sizeof(J));
         J.inv1 = B.inv1; J.inv2 = B.inv2;
         J.cell = cell; J.egSize = egSize;
-        int K1[4], K2[4];
-        ppf_compute(c->h_spos[B.ids[0]], c->h_snrm[B.ids[0]], c->h_spos[B.ids[1]], c->h_snrm[B.ids[1]], ix.tr, ix.rot, K1);  // stocs.cpp:771
-        ppf_compute(c->h_spos[B.ids[2]], c->h_snrm[B.ids[2]], c->h_spos[B.ids[3]], c->h_snrm[B.ids[3]], ix.tr, ix.rot, K2);  // stocs.cpp:772
+        const int* K1 = &keys8[(size_t)b * 8];
+        const int* K2 = K1 + 4;
         plan_lookup(ix, K1, &pr);
         plan_lookup(ix, K2, &qr);
         uint64_t np = 0, nq = 0;
@@ -747,7 +848,10 @@ int stocs_get_quads_at(stocs_ctx* c, int slot, const int64_t* ranks, int n, int3
 
 // device side of stocs_make_transforms: picks4 = (base, rank, destination job, sorted?) records -> XformJob records
 // on the device.  Bases picked with sorted != 0 are materialised and sorted first (they are the small ones).
-int stocs_internal_make_jobs(stocs_ctx* c, const int32_t* picks4_host, int n, void* d_jobs_out) {
+// *d_unresolved_out: device counter of the picks the kernel could not resolve (0 while counts and join agree); the
+// caller reads it behind its own synchronisation point, this call does not wait for the device
+int stocs_internal_make_jobs(stocs_ctx* c, const int32_t* picks4_host, int n, void* d_jobs_out, const unsigned int** d_unresolved_out) {
+    if (d_unresolved_out) *d_unresolved_out = NULL;
     if (n <= 0) return STOCS_OK;
     CongruentState* S = (CongruentState*)c->cong;
     if (!S || !S->valid) { set_error("stocs_make_transforms: no congruent state (call stocs_find_congruent_all first)"); return STOCS_ERR_STATE; }
@@ -758,7 +862,7 @@ int stocs_internal_make_jobs(stocs_ctx* c, const int32_t* picks4_host, int n, vo
     bool any_sorted = false;
     for (int i = 0; i < n; ++i) if (picks[i].sorted) { sel[picks[i].base] = 1; any_sorted = true; }
     DevBuf<uint64_t> d_sorted; DevBuf<unsigned long long> d_soff; DevBuf<Pick> d_picks;
-    std::vector<unsigned long long> off;
+    std::vector<unsigned long long>& off = S->h_off;
     int rc;
     if (any_sorted) {
         if ((rc = materialise(c, S, sel, &d_sorted, &off)) || (rc = d_soff.alloc(off.size()))) return rc;
@@ -773,10 +877,7 @@ int stocs_internal_make_jobs(stocs_ctx* c, const int32_t* picks4_host, int n, vo
         hipLaunchKernelGGL(resolve_picks_kernel<uint32_t>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, S->args<uint32_t>(c), S->d_qoffe.p, d_picks.p, n, d_sorted.p,
                            d_soff.p, S->d_bids.p, (XformJobC*)d_jobs_out, (uint64_t*)NULL, S->d_err.p);
     STOCS_HIP_CHECK(hipGetLastError());
-    unsigned int n_err = 0;
-    STOCS_HIP_CHECK(hipMemcpyAsync(&n_err, S->d_err.p, 4, hipMemcpyDeviceToHost, c->stream));
-    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
-    if (n_err) { set_error("stocs_make_transforms: %u picks could not be resolved (internal inconsistency)", n_err); return STOCS_ERR_STATE; }
+    if (d_unresolved_out) *d_unresolved_out = S->d_err.p;
     return STOCS_OK;
 }
 

@@ -166,30 +166,43 @@ int plan_lookup(const PpfIndex& ix, const int* K, std::vector<std::pair<uint32_t
     if (K[0] <= 5 || K[1] < 0 || K[2] < 0 || K[3] < 0) return 0;
     if (K[0] % ix.tr || K[1] % ix.rot || K[2] % ix.rot || K[3] % ix.rot) return 0;
     int64_t total = 0;
+    // F = K - o, o0 in {-tr,0}, ok in {-2rot,-rot,0,rot}, visited in ASCENDING key order (every F component ascending), so
+    // the ranges come out in ascending index position; adjacent buckets are merged on the fly (the 4 consecutive a3 bins of
+    // a lookup are neighbours in the CSR array).  The gathered list of a lookup is then in INDEX ORDER -- ascending
+    // quantised feature, then ascending (id1, id2) -- which is what the enumeration of congruent.hip is defined on.
     for (int a = 0; a < 2; ++a)
-        for (int b = 0; b < 4; ++b)
-            for (int cc = 0; cc < 4; ++cc)
-                for (int d = 0; d < 4; ++d) {
-                    // F = K - o, o0 in {-tr,0}, ok in {-2rot,-rot,0,rot}
+        for (int b = 3; b >= 0; --b)
+            for (int cc = 3; cc >= 0; --cc)
+                for (int d = 3; d >= 0; --d) {
                     const int F0 = K[0] + a * ix.tr, F1 = K[1] + (2 - b) * ix.rot, F2 = K[2] + (2 - cc) * ix.rot, F3 = K[3] + (2 - d) * ix.rot;
                     if (F1 < 0 || F2 < 0 || F3 < 0) continue;
                     const int fd = F0 / ix.tr, f1 = F1 / ix.rot, f2 = F2 / ix.rot, f3 = F3 / ix.rot;
                     if (fd >= ix.nD || f1 >= ix.NA || f2 >= ix.NA || f3 >= ix.NA) continue;
                     const uint32_t key = ppf_pack(fd, f1, f2, f3, ix.NA);
                     const uint32_t s = ix.h_bucket_start[key], e = ix.h_bucket_start[key + 1];
-                    if (e > s) { ranges->push_back(std::make_pair(s, e)); total += e - s; }
+                    if (e <= s) continue;
+                    total += e - s;
+                    if (!ranges->empty() && ranges->back().second == s) ranges->back().second = e;
+                    else ranges->push_back(std::make_pair(s, e));
                 }
-    // ascending index position, adjacent buckets merged (the 4 consecutive a3 bins of a lookup are neighbours in the CSR
-    // array): the gathered list of a lookup is then in INDEX ORDER -- ascending quantised feature, then ascending
-    // (id1, id2) -- which is what the enumeration of congruent.hip is defined on
-    std::sort(ranges->begin(), ranges->end());
-    size_t w = 0;
-    for (size_t r = 0; r < ranges->size(); ++r) {
-        if (w && (*ranges)[w - 1].second == (*ranges)[r].first) (*ranges)[w - 1].second = (*ranges)[r].second;
-        else (*ranges)[w++] = (*ranges)[r];
-    }
-    ranges->resize(w);
     return (int)std::min<int64_t>(total, 0x7fffffff);
+}
+
+// touches the lines of the bucket table that plan_lookup(K) will read (the 4 a3 bins of a probe share a line or two)
+void prefetch_lookup(const PpfIndex& ix, const int* K) {
+    if (K[0] <= 5 || K[1] < 0 || K[2] < 0 || K[3] < 0) return;
+    if (K[0] % ix.tr || K[1] % ix.rot || K[2] % ix.rot || K[3] % ix.rot) return;
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 4; ++b)
+            for (int cc = 0; cc < 4; ++cc) {
+                const int F0 = K[0] + a * ix.tr, F1 = K[1] + (2 - b) * ix.rot, F2 = K[2] + (2 - cc) * ix.rot, F3 = K[3] - ix.rot;
+                if (F1 < 0 || F2 < 0) continue;
+                const int fd = F0 / ix.tr, f1 = F1 / ix.rot, f2 = F2 / ix.rot, f3 = F3 < 0 ? 0 : F3 / ix.rot;
+                if (fd >= ix.nD || f1 >= ix.NA || f2 >= ix.NA || f3 >= ix.NA) continue;
+                const uint32_t* p = &ix.h_bucket_start[ppf_pack(fd, f1, f2, f3, ix.NA)];
+                __builtin_prefetch(p);
+                __builtin_prefetch(p + 4);
+            }
 }
 
 }  // namespace stocs

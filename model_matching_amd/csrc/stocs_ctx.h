@@ -238,10 +238,11 @@ int ensure_scratch(stocs_ctx* c, size_t bytes);
 int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d_hit, uint8_t* d_counted);
 int build_ppf_index(stocs_ctx* c);
 int build_grid_gpu(stocs_ctx* c, int div, int dense);
-extern "C" int stocs_internal_make_jobs(stocs_ctx* c, const int32_t* picks4_host, int n, void* d_jobs_out);
+extern "C" int stocs_internal_make_jobs(stocs_ctx* c, const int32_t* picks4_host, int n, void* d_jobs_out, const unsigned int** d_unresolved_out);
 extern "C" void stocs_internal_free_congruent(stocs_ctx* c);
 extern "C" void stocs_internal_invalidate_congruent(stocs_ctx* c);
 int plan_lookup(const PpfIndex& ix, const int* K, std::vector<std::pair<uint32_t, uint32_t> >* ranges);
+void prefetch_lookup(const PpfIndex& ix, const int* K);
 void compute_thresholds(const stocs_params& prm, Thresholds* t);
 }  // namespace stocs
 

@@ -250,7 +250,8 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
         int32_t* dPos = (int32_t*)(base + jb + 2 * tb + ob);   // their exclusive scan; dPos[n] = accepted count
         int32_t* dB = (int32_t*)(base + jb + 2 * tb + 2 * ob);
         void* dTmp = base + jb + 2 * tb + 3 * ob;
-        rc = stocs_internal_make_jobs(c, picks.data(), (int)n, dJ);
+        const unsigned int* d_unresolved = NULL;
+        rc = stocs_internal_make_jobs(c, picks.data(), (int)n, dJ, &d_unresolved);
         if (rc) return rc;
         tick("resolve picks");
         STOCS_HIP_CHECK(hipMemcpyAsync(dB, job_base.data(), n * 4, hipMemcpyHostToDevice, c->stream));
@@ -263,8 +264,11 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
                            (int)n, (float4*)cand_T(c), (float4*)cand_P(c), cand_lcp(c), cand_base(c));
         STOCS_HIP_CHECK(hipGetLastError());
         int32_t n_ok = 0;
+        unsigned int n_unresolved = 0;
         STOCS_HIP_CHECK(hipMemcpyAsync(&n_ok, dPos + n, 4, hipMemcpyDeviceToHost, c->stream));
-        STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (d_unresolved) STOCS_HIP_CHECK(hipMemcpyAsync(&n_unresolved, d_unresolved, 4, hipMemcpyDeviceToHost, c->stream));
+        STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));   // the one synchronisation point of this call
+        if (n_unresolved) { set_error("stocs_make_transforms: %u picks could not be resolved (internal inconsistency)", n_unresolved); return STOCS_ERR_STATE; }
         c->n_cands = n_ok;
         c->cands_stale = n_ok > 0;
         tick("transform+compact");
