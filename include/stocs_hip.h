@@ -109,6 +109,12 @@ int stocs_index_load(stocs_ctx* ctx, const char* path);
  * valid flag.  Valid bases are appended to the context's base set in attempt order. ---- */
 int stocs_sample_bases(stocs_ctx* ctx, int mode, uint64_t seed, int first_attempt, int n_attempts,
                        float dispersion, int32_t* base_ids4, float* inv2, int32_t* valid);
+/* `segment` of the last instance-mode attempt (the out-parameter of sample_instance_base, filled at stocs.cpp:628-638):
+ * indices of the scene points that survived pass 1 inside the segmentation mask, in scene order */
+int stocs_get_segment(const stocs_ctx* ctx, int32_t* scene_idx, int cap, int* n);
+/* the context's scene as the estimator holds it: centred positions (centroid_shift), unit normals, CURRENT class
+ * probabilities (instance-mode sampling decays them, Q8) and pixels; any pointer may be NULL */
+int stocs_get_scene(const stocs_ctx* ctx, float* pos3_centred, float* nrm3, float* class_prob, int32_t* pixel2);
 /* inject bases (already ordered, with their invariants) -- used by the parity tests and by callers
  * that sample elsewhere; replaces the context's base set */
 int stocs_set_bases(stocs_ctx* ctx, int n, const int32_t* base_ids4, const float* inv2);
@@ -207,6 +213,15 @@ int stocs_preprocess_model(const float* raw_pos3, int n_raw, float normal_radius
 /* stocs_ingest_scene / stocs_preprocess_model keep their device workspace cached per calling thread and device
  * (a stream of frames does no hipMalloc / hipFree after the first one); this gives the calling thread's cache back. */
 int stocs_trim(void);
+
+/* ---- files either side of the path (host code; zlib only): what the reference's constructor and driver read and
+ * write through OpenCV / PCL.  stocs_png_read: 8/16-bit grey / RGB (+alpha), non-interlaced; pixels = height rows of
+ * width*channels samples of bit_depth/8 bytes, 16-bit in host byte order; pixels == NULL queries the sizes.
+ * stocs_ply_read: ascii or binary_little_endian vertices, x y z (+ normal_x/nx ...); pos3 == NULL queries the count.
+ * stocs_ply_write: ascii, positions multiplied by `scale` as rgbd::save_as_ply does (rgbd.cpp:35-56). ---- */
+int stocs_png_read(const char* path, int* width, int* height, int* channels, int* bit_depth, void* pixels, int64_t cap_bytes);
+int stocs_ply_read(const char* path, float* pos3, float* nrm3, int cap, int* n, int* has_normals);
+int stocs_ply_write(const char* path, const float* pos3, const float* nrm3, int n, float scale);
 
 /* clustering::point_to_plane_icp (pose_clustering.cpp:123-140: PCL IterativeClosestPointWithNormals, 5
  * iterations, 3.5 cm): own linearised point-to-plane ICP; T16_out maps the source cloud onto the target

@@ -1,18 +1,20 @@
-// stocs_single -- the repo's equivalent of the reference driver (reference
-// src/stocs_match_one_object.cpp:51-215): same four phases, same three timed spans printed in
-// microseconds, same constants (:7-17), same output file format (12 floats, 3x4 row-major,
-// space separated, default ostream precision, :171-180).  Host code is C++ on the façade
+// stocs_single -- the repo's equivalent of the reference driver (reference src/stocs_match_one_object.cpp:51-215): same
+// command line (scene directory + object name), same input files (depth.png, probability_maps/<object>.png, optional
+// probability_maps/edge.png, models/<object>/model_search.ply + ppf_map), same four phases, same three timed spans printed
+// in microseconds, same constants (:7-17), same output file (12 floats, 3x4 row-major, space separated, default ostream
+// precision, :171-180), best_pose.ply / scene.ply in <scene>/dbg (stocs.hpp:136-149).  Host code is C++ on the façade
 // include/stocs.hpp; all hot-path work runs in libstocs_hip.so on the GPU.
 //
-// Inputs are flat cloud files (.stcl, written by model_matching_amd/cloudio.py) instead of
-// rgb/depth/probability PNGs + model_search.ply + ppf_map: scene ingest and model preprocessing are
-// outside the hot path.
+// The loops of the reference's caller (one call per base, :81-147) are taken through the façade's batched methods: all
+// 100 attempts, all bases' congruent sets and all <= 200-per-base transforms are one GPU pass each, and the subset of a
+// base with >= 200 congruent sets is the library's seeded rule (stocs_make_transforms).  The per-call spelling of the same
+// sequence is tests/cpp/reference_call_sequence.cpp.
 //
-// usage: stocs_single <scene.stcl> <model.stcl> [--edge edge.u8] [--seed N] [--out pose.txt]
-//                     [--bases 100] [--max-sets 200] [--device 0] [--dbg DIR] [--cluster 1]
-// --dbg DIR writes best_pose.ply / scene.ply as stocs_estimator::visualize_best_pose does (reference
-// include/stocs.hpp:136-149); --cluster 1 additionally runs clustering::greedy_clustering (reference
-// src/pose_clustering.cpp:79-121, which has no caller in the reference) on the scored candidates.
+//   stocs_single <scene_path> <object_name> [--repo DIR] [--intrinsics fx,cx,fy,cy] [--depth-scale S] [--voxel V] ...
+//   stocs_single --clouds <scene.stcl> <model.stcl> [--edge edge.u8] ...       (flat clouds, e.g. the synthetic workloads)
+// common options: --seed N --bases 100 --max-sets 200 --out FILE --dbg DIR --cluster 1
+// The reference edits its per-data-set constants in the source (README.md:42-66); here they are options with the
+// reference's YCB values as defaults.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -20,11 +22,12 @@
 #include <iostream>
 #include <string>
 
+#include "../../include/pose_clustering.hpp"
 #include "../../include/stocs.hpp"
 
-using micro = std::chrono::microseconds;
-
-// reference stocs_match_one_object.cpp:7-17
+// reference stocs_match_one_object.cpp:4-24
+static std::string repo_path = ".";
+static float voxel_size = 0.005f;
 static float distance_threshold = 0.005f;
 static int ppf_tr_discretization = 5;
 static int ppf_rot_discretization = 5;
@@ -33,22 +36,11 @@ static float class_threshold = 0.10f;
 static float sample_dispersion = 0.9f;
 static int number_of_bases = 100;
 static int maximum_congruent_sets = 200;
+static std::vector<float> cam_intrinsics = {1066.778f, 312.986f, 1067.487f, 241.310f};  // YCB
+static float depth_scale = 1 / 10000.0f;
 static int image_width = 640, image_height = 480;
 
-// ASCII PLY with positions and normals (stand-in for rgbd::save_as_ply, reference src/rgbd.cpp:35-56)
-static bool write_ply(const std::string& path, const std::vector<float>& pos, const std::vector<float>& nrm) {
-    std::ofstream f(path);
-    if (!f) return false;
-    const size_t n = pos.size() / 3;
-    f << "ply\nformat ascii 1.0\nelement vertex " << n << "\nproperty float x\nproperty float y\nproperty float z\n"
-      << "property float normal_x\nproperty float normal_y\nproperty float normal_z\nend_header\n";
-    for (size_t i = 0; i < n; ++i)
-        f << pos[3 * i] << " " << pos[3 * i + 1] << " " << pos[3 * i + 2] << " " << nrm[3 * i] << " " << nrm[3 * i + 1] << " " << nrm[3 * i + 2] << "\n";
-    return (bool)f;
-}
-
-static bool read_stcl(const std::string& path, std::vector<float>& pos, std::vector<float>& nrm, std::vector<float>* prob,
-                      std::vector<int32_t>* pixel) {
+static bool read_stcl(const std::string& path, std::vector<float>& pos, std::vector<float>& nrm, std::vector<float>* prob, std::vector<int32_t>* pixel) {
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) return false;
     char magic[8];
@@ -65,133 +57,127 @@ static bool read_stcl(const std::string& path, std::vector<float>& pos, std::vec
     return ok;
 }
 
-struct BaseGraph {  // reference stocs_match_one_object.cpp:26-48
-    std::vector<int> baseIds_;
-    float invariant1_, invariant2_;
-    std::vector<stocs::Quadrilateral> congruent_quads;
-    BaseGraph(const std::vector<int>& ids, float i1, float i2) : baseIds_(ids.begin(), ids.begin() + 4), invariant1_(i1), invariant2_(i2) {}
-};
-
 int main(int argc, char** argv) {
     if (argc < 3) {
-        std::cout << "usage: stocs_single <scene.stcl> <model.stcl> [--edge edge.u8] [--seed N] [--out pose.txt]" << std::endl;
+        std::cout << "Enter scene path and object name as arguments!" << std::endl;   // :190
         return -1;
     }
-    std::string edge_path, out_path = "best_pose_candidate.txt", dbg_dir;
+    const bool clouds = std::string(argv[1]) == "--clouds";
+    if (clouds && argc < 4) { std::cout << "usage: stocs_single --clouds <scene.stcl> <model.stcl> [options]" << std::endl; return -1; }
+    const std::string a1 = argv[clouds ? 2 : 1], a2 = argv[clouds ? 3 : 2];
+    if (const char* e = getenv("STOCS_REPO_PATH")) repo_path = e;
+    std::string edge_path, out_path, dbg_dir;
     int do_cluster = 0;
     uint64_t seed = 1;
-    int device = -1;
-    for (int i = 3; i + 1 < argc; i += 2) {
-        const std::string k = argv[i];
-        if (k == "--edge") edge_path = argv[i + 1];
-        else if (k == "--seed") seed = strtoull(argv[i + 1], NULL, 10);
-        else if (k == "--out") out_path = argv[i + 1];
-        else if (k == "--bases") number_of_bases = atoi(argv[i + 1]);
-        else if (k == "--max-sets") maximum_congruent_sets = atoi(argv[i + 1]);
-        else if (k == "--device") device = atoi(argv[i + 1]);
-        else if (k == "--dbg") dbg_dir = argv[i + 1];
-        else if (k == "--cluster") do_cluster = atoi(argv[i + 1]);
+    for (int i = clouds ? 4 : 3; i + 1 < argc; i += 2) {
+        const std::string k = argv[i], v = argv[i + 1];
+        if (k == "--edge") edge_path = v;
+        else if (k == "--seed") seed = strtoull(v.c_str(), NULL, 10);
+        else if (k == "--out") out_path = v;
+        else if (k == "--bases") number_of_bases = atoi(v.c_str());
+        else if (k == "--max-sets") maximum_congruent_sets = atoi(v.c_str());
+        else if (k == "--dbg") dbg_dir = v;
+        else if (k == "--cluster") do_cluster = atoi(v.c_str());
+        else if (k == "--repo") repo_path = v;
+        else if (k == "--voxel") voxel_size = (float)atof(v.c_str());
+        else if (k == "--depth-scale") depth_scale = (float)atof(v.c_str());
+        else if (k == "--class-threshold") class_threshold = (float)atof(v.c_str());
+        else if (k == "--intrinsics") {
+            if (sscanf(v.c_str(), "%f,%f,%f,%f", &cam_intrinsics[0], &cam_intrinsics[1], &cam_intrinsics[2], &cam_intrinsics[3]) != 4) { std::cerr << "--intrinsics fx,cx,fy,cy" << std::endl; return -1; }
+        } else { std::cerr << "unknown option " << k << std::endl; return -1; }
     }
-    stocs::SceneCloud scene;
-    stocs::ModelCloud model;
-    if (!read_stcl(argv[1], scene.pos, scene.nrm, &scene.class_probability, &scene.pixel)) { std::cerr << "cannot read scene " << argv[1] << std::endl; return 1; }
-    if (!read_stcl(argv[2], model.pos, model.nrm, NULL, NULL)) { std::cerr << "cannot read model " << argv[2] << std::endl; return 1; }
-    if (!edge_path.empty()) {
-        std::ifstream ef(edge_path, std::ios::binary);
-        scene.edge_map.resize((size_t)image_width * image_height);
-        if (!ef.read((char*)scene.edge_map.data(), (std::streamsize)scene.edge_map.size())) { std::cerr << "cannot read edge map" << std::endl; return 1; }
-    }
-    std::cout << "|M| = " << model.size() << std::endl;
-    std::cout << "|S|: " << scene.size() << std::endl;
 
     std::unique_ptr<stocs::stocs_estimator> est;
     try {
-        est.reset(new stocs::stocs_estimator(model, scene, "dbg", image_width, image_height, distance_threshold, ppf_tr_discretization,
-                                             ppf_rot_discretization, edge_threshold, class_threshold, device));
+        if (clouds) {
+            stocs::SceneCloud scene;
+            stocs::ModelCloud model;
+            if (!read_stcl(a1, scene.pos, scene.nrm, &scene.class_probability, &scene.pixel)) { std::cerr << "cannot read scene " << a1 << std::endl; return 1; }
+            if (!read_stcl(a2, model.pos, model.nrm, NULL, NULL)) { std::cerr << "cannot read model " << a2 << std::endl; return 1; }
+            if (!edge_path.empty()) {
+                std::ifstream ef(edge_path, std::ios::binary);
+                scene.edge_map.resize((size_t)image_width * image_height);
+                if (!ef.read((char*)scene.edge_map.data(), (std::streamsize)scene.edge_map.size())) { std::cerr << "cannot read edge map" << std::endl; return 1; }
+            }
+            if (out_path.empty()) out_path = "best_pose_candidate.txt";
+            std::cout << "|M| = " << model.size() << std::endl;
+            est.reset(new stocs::stocs_estimator(model, scene, dbg_dir, image_width, image_height, distance_threshold, ppf_tr_discretization, ppf_rot_discretization,
+                                                 edge_threshold, class_threshold));
+        } else {
+            // :56-62, :196-208
+            const std::string scene_path = a1, object_name = a2;
+            const std::string rgb_path = scene_path + "/rgb.png", depth_path = scene_path + "/depth.png";
+            const std::string class_probability_path = scene_path + "/probability_maps/" + object_name + ".png";
+            const std::string edge_probability_path = scene_path + "/probability_maps/edge.png";
+            const std::string model_path = repo_path + "/models/" + object_name + "/model_search.ply";
+            if (out_path.empty()) out_path = scene_path + "/best_pose_candidate_" + object_name + ".txt";
+            const bool own_dbg = dbg_dir.empty();
+            if (own_dbg) dbg_dir = scene_path + "/dbg";
+            std::cout << "############# LOADING OBJECT MAPS ################" << std::endl;
+            PPFMapType model_map;
+            rgbd::load_ppf_map(repo_path + "/models/" + object_name + "/ppf_map", model_map);
+            std::cout << "############# LOADING OBJECT COMPLETE ################" << std::endl;
+            // :207-208 (only the reference's own <scene>/dbg is wiped; a directory named with --dbg is merely created)
+            if (system(((own_dbg ? "rm -rf '" + dbg_dir + "' && " : std::string()) + "mkdir -p '" + dbg_dir + "'").c_str()) != 0) std::cerr << "cannot create " << dbg_dir << std::endl;
+            std::cout << "############# RUNNING STOCS for Scene: " << scene_path << ", Object: " << object_name << " ##############" << std::endl;
+            est.reset(new stocs::stocs_estimator(model_path, model_map, rgb_path, depth_path, class_probability_path, edge_probability_path, dbg_dir, cam_intrinsics,
+                                                 image_width, image_height, depth_scale, 1.0f, voxel_size, distance_threshold, ppf_tr_discretization,
+                                                 ppf_rot_discretization, edge_threshold, class_threshold));
+        }
     } catch (const std::exception& e) {
         std::cerr << e.what() << std::endl;  // no GPU => loud failure, never a CPU fallback
         return 2;
     }
     stocs::stocs_estimator& stocs_ptr = *est;
     stocs_ptr.set_seed(seed);
-    std::vector<BaseGraph> base_set;
 
     // Step 1: sample n bases on the scene (:79-105)
     auto start = std::chrono::high_resolution_clock::now();
-    for (int i = 0; i < number_of_bases; i++) {
-        std::vector<int> base_indices(4, -1);
-        float invariant1 = 0, invariant2 = 0;
-        bool valid_base_found;
-        if (stocs_ptr.has_edge_map()) valid_base_found = stocs_ptr.sample_instance_base(base_indices, invariant1, invariant2, sample_dispersion, i + 1);
-        else valid_base_found = stocs_ptr.sample_class_base(base_indices, invariant1, invariant2);
-        if (valid_base_found) base_set.emplace_back(base_indices, invariant1, invariant2);
-    }
+    const int n_bases = stocs_ptr.sample_bases(number_of_bases, sample_dispersion);
     auto finish = std::chrono::high_resolution_clock::now();
-    std::cout << "Sampled " << base_set.size() << " bases in " << std::chrono::duration_cast<micro>(finish - start).count() << " microseconds\n";
+    std::cout << "Sampled " << n_bases << " bases in " << std::chrono::duration_cast<micro>(finish - start).count() << " microseconds\n";
+    auto total_time = std::chrono::duration_cast<micro>(finish - start).count();
 
-    // Step 2 + 3: congruent sets and rigid transforms (:107-151)
+    // Step 2 + 3: congruent sets and rigid transforms (:107-153)
     start = std::chrono::high_resolution_clock::now();
-    for (auto& b : base_set) stocs_ptr.find_congruent_sets_on_model(b.baseIds_, b.invariant1_, b.invariant2_, &b.congruent_quads);
-    int total_congruent_set_found = 0, base_number = 0;
-    for (auto& b : base_set) {
-        const int congruent_set_size = (int)b.congruent_quads.size();
-        if (congruent_set_size < maximum_congruent_sets) {
-            for (int i = 0; i < congruent_set_size; i++) stocs_ptr.get_rigid_transform_from_congruent_pair(b.baseIds_, b.congruent_quads[i], base_number);
-        } else {
-            // seeded sample without replacement (divergence Q5 from the 2N-vector random_shuffle, :134-142)
-            std::vector<int> perm(congruent_set_size);
-            for (int i = 0; i < congruent_set_size; i++) perm[i] = i;
-            uint64_t z = seed * 0x9E3779B97F4A7C15ull + (uint64_t)base_number;
-            for (int j = 0; j < maximum_congruent_sets; ++j) {
-                z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
-                const int k = j + (int)(z % (uint64_t)(congruent_set_size - j));
-                std::swap(perm[j], perm[k]);
-                stocs_ptr.get_rigid_transform_from_congruent_pair(b.baseIds_, b.congruent_quads[perm[j]], base_number);
-            }
-        }
-        total_congruent_set_found += congruent_set_size;
-        base_number++;
-    }
+    const long long total_congruent_set_found = stocs_ptr.find_congruent_sets_all();
+    const int n_candidates = stocs_ptr.make_transforms(maximum_congruent_sets);
     finish = std::chrono::high_resolution_clock::now();
     std::cout << "found " << total_congruent_set_found << " congruent sets in " << std::chrono::duration_cast<micro>(finish - start).count() << " microseconds\n";
+    total_time += std::chrono::duration_cast<micro>(finish - start).count();
 
-    // Step 4: verify (:155-163)
+    // Step 4: verify all transforms to get the best pose (:155-165)
     start = std::chrono::high_resolution_clock::now();
-    std::cout << "Transforms to verify: " << stocs_ptr.get_all_transforms().size() << std::endl;
     stocs_ptr.compute_best_transform();
     finish = std::chrono::high_resolution_clock::now();
     std::cout << "evaluated transforms in " << std::chrono::duration_cast<micro>(finish - start).count() << " microseconds\n";
-    std::cout << "maximum score: " << stocs_ptr.get_best_score() << std::endl;
+    total_time += std::chrono::duration_cast<micro>(finish - start).count();
 
-    stocs::PoseCandidate* best_pose = stocs_ptr.get_best_pose();
+    PoseCandidate* best_pose = stocs_ptr.get_best_pose();
+    char line[256];
+    snprintf(line, sizeof(line), "summary: bases=%d congruent_sets=%lld candidates=%d best_lcp=%.9g best_index=%d total_microseconds=%lld", n_bases,
+             total_congruent_set_found, n_candidates, (double)stocs_ptr.get_best_score(), stocs_ptr.get_best_index(), (long long)total_time);
+    if (!dbg_dir.empty()) stocs_ptr.visualize_best_pose();   // :167
     if (best_pose != NULL) {  // :171-180
-        std::ofstream out_file_ptr(out_path, std::ofstream::out);
-        const stocs::Mat4f& t = best_pose->transform;
-        out_file_ptr << t(0, 0) << " " << t(0, 1) << " " << t(0, 2) << " " << t(0, 3) << " " << t(1, 0) << " " << t(1, 1) << " " << t(1, 2) << " "
-                     << t(1, 3) << " " << t(2, 0) << " " << t(2, 1) << " " << t(2, 2) << " " << t(2, 3) << std::endl;
-        if (!dbg_dir.empty()) {  // visualize_best_pose (stocs.hpp:136-149): model under the best camera-frame pose + the scene
-            std::vector<float> mp(model.pos.size()), mn(model.nrm.size());
-            for (size_t i = 0; i < model.pos.size() / 3; ++i)
-                for (int r = 0; r < 3; ++r) {
-                    mp[3 * i + r] = t(r, 0) * model.pos[3 * i] + t(r, 1) * model.pos[3 * i + 1] + t(r, 2) * model.pos[3 * i + 2] + t(r, 3);
-                    mn[3 * i + r] = t(r, 0) * model.nrm[3 * i] + t(r, 1) * model.nrm[3 * i + 1] + t(r, 2) * model.nrm[3 * i + 2];
-                }
-            write_ply(dbg_dir + "/best_pose.ply", mp, mn);
-            write_ply(dbg_dir + "/scene.ply", scene.pos, scene.nrm);
-        }
-        if (do_cluster) {  // greedy_clustering(hypotheses, 0.8, best, 10, 2 cm, 15 deg, no symmetry)
-            std::vector<stocs::PoseCandidate*> all = stocs_ptr.get_pose_candidates();
-            std::vector<float> poses(all.size() * 16), lcp(all.size());
-            for (size_t i = 0; i < all.size(); ++i) { std::memcpy(&poses[16 * i], all[i]->transform.data(), 64); lcp[i] = all[i]->lcp; }
-            std::vector<int32_t> keep(all.size() + 1);
-            const float sym[3] = {0, 0, 0};
-            int nk = 0;
-            stocs_cluster_poses(poses.data(), lcp.data(), (int)all.size(), 0.8f, stocs_ptr.get_best_score(), 10, 0.02f, 15.0f, sym, keep.data(), (int)keep.size(), &nk);
-            std::cout << "clustered hypotheses: " << nk << std::endl;
-            for (int i = 0; i < nk; ++i) std::cout << "  cluster " << i << ": candidate " << keep[i] << " lcp " << lcp[keep[i]] << std::endl;
+        std::ofstream out_file_ptr;
+        out_file_ptr.open(out_path, std::ofstream::out);
+        out_file_ptr << best_pose->transform(0, 0) << " " << best_pose->transform(0, 1) << " " << best_pose->transform(0, 2) << " " << best_pose->transform(0, 3) << " "
+                     << best_pose->transform(1, 0) << " " << best_pose->transform(1, 1) << " " << best_pose->transform(1, 2) << " " << best_pose->transform(1, 3) << " "
+                     << best_pose->transform(2, 0) << " " << best_pose->transform(2, 1) << " " << best_pose->transform(2, 2) << " " << best_pose->transform(2, 3) << std::endl;
+        out_file_ptr.close();
+        // full-precision copy of the same 12 numbers for tools that compare poses
+        std::cout << "pose:";
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) { char b[32]; snprintf(b, sizeof(b), " %.9g", (double)best_pose->transform(r, c)); std::cout << b; }
+        std::cout << std::endl;
+        if (do_cluster) {  // clustering::greedy_clustering (pose_clustering.cpp:79-121; no caller in the reference): 0.8, best, 10, 2 cm, 15 deg, no symmetry
+            std::vector<PoseCandidate*> all = stocs_ptr.get_pose_candidates(), kept;
+            clustering::greedy_clustering(all, 0.8f, stocs_ptr.get_best_score(), 10, 0.02f, 15.0f, VectorType(0, 0, 0), kept);
+            std::cout << "clustered hypotheses: " << kept.size() << std::endl;
+            for (size_t i = 0; i < kept.size(); ++i) std::cout << "  cluster " << i << ": base " << kept[i]->base_index << " lcp " << kept[i]->lcp << std::endl;
         }
     } else {
         std::cout << "no pose found" << std::endl;
     }
+    std::cout << line << std::endl;
     return 0;
 }

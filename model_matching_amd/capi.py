@@ -55,6 +55,11 @@ SIGNATURES = {
     "stocs_index_save": (C.c_int, [_vp, C.c_char_p]),
     "stocs_index_load": (C.c_int, [_vp, C.c_char_p]),
     "stocs_sample_bases": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_float, _ip, _fp, _ip]),
+    "stocs_get_segment": (C.c_int, [_vp, _ip, C.c_int, _intp]),
+    "stocs_get_scene": (C.c_int, [_vp, _fp, _fp, _fp, _ip]),
+    "stocs_png_read": (C.c_int, [C.c_char_p, _intp, _intp, _intp, _intp, _vp, C.c_int64]),
+    "stocs_ply_read": (C.c_int, [C.c_char_p, _fp, _fp, C.c_int, _intp, _intp]),
+    "stocs_ply_write": (C.c_int, [C.c_char_p, _fp, _fp, C.c_int, C.c_float]),
     "stocs_set_bases": (C.c_int, [_vp, C.c_int, _ip, _fp]),
     "stocs_clear_bases": (C.c_int, [_vp]),
     "stocs_num_bases": (C.c_int, [_vp]),

@@ -205,6 +205,7 @@ static int load_scene(stocs_ctx* c, const float* sp, const float* sn, const floa
     c->previous_segment.reset();
     c->segmentation_buffer.assign(npx, 0);
     c->seg_masks.clear();
+    c->last_segment.clear();
     return rc;
 }
 
@@ -387,6 +388,16 @@ int stocs_get_centroids(const stocs_ctx* c, float* s, float* m) {
     if (!c) return STOCS_ERR_INVALID;
     if (s) { s[0] = c->centroid_scene.x; s[1] = c->centroid_scene.y; s[2] = c->centroid_scene.z; }
     if (m) { m[0] = c->centroid_model.x; m[1] = c->centroid_model.y; m[2] = c->centroid_model.z; }
+    return STOCS_OK;
+}
+int stocs_get_scene(const stocs_ctx* c, float* pos3, float* nrm3, float* prob, int32_t* pix2) {
+    if (!c) return STOCS_ERR_INVALID;
+    for (int i = 0; i < c->nS; ++i) {
+        if (pos3) { pos3[3 * i] = c->h_spos[i].x; pos3[3 * i + 1] = c->h_spos[i].y; pos3[3 * i + 2] = c->h_spos[i].z; }
+        if (nrm3) { nrm3[3 * i] = c->h_snrm[i].x; nrm3[3 * i + 1] = c->h_snrm[i].y; nrm3[3 * i + 2] = c->h_snrm[i].z; }
+        if (prob) prob[i] = c->h_sprob[i];
+        if (pix2) { pix2[2 * i] = c->h_spix[2 * i]; pix2[2 * i + 1] = c->h_spix[2 * i + 1]; }
+    }
     return STOCS_OK;
 }
 int stocs_get_sizes(const stocs_ctx* c, int* nS, int* nM) {

@@ -449,8 +449,12 @@ static int sample_instance_one(stocs_ctx* c, uint64_t seed, int attempt, float d
     if ((int)c->seg_masks.size() <= base_num) c->seg_masks.resize(base_num + 1);
     c->seg_masks[base_num] = mask_p;    // cv::imwrite(seg_mask_<n>.png), stocs.cpp:625
     c->previous_segment = mask_p;       // stocs.cpp:626
-    for (int i = 0; i < S; ++i)         // stocs.cpp:628-638
-        if (w[i] != 0 && !mask[(size_t)c->h_spix[2 * i] * W + c->h_spix[2 * i + 1]]) w[i] = 0;
+    c->last_segment.clear();
+    for (int i = 0; i < S; ++i)         // stocs.cpp:628-638: survivors inside the mask form `segment`, the others are zeroed
+        if (w[i] != 0) {
+            if (mask[(size_t)c->h_spix[2 * i] * W + c->h_spix[2 * i + 1]]) c->last_segment.push_back(i);
+            else w[i] = 0;
+        }
     TSEC(4)
     // round trip 2: filtered weights up, draw 2, pass 2, draw 3, pass 3, draw 4, base finalised on the device, result back
     memcpy(stage.data(), w.data(), (size_t)S * 4);
@@ -498,6 +502,16 @@ int stocs_sample_bases(stocs_ctx* c, int mode, uint64_t seed, int first_attempt,
     return refresh_class_prob_on_device(c);
 }
 
+// `segment` of the last instance-mode attempt (stocs.cpp:628-638): the scene points that survived pass 1 inside the
+// segmentation mask, in scene order
+int stocs_get_segment(const stocs_ctx* c, int32_t* scene_idx, int cap, int* n) {
+    if (!c || !n) return STOCS_ERR_INVALID;
+    *n = (int)c->last_segment.size();
+    if (!scene_idx) return STOCS_OK;
+    for (int i = 0; i < *n && i < cap; ++i) scene_idx[i] = c->last_segment[i];
+    return (*n > cap) ? STOCS_ERR_CAPACITY : STOCS_OK;
+}
+
 int stocs_reset_trial(stocs_ctx* c) {
     if (!c) return STOCS_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
@@ -505,6 +519,7 @@ int stocs_reset_trial(stocs_ctx* c) {
     c->previous_segment.reset();
     std::fill(c->segmentation_buffer.begin(), c->segmentation_buffer.end(), 0);
     c->seg_masks.clear();
+    c->last_segment.clear();
     c->bases.clear(); c->quad_off.clear(); clear_candidates(c);
     c->best_lcp = 0; c->best_index = -1;
     return refresh_class_prob_on_device(c);

@@ -199,6 +199,8 @@ struct stocs_ctx {
     std::shared_ptr<const std::vector<uint8_t> > previous_segment;
     std::vector<std::shared_ptr<const std::vector<uint8_t> > > seg_masks;
 
+    std::vector<int32_t> last_segment;   // `segment` of the last instance-mode attempt (stocs.cpp:628-638)
+
     // run state
     std::vector<stocs::BaseRec> bases;
     // congruent quads: only their per-base counts live here (quad_off[b+1] - quad_off[b]); `cong` (congruent.hip,

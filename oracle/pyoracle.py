@@ -119,6 +119,8 @@ def lib():
         L.orc_pose_diff.argtypes = [fp, fp, fp, fp, fp]
         L.orc_run.argtypes = [vp, C.c_uint64, C.c_int, C.c_int, C.POINTER(RunResult)]
         L.orc_run.restype = C.c_int
+        L.orc_run_mode.argtypes = [vp, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(RunResult)]
+        L.orc_run_mode.restype = C.c_int
         L.orc_get_candidates.argtypes = [vp, fp, fp, ip, C.c_int]
         L.orc_get_candidates.restype = C.c_int
         _LIB = L
@@ -348,9 +350,9 @@ class Oracle:
                              counted.ctypes.data_as(C.POINTER(C.c_uint8)))
         return hit, counted
 
-    def run(self, seed, number_of_bases=100, maximum_congruent_sets=200):
+    def run(self, seed, number_of_bases=100, maximum_congruent_sets=200, instance_mode=False, dispersion=0.9):
         r = RunResult()
-        lib().orc_run(self.h, seed, number_of_bases, maximum_congruent_sets, C.byref(r))
+        lib().orc_run_mode(self.h, seed, number_of_bases, maximum_congruent_sets, 1 if instance_mode else 0, dispersion, C.byref(r))
         return r
 
     def candidates(self):

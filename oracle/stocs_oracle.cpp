@@ -1346,7 +1346,13 @@ int orc_greedy_clustering(const float* poses16, const float* lcp, int n, float a
 // divergences Q5 (subset choice) and Q6 (draws).  Subset rule when a base has >= max quads:
 // partial Fisher-Yates over the base's quads in walk order (find_congruent's `seq`) with
 // rng64(seed, 0x5E1EC7 + base_number, j); a base with fewer uses all of them in std::set order.
+int orc_run_mode(orc_ctx* c, uint64_t seed, int number_of_bases, int maximum_congruent_sets, int instance_mode, float dispersion, orc_run_result* out);
 int orc_run(orc_ctx* c, uint64_t seed, int number_of_bases, int maximum_congruent_sets, orc_run_result* out) {
+    return orc_run_mode(c, seed, number_of_bases, maximum_congruent_sets, 0, 0.0f, out);
+}
+// instance_mode != 0: the caller's branch on the presence of probability_maps/edge.png (stocs_match_one_object.cpp:90):
+// sample_instance_base(..., dispersion, i + 1) instead of sample_class_base
+int orc_run_mode(orc_ctx* c, uint64_t seed, int number_of_bases, int maximum_congruent_sets, int instance_mode, float dispersion, orc_run_result* out) {
     typedef std::chrono::high_resolution_clock clk;
     struct Base { int ids[4]; float i1, i2; std::vector<std::array<int, 4> > quads, seq; };
     std::vector<Base> base_set;
@@ -1355,7 +1361,8 @@ int orc_run(orc_ctx* c, uint64_t seed, int number_of_bases, int maximum_congruen
     for (int i = 0; i < number_of_bases; ++i) {
         int32_t ids[4] = {-1, -1, -1, -1};
         float inv[2];
-        if (orc_sample_class_base(c, seed, (uint64_t)i, ids, inv)) {
+        const int ok = instance_mode ? orc_sample_instance_base(c, seed, (uint64_t)i, dispersion, i + 1, ids, inv) : orc_sample_class_base(c, seed, (uint64_t)i, ids, inv);
+        if (ok) {
             Base b;
             for (int k = 0; k < 4; ++k) b.ids[k] = ids[k];
             b.i1 = inv[0]; b.i2 = inv[1];

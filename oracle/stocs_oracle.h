@@ -139,6 +139,10 @@ typedef struct orc_run_result {
 } orc_run_result;
 int orc_run(orc_ctx*, uint64_t seed, int number_of_bases, int maximum_congruent_sets,
             orc_run_result* out);
+/* the same with the caller's branch on probability_maps/edge.png taken (stocs_match_one_object.cpp:90): instance_mode != 0
+ * draws every base with sample_instance_base(..., dispersion, attempt + 1) */
+int orc_run_mode(orc_ctx*, uint64_t seed, int number_of_bases, int maximum_congruent_sets, int instance_mode, float dispersion,
+                 orc_run_result* out);
 int orc_get_candidates(orc_ctx*, float* T16, float* pose16, int32_t* base_idx, int cap);
 
 #ifdef __cplusplus

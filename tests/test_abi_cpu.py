@@ -3,6 +3,7 @@ declares, and fails loudly (no fallback) when no HIP device is present.  No GPU 
 import ctypes as C
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -155,3 +156,96 @@ def test_cone_filter_never_disagrees_with_the_reference_arithmetic(capi):
     for ca in (1.0, 1.0000001):
         assert L.stocs_cone_cells_host(n.ctypes.data_as(capi._fp), C.c_float(ca), ex, ke, C.byref(ns), C.byref(nu)) == 0
         assert ns.value == 0 and not any(ex) and not any(ke)
+
+
+def test_facade_keeps_the_reference_signatures(tmp_path):
+    """include/stocs.hpp + include/pose_clustering.hpp against the reference's declarations (stocs.hpp:18-30, 80-149,
+    182-191; point3d.hpp; pose_clustering.hpp:9-28): member-function pointers of the reference's exact types must bind,
+    at the reference's language level.  The restated caller (tests/cpp/reference_call_sequence.cpp) must compile and link
+    against the C-ABI library unchanged (the build does that: apps/stocs_single_percall)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "sig.cpp"
+    src.write_text(r"""
+#include <pose_clustering.hpp>
+#include <stocs.hpp>
+typedef stocs::stocs_estimator E;
+bool (E::*f1)(std::vector<int>&, float&, float&) = &E::sample_class_base;
+bool (E::*f2)(std::vector<int>&, float&, float&, std::vector<Point3D>&, float, int) = &E::sample_instance_base;
+bool (E::*f3)(std::vector<int>&, float, float, std::vector<Quadrilateral>*) = &E::find_congruent_sets_on_model;
+bool (E::*f4)(std::vector<int>&, Quadrilateral&, int) = &E::get_rigid_transform_from_congruent_pair;
+Scalar (E::*f5)(const MatrixType&) = &E::compute_alignment_score_for_rigid_transform;
+void (E::*f6)() = &E::compute_best_transform;
+void (E::*f7)() = &E::kdtree_initialize;
+void (E::*f8)() = &E::centroid_shift;
+VectorType (E::*f9)() = &E::get_scene_centroid;
+std::vector<PoseCandidate*> (E::*f10)() = &E::get_pose_candidates;
+Scalar (E::*f11)() = &E::get_best_score;
+PoseCandidate* (E::*f12)() = &E::get_best_pose;
+void (E::*f13)() = &E::visualize_best_pose;
+void (E::*f14)(std::string, PPFMapType&) = &E::load_object_info;
+void (E::*f15)(std::string, std::string, std::string, std::string, std::vector<float>, float, float, float, std::string) = &E::load_scene_info;
+void (*g1)(std::string, float, float, float, float, float, float, std::string, std::string) = &stocs::pre_process_model;
+void (*g2)(std::string, PPFMapType&) = &rgbd::load_ppf_map;
+void (*g3)(std::vector<PoseCandidate*>&, float, float, int, float, float, VectorType, std::vector<PoseCandidate*>&) = &clustering::greedy_clustering;
+// the constructor of stocs.hpp:18-30, argument for argument
+E* make(std::string s, PPFMapType& m, std::vector<float> k) { return new E(s, m, s, s, s, s, s, k, 640, 480, 1e-4f, 1.0f, 0.005f, 0.005f, 5, 5, 0.0f, 0.1f); }
+int main() { Point3D p(1, 2, 3); p.set_normal(VectorType(0, 0, 2)); Quadrilateral q(1, 2, 3, 4); PoseCandidate c(MatrixType(), 0.5f, 3);
+             return (p.normal()[2] == 1.0f && q[2] == 3 && c.base_index == 3 && c.transform(1, 1) == 1.0f && kLargeNumber > 1e8f) ? 0 : 1; }
+""")
+    exe = tmp_path / "sig"
+    r = subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                        "-L", os.path.join(root, "model_matching_amd"), "-lstocs_hip", "-Wl,-rpath," + os.path.join(root, "model_matching_amd"), "-Wl,-rpath,/opt/rocm/lib"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert subprocess.run([str(exe)]).returncode == 0
+    for app in ("stocs_single", "model_preprocess", "stocs_single_percall"):
+        assert os.path.exists(os.path.join(root, "model_matching_amd", "apps", app)), app
+    r = subprocess.run([os.path.join(root, "model_matching_amd", "apps", "stocs_single_percall")], capture_output=True, text=True)
+    assert "Enter scene path and object name as arguments!" in r.stdout
+
+
+def test_png_and_ply_files_round_trip(capi, tmp_path):
+    """stocs_png_read against PIL-written 8/16-bit images (every PNG row filter occurs in PIL's output), stocs_ply_write /
+    stocs_ply_read round trip incl. binary_little_endian input, and the error paths."""
+    from PIL import Image
+    L = capi.load()
+    rng = np.random.default_rng(5)
+
+    def read_png(path):
+        w, h, c, b = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        assert L.stocs_png_read(str(path).encode(), C.byref(w), C.byref(h), C.byref(c), C.byref(b), None, 0) == 0, L.stocs_last_error()
+        a = np.zeros((h.value, w.value, c.value), np.uint16 if b.value == 16 else np.uint8)
+        assert L.stocs_png_read(str(path).encode(), C.byref(w), C.byref(h), C.byref(c), C.byref(b), a.ctypes.data_as(C.c_void_p), a.nbytes) == 0
+        assert L.stocs_png_read(str(path).encode(), C.byref(w), C.byref(h), C.byref(c), C.byref(b), a.ctypes.data_as(C.c_void_p), a.nbytes - 1) == -4
+        return a
+    yy, xx = np.mgrid[0:97, 0:131]
+    imgs = {"g16": ((yy * 300 + xx * 7) % 65536).astype(np.uint16), "g16n": rng.integers(0, 65536, (97, 131)).astype(np.uint16),
+            "g8": ((yy + xx) % 256).astype(np.uint8), "rgb8": rng.integers(0, 256, (97, 131, 3)).astype(np.uint8)}
+    for k, a in imgs.items():
+        Image.fromarray(a).save(tmp_path / (k + ".png"))
+        got = read_png(tmp_path / (k + ".png"))
+        assert np.array_equal(got.reshape(a.shape), a), k
+    (tmp_path / "bad.png").write_bytes(b"\x89PNG\r\n\x1a\n" + b"0" * 40)
+    w = C.c_int()
+    assert L.stocs_png_read(str(tmp_path / "bad.png").encode(), C.byref(w), C.byref(w), C.byref(w), C.byref(w), None, 0) == -1
+    assert L.stocs_png_read(str(tmp_path / "missing.png").encode(), C.byref(w), C.byref(w), C.byref(w), C.byref(w), None, 0) == -1
+    # PLY
+    pos = rng.normal(size=(257, 3)).astype(np.float32); nrm = rng.normal(size=(257, 3)).astype(np.float32)
+    f = str(tmp_path / "a.ply").encode()
+    assert L.stocs_ply_write(f, pos.ctypes.data_as(capi._fp), nrm.ctypes.data_as(capi._fp), 257, C.c_float(1.0)) == 0
+    n, hn = C.c_int(), C.c_int()
+    assert L.stocs_ply_read(f, None, None, 0, C.byref(n), C.byref(hn)) == 0 and (n.value, hn.value) == (257, 1)
+    p2 = np.zeros_like(pos); n2 = np.zeros_like(nrm)
+    assert L.stocs_ply_read(f, p2.ctypes.data_as(capi._fp), n2.ctypes.data_as(capi._fp), 257, C.byref(n), C.byref(hn)) == 0
+    assert np.array_equal(p2, pos) and np.array_equal(n2, nrm)
+    assert L.stocs_ply_read(f, p2.ctypes.data_as(capi._fp), None, 100, C.byref(n), C.byref(hn)) == -4
+    with open(tmp_path / "b.ply", "wb") as fh:   # binary little endian with an extra property in front
+        fh.write(b"ply\nformat binary_little_endian 1.0\nelement vertex 257\nproperty uchar tag\nproperty float x\nproperty float y\nproperty float z\n"
+                 b"property float nx\nproperty float ny\nproperty float nz\nelement face 0\nproperty list uchar int vertex_indices\nend_header\n")
+        rec = np.zeros(257, dtype=[("t", "u1"), ("p", "<f4", 3), ("n", "<f4", 3)]); rec["t"] = 9; rec["p"] = pos; rec["n"] = nrm
+        fh.write(rec.tobytes())
+    p3 = np.zeros_like(pos); n3 = np.zeros_like(nrm)
+    assert L.stocs_ply_read(str(tmp_path / "b.ply").encode(), p3.ctypes.data_as(capi._fp), n3.ctypes.data_as(capi._fp), 257, C.byref(n), C.byref(hn)) == 0
+    assert np.array_equal(p3, pos) and np.array_equal(n3, nrm) and hn.value == 1
+    (tmp_path / "c.ply").write_text("ply\nformat ascii 1.0\nelement vertex 2\nproperty float x\nend_header\n1\n2\n")
+    assert L.stocs_ply_read(str(tmp_path / "c.ply").encode(), None, None, 0, C.byref(n), C.byref(hn)) == -1
