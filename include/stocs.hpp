@@ -377,7 +377,7 @@ public:
             float pose[16];
             stocs_verify_all(ctx_, &best_lcp, &best_index, pose);
             std::cout << "Transforms to verify: " << n_batched_ << std::endl;   // stocs.cpp:985
-            if (best_index != -1) std::cout << "maximum score: " << best_lcp << ", best index: " << best_index << std::endl;   // :1003
+            std::cout << "best index: " << best_index << ", maximum score: " << best_lcp << std::endl;   // :1003
             fetched_ = false;
             return;
         }
@@ -395,7 +395,7 @@ public:
         }
         best_lcp = max_score;
         best_index = index;
-        if (index != -1) std::cout << "maximum score: " << best_lcp << ", best index: " << best_index << std::endl;
+        std::cout << "best index: " << best_index << ", maximum score: " << best_lcp << std::endl;
     }
 
     // reference stocs.hpp:109-113: run by the constructor there; here both are part of stocs_ctx_create (sequential f32
