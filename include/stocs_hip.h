@@ -235,6 +235,9 @@ int stocs_icp_point_to_plane(const float* src_pos3, int nsrc, const float* tgt_p
  *   candidate lists (24), cooperative scan with 4 list lines in flight for medium lists (15), centre-sorted lists with
  *   triangle-inequality early exit for dense scenes (31); 0 = plain lane-per-query scan (independent cross-check).
  *   Every selectable kernel returns the reference's scores; any other value is STOCS_ERR_INVALID.
+ * "lcp_flat": 1 (default) = sparse scenes address a flat copy of the cell table (one look-up per query), 0 = brick look-ups.
+ * "lcp_split": 1 (default) = four wavefronts share a candidate's model points, 0 = one wavefront per candidate.  Scores are
+ *   accumulated as integers, so neither option changes a single bit of them.
  * "lcp_order": 0 = candidates in batch order, 1 (default) = big batches are processed in a spatial order of their
  *   translations (scores are bitwise independent of it), >= 2 = XCD-blocked variants of that order. ---- */
 int stocs_set_option(stocs_ctx* ctx, const char* key, int value);

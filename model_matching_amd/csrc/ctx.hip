@@ -114,7 +114,7 @@ static int upload(T** dptr, const T* h, size_t n) {
 }
 
 static void free_grid(stocs_ctx* c) {   // the grid lives in c->grid_mem, which the next build resets
-    c->grid.d_top = NULL; c->grid.d_cells = NULL; c->grid.d_list = NULL; c->grid.d_chunk_r = NULL;
+    c->grid.d_top = NULL; c->grid.d_cells = NULL; c->grid.d_list = NULL; c->grid.d_chunk_r = NULL; c->grid.d_flat = NULL;
 }
 
 // one build at cell edge eps / div; lists longer than 16 on average get the centre-sorted layout + chunk bounds
@@ -274,6 +274,8 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     c->has_edge = false;
     c->grid_div = 1;
     c->lcp_variant = -1;
+    c->lcp_split = 1;
+    c->lcp_flat = getenv("STOCS_LCP_FLAT") ? atoi(getenv("STOCS_LCP_FLAT")) : 1;
     c->lcp_order = getenv("STOCS_LCP_ORDER") ? atoi(getenv("STOCS_LCP_ORDER")) : 1;
     c->d_order = NULL; c->order_bytes = 0;
     memset(&c->grid, 0, sizeof(c->grid));

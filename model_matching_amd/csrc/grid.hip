@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256) void zero_cells_kernel(uint4* __restrict__ a, 
 __global__ __launch_bounds__(256) void cell_words_kernel(GridGeom G, int div, const uint32_t* __restrict__ cell_first, const uint64_t* __restrict__ cell_key,
                                                          const uint32_t* __restrict__ cell_brick, const uint32_t* __restrict__ list_off,
                                                          uint32_t n_cells, uint32_t n_inc, const uint32_t* __restrict__ vals,
-                                                         const float4* __restrict__ spos, int32_t* __restrict__ top, uint4* __restrict__ cells) {
+                                                         const float4* __restrict__ spos, int32_t* __restrict__ top, uint4* __restrict__ cells,
+                                                         uint4* __restrict__ flat) {
     const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int s = threadIdx.x & 63;
     if (c >= n_cells) return;   // whole wavefront
@@ -182,7 +183,13 @@ __global__ __launch_bounds__(256) void cell_words_kernel(GridGeom G, int div, co
     }
     if (s == 0) {
         top[brick] = (int32_t)b;   // every cell of the brick writes the same value
-        cells[(size_t)b * 512 + local] = make_uint4(list_off[c], cnt, mlo, mhi);
+        const uint4 w = make_uint4(list_off[c], cnt, mlo, mhi);
+        cells[(size_t)b * 512 + local] = w;
+        if (flat) {
+            const int bx = (int)(brick % (uint64_t)G.nbx), by = (int)((brick / (uint64_t)G.nbx) % (uint64_t)G.nby), bz = (int)(brick / ((uint64_t)G.nbx * (uint64_t)G.nby));
+            const int cx = bx * 8 + (int)(local & 7), cy = by * 8 + (int)((local >> 3) & 7), cz = bz * 8 + (int)(local >> 6);
+            if (cx < G.n[0] && cy < G.n[1] && cz < G.n[2]) flat[((size_t)cz * G.n[1] + cy) * G.n[0] + cx] = w;
+        }
     }
 }
 
@@ -259,7 +266,7 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense) {
     g.nbx = (n[0] + 7) / 8; g.nby = (n[1] + 7) / 8; g.nbz = (n[2] + 7) / 8;
     g.h = (float)h;
     g.n_bricks = 0; g.n_entries = 0; g.avg_list_len = 0;
-    g.d_top = NULL; g.d_cells = NULL; g.d_list = NULL; g.d_chunk_r = NULL;
+    g.d_top = NULL; g.d_cells = NULL; g.d_list = NULL; g.d_chunk_r = NULL; g.d_flat = NULL;
     const int64_t n_top = (int64_t)g.nbx * g.nby * g.nbz;
     if (n_top > (int64_t)400 * 1000 * 1000) { set_error("scene extent too large for the brick grid"); return STOCS_ERR_INVALID; }
     int cell_bits = 1;
@@ -357,9 +364,16 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense) {
         (rc = c->grid_mem.take(std::max<size_t>(n_list, 8) * sizeof(float4), (void**)&g.d_list)))
         return rc;
     hipLaunchKernelGGL(zero_cells_kernel, dim3(grid_of((size_t)n_bricks * 512)), dim3(256), 0, st, g.d_cells, (size_t)n_bricks * 512);
+    {   // flat copy of the cell words for the sparse-scene kernel: one look-up per query instead of two dependent ones
+        const size_t n_flat = (size_t)n[0] * n[1] * n[2];
+        if (!dense && div == 1 && c->lcp_flat && n_flat * sizeof(uint4) <= ((size_t)512 << 20)) {
+            if ((rc = c->grid_mem.take(n_flat * sizeof(uint4), (void**)&g.d_flat))) return rc;
+            hipLaunchKernelGGL(zero_cells_kernel, dim3(grid_of(n_flat)), dim3(256), 0, st, g.d_flat, n_flat);
+        }
+    }
     hipLaunchKernelGGL(fill_list_kernel, dim3(grid_of(std::max<size_t>(n_list, 8))), dim3(256), 0, st, g.d_list, std::max<size_t>(n_list, 8));
     hipLaunchKernelGGL(cell_words_kernel, dim3((unsigned)((n_cells + 3) / 4)), dim3(256), 0, st, G, div, d_cell_first, d_cell_key, d_cell_brick, d_list_off, n_cells,
-                       (uint32_t)n_inc, d_vals_s, c->d_spos, g.d_top, g.d_cells);
+                       (uint32_t)n_inc, d_vals_s, c->d_spos, g.d_top, g.d_cells, g.d_flat);
     hipLaunchKernelGGL(list_fill_kernel, dim3(grid_of(n_inc)), dim3(256), 0, st, d_cflag, d_cidx, d_cell_first, d_list_off, d_vals_s, n_inc, c->d_spos, g.d_list);
     STOCS_HIP_CHECK(hipGetLastError());
     // ---- 5. dense scenes: chunk bounds ----

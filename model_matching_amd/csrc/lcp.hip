@@ -35,6 +35,7 @@ struct LcpArgs {
     int M;
     const int32_t* top;
     const uint4* cells;
+    const uint4* flat;    // cell words addressed by (cz*ny + cy)*nx + cx, or NULL (brick look-up through top / cells)
     const float4* list;
     const float4* snrmw;  // scene unit normal + class-probability weight
     const float* chunk_r; // per 8-entry chunk: lower bound of |entry - cell centre| (dense scenes), else NULL
@@ -70,6 +71,22 @@ __device__ __forceinline__ int lcp_candidate(const LcpArgs& a, int n, int w, int
 #define DPP_HALF_MIRROR 0x141 /* lane k <-> 7-k inside each group of 8 */
 #define DPP_ROW_SHR(n) (0x110 + (n))
 
+// Score accumulation.  The reference adds class probabilities in a sequential float loop (stocs.cpp:1033); a parallel
+// kernel cannot keep that order, so the weights are added as 2^32 fixed-point integers instead: exact for every weight
+// >= 2^-9 (class probabilities are >= the 0.10 threshold), hence independent of the order -- of the lane a point lands on,
+// of how a candidate's model points are split over wavefronts, of the batch it is scored in.  The score is the correctly
+// rounded float of the exact mean; the reference's running float sum differs from it by ~1e-7 (tests: <= 1e-5).
+__device__ __forceinline__ void lcp_add(unsigned long long& acc, float w) {
+    if (w > 0.0f) acc += (unsigned long long)(w * 4294967296.0f);   // exact product (power of two), truncating conversion
+}
+__device__ __forceinline__ unsigned long long lcp_wave_sum(unsigned long long acc) {
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    return acc;
+}
+__device__ __forceinline__ float lcp_finish(unsigned long long total, int M) {
+    return (float)((double)total * (1.0 / 4294967296.0) / (double)M);
+}
+
 // candidate update: inclusive radius (kdtree.h:424), ties -> larger scene index.  When a list is stored in
 // ascending index order (IDX: every grid except the dense, centre-sorted one) `<=` implements the tie rule.
 template <bool IDX>
@@ -87,7 +104,7 @@ __global__ __launch_bounds__(256) void lcp_kernel(LcpArgs a, const float* __rest
     const float* T = T16 + (size_t)cand * 16;
     const float t0 = T[0], t1 = T[1], t2 = T[2], t4 = T[4], t5 = T[5], t6 = T[6], t8 = T[8], t9 = T[9], t10 = T[10],
                 t12 = T[12], t13 = T[13], t14 = T[14];
-    float acc = 0.0f;
+    unsigned long long acc = 0ull;
     for (int i = lane; i < a.M; i += 64) {
         const float4 p = a.mpos[i];
         // (mat * p.homogeneous()).head<3>()
@@ -123,7 +140,7 @@ __global__ __launch_bounds__(256) void lcp_kernel(LcpArgs a, const float* __rest
             const float d = sn.x * nx + (sn.y * ny + sn.z * nz);
             // acos(d)*180/pi < 30 as an exact threshold; d > 1 -> NaN angle -> not counted (Q7)
             counted = (d >= a.dot_lo) && (d <= 1.0f);
-            if (counted) acc += sn.w;
+            if (counted) lcp_add(acc, sn.w);
         }
         if (DETAIL) {
             const int orig = a.mperm[i];
@@ -132,8 +149,8 @@ __global__ __launch_bounds__(256) void lcp_kernel(LcpArgs a, const float* __rest
         }
     }
     // fixed-shape butterfly: deterministic
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (lane == 0) out[cand] = acc / (float)a.M;
+    acc = lcp_wave_sum(acc);
+    if (lane == 0) out[cand] = lcp_finish(acc, a.M);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -173,7 +190,7 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coop_kernel(LcpArgs a, const flo
     const float* T = T16 + (size_t)cand * 16;
     const float t0 = T[0], t1 = T[1], t2 = T[2], t4 = T[4], t5 = T[5], t6 = T[6], t8 = T[8], t9 = T[9], t10 = T[10],
                 t12 = T[12], t13 = T[13], t14 = T[14];
-    float acc = 0.0f;
+    unsigned long long acc = 0ull;
     for (int base = 0; base < a.M; base += 64) {
         const int i = base + lane;
         float qx = 0.f, qy = 0.f, qz = 0.f, qcd = 0.f;
@@ -288,7 +305,7 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coop_kernel(LcpArgs a, const flo
             const float4 sn = a.snrmw[best];
             const float d = sn.x * nx + (sn.y * ny + sn.z * nz);
             counted = (d >= a.dot_lo) && (d <= 1.0f);
-            if (counted) acc += sn.w;
+            if (counted) lcp_add(acc, sn.w);
         }
         if (DETAIL && i < a.M) {
             const int orig = a.mperm[i];
@@ -296,8 +313,8 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coop_kernel(LcpArgs a, const flo
             cnt_out[(size_t)cand * a.M + orig] = counted ? 1 : 0;
         }
     }
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (lane == 0) out[cand] = acc / (float)a.M;
+    acc = lcp_wave_sum(acc);
+    if (lane == 0) out[cand] = lcp_finish(acc, a.M);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -307,7 +324,10 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coop_kernel(LcpArgs a, const flo
 // normal test runs on full wavefronts.  Lane <-> point assignment of the accumulation differs from v0,
 // so scores agree with v0 to rounding (1e-7), not bitwise; still run-to-run deterministic.
 // ---------------------------------------------------------------------------------------------
-template <bool DETAIL, int UNR, bool SORTQ = false, int PIPE = 4, bool IDX = true, int WPB = 4>
+// SPLIT: the WPB wavefronts of a workgroup share ONE candidate and take its 64-point steps round-robin (a trial's ~8 000
+// candidates are a single round of wavefronts on the chip, and four times as many, four times shorter wavefronts finish
+// it sooner; big batches lose nothing); the partial sums are integers, so the score is the same bit for bit.
+template <bool DETAIL, int UNR, bool SORTQ = false, int PIPE = 4, bool IDX = true, int WPB = 4, bool FLAT = false, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
                                                         int n, int32_t* __restrict__ hit_out, uint8_t* __restrict__ cnt_out) {
     __shared__ float4 qt[WPB][128];     // qx, qy, qz, bits(list offset)
@@ -315,15 +335,17 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
     __shared__ uint32_t qs[WPB][128];   // model slot (Morton order)
     __shared__ int ri[WPB][128];        // best scene index
     __shared__ uint8_t ord[WPB][64];    // batch order sorted by list length (SORTQ)
+    __shared__ unsigned long long part[WPB];
     const int lane = threadIdx.x & 63;
     const int sub = lane & 7, grp = lane >> 3;
     const int w = threadIdx.x >> 6;
-    const int cand = lcp_candidate(a, n, w, WPB);
-    if (cand < 0) return;
+    const int cand = SPLIT ? lcp_candidate(a, n, 0, 1) : lcp_candidate(a, n, w, WPB);
+    if (cand < 0) return;   // SPLIT: the whole workgroup leaves together
+    const int first = SPLIT ? 64 * w : 0, stride = SPLIT ? 64 * WPB : 64;
     const float* T = T16 + (size_t)cand * 16;
     const float t0 = T[0], t1 = T[1], t2 = T[2], t4 = T[4], t5 = T[5], t6 = T[6], t8 = T[8], t9 = T[9], t10 = T[10],
                 t12 = T[12], t13 = T[13], t14 = T[14];
-    float acc = 0.0f;
+    unsigned long long acc = 0ull;
     int head = 0, tail = 0;
 
     auto process = [&](int nq) {
@@ -407,7 +429,7 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
                 const float4 sn = a.snrmw[best];
                 const float d = sn.x * nx + (sn.y * ny + sn.z * nz);
                 counted = (d >= a.dot_lo) && (d <= 1.0f);
-                if (counted) acc += sn.w;
+                if (counted) lcp_add(acc, sn.w);
             }
             if (DETAIL) {
                 const int orig = a.mperm[slot_i];
@@ -421,13 +443,13 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
     // the model point of the NEXT step is requested one step ahead (takes one of the three dependent
     // loads of the look-up chain off the critical path)
     float4 p_next = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < a.M) p_next = a.mpos[lane];
-    for (int base = 0; base < a.M; base += 64) {
+    if (first + lane < a.M) p_next = a.mpos[first + lane];
+    for (int base = first; base < a.M; base += stride) {
         const int i = base + lane;
         float qx = 0.f, qy = 0.f, qz = 0.f;
         uint32_t off = 0, cnt = 0;
         const float4 p = p_next;
-        if (i + 64 < a.M) p_next = a.mpos[i + 64];
+        if (i + stride < a.M) p_next = a.mpos[i + stride];
         if (i < a.M) {
             qx = ((t0 * p.x + t4 * p.y) + t8 * p.z) + t12;
             qy = ((t1 * p.x + t5 * p.y) + t9 * p.z) + t13;
@@ -439,12 +461,18 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
                       c4z = __float2int_rd((qz - a.oz) * a.inv_h4);
             const int cx = c4x >> 2, cy = c4y >> 2, cz = c4z >> 2;
             if ((unsigned)cx < (unsigned)a.nx && (unsigned)cy < (unsigned)a.ny && (unsigned)cz < (unsigned)a.nz) {
-                const int brick = a.top[((cz >> 3) * a.nby + (cy >> 3)) * a.nbx + (cx >> 3)];
-                if (brick >= 0) {
-                    const uint4 cw = a.cells[(uint32_t)brick * 512u + (uint32_t)(((cz & 7) << 6) | ((cy & 7) << 3) | (cx & 7))];
-                    const int sb = ((c4z & 3) << 4) | ((c4y & 3) << 2) | (c4x & 3);
+                const int sb = ((c4z & 3) << 4) | ((c4y & 3) << 2) | (c4x & 3);
+                if (FLAT) {   // one look-up: an empty cell is an all-zero word (count 0, mask 0)
+                    const uint4 cw = a.flat[(uint32_t)((cz * a.ny + cy) * a.nx + cx)];
                     const uint32_t mw = sb < 32 ? cw.z : cw.w;
                     off = cw.x; cnt = ((mw >> (sb & 31)) & 1u) ? cw.y : 0u;
+                } else {
+                    const int brick = a.top[((cz >> 3) * a.nby + (cy >> 3)) * a.nbx + (cx >> 3)];
+                    if (brick >= 0) {
+                        const uint4 cw = a.cells[(uint32_t)brick * 512u + (uint32_t)(((cz & 7) << 6) | ((cy & 7) << 3) | (cx & 7))];
+                        const uint32_t mw = sb < 32 ? cw.z : cw.w;
+                        off = cw.x; cnt = ((mw >> (sb & 31)) & 1u) ? cw.y : 0u;
+                    }
                 }
             }
             if (DETAIL && cnt == 0) {
@@ -472,8 +500,17 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
         }
     }
     if (tail - head > 0) process(tail - head);
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (lane == 0) out[cand] = acc / (float)a.M;
+    acc = lcp_wave_sum(acc);
+    if (SPLIT) {
+        if (lane == 0) part[w] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long total = 0;
+#pragma unroll
+            for (int k = 0; k < WPB; ++k) total += part[k];
+            out[cand] = lcp_finish(total, a.M);
+        }
+    } else if (lane == 0) out[cand] = lcp_finish(acc, a.M);
 }
 
 // compute_best_transform (stocs.cpp:982-1004) on the device: max of the packed (score, ~id) keys --
@@ -566,7 +603,7 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
     if (n <= 0) return STOCS_OK;
     LcpArgs a;
     a.mpos = c->d_mpos_s; a.mnrm = c->d_mnrm_s; a.mperm = c->d_mperm; a.M = c->nM;
-    a.top = c->grid.d_top; a.cells = c->grid.d_cells; a.list = c->grid.d_list; a.snrmw = c->d_snrmw;
+    a.top = c->grid.d_top; a.cells = c->grid.d_cells; a.flat = c->grid.d_flat; a.list = c->grid.d_list; a.snrmw = c->d_snrmw;
     a.ox = c->grid.ox; a.oy = c->grid.oy; a.oz = c->grid.oz; a.inv_h = c->grid.inv_h; a.inv_h4 = c->grid.inv_h * 4.0f; a.h = c->grid.h; a.chunk_r = c->grid.d_chunk_r;
     a.nx = c->grid.nx; a.ny = c->grid.ny; a.nz = c->grid.nz; a.nbx = c->grid.nbx; a.nby = c->grid.nby;
     a.sq_eps = c->prm.distance_threshold * c->prm.distance_threshold;  // sq_eps = epsilon*epsilon, stocs.cpp:1014
@@ -639,7 +676,17 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
             case 40: hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 4, true, 8>), dim3((n + 7) / 8), dim3(512), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); break;
             case 44: STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 4, true, 4>); break;
 #endif
-            default: hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 4, true, 1>), dim3(n), dim3(64), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); break;   // 24
+            default: {  // 24
+                const bool flat = a.flat && c->lcp_flat;
+                // four wavefronts per candidate: a trial's ~8 000 candidates finish 40 % sooner (one round of long wavefronts
+                // becomes four rounds of short ones), 32 768 candidates 9 % sooner, 65 536 the same (tools/lcp_flat_ab.py)
+                const bool split = c->lcp_split && a.M >= 512;
+                if (split && flat) hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 4, true, 4, true, true>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
+                else if (split) hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 4, true, 4, false, true>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
+                else if (flat) hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 4, true, 1, true>), dim3(n), dim3(64), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
+                else hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 4, true, 1>), dim3(n), dim3(64), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
+                break;
+            }
         }
     }
 #undef STOCS_LCP_LAUNCH
@@ -745,6 +792,11 @@ int stocs_set_option(stocs_ctx* c, const char* key, int value) {
     }
     // 0 off, 1 spatial order, 2 + XCD-contiguous halves of the list, k > 2 + chunks of k consecutive slots per XCD
     if (!strcmp(key, "lcp_order") && value >= 0 && value <= 4096) { c->lcp_order = value; return STOCS_OK; }
+    // 0: brick look-ups only, 1: the flat cell table when the grid has one (takes effect for kernels launched afterwards;
+    // the table itself is built with the scene grid)
+    if (!strcmp(key, "lcp_flat") && (value == 0 || value == 1)) { c->lcp_flat = value; return STOCS_OK; }
+    // 0: one wavefront per candidate, 1 (default): four wavefronts share a candidate's model points (same scores)
+    if (!strcmp(key, "lcp_split") && (value == 0 || value == 1)) { c->lcp_split = value; return STOCS_OK; }
     set_error("stocs_set_option: unknown option or value");
     return STOCS_ERR_INVALID;
 }
