@@ -677,6 +677,7 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));   // the previous trial's buffers are about to be reused
     { int rc0 = S->arena_state.reset(); if (rc0) return rc0; }
     tl_arena = &S->arena_state;
+    if (dbg) { const double t_ = now_s(); fprintf(stderr, "[stocs congruent] %-18s %8.3f ms\n", "sync+reset", (t_ - tprev) * 1e3); tprev = t_; }
     c->quad_off.assign(nB + 1, 0);
     c->quad_id_bits = 16;
     if (total_quads) *total_quads = 0;
@@ -707,6 +708,7 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
         prefetch_lookup(ix, K1);
         prefetch_lookup(ix, K2);
     }
+    if (dbg) { const double t_ = now_s(); fprintf(stderr, "[stocs congruent] %-18s %8.3f ms\n", "keys+prefetch", (t_ - tprev) * 1e3); tprev = t_; }
     for (int b = 0; b < nB; ++b) {
         const BaseRec& B = c->bases[b];
         BaseJob& J = jobs[b];

@@ -202,9 +202,7 @@ static int load_scene(stocs_ctx* c, const float* sp, const float* sn, const floa
     const size_t npx = (size_t)c->prm.image_width * c->prm.image_height;
     c->has_edge = false;
     c->edge_map.assign(npx, 0);
-    c->previous_segment.reset();
-    c->segmentation_buffer.assign(npx, 0);
-    c->seg_masks.clear();
+    stocs_internal_invalidate_instance(c);
     c->last_segment.clear();
     return rc;
 }
@@ -268,6 +266,7 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     c->index.built = false;
     c->index.d_bucket_start = NULL; c->index.d_pairs = NULL; c->index.d_exists = NULL;
     c->cong = NULL; c->quad_id_bits = 16;
+    c->inst = NULL;
     c->d_cand = NULL; c->cand_bytes = 0; c->n_cands = 0; c->cand_cap = 0; c->cands_stale = false;
     c->d_best = NULL;
     c->best_lcp = 0; c->best_index = -1;
@@ -369,6 +368,7 @@ int stocs_ctx_destroy(stocs_ctx* c) {
                     c->d_mnrm_s, c->d_mperm, c->index.d_bucket_start,
                     c->index.d_pairs, c->index.d_exists, c->d_scratch, c->d_best, c->d_cand, c->d_order};
     stocs_internal_free_congruent(c);
+    stocs_internal_free_instance(c);
     c->grid_mem.destroy(); c->grid_ws.destroy();
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (void* p : ptrs) if (p) hipFree(p);
@@ -413,6 +413,7 @@ int stocs_set_edge_map(stocs_ctx* c, const uint8_t* edge) {
     DeviceGuard dev_guard(c->device);
     c->edge_map.assign(edge, edge + (size_t)c->prm.image_width * c->prm.image_height);
     c->has_edge = true;
+    stocs_internal_invalidate_instance(c);   // runs and per-point tables follow the edge map
     return STOCS_OK;
 }
 

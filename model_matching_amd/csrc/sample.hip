@@ -16,15 +16,14 @@
 // owning chunk, i.e. an exact, order-independent replacement of std::discrete_distribution with a
 // counter-based RNG (documented divergence Q6).
 // Instance mode is sequential across attempts by construction (compounding prior decay and the
-// previous segment, stocs.cpp:572-580,626); its image-space flood fill stays on the host as in the
-// reference, the PPF passes and draws run on the device.
+// previous segment, stocs.cpp:572-580,626): one persistent workgroup runs all its attempts on the device,
+// image-space flood fill included (instance_attempts_kernel below); the host only reads the results.
 #include <math.h>
 #include <string.h>
 #include <time.h>
 
 #include <algorithm>
 #include <limits>
-#include <queue>
 
 #include "stocs_ctx.h"
 
@@ -342,34 +341,195 @@ static int sample_class(stocs_ctx* c, uint64_t seed, int first_attempt, int nB, 
     return record_bases(c, nB, res.data(), ids, inv, valid);
 }
 
-// rgbd.cpp:314-367 with the PNG round trip through dbg/seg_mask_<n>.png replaced by seg_masks (Q14)
-static std::shared_ptr<const std::vector<uint8_t> > generate_segmentation_mask(stocs_ctx* c, int prow, int pcol, float max_distance, int base_num) {
-    const int W = c->prm.image_width, H = c->prm.image_height;
-    const int segment_index = c->segmentation_buffer[(size_t)prow * W + pcol];
-    if (segment_index != 0) return c->seg_masks[segment_index];   // the mask file of that attempt is read back (rgbd.cpp:322-326)
-    std::shared_ptr<std::vector<uint8_t> > closed(new std::vector<uint8_t>((size_t)W * H, 0));
-    std::vector<uint8_t>& closed_list = *closed;
-    std::queue<std::pair<int, int> > open_list;
-    open_list.push(std::make_pair(prow, pcol));
-    while (!open_list.empty()) {
-        const std::pair<int, int> curr = open_list.front();
-        closed_list[(size_t)curr.first * W + curr.second] = 255;
-        c->segmentation_buffer[(size_t)curr.first * W + curr.second] = (uint8_t)base_num;
-        open_list.pop();
-        for (int i = curr.first - 1; i <= curr.first + 1; ++i)
-            for (int j = curr.second - 1; j <= curr.second + 1; ++j) {
-                if (i < 0 || j < 0 || i >= H || j >= W) continue;
-                const float edge_probability = (float)(255.0 - c->edge_map[(size_t)i * W + j]) / 255.0;
-                const int expanded = (int)closed_list[(size_t)i * W + j];
-                const float dist = (float)sqrt(pow((double)(prow - i), 2) + pow((double)(pcol - j), 2));
-                if (expanded == 0 && edge_probability == 0 && dist < max_distance) {
-                    open_list.push(std::make_pair(i, j));
-                    closed_list[(size_t)i * W + j] = 255;
-                    c->segmentation_buffer[(size_t)i * W + j] = (uint8_t)base_num;
-                }
-            }
+// ---------------------------------------------------------------------------------------------------------------
+// Instance mode (stocs.cpp:559-751) entirely on the device: ONE persistent 1024-thread workgroup runs the attempts one
+// after the other -- they are sequential by construction (compounding prior decay :572-580, previous_segment :626, the
+// segmentation buffer) -- with workgroup barriers between the stages and no host involvement until the results are read.
+//
+// Image-space state per SCENE POINT instead of per pixel: everything the reference reads from previous_segment /
+// segmentation_buffer / seg_mask_<n>.png (rgbd.cpp:314-367, Q14) it reads at the pixel of a scene point, so the state is
+//   prev_in[i]      pixel of point i lies in previous_segment
+//   label[i]        segmentation_buffer at that pixel (attempt that last flood-filled it, 0 = none)
+//   maskbits[n][i]  pixel of point i lies in attempt n's mask (the seg_mask_<n>.png read back at rgbd.cpp:322-326)
+// The flood fill itself (rgbd.cpp:334-366: 8-neighbourhood over passable pixels -- png value 255 -- closer to the seed
+// than max_distance) is a connected-component query: the passable pixels of every image row are kept as runs (built once
+// per edge map), the runs of the rows inside the disc are clipped to it and united when they touch (lock-free union-find
+// in LDS), and a point is in the mask when its run has the seed's root.  sqrt(d2) < sqrt(max d2) in float is decided on
+// the integers d2 (distinct integers below 2^20 have distinct float square roots).
+// ---------------------------------------------------------------------------------------------------------------
+#define INST_MAX_NODES 16384
+
+struct InstanceArgs {
+    PassArgs pa;
+    const int2* pix;            // (row, col) per scene point
+    const uint8_t* edge_pt;     // point's pixel has edge_probability == 1 (png value 0): pruned (stocs.cpp:521-535)
+    const int32_t* pt_run;      // run holding the point's pixel, -1 when the pixel is not passable
+    const uint16_t* run_s; const uint16_t* run_e;   // [start, end) columns of the passable runs, row by row
+    const uint32_t* row_off;    // H + 1
+    int H, W, Sw;               // Sw = words per point bitset
+    float* cls;                 // current class probabilities (decay in place, Q8)
+    uint8_t* prev_in; uint8_t* label;
+    uint32_t* maskbits;         // 256 x Sw
+    uint32_t* segbits;          // Sw: `segment` of the last attempt
+    uint32_t* parent_g;         // union-find parents when the disc holds more than INST_MAX_NODES runs (+ 1)
+    float* w;                   // S weights
+    float4* spos_w; float4* snrm_w;   // the scene arrays whose .w the LCP adds: refreshed with the decayed prior at the end
+    BaseOut* res;
+};
+
+__device__ __forceinline__ uint32_t uf_find(uint32_t* parent, uint32_t x) {
+    uint32_t p = parent[x];
+    while (p != x) { const uint32_t g = parent[p]; parent[x] = g; x = p; p = g; }   // path halving; races only ever shorten paths
+    return x;
+}
+__device__ __forceinline__ void uf_unite(uint32_t* parent, uint32_t a, uint32_t b) {
+    for (;;) {
+        a = uf_find(parent, a); b = uf_find(parent, b);
+        if (a == b) return;
+        if (a < b) { const uint32_t t = a; a = b; b = t; }      // the larger root goes under the smaller one
+        if (atomicCAS(&parent[a], a, b) == a) return;
     }
-    return closed;
+}
+// largest h >= 0 with h*h < rem (rem > 0)
+__device__ __forceinline__ int half_width(int rem) {
+    int h = (int)sqrtf((float)rem);
+    while (h * h >= rem) --h;
+    while ((h + 1) * (h + 1) < rem) ++h;
+    return h;
+}
+
+// connected component of the seed: after this call a point whose run r satisfies in_mask_run(r) is inside the mask
+template <class ParentPtr>
+__device__ void flood_fill_runs(const InstanceArgs& A, ParentPtr parent, int r0, int c0, int maxd2, int rlo, int rhi, uint32_t base, uint32_t nodes) {
+    const int t = threadIdx.x;
+    for (uint32_t k = t; k <= nodes; k += blockDim.x) parent[k] = k;   // node `nodes` is the seed pixel itself
+    __syncthreads();
+    // clipped interval of run g (global index) in row r: empty when cs >= ce
+    auto clip = [&](uint32_t g, int r, int* cs, int* ce) {
+        const int dr = r - r0, rem = maxd2 - dr * dr;
+        if (rem <= 0) { *cs = 0; *ce = 0; return; }
+        const int hw = half_width(rem);
+        *cs = max((int)A.run_s[g], c0 - hw);
+        *ce = min((int)A.run_e[g], c0 + hw + 1);
+    };
+    for (int r = rlo + (int)(t >> 6); r <= rhi; r += (int)(blockDim.x >> 6)) {   // one wavefront per row pair (r, r + 1)
+        const uint32_t a0 = A.row_off[r], a1 = A.row_off[r + 1], b1 = (r < rhi) ? A.row_off[r + 2] : a1;
+        for (uint32_t g = a0 + (t & 63); g < a1; g += 64) {
+            int cs, ce;
+            clip(g, r, &cs, &ce);
+            if (cs >= ce) continue;
+            // the seed pixel touches every clipped run that meets its 3x3 neighbourhood
+            if (r >= r0 - 1 && r <= r0 + 1 && cs < c0 + 2 && ce > c0 - 1) uf_unite(parent, g - base, nodes);
+            for (uint32_t h = a1; h < b1; ++h) {           // runs of the next row, in column order
+                if ((int)A.run_s[h] >= ce + 1) break;
+                int ds, de;
+                clip(h, r + 1, &ds, &de);
+                if (ds < de && ds < ce + 1 && de > cs - 1) uf_unite(parent, g - base, h - base);   // 8-neighbourhood: overlap widened by one
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void instance_attempts_kernel(InstanceArgs A, uint64_t seed, int first_attempt, int n_attempts, float dispersion) {
+    __shared__ uint64_t sh[1024];
+    __shared__ uint64_t sh_total;
+    __shared__ int sh_pick;
+    __shared__ int sh_max;
+    __shared__ uint32_t parent_l[INST_MAX_NODES + 1];
+    const int t = threadIdx.x, S = A.pa.S, lane = t & 63;
+    for (int a = 0; a < n_attempts; ++a) {
+        const int attempt = first_attempt + a, base_num = attempt + 1;
+        BaseOut* out = A.res + a;
+        // ---- weights: compounding decay of the prior inside the previous segment, edge pixels pruned (stocs.cpp:572-584) ----
+        for (int i = t; i < S; i += 1024) {
+            float c = A.cls[i];
+            if (A.prev_in[i]) { c = dispersion * c; A.cls[i] = c; }
+            A.w[i] = A.edge_pt[i] ? 0.0f : c;
+        }
+        if (t == 0) sh_max = 0;
+        __syncthreads();
+        int32_t bidx[4] = {-1, -1, -1, -1};
+        int fail = 0;
+        bidx[0] = draw_block(A.w, S, rng64(seed, (uint64_t)attempt, 0), sh, &sh_total, &sh_pick);
+        if (bidx[0] < 0) {   // "FAILED SAMPLING": no base, no mask, previous_segment stays (stocs.cpp:586-589)
+            if (t == 0) { for (int k = 0; k < 4; ++k) out->ids[k] = -1; out->inv[0] = out->inv[1] = 0; out->valid = 0; out->pad = 0; }
+            __syncthreads();
+            continue;
+        }
+        const int b1 = bidx[0];
+        const int2 sp = A.pix[b1];
+        // ---- pass 1 + the largest pixel distance of a survivor (stocs.cpp:596-618) ----
+        int my_max = 0;
+        for (int i = t; i < S; i += 1024) {
+            float wi = A.w[i];
+            if (wi != 0.0f && pass_zeroes<1>(A.pa, b1, -1, -1, i)) { wi = 0.0f; A.w[i] = 0.0f; }
+            if (wi != 0.0f) { const int2 p = A.pix[i]; const int dr = sp.x - p.x, dc = sp.y - p.y; my_max = max(my_max, dr * dr + dc * dc); }
+        }
+        for (int off = 32; off > 0; off >>= 1) my_max = max(my_max, __shfl_xor(my_max, off, 64));
+        if (lane == 0 && my_max) atomicMax(&sh_max, my_max);
+        __syncthreads();
+        const int maxd2 = sh_max;
+        // ---- the mask: an earlier attempt's when the seed pixel is already labelled, else a new flood fill (rgbd.cpp:314-367) ----
+        const int lab = A.label[b1];
+        const int rad = maxd2 > 0 ? half_width(maxd2) : 0;
+        const int rlo = max(0, sp.x - rad), rhi = min(A.H - 1, sp.x + rad);
+        const uint32_t base = A.row_off[rlo], nodes = A.row_off[rhi + 1] - base;
+        const bool in_lds = nodes <= INST_MAX_NODES;
+        uint32_t root_s = 0;
+        if (lab == 0) {
+            if (in_lds) flood_fill_runs(A, parent_l, sp.x, sp.y, maxd2, rlo, rhi, base, nodes);
+            else flood_fill_runs(A, A.parent_g, sp.x, sp.y, maxd2, rlo, rhi, base, nodes);
+            root_s = in_lds ? uf_find(parent_l, nodes) : uf_find(A.parent_g, nodes);
+        }
+        // ---- bookkeeping per scene point: mask membership, previous_segment, labels, the survivors inside (`segment`) ----
+        for (int i0 = t - lane; i0 < S; i0 += 1024) {    // whole wavefronts: the bitset words are ballots
+            const int i = i0 + lane;
+            bool in = false;
+            float wi = 0.0f;
+            if (i < S) {
+                wi = A.w[i];
+                if (lab != 0) in = (A.maskbits[(size_t)lab * A.Sw + (i >> 5)] >> (i & 31)) & 1u;
+                else {
+                    const int2 p = A.pix[i];
+                    const int dr = p.x - sp.x, dc = p.y - sp.y;
+                    if (dr == 0 && dc == 0) in = true;                       // the seed pixel is always part of its mask
+                    else if (dr * dr + dc * dc < maxd2) {
+                        const int g = A.pt_run[i];
+                        if (g >= 0) in = (in_lds ? uf_find(parent_l, (uint32_t)g - base) : uf_find(A.parent_g, (uint32_t)g - base)) == root_s;
+                    }
+                }
+                A.prev_in[i] = in ? 1 : 0;                                   // segmentation_mask.copyTo(previous_segment), stocs.cpp:626
+                if (lab == 0 && in) A.label[i] = (uint8_t)base_num;          // segmentation_buffer = base_num over the new mask
+                if (wi != 0.0f && !in) { wi = 0.0f; A.w[i] = 0.0f; }        // stocs.cpp:628-638
+            }
+            const unsigned long long mb = __ballot(in), sb = __ballot(wi != 0.0f);
+            if (lane == 0) {
+                const int wd = i0 >> 5;
+                A.maskbits[(size_t)base_num * A.Sw + wd] = (uint32_t)mb;     // seg_mask_<base_num>.png, whichever mask it is
+                A.segbits[wd] = (uint32_t)sb;
+                if (wd + 1 < A.Sw) { A.maskbits[(size_t)base_num * A.Sw + wd + 1] = (uint32_t)(mb >> 32); A.segbits[wd + 1] = (uint32_t)(sb >> 32); }
+            }
+        }
+        __syncthreads();
+        // ---- points 2..4 (stocs.cpp:640-751 = the class-mode passes) ----
+        for (int k = 1; k < 4 && !fail; ++k) {
+            bidx[k] = draw_block(A.w, S, rng64(seed, (uint64_t)attempt, (uint64_t)k), sh, &sh_total, &sh_pick);
+            if (bidx[k] < 0) { fail = 1; break; }
+            if (k < 3) {
+                for (int i = t; i < S; i += 1024) {
+                    if (A.w[i] == 0.0f) continue;                              // already zero: nothing to decide
+                    const bool z = (k == 1) ? pass_zeroes<2>(A.pa, bidx[0], bidx[1], -1, i) : pass_zeroes<3>(A.pa, bidx[0], bidx[1], bidx[2], i);
+                    if (z) A.w[i] = 0.0f;
+                }
+                __syncthreads();
+            }
+        }
+        if (t == 0) finalize_one(A.pa.spos, bidx, fail, out);
+        __syncthreads();
+    }
+    // the LCP adds class_probability_, which this sampling decays in place (Q8): refresh the scene arrays it reads
+    for (int i = t; i < S; i += 1024) { const float c = A.cls[i]; A.spos_w[i].w = c; A.snrm_w[i].w = c; }
 }
 
 static int refresh_class_prob_on_device(stocs_ctx* c) {
@@ -385,92 +545,132 @@ static int refresh_class_prob_on_device(stocs_ctx* c) {
     return STOCS_OK;
 }
 
-static thread_local double g_t_inst[6];   // STOCS_DEBUG_TIMING accumulators
-static inline double now_s_() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
-#define TSEC(k) { const double t_ = now_s_(); g_t_inst[k] += t_ - tprev_; tprev_ = t_; }
-static int sample_instance_one(stocs_ctx* c, uint64_t seed, int attempt, float dispersion, int base_num, int32_t* ids, float* inv, int32_t* valid) {
-    const int S = c->nS, W = c->prm.image_width;
-    double tprev_ = now_s_();
-    SampleBuffers sb;
-    int rc = carve(c, 1, &sb);
+// Device-side state of instance mode, owned by the context (stocs_ctx::inst)
+struct InstanceState {
+    bool runs_valid = false;     // runs / pt_run / edge_pt match the current edge map and scene
+    int S = 0, Sw = 0;
+    char* d_mem = NULL; size_t mem_bytes = 0;
+    uint16_t* d_run_s = NULL; uint16_t* d_run_e = NULL; uint32_t* d_row_off = NULL;
+    int32_t* d_pt_run = NULL; uint8_t* d_edge_pt = NULL; uint8_t* d_prev_in = NULL; uint8_t* d_label = NULL;
+    float* d_cls = NULL; uint32_t* d_maskbits = NULL; uint32_t* d_segbits = NULL; uint32_t* d_parent = NULL;
+    size_t n_runs = 0;
+    std::vector<uint32_t> h_segbits;
+};
+
+static void free_instance_state(stocs_ctx* c) {
+    InstanceState* I = (InstanceState*)c->inst;
+    if (!I) return;
+    if (I->d_mem) (void)hipFree(I->d_mem);
+    delete I;
+    c->inst = NULL;
+}
+
+// (re)builds what depends on the edge map and the scene's pixels; clears the per-trial state
+static int prepare_instance_state(stocs_ctx* c) {
+    if (!c->inst) c->inst = new InstanceState();
+    InstanceState* I = (InstanceState*)c->inst;
+    if (I->runs_valid && I->S == c->nS) return STOCS_OK;
+    const int S = c->nS, W = c->prm.image_width, H = c->prm.image_height;
+    // passable runs (png value 255 <=> edge_probability == 0, rgbd.cpp:350) row by row
+    std::vector<uint16_t> rs, re;
+    std::vector<uint32_t> row_off((size_t)H + 1, 0);
+    for (int r = 0; r < H; ++r) {
+        row_off[r] = (uint32_t)rs.size();
+        const uint8_t* row = &c->edge_map[(size_t)r * W];
+        int col = 0;
+        while (col < W) {
+            if (row[col] != 255) { ++col; continue; }
+            const int s0 = col;
+            while (col < W && row[col] == 255) ++col;
+            rs.push_back((uint16_t)s0); re.push_back((uint16_t)col);
+        }
+    }
+    row_off[H] = (uint32_t)rs.size();
+    std::vector<int32_t> pt_run(S, -1);
+    std::vector<uint8_t> edge_pt(S, 0);
+    for (int i = 0; i < S; ++i) {
+        const int r = c->h_spix[2 * i], col = c->h_spix[2 * i + 1];
+        const uint8_t v = c->edge_map[(size_t)r * W + col];
+        edge_pt[i] = ((float)(255.0 - v) / 255.0 == 1) ? 1 : 0;    // prune_edge_pixels, stocs.cpp:529-533
+        if (v == 255) {   // binary search of the run that holds the column
+            uint32_t lo = row_off[r], hi = row_off[r + 1];
+            while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (rs[mid] <= col) lo = mid; else hi = mid; }
+            pt_run[i] = (int32_t)lo;
+        }
+    }
+    const int Sw = ((S + 63) / 64) * 2;   // whole 64-bit ballots
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t nr = std::max<size_t>(rs.size(), 1);
+    const size_t o_rs = 0, o_re = o_rs + al(nr * 2), o_ro = o_re + al(nr * 2), o_pr = o_ro + al(((size_t)H + 1) * 4), o_ep = o_pr + al((size_t)S * 4),
+                 o_pi = o_ep + al(S), o_lb = o_pi + al(S), o_cl = o_lb + al(S), o_mb = o_cl + al((size_t)S * 4), o_sb = o_mb + al((size_t)256 * Sw * 4),
+                 o_pa = o_sb + al((size_t)Sw * 4), total = o_pa + al((nr + 1) * 4);
+    if (I->mem_bytes < total) {
+        if (I->d_mem) { STOCS_HIP_CHECK(hipStreamSynchronize(c->stream)); (void)hipFree(I->d_mem); I->d_mem = NULL; I->mem_bytes = 0; }
+        STOCS_HIP_CHECK(dev_malloc((void**)&I->d_mem, total + total / 4));
+        I->mem_bytes = total + total / 4;
+    }
+    char* m = I->d_mem;
+    I->d_run_s = (uint16_t*)(m + o_rs); I->d_run_e = (uint16_t*)(m + o_re); I->d_row_off = (uint32_t*)(m + o_ro); I->d_pt_run = (int32_t*)(m + o_pr);
+    I->d_edge_pt = (uint8_t*)(m + o_ep); I->d_prev_in = (uint8_t*)(m + o_pi); I->d_label = (uint8_t*)(m + o_lb); I->d_cls = (float*)(m + o_cl);
+    I->d_maskbits = (uint32_t*)(m + o_mb); I->d_segbits = (uint32_t*)(m + o_sb); I->d_parent = (uint32_t*)(m + o_pa);
+    I->S = S; I->Sw = Sw; I->n_runs = rs.size();
+    hipStream_t st = c->stream;
+    if (!rs.empty()) {
+        STOCS_HIP_CHECK(hipMemcpyAsync(I->d_run_s, rs.data(), rs.size() * 2, hipMemcpyHostToDevice, st));
+        STOCS_HIP_CHECK(hipMemcpyAsync(I->d_run_e, re.data(), re.size() * 2, hipMemcpyHostToDevice, st));
+    }
+    STOCS_HIP_CHECK(hipMemcpyAsync(I->d_row_off, row_off.data(), ((size_t)H + 1) * 4, hipMemcpyHostToDevice, st));
+    STOCS_HIP_CHECK(hipMemcpyAsync(I->d_pt_run, pt_run.data(), (size_t)S * 4, hipMemcpyHostToDevice, st));
+    STOCS_HIP_CHECK(hipMemcpyAsync(I->d_edge_pt, edge_pt.data(), S, hipMemcpyHostToDevice, st));
+    STOCS_HIP_CHECK(hipMemcpyAsync(I->d_cls, c->h_sprob.data(), (size_t)S * 4, hipMemcpyHostToDevice, st));
+    STOCS_HIP_CHECK(hipMemsetAsync(I->d_prev_in, 0, S, st));
+    STOCS_HIP_CHECK(hipMemsetAsync(I->d_label, 0, S, st));
+    STOCS_HIP_CHECK(hipMemsetAsync(I->d_maskbits, 0, (size_t)256 * Sw * 4, st));
+    STOCS_HIP_CHECK(hipMemsetAsync(I->d_segbits, 0, (size_t)Sw * 4, st));
+    STOCS_HIP_CHECK(hipStreamSynchronize(st));   // the host vectors above die here
+    I->runs_valid = true;
+    return STOCS_OK;
+}
+
+// a new trial stream on the same scene and edge map: prior restored, image-space state cleared
+static int reset_instance_trial(stocs_ctx* c) {
+    InstanceState* I = (InstanceState*)c->inst;
+    if (!I || !I->runs_valid || I->S != c->nS) return STOCS_OK;
+    hipStream_t st = c->stream;
+    STOCS_HIP_CHECK(hipMemcpyAsync(I->d_cls, c->h_sprob.data(), (size_t)I->S * 4, hipMemcpyHostToDevice, st));
+    STOCS_HIP_CHECK(hipMemsetAsync(I->d_prev_in, 0, I->S, st));
+    STOCS_HIP_CHECK(hipMemsetAsync(I->d_label, 0, I->S, st));
+    STOCS_HIP_CHECK(hipMemsetAsync(I->d_maskbits, 0, (size_t)256 * I->Sw * 4, st));
+    STOCS_HIP_CHECK(hipMemsetAsync(I->d_segbits, 0, (size_t)I->Sw * 4, st));
+    STOCS_HIP_CHECK(hipStreamSynchronize(st));
+    I->h_segbits.clear();
+    return STOCS_OK;
+}
+
+static int sample_instance(stocs_ctx* c, uint64_t seed, int first_attempt, int nB, float dispersion, int32_t* ids, float* inv, int32_t* valid) {
+    int rc = prepare_instance_state(c);
     if (rc) return rc;
-    std::vector<float> w(S);
-    for (int i = 0; i < S; ++i) {  // stocs.cpp:572-580 (compounding decay) + prune_edge_pixels :521-535
-        const size_t px = (size_t)c->h_spix[2 * i] * W + c->h_spix[2 * i + 1];
-        if (c->previous_segment && (*c->previous_segment)[px]) c->h_sprob[i] = dispersion * c->h_sprob[i];
-        w[i] = c->h_sprob[i];
-        const float edge_probability = (float)(255.0 - c->edge_map[px]) / 255.0;
-        if (edge_probability == 1) w[i] = 0;
-    }
-    TSEC(0)
-    // round trip 1: weights up, draw point 1, pass 1, weights + (bidx, fail) back in one copy
-    const size_t span = (size_t)((char*)sb.fail - (char*)sb.w) + 4;   // w .. fail, contiguous (carve)
-    // pinned staging (grown on demand, owned by the context): the small copies of every attempt go straight over DMA
-    if (c->pin_bytes < span + 64) {
-        if (c->h_pin) { (void)hipHostFree(c->h_pin); c->h_pin = NULL; c->pin_bytes = 0; }
-        STOCS_HIP_CHECK(hipHostMalloc(&c->h_pin, span + 4096, hipHostMallocDefault));
-        c->pin_bytes = span + 4096;
-    }
-    struct { char* p; char* data() { return p; } } stage = {(char*)c->h_pin};
-    {
-        // weights + (bidx = -1, fail = 0) go up in ONE copy (they are contiguous, carve); draw and pass are separate
-        // launches so that the double-precision pass runs on the whole chip (a fused one-workgroup kernel was 25 % slower)
-        memcpy(stage.data(), w.data(), (size_t)S * 4);
-        const int32_t init_bidx[4] = {-1, -1, -1, -1}, init_fail = 0;
-        memcpy(stage.data() + ((char*)sb.bidx - (char*)sb.w), init_bidx, 16);
-        memcpy(stage.data() + ((char*)sb.fail - (char*)sb.w), &init_fail, 4);
-        STOCS_HIP_CHECK(hipMemcpyAsync(sb.w, stage.data(), span, hipMemcpyHostToDevice, c->stream));
-        launch_draw(c, 1, sb, seed, (uint64_t)attempt, 0);
-        launch_pass(c, 1, 1, sb);
-    }
+    InstanceState* I = (InstanceState*)c->inst;
+    SampleBuffers sb;
+    if ((rc = carve(c, std::max(nB, 1), &sb))) return rc;
+    InstanceArgs A;
+    A.pa = pass_args(c);
+    A.pix = c->d_spix; A.edge_pt = I->d_edge_pt; A.pt_run = I->d_pt_run; A.run_s = I->d_run_s; A.run_e = I->d_run_e; A.row_off = I->d_row_off;
+    A.H = c->prm.image_height; A.W = c->prm.image_width; A.Sw = I->Sw;
+    A.cls = I->d_cls; A.prev_in = I->d_prev_in; A.label = I->d_label; A.maskbits = I->d_maskbits; A.segbits = I->d_segbits; A.parent_g = I->d_parent;
+    A.w = sb.w; A.spos_w = c->d_spos; A.snrm_w = c->d_snrmw; A.res = sb.res;
+    hipLaunchKernelGGL(instance_attempts_kernel, dim3(1), dim3(1024), 0, c->stream, A, seed, first_attempt, nB, dispersion);
     STOCS_HIP_CHECK(hipGetLastError());
-    STOCS_HIP_CHECK(hipMemcpyAsync(stage.data(), sb.w, span, hipMemcpyDeviceToHost, c->stream));
+    std::vector<BaseOut> res((size_t)nB);
+    I->h_segbits.assign((size_t)I->Sw, 0);
+    STOCS_HIP_CHECK(hipMemcpyAsync(res.data(), sb.res, (size_t)nB * sizeof(BaseOut), hipMemcpyDeviceToHost, c->stream));
+    STOCS_HIP_CHECK(hipMemcpyAsync(c->h_sprob.data(), I->d_cls, (size_t)c->nS * 4, hipMemcpyDeviceToHost, c->stream));   // the decayed prior (Q8)
+    STOCS_HIP_CHECK(hipMemcpyAsync(I->h_segbits.data(), I->d_segbits, (size_t)I->Sw * 4, hipMemcpyDeviceToHost, c->stream));
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
-    int32_t bidx[4], fail = 0;
-    memcpy(w.data(), stage.data(), (size_t)S * 4);
-    memcpy(bidx, stage.data() + ((char*)sb.bidx - (char*)sb.w), 16);
-    memcpy(&fail, stage.data() + ((char*)sb.fail - (char*)sb.w), 4);
-    TSEC(1)
-    BaseOut res;
-    memset(&res, 0, sizeof(res));
-    res.ids[0] = res.ids[1] = res.ids[2] = res.ids[3] = -1;   // "FAILED SAMPLING": no base, nothing to compute
-    if (fail || bidx[0] < 0) return record_bases(c, 1, &res, ids, inv, valid);
-    const int b1 = bidx[0];
-    float max_pixel_distance = 0;  // stocs.cpp:610-618
-    for (int i = 0; i < S; ++i)
-        if (w[i] != 0) {
-            const float dist = (float)sqrt(pow((double)(c->h_spix[2 * b1] - c->h_spix[2 * i]), 2) + pow((double)(c->h_spix[2 * b1 + 1] - c->h_spix[2 * i + 1]), 2));
-            if (dist > max_pixel_distance) max_pixel_distance = dist;
-        }
-    TSEC(2)
-    const std::shared_ptr<const std::vector<uint8_t> > mask_p = generate_segmentation_mask(c, c->h_spix[2 * b1], c->h_spix[2 * b1 + 1], max_pixel_distance, base_num);
-    const std::vector<uint8_t>& mask = *mask_p;
-    TSEC(3)
-    if ((int)c->seg_masks.size() <= base_num) c->seg_masks.resize(base_num + 1);
-    c->seg_masks[base_num] = mask_p;    // cv::imwrite(seg_mask_<n>.png), stocs.cpp:625
-    c->previous_segment = mask_p;       // stocs.cpp:626
     c->last_segment.clear();
-    for (int i = 0; i < S; ++i)         // stocs.cpp:628-638: survivors inside the mask form `segment`, the others are zeroed
-        if (w[i] != 0) {
-            if (mask[(size_t)c->h_spix[2 * i] * W + c->h_spix[2 * i + 1]]) c->last_segment.push_back(i);
-            else w[i] = 0;
-        }
-    TSEC(4)
-    // round trip 2: filtered weights up, draw 2, pass 2, draw 3, pass 3, draw 4, base finalised on the device, result back
-    memcpy(stage.data(), w.data(), (size_t)S * 4);
-    STOCS_HIP_CHECK(hipMemcpyAsync(sb.w, stage.data(), (size_t)S * 4, hipMemcpyHostToDevice, c->stream));
-    for (int k = 1; k < 4; ++k) {
-        launch_draw(c, 1, sb, seed, (uint64_t)attempt, k);
-        if (k < 3) launch_pass(c, k + 1, 1, sb);
-    }
-    hipLaunchKernelGGL(finalize_bases_kernel, dim3(1), dim3(64), 0, c->stream, c->d_spos, sb.bidx, sb.fail, 1, sb.res);
-    STOCS_HIP_CHECK(hipGetLastError());
-    BaseOut* pres = (BaseOut*)(stage.data() + (((size_t)S * 4 + 63) & ~(size_t)63));
-    STOCS_HIP_CHECK(hipMemcpyAsync(pres, sb.res, sizeof(res), hipMemcpyDeviceToHost, c->stream));   // ordered base + invariants, finalised on the device
-    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
-    res = *pres;
-    TSEC(5)
-    return record_bases(c, 1, &res, ids, inv, valid);
+    if (nB > 0 && res[(size_t)nB - 1].ids[0] >= 0)   // `segment` of the last attempt that got as far as its mask
+        for (int i = 0; i < c->nS; ++i) if ((I->h_segbits[(size_t)(i >> 5)] >> (i & 31)) & 1u) c->last_segment.push_back(i);
+    return record_bases(c, nB, res.data(), ids, inv, valid);
 }
 
 }  // namespace stocs
@@ -491,15 +691,7 @@ int stocs_sample_bases(stocs_ctx* c, int mode, uint64_t seed, int first_attempt,
     }
     if (mode == 0) return sample_class(c, seed, first_attempt, n_attempts, base_ids4, inv2, valid);
     if (n_attempts + first_attempt > 254) { set_error("instance mode labels segments with a u8 (<= 254 attempts, Q14)"); return STOCS_ERR_INVALID; }
-    for (int b = 0; b < n_attempts; ++b) {
-        int rc = sample_instance_one(c, seed, first_attempt + b, dispersion, first_attempt + b + 1, base_ids4 ? base_ids4 + 4 * b : NULL,
-                                     inv2 ? inv2 + 2 * b : NULL, valid ? valid + b : NULL);
-        if (rc) return rc;
-    }
-    if (getenv("STOCS_DEBUG_TIMING"))
-        fprintf(stderr, "[stocs instance] cumulative ms: weights %.2f | draw0+pass1+sync %.2f | maxdist %.2f | flood fill %.2f | mask copies+filter %.2f | draws 1-3 + sync %.2f\n",
-                g_t_inst[0] * 1e3, g_t_inst[1] * 1e3, g_t_inst[2] * 1e3, g_t_inst[3] * 1e3, g_t_inst[4] * 1e3, g_t_inst[5] * 1e3);
-    return refresh_class_prob_on_device(c);
+    return sample_instance(c, seed, first_attempt, n_attempts, dispersion, base_ids4, inv2, valid);
 }
 
 // `segment` of the last instance-mode attempt (stocs.cpp:628-638): the scene points that survived pass 1 inside the
@@ -512,16 +704,19 @@ int stocs_get_segment(const stocs_ctx* c, int32_t* scene_idx, int cap, int* n) {
     return (*n > cap) ? STOCS_ERR_CAPACITY : STOCS_OK;
 }
 
+void stocs_internal_free_instance(stocs_ctx* c) { if (c) free_instance_state(c); }
+// the edge map or the scene changed: runs, per-point tables and the per-trial state are rebuilt at the next instance-mode call
+void stocs_internal_invalidate_instance(stocs_ctx* c) { if (c && c->inst) ((InstanceState*)c->inst)->runs_valid = false; }
+
 int stocs_reset_trial(stocs_ctx* c) {
     if (!c) return STOCS_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
     c->h_sprob = c->h_sprob0;
-    c->previous_segment.reset();
-    std::fill(c->segmentation_buffer.begin(), c->segmentation_buffer.end(), 0);
-    c->seg_masks.clear();
     c->last_segment.clear();
     c->bases.clear(); c->quad_off.clear(); clear_candidates(c);
     c->best_lcp = 0; c->best_index = -1;
+    int rc = reset_instance_trial(c);
+    if (rc) return rc;
     return refresh_class_prob_on_device(c);
 }
 

@@ -197,11 +197,9 @@ struct stocs_ctx {
 
     // image-space state of instance mode (stocs.hpp:153-155)
     bool has_edge;
-    std::vector<uint8_t> edge_map, segmentation_buffer;
-    // masks are shared, never copied: seg_masks[n] is attempt n's mask (possibly the very mask of an earlier
-    // attempt), previous_segment the last one (null = all zero)
-    std::shared_ptr<const std::vector<uint8_t> > previous_segment;
-    std::vector<std::shared_ptr<const std::vector<uint8_t> > > seg_masks;
+    std::vector<uint8_t> edge_map;   // png values (all zero = "file absent", stocs.cpp:117-119)
+    void* inst;                      // device-side state of instance mode (sample.hip, InstanceState): runs of the edge map,
+                                     // previous_segment / segmentation_buffer / seg_mask_<n> per scene point, the decaying prior
 
     std::vector<int32_t> last_segment;   // `segment` of the last instance-mode attempt (stocs.cpp:628-638)
 
@@ -247,6 +245,8 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense);
 extern "C" int stocs_internal_make_jobs(stocs_ctx* c, const int32_t* picks4_host, int n, void* d_jobs_out, const unsigned int** d_unresolved_out);
 extern "C" void stocs_internal_free_congruent(stocs_ctx* c);
 extern "C" void stocs_internal_invalidate_congruent(stocs_ctx* c);
+extern "C" void stocs_internal_free_instance(stocs_ctx* c);
+extern "C" void stocs_internal_invalidate_instance(stocs_ctx* c);
 int plan_lookup(const PpfIndex& ix, const int* K, std::vector<std::pair<uint32_t, uint32_t> >* ranges);
 void prefetch_lookup(const PpfIndex& ix, const int* K);
 void compute_thresholds(const stocs_params& prm, Thresholds* t);
