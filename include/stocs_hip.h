@@ -123,6 +123,10 @@ int stocs_num_bases(const stocs_ctx* ctx);
 /* one pass of the weight update for fixed base points (kernel-level parity with the oracle):
  * pass k in 1..3, b3 = {P1,P2,P3} scene indices, w_in/w_out host arrays of nS floats */
 int stocs_class_pass(stocs_ctx* ctx, int pass, const int32_t* b3, const float* w_in, float* w_out);
+/* device self-check of the float filter that sits in front of the PPF arithmetic in the pass kernels: n_pairs seeded pairs
+ * of scene points keyed both ways; *n_mismatch must come back 0, *n_undecided counts the pairs the filter handed to the
+ * reference's double arithmetic */
+int stocs_ppf_filter_check(stocs_ctx* ctx, uint64_t seed, int64_t n_pairs, int64_t* n_tested, int64_t* n_undecided, int64_t* n_mismatch);
 /* try_sampled_base on four scene indices (stocs.cpp:224-268) */
 int stocs_try_sampled_base(stocs_ctx* ctx, int32_t* ids4_inout, float* inv2, int* valid);
 /* the seeded weighted draw itself (stocs.cpp:133-148 replacement): index or -1 */

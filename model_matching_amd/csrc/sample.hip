@@ -43,6 +43,36 @@ __device__ __forceinline__ bool ppf_exists(const IndexView& ix, const int* K) {
     return (ix.bits[key >> 5] >> (key & 31)) & 1u;
 }
 
+// PPF key of (p1, p2) as ppf_compute gives it (reference rgbd.cpp:99-121), by a float filter with an exact fallback.
+// The three angles of the reference are int(atan2(double, double) * 180 / pi); the quantised key only changes when an angle
+// crosses rot * k + ceil(rot / 2) (ppf_closest_bin, rgbd.cpp:85-97).  atan2f of the same float operands is within 1e-4 degree
+// of the double value (2 ulp of the device library + one rounding of the conversion), so when the float angle is more than
+// PPF_MARGIN_DEG = 1e-3 degree away from every such boundary the float key IS the reference's key; otherwise (about
+// 0.1 % of the pairs, and anything non-finite) the double evaluation of stocs_math.h decides.  Distance bin: float in both.
+#define PPF_MARGIN_DEG 1e-3f
+__device__ __forceinline__ bool ppf_angle_filtered(float y, float x, int rot, int* bin) {
+    const float a = atan2f(y, x) * 57.29577951308232f;          // [0, 180]: y is a norm
+    const float b = (float)((rot + 1) / 2);                      // ceil(rot / 2): remainders >= b round up
+    const float q = (a - b) / (float)rot;
+    const float fq = q - floorf(q);
+    const bool certain = fminf(fq, 1.0f - fq) * (float)rot > PPF_MARGIN_DEG;   // false for NaN
+    *bin = ppf_closest_bin((int)a, rot);
+    return certain;
+}
+__device__ __forceinline__ void ppf_compute_device(V3 p1, V3 n1, V3 p2, V3 n2, int tr, int rot, int* out4) {
+    const V3 u = p1 - p2;
+    int b1, b2, b3;
+    const bool c1 = ppf_angle_filtered(norm3(cross3(n1, u)), dot3(n1, u), rot, &b1);
+    const bool c2 = ppf_angle_filtered(norm3(cross3(n2, u)), dot3(n2, u), rot, &b2);
+    const bool c3 = ppf_angle_filtered(norm3(cross3(n1, n2)), dot3(n1, n2), rot, &b3);
+    if (c1 && c2 && c3) {
+        out4[0] = ppf_closest_bin(stocs_trunc_int((double)(norm3(u) * 1000.0f)), tr);
+        out4[1] = b1; out4[2] = b2; out4[3] = b3;
+        return;
+    }
+    ppf_compute(p1, n1, p2, n2, tr, rot, out4);   // the reference's arithmetic
+}
+
 struct PassArgs {
     const float4* spos;   // centred scene position (w unused here)
     const float4* snrm;   // unit normal
@@ -68,7 +98,7 @@ __device__ __forceinline__ bool pass_zeroes(const PassArgs& a, int b1, int b2, i
     const V3 pc = mk3(pc4.x, pc4.y, pc4.z), nc = mk3(nc4.x, nc4.y, nc4.z);
     const V3 pi = mk3(pi4.x, pi4.y, pi4.z), ni = mk3(ni4.x, ni4.y, ni4.z);
     int K[4];
-    ppf_compute(pc, nc, pi, ni, a.ix.tr, a.ix.rot, K);
+    ppf_compute_device(pc, nc, pi, ni, a.ix.tr, a.ix.rot, K);
     bool zero = !ppf_exists(a.ix, K) || i == cur;
     if (PASS == 2) {
         const float4 p14 = a.spos[b1];
@@ -164,6 +194,26 @@ __global__ __launch_bounds__(1024) void draw_kernel(const float* __restrict__ w,
         bidx[b * 4 + slot] = pick;
         if (pick < 0) fail[b] = 1;
     }
+}
+
+// self-check of the filter on the context's own scene: pair (i, j) of every thread with both evaluations
+__global__ __launch_bounds__(256) void ppf_filter_check_kernel(PassArgs a, uint64_t seed, uint32_t n_pairs, unsigned int* __restrict__ counts) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_pairs) return;
+    const uint64_t r = rng64(seed, e, 7);
+    const int i = (int)((r & 0xFFFFFFFFull) % (uint64_t)a.S), j = (int)((r >> 32) % (uint64_t)a.S);
+    if (i == j) return;
+    const float4 p1 = a.spos[i], n1 = a.snrm[i], p2 = a.spos[j], n2 = a.snrm[j];
+    const V3 P1 = mk3(p1.x, p1.y, p1.z), N1 = mk3(n1.x, n1.y, n1.z), P2 = mk3(p2.x, p2.y, p2.z), N2 = mk3(n2.x, n2.y, n2.z);
+    int Kf[4], Ke[4], bb;
+    ppf_compute_device(P1, N1, P2, N2, a.ix.tr, a.ix.rot, Kf);
+    ppf_compute(P1, N1, P2, N2, a.ix.tr, a.ix.rot, Ke);
+    const V3 u = P1 - P2;
+    const bool certain = ppf_angle_filtered(norm3(cross3(N1, u)), dot3(N1, u), a.ix.rot, &bb) && ppf_angle_filtered(norm3(cross3(N2, u)), dot3(N2, u), a.ix.rot, &bb) &&
+                         ppf_angle_filtered(norm3(cross3(N1, N2)), dot3(N1, N2), a.ix.rot, &bb);
+    atomicAdd(&counts[0], 1u);
+    if (!certain) atomicAdd(&counts[1], 1u);
+    if (Kf[0] != Ke[0] || Kf[1] != Ke[1] || Kf[2] != Ke[2] || Kf[3] != Ke[3]) atomicAdd(&counts[2], 1u);
 }
 
 // ---- host helpers ------------------------------------------------------------------------------
@@ -778,6 +828,28 @@ int stocs_try_sampled_base(stocs_ctx* c, int32_t* ids4, float* inv2, int* valid)
     *valid = res.valid;
     for (int k = 0; k < 4; ++k) ids4[k] = res.ids[k];
     inv2[0] = res.inv[0]; inv2[1] = res.inv[1];
+    return STOCS_OK;
+}
+
+// Device self-check of the float filter in front of the PPF arithmetic (ppf_compute_device): n_pairs seeded pairs of the
+// context's scene points are keyed with the filter and with the reference's double arithmetic alone; *n_mismatch must be 0.
+int stocs_ppf_filter_check(stocs_ctx* c, uint64_t seed, int64_t n_pairs, int64_t* n_tested, int64_t* n_undecided, int64_t* n_mismatch) {
+    if (!c || n_pairs <= 0 || n_pairs > 0x7FFFFFFF || c->nS < 2) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
+    int rc = ensure_scratch(c, 256);
+    if (rc) return rc;
+    unsigned int* d_counts = (unsigned int*)c->d_scratch;
+    STOCS_HIP_CHECK(hipMemsetAsync(d_counts, 0, 16, c->stream));
+    PassArgs a = pass_args(c);
+    a.ix.tr = c->prm.ppf_tr_discretization; a.ix.rot = c->prm.ppf_rot_discretization;   // no index needed for this check
+    hipLaunchKernelGGL(ppf_filter_check_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, c->stream, a, seed, (uint32_t)n_pairs, d_counts);
+    STOCS_HIP_CHECK(hipGetLastError());
+    unsigned int h[4] = {0, 0, 0, 0};
+    STOCS_HIP_CHECK(hipMemcpyAsync(h, d_counts, 16, hipMemcpyDeviceToHost, c->stream));
+    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (n_tested) *n_tested = h[0];
+    if (n_undecided) *n_undecided = h[1];
+    if (n_mismatch) *n_mismatch = h[2];
     return STOCS_OK;
 }
 

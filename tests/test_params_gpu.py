@@ -150,3 +150,22 @@ def test_on_demand_quads_at_metric_size():
     assert nc == len(T) and nc <= np.minimum(sizes, 200).sum()
     per_base = np.bincount(bidx, minlength=nb)
     assert np.all(per_base <= np.minimum(sizes, 200))
+
+
+def test_ppf_float_filter_never_changes_a_key():
+    """The pass kernels key point pairs with a float atan2 and fall back to the reference's double arithmetic within 1e-3
+    degree of a bin boundary (sample.hip, ppf_compute_device).  Device self-check on 20 million seeded pairs of the Cm scene
+    and of a scene with axis-aligned normals (exact 0 / 90 / 180 degree angles sit ON integer angles): no key may differ."""
+    import ctypes as C
+    from model_matching_amd import synth
+    from model_matching_amd.estimator import StocsEstimator
+    m, s, k = synth.workload("Cm")
+    nrm2 = np.zeros_like(s.nrm); nrm2[np.arange(len(s.nrm)), np.arange(len(s.nrm)) % 3] = 1.0
+    for nrm, n_pairs in ((s.nrm, 20_000_000), (nrm2, 2_000_000)):
+        est = StocsEstimator(s.pos, nrm, s.prob, s.pixel, m.pos[:200], m.nrm[:200], build_index=False)
+        nt, nu, nm = C.c_int64(), C.c_int64(), C.c_int64()
+        assert est.L.stocs_ppf_filter_check(est.h, 99, n_pairs, C.byref(nt), C.byref(nu), C.byref(nm)) == 0
+        assert nm.value == 0 and nt.value > 0.99 * n_pairs
+        if nrm is s.nrm:
+            assert nu.value < 0.01 * nt.value       # the filter decides all but ~0.1 % of generic pairs
+        est.close()
