@@ -294,6 +294,43 @@ __device__ __forceinline__ void finalize_one(const float4* __restrict__ spos, co
     o->pad = 0;
 }
 
+// the same by twelve lanes of one wavefront (the 12 ordered pairings of try_sampled_base evaluated side by side, then the
+// reference's first-strict-minimum rule applied in its enumeration order): callers pass whole wavefront 0
+__device__ __forceinline__ void finalize_one_wave(const float4* __restrict__ spos, const int32_t* bidx4, int fail, BaseOut* o) {
+    const int lane = threadIdx.x & 63;
+    int ids[4] = {bidx4[0], bidx4[1], bidx4[2], bidx4[3]};
+    const bool ok0 = !fail && ids[0] >= 0 && ids[1] >= 0 && ids[2] >= 0 && ids[3] >= 0;
+    float dist = 3.402823466e+38f, fi1 = 0, fi2 = 0;
+    int pi = 0, pj = 1, pk = 2, pl = 3;
+    if (ok0 && lane < 12) {
+        // pairing number lane in the order of the loops of stocs.cpp:230-257: i outer, j != i inner
+        pi = lane / 3;
+        const int jj = lane % 3;
+        pj = jj + (jj >= pi ? 1 : 0);
+        pk = 0; while (pk == pi || pk == pj) pk++;
+        pl = 0; while (pl == pi || pl == pj || pl == pk) pl++;
+        V3 base[4];
+        for (int k = 0; k < 4; ++k) { const float4 p = spos[ids[k]]; base[k] = mk3(p.x, p.y, p.z); }
+        double li1, li2;
+        dist = (float)seg_dist_inv(base[pi], base[pj], base[pk], base[pl], li1, li2);
+        fi1 = (float)li1; fi2 = (float)li2;
+    }
+    // first strict minimum in enumeration order == smallest distance, lowest lane among equals (NaN distances never win)
+    float best = dist;
+    for (int off = 8; off > 0; off >>= 1) best = fminf(best, __shfl_xor(best, off, 64));   // lanes 0..15 hold the 12 values + max floats
+    const unsigned long long m = __ballot(lane < 12 && dist == best && dist < 3.402823466e+38f);
+    const int win = m ? __ffsll((long long)m) - 1 : -1;
+    if (lane == (win < 0 ? 0 : win)) {
+        const bool ok = ok0 && win >= 0;
+        const int tmp[4] = {ids[0], ids[1], ids[2], ids[3]};
+        if (ok) { ids[0] = tmp[pi]; ids[1] = tmp[pj]; ids[2] = tmp[pk]; ids[3] = tmp[pl]; }
+        for (int k = 0; k < 4; ++k) o->ids[k] = ids[k];
+        o->inv[0] = ok ? fi1 : 0.0f; o->inv[1] = ok ? fi2 : 0.0f;
+        o->valid = ok ? 1 : 0;
+        o->pad = 0;
+    }
+}
+
 __global__ __launch_bounds__(64) void finalize_bases_kernel(const float4* __restrict__ spos, const int32_t* __restrict__ bidx,
                                                             const int32_t* __restrict__ fail, int nB, BaseOut* __restrict__ out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -423,6 +460,8 @@ struct InstanceArgs {
     uint32_t* segbits;          // Sw: `segment` of the last attempt
     uint32_t* parent_g;         // union-find parents when the disc holds more than INST_MAX_NODES runs (+ 1)
     float* w;                   // S weights
+    unsigned long long* stamps; // STOCS_DEBUG_TIMING only: cycles per stage, summed over the attempts (else NULL)
+    int32_t* sv; float* wc;     // survivors of pass 1 inside the mask (scene indices, weights), compacted in scene order
     float4* spos_w; float4* snrm_w;   // the scene arrays whose .w the LCP adds: refreshed with the decayed prior at the end
     BaseOut* res;
 };
@@ -481,13 +520,95 @@ __device__ void flood_fill_runs(const InstanceArgs& A, ParentPtr parent, int r0,
     __syncthreads();
 }
 
+// Seeded weighted draw over n weights by the whole 1024-thread workgroup (same rule as draw_block: 2^32 fixed-point weights,
+// r = mulhi(r64, total), first index whose inclusive prefix exceeds r), with wavefront scans instead of the 20-barrier
+// Hillis-Steele scan: 3 barriers.  Returns the position in wb (or -1 when every weight is zero) to every thread.
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
+    const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+// the same draw by wavefront 0 alone (few weights: the survivors of a mask): one barrier instead of four
+__device__ __forceinline__ int draw_wave0(const float* __restrict__ wb, int n, uint64_t r64, int* sh_pick) {
+    const int t = threadIdx.x;
+    if (t < 64) {
+        const int chunk = (n + 63) / 64;
+        const int lo = min(n, t * chunk), hi = min(n, lo + chunk);
+        uint64_t local = 0;
+        for (int i = lo; i < hi; ++i) local += weight_fix(wb[i]);
+        uint64_t incl = local;
+        for (int d = 1; d < 64; d <<= 1) { const uint64_t o = shfl_up_u64(incl, d); if (t >= d) incl += o; }
+        const uint64_t total = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(incl >> 32), 63, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)incl, 63, 64);
+        int pick = -1;
+        bool mine = false;
+        if (total != 0) {
+            const uint64_t r = mulhi64(r64, total);
+            const uint64_t ex = incl - local;
+            mine = r >= ex && r < incl;
+            if (mine) {
+                uint64_t c = ex;
+                for (int i = lo; i < hi; ++i) { c += weight_fix(wb[i]); if (c > r) { pick = i; break; } }
+            }
+        }
+        const unsigned long long m = __ballot(mine);
+        if (m == 0ull) { if (t == 0) *sh_pick = -1; }
+        else if (mine) *sh_pick = pick;
+    }
+    __syncthreads();
+    const int pick = *sh_pick;
+    __syncthreads();
+    return pick;
+}
+
+__device__ __forceinline__ int draw_block_fast(const float* __restrict__ wb, int n, uint64_t r64, uint64_t* sh16 /*>= 17*/, int* sh_pick) {
+    if (n <= 1024) return draw_wave0(wb, n, r64, sh_pick);
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int chunk = (n + 1023) / 1024;
+    const int lo = min(n, t * chunk), hi = min(n, lo + chunk);
+    uint64_t local = 0;
+    for (int i = lo; i < hi; ++i) local += weight_fix(wb[i]);
+    uint64_t incl = local;                                     // inclusive scan inside the wavefront
+    for (int d = 1; d < 64; d <<= 1) { const uint64_t o = shfl_up_u64(incl, d); if (lane >= d) incl += o; }
+    if (lane == 63) sh16[wv] = incl;
+    if (t == 0) *sh_pick = -1;
+    __syncthreads();
+    if (wv == 0) {                                             // exclusive scan of the 16 wavefront totals
+        uint64_t v = lane < 16 ? sh16[lane] : 0, inc = v;
+        for (int d = 1; d < 16; d <<= 1) { const uint64_t o = shfl_up_u64(inc, d); if (lane >= d) inc += o; }
+        if (lane < 16) sh16[lane] = inc - v;
+        if (lane == 15) sh16[16] = inc;
+    }
+    __syncthreads();
+    const uint64_t total = sh16[16];
+    if (total != 0) {
+        const uint64_t r = mulhi64(r64, total);
+        const uint64_t in2 = sh16[wv] + incl, ex2 = in2 - local;
+        if (r >= ex2 && r < in2) {  // exactly one thread (local > 0)
+            uint64_t c = ex2;
+            int pick = -1;
+            for (int i = lo; i < hi; ++i) {
+                c += weight_fix(wb[i]);
+                if (c > r) { pick = i; break; }
+            }
+            *sh_pick = pick;
+        }
+    }
+    __syncthreads();
+    const int pick = *sh_pick;
+    __syncthreads();   // sh16 / sh_pick are reused by the next draw
+    return pick;
+}
+
 __global__ __launch_bounds__(1024) void instance_attempts_kernel(InstanceArgs A, uint64_t seed, int first_attempt, int n_attempts, float dispersion) {
-    __shared__ uint64_t sh[1024];
-    __shared__ uint64_t sh_total;
+    __shared__ uint64_t sh16[17];
     __shared__ int sh_pick;
     __shared__ int sh_max;
+    __shared__ int sh_cnt[17];
     __shared__ uint32_t parent_l[INST_MAX_NODES + 1];
-    const int t = threadIdx.x, S = A.pa.S, lane = t & 63;
+    const int t = threadIdx.x, S = A.pa.S, lane = t & 63, wv = t >> 6;
+    int32_t* sv = A.sv;       // survivors of pass 1 inside the mask, compacted in scene order
+    float* wc = A.wc;         // their weights
+    unsigned long long tprev = A.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+#define INST_STAMP(k) if (A.stamps && t == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); A.stamps[k] += now_ - tprev; tprev = now_; }
     for (int a = 0; a < n_attempts; ++a) {
         const int attempt = first_attempt + a, base_num = attempt + 1;
         BaseOut* out = A.res + a;
@@ -499,9 +620,11 @@ __global__ __launch_bounds__(1024) void instance_attempts_kernel(InstanceArgs A,
         }
         if (t == 0) sh_max = 0;
         __syncthreads();
+        INST_STAMP(0)
         int32_t bidx[4] = {-1, -1, -1, -1};
         int fail = 0;
-        bidx[0] = draw_block(A.w, S, rng64(seed, (uint64_t)attempt, 0), sh, &sh_total, &sh_pick);
+        bidx[0] = draw_block_fast(A.w, S, rng64(seed, (uint64_t)attempt, 0), sh16, &sh_pick);
+        INST_STAMP(1)
         if (bidx[0] < 0) {   // "FAILED SAMPLING": no base, no mask, previous_segment stays (stocs.cpp:586-589)
             if (t == 0) { for (int k = 0; k < 4; ++k) out->ids[k] = -1; out->inv[0] = out->inv[1] = 0; out->valid = 0; out->pad = 0; }
             __syncthreads();
@@ -519,6 +642,7 @@ __global__ __launch_bounds__(1024) void instance_attempts_kernel(InstanceArgs A,
         for (int off = 32; off > 0; off >>= 1) my_max = max(my_max, __shfl_xor(my_max, off, 64));
         if (lane == 0 && my_max) atomicMax(&sh_max, my_max);
         __syncthreads();
+        INST_STAMP(2)
         const int maxd2 = sh_max;
         // ---- the mask: an earlier attempt's when the seed pixel is already labelled, else a new flood fill (rgbd.cpp:314-367) ----
         const int lab = A.label[b1];
@@ -532,9 +656,12 @@ __global__ __launch_bounds__(1024) void instance_attempts_kernel(InstanceArgs A,
             else flood_fill_runs(A, A.parent_g, sp.x, sp.y, maxd2, rlo, rhi, base, nodes);
             root_s = in_lds ? uf_find(parent_l, nodes) : uf_find(A.parent_g, nodes);
         }
-        // ---- bookkeeping per scene point: mask membership, previous_segment, labels, the survivors inside (`segment`) ----
-        for (int i0 = t - lane; i0 < S; i0 += 1024) {    // whole wavefronts: the bitset words are ballots
-            const int i = i0 + lane;
+        INST_STAMP(3)
+        // ---- bookkeeping per scene point: mask membership, previous_segment, labels, and the survivors inside the mask
+        //      (`segment`, stocs.cpp:628-638) compacted in scene order: points 2..4 are drawn among them alone ----
+        int n_surv = 0;
+        for (int i0 = 0; i0 < S; i0 += 1024) {    // whole wavefronts: the bitset words are ballots
+            const int i = i0 + t;
             bool in = false;
             float wi = 0.0f;
             if (i < S) {
@@ -551,33 +678,50 @@ __global__ __launch_bounds__(1024) void instance_attempts_kernel(InstanceArgs A,
                 }
                 A.prev_in[i] = in ? 1 : 0;                                   // segmentation_mask.copyTo(previous_segment), stocs.cpp:626
                 if (lab == 0 && in) A.label[i] = (uint8_t)base_num;          // segmentation_buffer = base_num over the new mask
-                if (wi != 0.0f && !in) { wi = 0.0f; A.w[i] = 0.0f; }        // stocs.cpp:628-638
+                if (!in) wi = 0.0f;
             }
-            const unsigned long long mb = __ballot(in), sb = __ballot(wi != 0.0f);
+            const bool keep = wi != 0.0f;
+            const unsigned long long mb = __ballot(in), sb = __ballot(keep);
             if (lane == 0) {
-                const int wd = i0 >> 5;
-                A.maskbits[(size_t)base_num * A.Sw + wd] = (uint32_t)mb;     // seg_mask_<base_num>.png, whichever mask it is
-                A.segbits[wd] = (uint32_t)sb;
-                if (wd + 1 < A.Sw) { A.maskbits[(size_t)base_num * A.Sw + wd + 1] = (uint32_t)(mb >> 32); A.segbits[wd + 1] = (uint32_t)(sb >> 32); }
+                const int wd = (i0 >> 5) + 2 * wv;
+                if (wd < A.Sw) {
+                    A.maskbits[(size_t)base_num * A.Sw + wd] = (uint32_t)mb;     // seg_mask_<base_num>.png, whichever mask it is
+                    A.segbits[wd] = (uint32_t)sb;
+                    A.maskbits[(size_t)base_num * A.Sw + wd + 1] = (uint32_t)(mb >> 32); A.segbits[wd + 1] = (uint32_t)(sb >> 32);
+                }
+                sh_cnt[wv] = __popcll(sb);
             }
+            __syncthreads();
+            int before = n_surv;                                              // order-preserving compaction
+            for (int k = 0; k < wv; ++k) before += sh_cnt[k];
+            int all = 0;
+            for (int k = 0; k < 16; ++k) all += sh_cnt[k];
+            if (keep) { const int pos = before + __popcll(sb & ((1ull << lane) - 1ull)); sv[pos] = i; wc[pos] = wi; }
+            n_surv += all;
+            __syncthreads();
         }
-        __syncthreads();
-        // ---- points 2..4 (stocs.cpp:640-751 = the class-mode passes) ----
+        INST_STAMP(4)
+        // ---- points 2..4 (stocs.cpp:640-751 = the class-mode passes) over the survivors ----
         for (int k = 1; k < 4 && !fail; ++k) {
-            bidx[k] = draw_block(A.w, S, rng64(seed, (uint64_t)attempt, (uint64_t)k), sh, &sh_total, &sh_pick);
-            if (bidx[k] < 0) { fail = 1; break; }
+            const int pos = draw_block_fast(wc, n_surv, rng64(seed, (uint64_t)attempt, (uint64_t)k), sh16, &sh_pick);
+            if (pos < 0) { fail = 1; break; }
+            bidx[k] = sv[pos];
             if (k < 3) {
-                for (int i = t; i < S; i += 1024) {
-                    if (A.w[i] == 0.0f) continue;                              // already zero: nothing to decide
+                for (int j = t; j < n_surv; j += 1024) {
+                    if (wc[j] == 0.0f) continue;                              // already zero: nothing to decide
+                    const int i = sv[j];
                     const bool z = (k == 1) ? pass_zeroes<2>(A.pa, bidx[0], bidx[1], -1, i) : pass_zeroes<3>(A.pa, bidx[0], bidx[1], bidx[2], i);
-                    if (z) A.w[i] = 0.0f;
+                    if (z) wc[j] = 0.0f;
                 }
                 __syncthreads();
             }
         }
-        if (t == 0) finalize_one(A.pa.spos, bidx, fail, out);
+        INST_STAMP(5)
+        if (t < 64) finalize_one_wave(A.pa.spos, bidx, fail, out);
         __syncthreads();
+        INST_STAMP(6)
     }
+#undef INST_STAMP
     // the LCP adds class_probability_, which this sampling decays in place (Q8): refresh the scene arrays it reads
     for (int i = t; i < S; i += 1024) { const float c = A.cls[i]; A.spos_w[i].w = c; A.snrm_w[i].w = c; }
 }
@@ -603,6 +747,7 @@ struct InstanceState {
     uint16_t* d_run_s = NULL; uint16_t* d_run_e = NULL; uint32_t* d_row_off = NULL;
     int32_t* d_pt_run = NULL; uint8_t* d_edge_pt = NULL; uint8_t* d_prev_in = NULL; uint8_t* d_label = NULL;
     float* d_cls = NULL; uint32_t* d_maskbits = NULL; uint32_t* d_segbits = NULL; uint32_t* d_parent = NULL;
+    int32_t* d_sv = NULL; float* d_wc = NULL;
     size_t n_runs = 0;
     std::vector<uint32_t> h_segbits;
 };
@@ -653,7 +798,7 @@ static int prepare_instance_state(stocs_ctx* c) {
     const size_t nr = std::max<size_t>(rs.size(), 1);
     const size_t o_rs = 0, o_re = o_rs + al(nr * 2), o_ro = o_re + al(nr * 2), o_pr = o_ro + al(((size_t)H + 1) * 4), o_ep = o_pr + al((size_t)S * 4),
                  o_pi = o_ep + al(S), o_lb = o_pi + al(S), o_cl = o_lb + al(S), o_mb = o_cl + al((size_t)S * 4), o_sb = o_mb + al((size_t)256 * Sw * 4),
-                 o_pa = o_sb + al((size_t)Sw * 4), total = o_pa + al((nr + 1) * 4);
+                 o_pa = o_sb + al((size_t)Sw * 4), o_sv = o_pa + al((nr + 1) * 4), o_wc = o_sv + al((size_t)S * 4), total = o_wc + al((size_t)S * 4);
     if (I->mem_bytes < total) {
         if (I->d_mem) { STOCS_HIP_CHECK(hipStreamSynchronize(c->stream)); (void)hipFree(I->d_mem); I->d_mem = NULL; I->mem_bytes = 0; }
         STOCS_HIP_CHECK(dev_malloc((void**)&I->d_mem, total + total / 4));
@@ -663,6 +808,7 @@ static int prepare_instance_state(stocs_ctx* c) {
     I->d_run_s = (uint16_t*)(m + o_rs); I->d_run_e = (uint16_t*)(m + o_re); I->d_row_off = (uint32_t*)(m + o_ro); I->d_pt_run = (int32_t*)(m + o_pr);
     I->d_edge_pt = (uint8_t*)(m + o_ep); I->d_prev_in = (uint8_t*)(m + o_pi); I->d_label = (uint8_t*)(m + o_lb); I->d_cls = (float*)(m + o_cl);
     I->d_maskbits = (uint32_t*)(m + o_mb); I->d_segbits = (uint32_t*)(m + o_sb); I->d_parent = (uint32_t*)(m + o_pa);
+    I->d_sv = (int32_t*)(m + o_sv); I->d_wc = (float*)(m + o_wc);
     I->S = S; I->Sw = Sw; I->n_runs = rs.size();
     hipStream_t st = c->stream;
     if (!rs.empty()) {
@@ -708,7 +854,10 @@ static int sample_instance(stocs_ctx* c, uint64_t seed, int first_attempt, int n
     A.pix = c->d_spix; A.edge_pt = I->d_edge_pt; A.pt_run = I->d_pt_run; A.run_s = I->d_run_s; A.run_e = I->d_run_e; A.row_off = I->d_row_off;
     A.H = c->prm.image_height; A.W = c->prm.image_width; A.Sw = I->Sw;
     A.cls = I->d_cls; A.prev_in = I->d_prev_in; A.label = I->d_label; A.maskbits = I->d_maskbits; A.segbits = I->d_segbits; A.parent_g = I->d_parent;
-    A.w = sb.w; A.spos_w = c->d_spos; A.snrm_w = c->d_snrmw; A.res = sb.res;
+    const bool dbg = getenv("STOCS_DEBUG_TIMING") != NULL;
+    A.stamps = NULL;
+    if (dbg) { A.stamps = (unsigned long long*)I->d_parent; STOCS_HIP_CHECK(hipMemsetAsync(I->d_parent, 0, 64, c->stream)); }   // parent_g is idle for small discs
+    A.w = sb.w; A.sv = I->d_sv; A.wc = I->d_wc; A.spos_w = c->d_spos; A.snrm_w = c->d_snrmw; A.res = sb.res;
     hipLaunchKernelGGL(instance_attempts_kernel, dim3(1), dim3(1024), 0, c->stream, A, seed, first_attempt, nB, dispersion);
     STOCS_HIP_CHECK(hipGetLastError());
     std::vector<BaseOut> res((size_t)nB);
@@ -717,6 +866,13 @@ static int sample_instance(stocs_ctx* c, uint64_t seed, int first_attempt, int n
     STOCS_HIP_CHECK(hipMemcpyAsync(c->h_sprob.data(), I->d_cls, (size_t)c->nS * 4, hipMemcpyDeviceToHost, c->stream));   // the decayed prior (Q8)
     STOCS_HIP_CHECK(hipMemcpyAsync(I->h_segbits.data(), I->d_segbits, (size_t)I->Sw * 4, hipMemcpyDeviceToHost, c->stream));
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (dbg) {
+        unsigned long long st[8];
+        STOCS_HIP_CHECK(hipMemcpy(st, I->d_parent, 64, hipMemcpyDeviceToHost));
+        const double per = 1.0 / std::max(nB, 1);
+        fprintf(stderr, "[stocs instance] %d attempts, shader cycles per attempt (s_memtime): weights %.0f | draw0 %.0f | pass1+maxdist %.0f | flood fill %.0f | bookkeeping+compaction %.0f | points 2-4 %.0f | finalize %.0f\n",
+                nB, st[0] * per, st[1] * per, st[2] * per, st[3] * per, st[4] * per, st[5] * per, st[6] * per);
+    }
     c->last_segment.clear();
     if (nB > 0 && res[(size_t)nB - 1].ids[0] >= 0)   // `segment` of the last attempt that got as far as its mask
         for (int i = 0; i < c->nS; ++i) if ((I->h_segbits[(size_t)(i >> 5)] >> (i & 31)) & 1u) c->last_segment.push_back(i);
