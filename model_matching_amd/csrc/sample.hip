@@ -140,31 +140,70 @@ __global__ __launch_bounds__(256) void pass_kernel(PassArgs a, const int32_t* __
     if (pass_zeroes<PASS>(a, bidx[b * 4 + 0], bidx[b * 4 + 1], bidx[b * 4 + 2], i)) w[(size_t)b * a.S + i] = 0.0f;
 }
 
-// seeded weighted draw by one workgroup of 1024 threads: index into wb, or -1 when every weight is zero
-// ("FAILED SAMPLING:: Zero probability returned", stocs.cpp:386-389).  Every thread returns the same value.
-__device__ __forceinline__ int draw_block(const float* __restrict__ wb, int S, uint64_t r64, uint64_t* sh /*1024*/, uint64_t* sh_total, int* sh_pick) {
+// Seeded weighted draw over n weights by the whole 1024-thread workgroup (an exact, order-independent replacement of std::discrete_distribution: 2^32 fixed-point weights,
+// r = mulhi(r64, total), first index whose inclusive prefix exceeds r; -1 when every weight is zero = "FAILED SAMPLING::
+// Zero probability returned", stocs.cpp:386-389), with wavefront scans: 3 barriers.  Returns the position in wb (or -1 when every weight is zero) to every thread.
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
+    const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+// the same draw by wavefront 0 alone (few weights: the survivors of a mask): one barrier instead of four
+__device__ __forceinline__ int draw_wave0(const float* __restrict__ wb, int n, uint64_t r64, int* sh_pick) {
     const int t = threadIdx.x;
-    const int chunk = (S + 1023) / 1024;
-    const int lo = min(S, t * chunk), hi = min(S, lo + chunk);
+    if (t < 64) {
+        const int chunk = (n + 63) / 64;
+        const int lo = min(n, t * chunk), hi = min(n, lo + chunk);
+        uint64_t local = 0;
+        for (int i = lo; i < hi; ++i) local += weight_fix(wb[i]);
+        uint64_t incl = local;
+        for (int d = 1; d < 64; d <<= 1) { const uint64_t o = shfl_up_u64(incl, d); if (t >= d) incl += o; }
+        const uint64_t total = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(incl >> 32), 63, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)incl, 63, 64);
+        int pick = -1;
+        bool mine = false;
+        if (total != 0) {
+            const uint64_t r = mulhi64(r64, total);
+            const uint64_t ex = incl - local;
+            mine = r >= ex && r < incl;
+            if (mine) {
+                uint64_t c = ex;
+                for (int i = lo; i < hi; ++i) { c += weight_fix(wb[i]); if (c > r) { pick = i; break; } }
+            }
+        }
+        const unsigned long long m = __ballot(mine);
+        if (m == 0ull) { if (t == 0) *sh_pick = -1; }
+        else if (mine) *sh_pick = pick;
+    }
+    __syncthreads();
+    const int pick = *sh_pick;
+    __syncthreads();
+    return pick;
+}
+
+__device__ __forceinline__ int draw_block_fast(const float* __restrict__ wb, int n, uint64_t r64, uint64_t* sh16 /*>= 17*/, int* sh_pick) {
+    if (n <= 1024) return draw_wave0(wb, n, r64, sh_pick);
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int chunk = (n + 1023) / 1024;
+    const int lo = min(n, t * chunk), hi = min(n, lo + chunk);
     uint64_t local = 0;
     for (int i = lo; i < hi; ++i) local += weight_fix(wb[i]);
-    sh[t] = local;
+    uint64_t incl = local;                                     // inclusive scan inside the wavefront
+    for (int d = 1; d < 64; d <<= 1) { const uint64_t o = shfl_up_u64(incl, d); if (lane >= d) incl += o; }
+    if (lane == 63) sh16[wv] = incl;
+    if (t == 0) *sh_pick = -1;
     __syncthreads();
-    // Hillis-Steele inclusive scan (integer adds: exact, order-independent)
-    for (int off = 1; off < 1024; off <<= 1) {
-        uint64_t v = (t >= off) ? sh[t - off] : 0;
-        __syncthreads();
-        sh[t] += v;
-        __syncthreads();
+    if (wv == 0) {                                             // exclusive scan of the 16 wavefront totals
+        uint64_t v = lane < 16 ? sh16[lane] : 0, inc = v;
+        for (int d = 1; d < 16; d <<= 1) { const uint64_t o = shfl_up_u64(inc, d); if (lane >= d) inc += o; }
+        if (lane < 16) sh16[lane] = inc - v;
+        if (lane == 15) sh16[16] = inc;
     }
-    if (t == 1023) { *sh_total = sh[t]; *sh_pick = -1; }
     __syncthreads();
-    const uint64_t total = *sh_total;
+    const uint64_t total = sh16[16];
     if (total != 0) {
         const uint64_t r = mulhi64(r64, total);
-        const uint64_t incl = sh[t], excl = incl - local;
-        if (r >= excl && r < incl) {  // exactly one thread (local > 0)
-            uint64_t c = excl;
+        const uint64_t in2 = sh16[wv] + incl, ex2 = in2 - local;
+        if (r >= ex2 && r < in2) {  // exactly one thread (local > 0)
+            uint64_t c = ex2;
             int pick = -1;
             for (int i = lo; i < hi; ++i) {
                 c += weight_fix(wb[i]);
@@ -175,7 +214,7 @@ __device__ __forceinline__ int draw_block(const float* __restrict__ wb, int S, u
     }
     __syncthreads();
     const int pick = *sh_pick;
-    __syncthreads();   // sh / sh_pick may be reused by the next draw
+    __syncthreads();   // sh16 / sh_pick are reused by the next draw
     return pick;
 }
 
@@ -183,13 +222,12 @@ __device__ __forceinline__ int draw_block(const float* __restrict__ wb, int S, u
 __global__ __launch_bounds__(1024) void draw_kernel(const float* __restrict__ w, size_t stride, int S, uint64_t seed,
                                                     uint64_t first_attempt, uint64_t k, const uint64_t* __restrict__ r_explicit,
                                                     int slot, int32_t* __restrict__ bidx, int32_t* __restrict__ fail) {
-    __shared__ uint64_t sh[1024];
-    __shared__ uint64_t sh_total;
+    __shared__ uint64_t sh16[17];
     __shared__ int sh_pick;
     const int b = blockIdx.x;
     if (fail[b]) return;
     const uint64_t r64 = r_explicit ? r_explicit[b] : rng64(seed, first_attempt + (uint64_t)b, k);
-    const int pick = draw_block(w + (size_t)b * stride, S, r64, sh, &sh_total, &sh_pick);
+    const int pick = draw_block_fast(w + (size_t)b * stride, S, r64, sh16, &sh_pick);
     if (threadIdx.x == 0) {
         bidx[b * 4 + slot] = pick;
         if (pick < 0) fail[b] = 1;
@@ -279,23 +317,9 @@ __host__ __device__ static bool try_sampled_base(const V3 base[4], float& invari
 // rows 6-7 on the device: ordered base + invariants of one attempt (try_sampled_base, stocs.cpp:224-268)
 struct BaseOut { int32_t ids[4]; float inv[2]; int32_t valid; int32_t pad; };
 
-__device__ __forceinline__ void finalize_one(const float4* __restrict__ spos, const int32_t* bidx4, int fail, BaseOut* o) {
-    int ids[4] = {bidx4[0], bidx4[1], bidx4[2], bidx4[3]};
-    float i1 = 0, i2 = 0;
-    bool ok = !fail && ids[0] >= 0 && ids[1] >= 0 && ids[2] >= 0 && ids[3] >= 0;
-    if (ok) {
-        V3 base[4];
-        for (int k = 0; k < 4; ++k) { const float4 p = spos[ids[k]]; base[k] = mk3(p.x, p.y, p.z); }
-        ok = try_sampled_base(base, i1, i2, ids);
-    }
-    for (int k = 0; k < 4; ++k) o->ids[k] = ids[k];
-    o->inv[0] = i1; o->inv[1] = i2;
-    o->valid = ok ? 1 : 0;
-    o->pad = 0;
-}
-
-// the same by twelve lanes of one wavefront (the 12 ordered pairings of try_sampled_base evaluated side by side, then the
-// reference's first-strict-minimum rule applied in its enumeration order): callers pass whole wavefront 0
+// ordered base + invariants of one attempt by twelve lanes of one wavefront: the 12 ordered pairings of try_sampled_base
+// (stocs.cpp:224-268) evaluated side by side, then the reference's first-strict-minimum rule in its enumeration order.
+// Callers pass a whole wavefront.
 __device__ __forceinline__ void finalize_one_wave(const float4* __restrict__ spos, const int32_t* bidx4, int fail, BaseOut* o) {
     const int lane = threadIdx.x & 63;
     int ids[4] = {bidx4[0], bidx4[1], bidx4[2], bidx4[3]};
@@ -333,8 +357,8 @@ __device__ __forceinline__ void finalize_one_wave(const float4* __restrict__ spo
 
 __global__ __launch_bounds__(64) void finalize_bases_kernel(const float4* __restrict__ spos, const int32_t* __restrict__ bidx,
                                                             const int32_t* __restrict__ fail, int nB, BaseOut* __restrict__ out) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nB) finalize_one(spos, bidx + 4 * b, fail[b], out + b);
+    const int b = blockIdx.x;   // one wavefront per attempt, the 12 pairings side by side
+    if (b < nB) finalize_one_wave(spos, bidx + 4 * b, fail[b], out + b);
 }
 
 struct SampleBuffers {
@@ -420,7 +444,7 @@ static int sample_class(stocs_ctx* c, uint64_t seed, int first_attempt, int nB, 
         if (k < 3) launch_pass(c, k + 1, nB, sb);
     }
     STOCS_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(finalize_bases_kernel, dim3((unsigned)((nB + 63) / 64)), dim3(64), 0, c->stream, c->d_spos, sb.bidx, sb.fail, nB, sb.res);
+    hipLaunchKernelGGL(finalize_bases_kernel, dim3((unsigned)nB), dim3(64), 0, c->stream, c->d_spos, sb.bidx, sb.fail, nB, sb.res);
     STOCS_HIP_CHECK(hipGetLastError());
     std::vector<BaseOut> res((size_t)nB);
     STOCS_HIP_CHECK(hipMemcpyAsync(res.data(), sb.res, (size_t)nB * sizeof(BaseOut), hipMemcpyDeviceToHost, c->stream));
@@ -518,84 +542,6 @@ __device__ void flood_fill_runs(const InstanceArgs& A, ParentPtr parent, int r0,
         }
     }
     __syncthreads();
-}
-
-// Seeded weighted draw over n weights by the whole 1024-thread workgroup (same rule as draw_block: 2^32 fixed-point weights,
-// r = mulhi(r64, total), first index whose inclusive prefix exceeds r), with wavefront scans instead of the 20-barrier
-// Hillis-Steele scan: 3 barriers.  Returns the position in wb (or -1 when every weight is zero) to every thread.
-__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
-    const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, 64);
-    return ((uint64_t)hi << 32) | lo;
-}
-// the same draw by wavefront 0 alone (few weights: the survivors of a mask): one barrier instead of four
-__device__ __forceinline__ int draw_wave0(const float* __restrict__ wb, int n, uint64_t r64, int* sh_pick) {
-    const int t = threadIdx.x;
-    if (t < 64) {
-        const int chunk = (n + 63) / 64;
-        const int lo = min(n, t * chunk), hi = min(n, lo + chunk);
-        uint64_t local = 0;
-        for (int i = lo; i < hi; ++i) local += weight_fix(wb[i]);
-        uint64_t incl = local;
-        for (int d = 1; d < 64; d <<= 1) { const uint64_t o = shfl_up_u64(incl, d); if (t >= d) incl += o; }
-        const uint64_t total = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(incl >> 32), 63, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)incl, 63, 64);
-        int pick = -1;
-        bool mine = false;
-        if (total != 0) {
-            const uint64_t r = mulhi64(r64, total);
-            const uint64_t ex = incl - local;
-            mine = r >= ex && r < incl;
-            if (mine) {
-                uint64_t c = ex;
-                for (int i = lo; i < hi; ++i) { c += weight_fix(wb[i]); if (c > r) { pick = i; break; } }
-            }
-        }
-        const unsigned long long m = __ballot(mine);
-        if (m == 0ull) { if (t == 0) *sh_pick = -1; }
-        else if (mine) *sh_pick = pick;
-    }
-    __syncthreads();
-    const int pick = *sh_pick;
-    __syncthreads();
-    return pick;
-}
-
-__device__ __forceinline__ int draw_block_fast(const float* __restrict__ wb, int n, uint64_t r64, uint64_t* sh16 /*>= 17*/, int* sh_pick) {
-    if (n <= 1024) return draw_wave0(wb, n, r64, sh_pick);
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int chunk = (n + 1023) / 1024;
-    const int lo = min(n, t * chunk), hi = min(n, lo + chunk);
-    uint64_t local = 0;
-    for (int i = lo; i < hi; ++i) local += weight_fix(wb[i]);
-    uint64_t incl = local;                                     // inclusive scan inside the wavefront
-    for (int d = 1; d < 64; d <<= 1) { const uint64_t o = shfl_up_u64(incl, d); if (lane >= d) incl += o; }
-    if (lane == 63) sh16[wv] = incl;
-    if (t == 0) *sh_pick = -1;
-    __syncthreads();
-    if (wv == 0) {                                             // exclusive scan of the 16 wavefront totals
-        uint64_t v = lane < 16 ? sh16[lane] : 0, inc = v;
-        for (int d = 1; d < 16; d <<= 1) { const uint64_t o = shfl_up_u64(inc, d); if (lane >= d) inc += o; }
-        if (lane < 16) sh16[lane] = inc - v;
-        if (lane == 15) sh16[16] = inc;
-    }
-    __syncthreads();
-    const uint64_t total = sh16[16];
-    if (total != 0) {
-        const uint64_t r = mulhi64(r64, total);
-        const uint64_t in2 = sh16[wv] + incl, ex2 = in2 - local;
-        if (r >= ex2 && r < in2) {  // exactly one thread (local > 0)
-            uint64_t c = ex2;
-            int pick = -1;
-            for (int i = lo; i < hi; ++i) {
-                c += weight_fix(wb[i]);
-                if (c > r) { pick = i; break; }
-            }
-            *sh_pick = pick;
-        }
-    }
-    __syncthreads();
-    const int pick = *sh_pick;
-    __syncthreads();   // sh16 / sh_pick are reused by the next draw
-    return pick;
 }
 
 __global__ __launch_bounds__(1024) void instance_attempts_kernel(InstanceArgs A, uint64_t seed, int first_attempt, int n_attempts, float dispersion) {
