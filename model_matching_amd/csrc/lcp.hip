@@ -173,7 +173,7 @@ __device__ __forceinline__ int dpp_i32(int v) {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
 
-template <bool DETAIL, int UNR, bool MASK = true, bool EARLY = false, bool IDX = true, int WPB = 4>
+template <bool DETAIL, int UNR, bool MASK = true, bool EARLY = false, bool IDX = true, int WPB = 4, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WPB) void lcp_coop_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
                                                        int n, int32_t* __restrict__ hit_out, uint8_t* __restrict__ cnt_out) {
     __shared__ float4 qt[WPB][64];     // per lane: qx, qy, qz, bits(list offset)
@@ -182,16 +182,19 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coop_kernel(LcpArgs a, const flo
     __shared__ float rd[WPB][64];      // per lane: best d^2
     __shared__ int ri[WPB][64];        // per lane: best scene index
     __shared__ float qd[WPB][64];      // per lane: |query - cell centre| (EARLY)
+    __shared__ unsigned long long part[WPB];
     const int lane = threadIdx.x & 63;
     const int sub = lane & 7, grp = lane >> 3;
     const int w = threadIdx.x >> 6;
-    const int cand = lcp_candidate(a, n, w, WPB);
+    // SPLIT: the WPB wavefronts of the workgroup share one candidate and take its 64-point steps round-robin (see lcp_coopq_kernel)
+    const int cand = SPLIT ? lcp_candidate(a, n, 0, 1) : lcp_candidate(a, n, w, WPB);
     if (cand < 0) return;
+    const int first = SPLIT ? 64 * w : 0, stride = SPLIT ? 64 * WPB : 64;
     const float* T = T16 + (size_t)cand * 16;
     const float t0 = T[0], t1 = T[1], t2 = T[2], t4 = T[4], t5 = T[5], t6 = T[6], t8 = T[8], t9 = T[9], t10 = T[10],
                 t12 = T[12], t13 = T[13], t14 = T[14];
     unsigned long long acc = 0ull;
-    for (int base = 0; base < a.M; base += 64) {
+    for (int base = first; base < a.M; base += stride) {
         const int i = base + lane;
         float qx = 0.f, qy = 0.f, qz = 0.f, qcd = 0.f;
         uint32_t off = 0, cnt = 0;
@@ -314,7 +317,16 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coop_kernel(LcpArgs a, const flo
         }
     }
     acc = lcp_wave_sum(acc);
-    if (lane == 0) out[cand] = lcp_finish(acc, a.M);
+    if (SPLIT) {
+        if (lane == 0) part[w] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long total = 0;
+#pragma unroll
+            for (int k = 0; k < WPB; ++k) total += part[k];
+            out[cand] = lcp_finish(total, a.M);
+        }
+    } else if (lane == 0) out[cand] = lcp_finish(acc, a.M);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -656,7 +668,11 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
             case 32: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 4, true, true, false>); break;
             case 33: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 2, true, true, false>); break;   // 31 with four waves per workgroup
 #endif
-            default: hipLaunchKernelGGL((lcp_coop_kernel<false, 2, true, true, false, 1>), dim3(n), dim3(64), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); break;   // 31
+            default:   // 31
+                // four wavefronts per candidate: C5 (16 384 candidates x 50 000 points) 11.6 -> 8.3 ms; eight: 8.1 ms, but 20 % slower at Cm
+                if (c->lcp_split && a.M >= 512) hipLaunchKernelGGL((lcp_coop_kernel<false, 2, true, true, false, 4, true>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
+                else hipLaunchKernelGGL((lcp_coop_kernel<false, 2, true, true, false, 1>), dim3(n), dim3(64), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
+                break;
         }
     } else {
         switch (variant) {
