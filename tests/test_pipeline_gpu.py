@@ -396,12 +396,15 @@ def test_set_scene_equals_fresh_context():
 
 
 def test_randomised_workloads_against_oracle():
-    """tools/fuzz_parity.py on a dozen random small workloads (400 were run for DESIGN.md section 2): whole hot path,
-    candidates bit-exact, scores within 1e-5."""
+    """tools/fuzz_parity.py on a dozen random small workloads (200 of these were run for DESIGN.md section 2: 0 mismatches
+    over 7 980 instance-mode bases, 344 k quads, 166 k candidates): whole hot path in class mode -- candidates bit-exact,
+    scores within 1e-5 -- then instance-mode sampling on a random edge map (device union-find flood fill against the oracle's
+    literal BFS, attempt by attempt, and the decayed class prior)."""
     import json, subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "12", "777"], capture_output=True, text=True, timeout=600,
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "12", "777", "--instance"], capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, PYTHONPATH=root), cwd=root)
     assert out.returncode == 0, out.stderr[-1500:]
     summ = json.loads(out.stdout.strip().splitlines()[-1])
     assert summ["workloads"] == 12 and summ["mismatches"] == 0 and summ["total_candidates"] > 1000 and summ["max_abs_lcp_diff"] <= 1e-5
+    assert summ["instance_mode"] and summ["instance_bases"] > 100

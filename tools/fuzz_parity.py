@@ -2,7 +2,11 @@
 """Randomised parity sweep: N small random workloads (model size, scene size, clutter, seeds all drawn), the whole
 hot path on the GPU against the CPU oracle: bases + invariants, per-base quad counts, candidate transforms
 (bit-exact) and scores (1e-5).  Prints one line per mismatch and a summary.
-usage: python tools/fuzz_parity.py [N] [first_seed]"""
+With --instance the workloads also get a random edge map (passable background, random edge segments and speckle,
+some in-between values, an isolated pocket around some points) and the sampling runs in instance mode (persistent
+device kernel with the union-find flood fill) against the oracle's literal BFS, attempt by attempt, plus the segment of
+the last attempt and the decayed class prior.
+usage: python tools/fuzz_parity.py [N] [first_seed] [--instance]"""
 import json
 import os
 import sys
@@ -16,11 +20,55 @@ from model_matching_amd.estimator import StocsEstimator  # noqa: E402
 from oracle import pyoracle  # noqa: E402
 
 
+def random_edge_map(rng, pix, H=480, W=640):
+    e = np.full((H, W), 255, np.uint8)
+    for _ in range(int(rng.integers(5, 60))):          # edge segments (value 0) of thickness 1-3
+        r0, c0 = rng.integers(0, H), rng.integers(0, W)
+        ang = rng.uniform(0, np.pi); L = int(rng.integers(20, 400)); th = int(rng.integers(1, 4))
+        t = np.arange(L)
+        rr = np.clip((r0 + t * np.sin(ang)).astype(int), 0, H - 1); cc = np.clip((c0 + t * np.cos(ang)).astype(int), 0, W - 1)
+        for d in range(th):
+            e[np.clip(rr + d, 0, H - 1), cc] = 0
+    k = int(rng.integers(0, 4000))                       # speckle: edge pixels and in-between values (neither pruned nor passable)
+    e[rng.integers(0, H, k), rng.integers(0, W, k)] = rng.choice(np.array([0, 0, 128, 254], np.uint8), k)
+    for _ in range(int(rng.integers(0, 4))):             # a closed box around a scene point: a pocket the fill cannot leave
+        r, c = pix[int(rng.integers(0, len(pix)))]
+        h = int(rng.integers(3, 25))
+        r0, r1, c0, c1 = max(r - h, 0), min(r + h, H - 1), max(c - h, 0), min(c + h, W - 1)
+        e[r0, c0:c1 + 1] = 0; e[r1, c0:c1 + 1] = 0; e[r0:r1 + 1, c0] = 0; e[r0:r1 + 1, c1] = 0
+    return e
+
+
+def instance_leg(est, orc, rng, s, seed, nb):
+    import ctypes as C
+    edge = random_edge_map(rng, s.pixel)
+    est.set_edge_map(edge); orc.set_edge_map(edge)
+    est.L.stocs_clear_bases(est.h)
+    valid, ids, inv = est.sample_bases(seed, nb, mode=1, dispersion=0.9)
+    ok = True
+    for a in range(nb):
+        o, oi, ov = orc.sample_instance_base(seed, a, 0.9, a + 1)
+        ok &= o == bool(valid[a])
+        if o and valid[a]:
+            ok &= bool(np.array_equal(oi, ids[a]) and np.array_equal(ov, inv[a]))
+    # the decayed prior after the attempts (Q8): what the LCP will add
+    n = len(s.pos)
+    pr = np.zeros(n, np.float32)
+    est.L.stocs_get_scene(est.h, None, None, pr.ctypes.data_as(C.POINTER(C.c_float)), None)
+    po = np.zeros(n, np.float32); pos3 = np.zeros((n, 3), np.float32); cls = np.zeros(n, np.float32)
+    pyoracle.lib().orc_get_scene(orc.h, pos3.ctypes.data_as(C.POINTER(C.c_float)), po.ctypes.data_as(C.POINTER(C.c_float)), cls.ctypes.data_as(C.POINTER(C.c_float)))
+    ok &= bool(np.array_equal(pr, cls))
+    return ok, int(valid.sum())
+
+
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-    first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    instance = "--instance" in sys.argv
+    argv = [a for a in sys.argv if a != "--instance"]
+    n = int(argv[1]) if len(argv) > 1 else 20
+    first = int(argv[2]) if len(argv) > 2 else 1000
     pyoracle.build()
     bad = 0
+    n_inst_bases = 0
     stats = []
     for k in range(n):
         rng = np.random.default_rng(first + k)
@@ -52,13 +100,19 @@ def main():
             ok &= dmax <= 1e-5
         else:
             dmax = 0.0
+        if instance:
+            iok, nv = instance_leg(est, orc, rng, s, seed + 1, nb)
+            if not iok:
+                print("INSTANCE MISMATCH", dict(k=k, nm=nm, ns=ns, seed=seed + 1, nb=nb), flush=True)
+            ok &= iok
+            n_inst_bases += nv
         stats.append((nm, ns, nb, r.n_bases, int(tot), int(nc), dmax))
         if not ok:
             bad += 1
             print("MISMATCH", dict(k=k, nm=nm, ns=ns, seed=seed, nb=nb, bases=(int(valid.sum()), r.n_bases), quads=(int(tot), r.n_quads_total),
                                    cands=(int(nc), r.n_candidates), dl=dl, dmax=dmax), flush=True)
         est.close()
-    print(json.dumps({"workloads": n, "mismatches": bad, "total_quads": int(sum(x[4] for x in stats)), "total_candidates": int(sum(x[5] for x in stats)),
+    print(json.dumps({"workloads": n, "instance_mode": instance, "instance_bases": n_inst_bases, "mismatches": bad, "total_quads": int(sum(x[4] for x in stats)), "total_candidates": int(sum(x[5] for x in stats)),
                       "max_abs_lcp_diff": max(x[6] for x in stats)}))
 
 
