@@ -568,20 +568,28 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const std::vector<Segment
     S->d_err.p = (unsigned int*)(d_up.p + o_err);
     const PpfIndex& ix = c->index;
     const long long cell_limit = S->use_table ? S->NC : ((long long)1 << 31);
-    hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, ix.d_pairs, d_psegs, (int)psegs.size(), (uint32_t)totP,
-                       S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p);
-    hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totQ + 255) / 256)), dim3(256), 0, st, ix.d_pairs, d_qsegs, (int)qsegs.size(), (uint32_t)totQ,
-                       S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p);
-    STOCS_HIP_CHECK(hipGetLastError());
-    // one stable sort per list: (base, position cell); inside a cell the entries keep the index order of the gather
+    // The P side (gather, sort, records) and the Q side (gather, sort) are independent until the join: the Q side runs on
+    // the context's auxiliary stream next to the P side (a radix pass of 7 M pairs moves ~1.8 TB/s: two of them share the chip)
     const unsigned end_bit = (unsigned)(S->cell_bits + S->base_bits);
     size_t tb1 = 0, tb2 = 0;
     STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb1, d_pk_raw.p, (KeyT*)S->d_pkeys.p, d_pv_raw.p, S->d_pvals.p, totP, 0, end_bit, st));
     STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb2, d_qk_raw.p, (KeyT*)S->d_qkeys.p, d_qv_raw.p, S->d_qvals.p, totQ, 0, end_bit, st));
-    size_t tmp_bytes = std::max(tb1, tb2);
-    if ((rc = d_tmp.alloc(tmp_bytes))) return rc;
-    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_pk_raw.p, (KeyT*)S->d_pkeys.p, d_pv_raw.p, S->d_pvals.p, totP, 0, end_bit, st));
-    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_qk_raw.p, (KeyT*)S->d_qkeys.p, d_qv_raw.p, S->d_qvals.p, totQ, 0, end_bit, st));
+    DevBuf<char> d_tmp2;
+    if ((rc = d_tmp.alloc(tb1)) || (rc = d_tmp2.alloc(tb2))) return rc;
+    hipStream_t sq = c->aux_stream ? c->aux_stream : st;
+    if (sq != st) {
+        STOCS_HIP_CHECK(hipEventRecord(c->ev_fork, st));          // the upload above is on st
+        STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_fork, 0));
+    }
+    hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totQ + 255) / 256)), dim3(256), 0, sq, ix.d_pairs, d_qsegs, (int)qsegs.size(), (uint32_t)totQ,
+                       S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p);
+    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_tmp2.p, tb2, d_qk_raw.p, (KeyT*)S->d_qkeys.p, d_qv_raw.p, S->d_qvals.p, totQ, 0, end_bit, sq));
+    if (sq != st) STOCS_HIP_CHECK(hipEventRecord(c->ev_join, sq));
+    hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, ix.d_pairs, d_psegs, (int)psegs.size(), (uint32_t)totP,
+                       S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p);
+    STOCS_HIP_CHECK(hipGetLastError());
+    // one stable sort per list: (base, position cell); inside a cell the entries keep the index order of the gather
+    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_tmp.p, tb1, d_pk_raw.p, (KeyT*)S->d_pkeys.p, d_pv_raw.p, S->d_pvals.p, totP, 0, end_bit, st));
     if (S->use_table) {
         const size_t ncell = (size_t)(S->NC * nB);
         if ((rc = S->d_cfirst.alloc(ncell)) || (rc = S->d_cend.alloc(ncell))) return rc;
@@ -591,6 +599,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const std::vector<Segment
                        S->cell_bits, S->NC, S->d_jobs.p, c->d_munit, c->d_mpos, S->nepsilon, S->d_prec.p, S->use_table ? S->d_cfirst.p : (uint32_t*)NULL,
                        S->use_table ? S->d_cend.p : (uint32_t*)NULL);
     STOCS_HIP_CHECK(hipGetLastError());
+    if (sq != st) STOCS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_join, 0));   // the join needs both sides
     STOCS_TICK("gather+sort+records")
     // join: count pass + exclusive scan.  The quads themselves are produced on demand (materialise / resolve_picks_kernel)
     DevBuf<unsigned long long> d_qcnt;   // 64-bit: the total can exceed 2^32
@@ -675,6 +684,7 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     CongruentState* S = (CongruentState*)c->cong;
     S->valid = false;
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));   // the previous trial's buffers are about to be reused
+    if (c->aux_stream) STOCS_HIP_CHECK(hipStreamSynchronize(c->aux_stream));   // (idle unless an earlier call failed half way)
     { int rc0 = S->arena_state.reset(); if (rc0) return rc0; }
     tl_arena = &S->arena_state;
     if (dbg) { const double t_ = now_s(); fprintf(stderr, "[stocs congruent] %-18s %8.3f ms\n", "sync+reset", (t_ - tprev) * 1e3); tprev = t_; }

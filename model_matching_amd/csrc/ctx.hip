@@ -280,8 +280,10 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     memset(&c->grid, 0, sizeof(c->grid));
     c->d_spos = c->d_snrmw = c->d_mpos = c->d_mnrm = c->d_munit = c->d_mpos_raw = c->d_mpos_s = c->d_mnrm_s = NULL;
     c->d_spix = NULL; c->d_mperm = NULL;
-    c->stream = NULL; c->own_stream = NULL;
-    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    c->stream = NULL; c->own_stream = NULL; c->aux_stream = NULL;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
         set_error("stream/event creation failed");
         delete c;
         return STOCS_ERR_NO_DEVICE;
@@ -374,6 +376,9 @@ int stocs_ctx_destroy(stocs_ctx* c) {
     for (void* p : ptrs) if (p) hipFree(p);
     hipEventDestroy(c->ev0);
     hipEventDestroy(c->ev1);
+    hipEventDestroy(c->ev_fork);
+    hipEventDestroy(c->ev_join);
+    if (c->aux_stream) { hipStreamSynchronize(c->aux_stream); hipStreamDestroy(c->aux_stream); }
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
     return STOCS_OK;

@@ -158,7 +158,8 @@ struct stocs_ctx {
     int device;
     hipStream_t stream;       // the stream all work is issued on
     hipStream_t own_stream;   // created with the context; `stream` may point to a caller's stream instead
-    hipEvent_t ev0, ev1;
+    hipStream_t aux_stream;   // second stream of the context for work that is independent of `stream` until an event joins it
+    hipEvent_t ev0, ev1, ev_fork, ev_join;
     int nS, nM;
     stocs::Thresholds thr;
 
