@@ -162,7 +162,7 @@ def test_trial_sharding_tool_single_and_two_ranks():
     the same winner as the single-process run over the same trials."""
     import json, socket, sys
     env = dict(os.environ, PYTHONPATH=ROOT)
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trials.py"), "--trials", "6", "--seed", "3"], capture_output=True, text=True,
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trials.py"), "--trials", "16", "--seed", "3"], capture_output=True, text=True,
                          timeout=600, env=env, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-2000:]
     r1 = json.loads(one.stdout.strip().splitlines()[-1])
@@ -171,11 +171,12 @@ def test_trial_sharding_tool_single_and_two_ranks():
         sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
     env2 = dict(env, STOCS_BENCH_REHEARSAL="1")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), os.path.join(ROOT, "tools", "trials.py"), "--trials", "6", "--seed", "3"],
+                          "--master-port", str(port), os.path.join(ROOT, "tools", "trials.py"), "--trials", "16", "--seed", "3"],
                          capture_output=True, text=True, timeout=900, env=env2, cwd=ROOT)
     assert two.returncode == 0, two.stderr[-3000:]
     r2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
-    assert r2["n_gpus"] == 2 and r2["rehearsal"] is True
+    assert r2["n_gpus"] == 2 and r2["rehearsal"] is True and r2["world_size"] == 2 and r2["backend"] == "gloo"
+    assert [x["rank"] for x in r2["ranks"]] == [0, 1] and [x["trials"] for x in r2["ranks"]] == [[0, 8], [8, 16]]
     assert (r2["best_lcp"], r2["best_trial"], r2["best_candidate"]) == (r1["best_lcp"], r1["best_trial"], r1["best_candidate"])
     assert r2["best_pose_row_major_3x4"] == r1["best_pose_row_major_3x4"] and r2["candidates_verified"] == r1["candidates_verified"]
 
