@@ -107,6 +107,7 @@ def lib():
         L.orc_lcp.restype = C.c_float
         L.orc_lcp_batch.argtypes = [vp, fp, C.c_int, fp, C.c_int]
         L.orc_lcp_detail.argtypes = [vp, fp, ip, u8p]
+        L.orc_lcp_batch_exact.argtypes = [vp, fp, C.c_int, fp, C.POINTER(C.c_double), C.c_int]
         L.orc_best.argtypes = [fp, C.c_int, fp]
         L.orc_best.restype = C.c_int
         L.orc_normal_compatible.argtypes = [C.c_float]
@@ -342,6 +343,14 @@ class Oracle:
         out = np.zeros(n, np.float32)
         lib().orc_lcp_batch(self.h, pT, n, out.ctypes.data_as(C.POINTER(C.c_float)), nthreads)
         return out
+
+    def lcp_batch_exact(self, T16, nthreads=1):
+        """(reference float-accumulated scores, the same matches summed in double)"""
+        T, pT = _f(T16)
+        n = T.size // 16
+        out = np.zeros(n, np.float32); ex = np.zeros(n, np.float64)
+        lib().orc_lcp_batch_exact(self.h, pT, n, out.ctypes.data_as(C.POINTER(C.c_float)), ex.ctypes.data_as(C.POINTER(C.c_double)), nthreads)
+        return out, ex
 
     def lcp_detail(self, T16):
         T, pT = _f(T16)

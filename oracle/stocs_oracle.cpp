@@ -840,9 +840,13 @@ bool rigid_transform(orc_ctx* c, const int ids[4], const int quad[4], float* T, 
 }
 
 // row 16: compute_alignment_score_for_rigid_transform -- stocs.cpp:1006-1041
-float lcp_score(const orc_ctx* c, const float* T, int32_t* hit, uint8_t* counted) {
+// `exact` (optional): the same weights summed in double -- NOT what the reference computes; a checker for the checker:
+// the product adds the weights as integers and returns the exact mean, so it must agree with this value to float
+// rounding, while the reference's running float sum (the return value) drifts from it by ~1e-9 * |M| on big models.
+float lcp_score(const orc_ctx* c, const float* T, int32_t* hit, uint8_t* counted, double* exact = NULL) {
     const float epsilon = c->prm.distance_threshold;
     float weighted_match = 0;
+    double weighted_exact = 0;
     const int n = (int)c->model.size();
     const float sq_eps = epsilon * epsilon;
     for (int i = 0; i < n; ++i) {
@@ -853,10 +857,12 @@ float lcp_score(const orc_ctx* c, const float* T, int32_t* hit, uint8_t* counted
             V3 n_q = xform_normal(T, c->model[i].nrm);
             if (normal_compatible(dot(c->scene[resId].nrm, n_q))) {
                 weighted_match += c->scene[resId].class_prob;
+                weighted_exact += (double)c->scene[resId].class_prob;
                 if (counted) counted[i] = 1;
             }
         }
     }
+    if (exact) *exact = weighted_exact / (double)n;
     return weighted_match / (float)n;
 }
 
@@ -1303,6 +1309,11 @@ void orc_lcp_batch(orc_ctx* c, const float* T16, int n, float* out, int nthreads
     for (int i = 0; i < n; ++i) out[i] = lcp_score(c, T16 + 16 * (size_t)i, NULL, NULL);
 }
 void orc_lcp_detail(orc_ctx* c, const float* T16, int32_t* hit, uint8_t* counted) { lcp_score(c, T16, hit, counted); }
+// out: the reference's float-accumulated scores; out_exact: the same matches summed in double (see lcp_score)
+void orc_lcp_batch_exact(orc_ctx* c, const float* T16, int n, float* out, double* out_exact, int nthreads) {
+#pragma omp parallel for num_threads(nthreads > 1 ? nthreads : 1) schedule(dynamic, 16)
+    for (int i = 0; i < n; ++i) out[i] = lcp_score(c, T16 + 16 * (size_t)i, NULL, NULL, out_exact + i);
+}
 // row 17: compute_best_transform -- stocs.cpp:982-1004 (strict >, from 0: first max wins, Q18)
 int orc_best(const float* lcp, int n, float* best_score) {
     float max_score = 0;

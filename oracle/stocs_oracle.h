@@ -116,6 +116,9 @@ float orc_lcp(orc_ctx*, const float* T16);
 void  orc_lcp_batch(orc_ctx*, const float* T16, int n, float* out, int nthreads);
 /* per-model-point hit index (-1 none) and counted flag, for kernel-level parity */
 void  orc_lcp_detail(orc_ctx*, const float* T16, int32_t* hit, uint8_t* counted);
+/* out: the reference's float-accumulated scores; out_exact: the same matches summed in double (a checker for the
+ * checker: the product returns the exact mean of the weights) */
+void  orc_lcp_batch_exact(orc_ctx*, const float* T16, int n, float* out, double* out_exact, int nthreads);
 int   orc_best(const float* lcp, int n, float* best_score);
 /* acosf-derived predicate of stocs.cpp:1028-1032 on a raw dot product */
 int   orc_normal_compatible(float dot);

@@ -16,6 +16,7 @@ python3 $R/tools/pmc.py join_count_kernel $OUT/pmc_join -- python3 $R/tools/pipe
 python3 $R/tools/pmc.py lcp_coop $OUT/pmc_lcp -- $B --steps 3 --warmup 1 > $OUT/lcp_pmc.json 2> $OUT/lcp_pmc.err
 cd $R
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+python3 bench.py --workload C5 --steps 40 --warmup 3 --no-pipeline --cpu-seconds 6 > $OUT/bench_C5.json 2> $OUT/bench_C5.err
 python3 tools/frame_latency.py 8 > $OUT/frame_latency.json
 python3 tools/sweep.py > $OUT/sweep.json
 python3 tools/trials.py --trials 64 --seed 3 > $OUT/trials64_s1.json
