@@ -250,6 +250,15 @@ class StocsEstimator:
     def score_device(self, dT, n, dL):
         capi.check(self.L.stocs_score_transforms_device(self.h, dT, n, dL))
 
+    def get_segment(self):
+        """`segment` of the last instance-mode attempt (stocs_get_segment): scene indices."""
+        n = C.c_int(0)
+        capi.check(self.L.stocs_get_segment(self.h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.int32)
+        if n.value:
+            capi.check(self.L.stocs_get_segment(self.h, out.ctypes.data_as(capi._ip), n.value, C.byref(n)))
+        return out
+
     def set_option(self, key, value):
         capi.check(self.L.stocs_set_option(self.h, key.encode(), int(value)))
 

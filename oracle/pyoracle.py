@@ -81,6 +81,8 @@ def lib():
         L.orc_sample_class_base.restype = C.c_int
         L.orc_sample_instance_base.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_float, C.c_int, ip, fp]
         L.orc_sample_instance_base.restype = C.c_int
+        L.orc_get_segment.argtypes = [vp, ip, C.c_int]
+        L.orc_get_segment.restype = C.c_int
         L.orc_class_pass.argtypes = [vp, C.c_int, ip, fp, fp]
         L.orc_segment_distance_and_invariants.argtypes = [fp, fp, fp, fp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_segment_distance_and_invariants.restype = C.c_double
@@ -286,6 +288,13 @@ class Oracle:
                                             ids.ctypes.data_as(C.POINTER(C.c_int32)),
                                             inv.ctypes.data_as(C.POINTER(C.c_float)))
         return bool(ok), ids, inv
+
+    def get_segment(self):
+        n = lib().orc_get_segment(self.h, None, 0)
+        out = np.zeros(n, np.int32)
+        if n:
+            lib().orc_get_segment(self.h, out.ctypes.data_as(C.POINTER(C.c_int32)), n)
+        return out
 
     def class_pass(self, k, b3, w_in):
         b, pb = _i(b3)

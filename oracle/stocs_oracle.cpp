@@ -478,6 +478,7 @@ struct orc_ctx {
     KdTree kd;
     orc_index* index;
     std::vector<uint8_t> edge_map;           // png values; all zero == "file absent" image of zeros
+    std::vector<int> last_segment;           // indices of the points pushed to `segment` by the last sample_instance_base
     std::vector<uint8_t> previous_segment;   // cv::Mat previous_segment
     std::vector<uint8_t> segmentation_buffer;
     std::map<int, std::vector<uint8_t> > seg_masks;  // in-memory stand-in for dbg/seg_mask_<n>.png (Q14)
@@ -1159,7 +1160,7 @@ int orc_sample_class_base(orc_ctx* c, uint64_t seed, uint64_t attempt, int32_t* 
     for (int i = 0; i < n; ++i) c->scene[i].cur_prob = c->scene[i].class_prob;
     std::vector<float> w;
     int b1 = draw_scene(c, seed, attempt, 0);
-    if (b1 < 0 || c->scene[b1].cur_prob == 0.0f) return 0;
+    if (b1 < 0 || c->scene[b1].cur_prob == 0.0f) { c->last_segment.clear(); return 0; }   // returns before `segment` is touched (:586-589)
     pull_w(c, w); pass1(c, b1, w.data()); push_w(c, w);
     int b2 = draw_scene(c, seed, attempt, 1);
     if (b2 < 0 || c->scene[b2].cur_prob == 0.0f) return 0;
@@ -1179,6 +1180,11 @@ int orc_sample_class_base(orc_ctx* c, uint64_t seed, uint64_t attempt, int32_t* 
 }
 
 // row 5: sample_instance_base -- stocs.cpp:559-751 (+ prune_edge_pixels :521-535)
+// `segment` of the last orc_sample_instance_base (the out-parameter of stocs.cpp:559-565, filled at :628-638), as scene indices
+int orc_get_segment(const orc_ctx* c, int32_t* idx, int cap) {
+    for (size_t i = 0; i < c->last_segment.size() && (int)i < cap; ++i) idx[i] = c->last_segment[i];
+    return (int)c->last_segment.size();
+}
 int orc_sample_instance_base(orc_ctx* c, uint64_t seed, uint64_t attempt, float dispersion, int base_num,
                              int32_t* ids4, float* inv2) {
     const int n = (int)c->scene.size();
@@ -1197,7 +1203,7 @@ int orc_sample_instance_base(orc_ctx* c, uint64_t seed, uint64_t attempt, float 
     }
     std::vector<float> w;
     int b1 = draw_scene(c, seed, attempt, 0);
-    if (b1 < 0 || c->scene[b1].cur_prob == 0.0f) return 0;
+    if (b1 < 0 || c->scene[b1].cur_prob == 0.0f) { c->last_segment.clear(); return 0; }   // returns before `segment` is touched (:586-589)
     pull_w(c, w); pass1(c, b1, w.data()); push_w(c, w);
     float max_pixel_distance = 0;  // :610-618
     for (int i = 0; i < n; ++i) {
@@ -1211,10 +1217,12 @@ int orc_sample_instance_base(orc_ctx* c, uint64_t seed, uint64_t attempt, float 
     generate_segmentation_mask(c, c->scene[b1].row, c->scene[b1].col, max_pixel_distance, segmentation_mask, base_num);
     c->seg_masks[base_num] = segmentation_mask;   // cv::imwrite(... seg_mask_<n>.png) :625
     c->previous_segment = segmentation_mask;      // :626
-    for (int i = 0; i < n; ++i) {                 // :628-638
+    c->last_segment.clear();
+    for (int i = 0; i < n; ++i) {                 // :628-638: survivors inside the mask are pushed to `segment`, the others zeroed
         if (c->scene[i].cur_prob != 0) {
             int isValid = (int)segmentation_mask[(size_t)c->scene[i].row * W + c->scene[i].col];
-            if (!isValid) c->scene[i].cur_prob = 0;
+            if (isValid) c->last_segment.push_back(i);
+            else c->scene[i].cur_prob = 0;
         }
     }
     int b2 = draw_scene(c, seed, attempt, 1);

@@ -82,6 +82,8 @@ const orc_index* orc_ctx_index(const orc_ctx*);
 uint64_t orc_rng(uint64_t seed, uint64_t attempt, uint64_t k);
 int  orc_draw(const float* w, int n, uint64_t r64);   /* -1 when all weights are zero */
 int  orc_sample_class_base(orc_ctx*, uint64_t seed, uint64_t attempt, int32_t* ids4, float* inv2);
+/* `segment` of the last orc_sample_instance_base (stocs.cpp:628-638) as scene indices; returns the count */
+int orc_get_segment(const orc_ctx*, int32_t* idx, int cap);
 int  orc_sample_instance_base(orc_ctx*, uint64_t seed, uint64_t attempt, float dispersion,
                               int base_num, int32_t* ids4, float* inv2);
 /* pass-by-pass access for kernel parity: weights after pass k (k=1..3) given fixed base points */

@@ -91,3 +91,28 @@ def test_hip_instance_mode_on_packed_dove(oracle_lib):
     best_lcp, best_idx, pose = est.compute_best_transform()
     T, P, l, b = est.get_pose_candidates()
     assert np.abs(l - orc.lcp_batch(T, nthreads=4)).max() <= LCP_TOL       # decayed class probabilities (Q8)
+
+
+@pytest.mark.gpu
+def test_instance_mode_per_call_segment_equals_oracle(oracle_lib):
+    """The per-call form (one attempt per stocs_sample_bases call, as the reference's caller loops, with the `segment`
+    out-parameter of stocs.cpp:559-565): base, validity and the segment filled at :628-638 equal the oracle's, attempt by
+    attempt; the image-space state lives on the device between the calls."""
+    from model_matching_amd.estimator import StocsEstimator
+    d = _load("packed_dove")
+    args = (d["scene_pos"], d["scene_nrm"], d["scene_prob"], d["scene_pixel"], d["model_pos"], d["model_nrm"])
+    est = StocsEstimator(*args, build_index=True)
+    orc = oracle_lib.Oracle(*args)
+    est.set_edge_map(d["edge_map"]); orc.set_edge_map(d["edge_map"])
+    n_seg = 0
+    for a in range(25):
+        valid, ids, inv = est.sample_bases(11, 1, mode=1, dispersion=0.9, first_attempt=a)
+        ok, oi, ov = orc.sample_instance_base(11, a, 0.9, a + 1)
+        assert ok == bool(valid[0]), a
+        if ok:
+            assert np.array_equal(oi, ids[0]) and np.array_equal(ov, inv[0]), a
+        sg, so = est.get_segment(), orc.get_segment()
+        assert np.array_equal(sg, so), a
+        n_seg += len(so)
+    assert n_seg > 100
+    est.close()
