@@ -127,6 +127,10 @@ int stocs_class_pass(stocs_ctx* ctx, int pass, const int32_t* b3, const float* w
  * of scene points keyed both ways; *n_mismatch must come back 0, *n_undecided counts the pairs the filter handed to the
  * reference's double arithmetic */
 int stocs_ppf_filter_check(stocs_ctx* ctx, uint64_t seed, int64_t n_pairs, int64_t* n_tested, int64_t* n_undecided, int64_t* n_mismatch);
+/* device self-check of the fixed-point weight of the seeded draws: the kernels read trunc(w * 2^32) off the bits of w; all
+ * 2^32 float patterns are compared with (uint64_t)((double)w * 4294967296.0) (0 for w <= 0 / NaN, saturating);
+ * *n_mismatch must come back 0 */
+int stocs_weight_fix_check(stocs_ctx* ctx, int64_t* n_mismatch);
 /* try_sampled_base on four scene indices (stocs.cpp:224-268) */
 int stocs_try_sampled_base(stocs_ctx* ctx, int32_t* ids4_inout, float* inv2, int* valid);
 /* the seeded weighted draw itself (stocs.cpp:133-148 replacement): index or -1 */

@@ -65,6 +65,7 @@ SIGNATURES = {
     "stocs_num_bases": (C.c_int, [_vp]),
     "stocs_class_pass": (C.c_int, [_vp, C.c_int, _ip, _fp, _fp]),
     "stocs_ppf_filter_check": (C.c_int, [_vp, C.c_uint64, C.c_int64, _i64p, _i64p, _i64p]),
+    "stocs_weight_fix_check": (C.c_int, [_vp, _i64p]),
     "stocs_try_sampled_base": (C.c_int, [_vp, _ip, _fp, _intp]),
     "stocs_draw": (C.c_int, [_vp, _fp, C.c_int, C.c_uint64, _intp]),
     "stocs_find_congruent_all": (C.c_int, [_vp, _i64p]),

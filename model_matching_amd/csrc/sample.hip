@@ -32,6 +32,9 @@ namespace stocs {
 struct IndexView {
     const uint32_t* bits;
     int tr, rot, NA, nD;
+    // a pair can only have a key when its squared length lies in [sq_lo, sq_hi): see set_distance_thresholds
+    float sq_lo, sq_hi;
+    int far_certain;   // 0: beyond sq_hi the exact path decides (an index reaching past a kilometre)
 };
 
 __device__ __forceinline__ bool ppf_exists(const IndexView& ix, const int* K) {
@@ -42,35 +45,105 @@ __device__ __forceinline__ bool ppf_exists(const IndexView& ix, const int* K) {
     const uint32_t key = ppf_pack(kd, k1, k2, k3, ix.NA);
     return (ix.bits[key >> 5] >> (key & 31)) & 1u;
 }
+// packed key of the existence bitmap for the PPF K, or PPF_NO_KEY when lookup(K) is empty by construction (rgbd.cpp:136)
+#define PPF_NO_KEY 0xFFFFFFFFu
+__device__ __forceinline__ uint32_t ppf_pack_or_none(const IndexView& ix, const int* K) {
+    if (K[0] <= 5 || K[1] < 0 || K[2] < 0 || K[3] < 0) return PPF_NO_KEY;
+    const int kd = K[0] / ix.tr, k1 = K[1] / ix.rot, k2 = K[2] / ix.rot, k3 = K[3] / ix.rot;
+    if (kd >= ix.nD || k1 >= ix.NA || k2 >= ix.NA || k3 >= ix.NA) return PPF_NO_KEY;
+    return ppf_pack(kd, k1, k2, k3, ix.NA);
+}
+__device__ __forceinline__ bool ppf_key_present(const IndexView& ix, uint32_t key) {
+    return key != PPF_NO_KEY && ((ix.bits[key >> 5] >> (key & 31)) & 1u);
+}
 
 // PPF key of (p1, p2) as ppf_compute gives it (reference rgbd.cpp:99-121), by a float filter with an exact fallback.
-// The three angles of the reference are int(atan2(double, double) * 180 / pi); the quantised key only changes when an angle
-// crosses rot * k + ceil(rot / 2) (ppf_closest_bin, rgbd.cpp:85-97).  atan2f of the same float operands is within 1e-4 degree
-// of the double value (2 ulp of the device library + one rounding of the conversion), so when the float angle is more than
-// PPF_MARGIN_DEG = 1e-3 degree away from every such boundary the float key IS the reference's key; otherwise (about
-// 0.1 % of the pairs, and anything non-finite) the double evaluation of stocs_math.h decides.  Distance bin: float in both.
+// The three angles of the reference are v = int(atan2(double, double) * 180 / pi), quantised by ppf_closest_bin
+// (rgbd.cpp:85-97) to rot * k with k = floor((v - b) / rot) + 1, b = ceil(rot / 2): since rot * k + b is an integer,
+// k = floor((a - b) / rot) + 1 for the untruncated angle a as well, and the key only changes where a crosses such a
+// boundary.  The filter evaluates a in float with its own atan2 (v_rcp_f32 + an odd polynomial of degree 15, |error| <
+// 2e-7 rad; with the roundings of the operands and of the conversion the float angle is within 1e-4 degree of the double
+// one) and no integer division; when the float angle is more than PPF_MARGIN_DEG = 1e-3 degree away from every boundary
+// the float key IS the reference's key; otherwise (about 0.1 % of the pairs, and anything non-finite) the double evaluation
+// of stocs_math.h decides.  Distance bin: the same float arithmetic in both.  stocs_ppf_filter_check counts disagreements.
 #define PPF_MARGIN_DEG 1e-3f
-__device__ __forceinline__ bool ppf_angle_filtered(float y, float x, int rot, int* bin) {
-    const float a = atan2f(y, x) * 57.29577951308232f;          // [0, 180]: y is a norm
-    const float b = (float)((rot + 1) / 2);                      // ceil(rot / 2): remainders >= b round up
-    const float q = (a - b) / (float)rot;
-    const float fq = q - floorf(q);
-    const bool certain = fminf(fq, 1.0f - fq) * (float)rot > PPF_MARGIN_DEG;   // false for NaN
-    *bin = ppf_closest_bin((int)a, rot);
-    return certain;
+// atan2(y, x) in degrees for y >= 0 (a norm): [0, 180]; NaN when both are zero or infinite
+__device__ __forceinline__ float atan2_deg_fast(float y, float x) {
+    const float ax = fabsf(x);
+    const float mx = fmaxf(ax, y), mn = fminf(ax, y);
+    const float r = mn * __builtin_amdgcn_rcpf(mx);              // [0, 1]
+    const float s = r * r;
+    float p = -0.00458501698449254f;                             // atan(r) = r * P(r^2) on [0, 1], max error 1.8e-7 rad in float
+    p = fmaf(p, s, 0.023815227672457695f);
+    p = fmaf(p, s, -0.05878564342856407f);
+    p = fmaf(p, s, 0.09857634454965591f);
+    p = fmaf(p, s, -0.13995274901390076f);
+    p = fmaf(p, s, 0.19964531064033508f);
+    p = fmaf(p, s, -0.3333152234554291f);
+    p = fmaf(p, s, 0.9999998211860657f);
+    p *= r;
+    if (y > ax) p = 1.5707963267948966f - p;
+    if (x < 0.0f) p = 3.14159265358979f - p;
+    return p * 57.29577951308232f;
 }
-__device__ __forceinline__ void ppf_compute_device(V3 p1, V3 n1, V3 p2, V3 n2, int tr, int rot, int* out4) {
+// bin index k of one angle; true when the angle is clear of the bin boundaries
+__device__ __forceinline__ bool ppf_angle_bin_fast(V3 cr, float x, float b, float inv_rot, float rot_f, int* k) {
+    const float y = __builtin_amdgcn_sqrtf(sqn3(cr));           // 1 ulp is plenty in front of the margin
+    const float a = atan2_deg_fast(y, x);
+    const float q = (a - b) * inv_rot;
+    const float fl = floorf(q), fq = q - fl;
+    *k = (int)fl + 1;
+    return fminf(fq, 1.0f - fq) * rot_f > PPF_MARGIN_DEG && x == x && y == y;   // false for NaN
+}
+// distance bin index of int(norm * 1000) (rgbd.cpp:103) for f = norm * 1000 < 2^20, ppf_closest_bin without the division:
+// k = floor((v - ceil(tr / 2)) / tr) + 1 = (v - ceil(tr / 2) + tr) / tr
+__device__ __forceinline__ int ppf_distance_bin(int tr, float f) {
+    const int n = (int)f - (tr + 1) / 2 + tr;
+    int kd = (int)((float)n * (1.0f / (float)tr));               // within one of the quotient for n < 2^21: one correction step
+    const int rem = n - kd * tr;
+    if (rem < 0) --kd; else if (rem >= tr) ++kd;
+    return kd;
+}
+// false when the distance component alone leaves no key (K0 <= 5, rgbd.cpp:136, or beyond the index), decided on the
+// squared length (set_distance_thresholds); NaN, and lengths beyond a kilometre, are left to the exact path: true
+__device__ __forceinline__ bool ppf_distance_may_have_key(const IndexView& ix, V3 u) {
+    const float sq = sqn3(u);
+    return (sq >= ix.sq_lo && sq < ix.sq_hi) || !(sq == sq) || (!ix.far_certain && sq >= ix.sq_hi);
+}
+// packed key from the float evaluation; *certain when it IS the key of the reference's arithmetic
+__device__ __forceinline__ uint32_t ppf_key_fast(const IndexView& ix, V3 p1, V3 n1, V3 p2, V3 n2, bool* certain) {
+    const float rot_f = (float)ix.rot, inv_rot = 1.0f / rot_f, b = (float)((ix.rot + 1) / 2);   // ceil(rot / 2): remainders >= b round up
     const V3 u = p1 - p2;
-    int b1, b2, b3;
-    const bool c1 = ppf_angle_filtered(norm3(cross3(n1, u)), dot3(n1, u), rot, &b1);
-    const bool c2 = ppf_angle_filtered(norm3(cross3(n2, u)), dot3(n2, u), rot, &b2);
-    const bool c3 = ppf_angle_filtered(norm3(cross3(n1, n2)), dot3(n1, n2), rot, &b3);
-    if (c1 && c2 && c3) {
-        out4[0] = ppf_closest_bin(stocs_trunc_int((double)(norm3(u) * 1000.0f)), tr);
-        out4[1] = b1; out4[2] = b2; out4[3] = b3;
-        return;
+    const float sq = sqn3(u);
+    if (!(sq >= ix.sq_lo && sq < ix.sq_hi)) {                    // no key whatever the angles -- or NaN / beyond a kilometre: the exact path
+        *certain = sq == sq && (ix.far_certain || sq < ix.sq_hi);
+        return PPF_NO_KEY;
     }
-    ppf_compute(p1, n1, p2, n2, tr, rot, out4);   // the reference's arithmetic
+    const int kd = ppf_distance_bin(ix.tr, stocs_sqrtf(sq) * 1000.0f);   // the same float arithmetic as the reference's
+    int k1, k2, k3;
+    const bool c1 = ppf_angle_bin_fast(cross3(n1, u), dot3(n1, u), b, inv_rot, rot_f, &k1);
+    const bool c2 = ppf_angle_bin_fast(cross3(n2, u), dot3(n2, u), b, inv_rot, rot_f, &k2);
+    const bool c3 = ppf_angle_bin_fast(cross3(n1, n2), dot3(n1, n2), b, inv_rot, rot_f, &k3);
+    *certain = c1 && c2 && c3;
+    if ((unsigned)k1 >= (unsigned)ix.NA || (unsigned)k2 >= (unsigned)ix.NA || (unsigned)k3 >= (unsigned)ix.NA) return PPF_NO_KEY;
+    return ppf_pack(kd, k1, k2, k3, ix.NA);
+}
+// the reference's arithmetic (double atan2) as a real call: it runs for about one pair in a thousand, and inlined its
+// constants and temporaries are hoisted into registers that the surrounding loops then spill
+__device__ __noinline__ uint32_t ppf_key_exact_call4(int tr, int rot, int NA, int nD, V3 p1, V3 n1, V3 p2, V3 n2) {
+    int K[4];
+    ppf_compute(p1, n1, p2, n2, tr, rot, K);
+    IndexView ix;
+    ix.bits = NULL; ix.tr = tr; ix.rot = rot; ix.NA = NA; ix.nD = nD; ix.sq_lo = ix.sq_hi = 0.0f; ix.far_certain = 1;
+    return ppf_pack_or_none(ix, K);
+}
+__device__ __forceinline__ uint32_t ppf_key_exact_call(const IndexView& ix, V3 p1, V3 n1, V3 p2, V3 n2) {
+    return ppf_key_exact_call4(ix.tr, ix.rot, ix.NA, ix.nD, p1, n1, p2, n2);
+}
+__device__ __forceinline__ uint32_t ppf_key_device(const IndexView& ix, V3 p1, V3 n1, V3 p2, V3 n2) {
+    bool certain;
+    const uint32_t key = ppf_key_fast(ix, p1, n1, p2, n2, &certain);
+    return certain ? key : ppf_key_exact_call(ix, p1, n1, p2, n2);
 }
 
 struct PassArgs {
@@ -97,9 +170,7 @@ __device__ __forceinline__ bool pass_zeroes(const PassArgs& a, int b1, int b2, i
     const float4 pi4 = a.spos[i], ni4 = a.snrm[i];
     const V3 pc = mk3(pc4.x, pc4.y, pc4.z), nc = mk3(nc4.x, nc4.y, nc4.z);
     const V3 pi = mk3(pi4.x, pi4.y, pi4.z), ni = mk3(ni4.x, ni4.y, ni4.z);
-    int K[4];
-    ppf_compute_device(pc, nc, pi, ni, a.ix.tr, a.ix.rot, K);
-    bool zero = !ppf_exists(a.ix, K) || i == cur;
+    bool zero = !ppf_key_present(a.ix, ppf_key_device(a.ix, pc, nc, pi, ni)) || i == cur;
     if (PASS == 2) {
         const float4 p14 = a.spos[b1];
         const V3 p1 = mk3(p14.x, p14.y, p14.z);
@@ -140,98 +211,118 @@ __global__ __launch_bounds__(256) void pass_kernel(PassArgs a, const int32_t* __
     if (pass_zeroes<PASS>(a, bidx[b * 4 + 0], bidx[b * 4 + 1], bidx[b * 4 + 2], i)) w[(size_t)b * a.S + i] = 0.0f;
 }
 
-// Seeded weighted draw over n weights by the whole 1024-thread workgroup (an exact, order-independent replacement of std::discrete_distribution: 2^32 fixed-point weights,
-// r = mulhi(r64, total), first index whose inclusive prefix exceeds r; -1 when every weight is zero = "FAILED SAMPLING::
-// Zero probability returned", stocs.cpp:386-389), with wavefront scans: 3 barriers.  Returns the position in wb (or -1 when every weight is zero) to every thread.
-__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
-    const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, 64);
+// Inclusive prefix sum over the 64 lanes of a wavefront with DPP row shifts and row broadcasts (no LDS traffic): lanes
+// 0..15 of each row first, then lane 15 of rows 0 / 2 into rows 1 / 3, then lane 31 into rows 2 and 3.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ uint64_t dpp_u64(uint64_t v) {   // lanes without a source (or masked off) read 0
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROW_MASK, BANK_MASK, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROW_MASK, BANK_MASK, true);
     return ((uint64_t)hi << 32) | lo;
 }
-// the same draw by wavefront 0 alone (few weights: the survivors of a mask): one barrier instead of four
-__device__ __forceinline__ int draw_wave0(const float* __restrict__ wb, int n, uint64_t r64, int* sh_pick) {
-    const int t = threadIdx.x;
-    if (t < 64) {
-        const int chunk = (n + 63) / 64;
-        const int lo = min(n, t * chunk), hi = min(n, lo + chunk);
-        uint64_t local = 0;
-        for (int i = lo; i < hi; ++i) local += weight_fix(wb[i]);
-        uint64_t incl = local;
-        for (int d = 1; d < 64; d <<= 1) { const uint64_t o = shfl_up_u64(incl, d); if (t >= d) incl += o; }
-        const uint64_t total = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(incl >> 32), 63, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)incl, 63, 64);
-        int pick = -1;
-        bool mine = false;
-        if (total != 0) {
-            const uint64_t r = mulhi64(r64, total);
-            const uint64_t ex = incl - local;
-            mine = r >= ex && r < incl;
-            if (mine) {
-                uint64_t c = ex;
-                for (int i = lo; i < hi; ++i) { c += weight_fix(wb[i]); if (c > r) { pick = i; break; } }
-            }
-        }
-        const unsigned long long m = __ballot(mine);
-        if (m == 0ull) { if (t == 0) *sh_pick = -1; }
-        else if (mine) *sh_pick = pick;
-    }
-    __syncthreads();
-    const int pick = *sh_pick;
-    __syncthreads();
-    return pick;
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t x) {
+    uint64_t v = x + dpp_u64<0x111, 0xf, 0xf>(x) + dpp_u64<0x112, 0xf, 0xf>(x) + dpp_u64<0x113, 0xf, 0xf>(x);   // row_shr:1..3
+    v += dpp_u64<0x114, 0xf, 0xe>(v);    // row_shr:4 into lanes 4..15 of each row
+    v += dpp_u64<0x118, 0xf, 0xc>(v);    // row_shr:8 into lanes 8..15
+    v += dpp_u64<0x142, 0xa, 0xf>(v);    // row_bcast:15 into rows 1 and 3
+    v += dpp_u64<0x143, 0xc, 0xf>(v);    // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {   // l uniform
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
 }
 
-__device__ __forceinline__ int draw_block_fast(const float* __restrict__ wb, int n, uint64_t r64, uint64_t* sh16 /*>= 17*/, int* sh_pick) {
-    if (n <= 1024) return draw_wave0(wb, n, r64, sh_pick);
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int chunk = (n + 1023) / 1024;
+// Seeded weighted draw over n weights by the whole 1024-thread workgroup (an exact, order-independent replacement of
+// std::discrete_distribution: 2^32 fixed-point weights, r = mulhi(r64, total), first index whose inclusive prefix exceeds r;
+// -1 when every weight is zero = "FAILED SAMPLING:: Zero probability returned", stocs.cpp:386-389).  Every thread sums
+// consecutive weights, the wavefronts scan with DPP, every wavefront scans the wavefront totals itself: two barriers.  sh16 (2 x 16) and sh_pick (2) are double-buffered by `slot`: consecutive draws alternate it, so no
+// barrier is needed behind the last read.  Returns the position in wb (or -1) to every thread.
+// weight_fix (stocs_math.h) without branches: the draws run it for every weight, and divergent branches cost more than the arithmetic
+__device__ __forceinline__ uint64_t weight_fix_dev(float w) {
+    const uint32_t b = __float_as_uint(w);
+    const int e = (int)((b >> 23) & 0xFFu);
+    const uint64_t m = (uint64_t)((b & 0x7FFFFFu) | 0x800000u);
+    const int sh = e - 118;
+    uint64_t r = sh >= 0 ? m << min(sh, 63) : m >> min(-sh, 63);
+    r = sh >= 41 ? 0xFFFFFFFFFFFFFFFFull : r;                   // 2^64 and beyond saturate (+inf included)
+    r = (e == 255 && (b & 0x7FFFFFu)) ? 0 : r;                   // NaN
+    r = ((int32_t)b <= 0 || e == 0) ? 0 : r;                     // negative, zero, denormal
+    return r;
+}
+
+__device__ __forceinline__ int draw_block_fast(const float* __restrict__ wb, int n, uint64_t r64, uint64_t* sh16, int* sh_pick, int slot, int per_thread = 2) {
+    // `per_thread` weights per thread, in as many wavefronts as that takes; the others only wait at the barriers.  Measured
+    // (s_memtime inside the instance kernel): a wavefront-level step costs its instructions x 4 cycles x the wavefronts
+    // sharing a SIMD, and the winner's rescan of its own weights is serial, so short chunks win despite the fixed scans.
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nt = min(1024, max(64, (((n + per_thread - 1) / per_thread) + 63) & ~63)), nw = nt >> 6;
+    const int chunk = (n + nt - 1) / nt;
     const int lo = min(n, t * chunk), hi = min(n, lo + chunk);
-    uint64_t local = 0;
-    for (int i = lo; i < hi; ++i) local += weight_fix(wb[i]);
-    uint64_t incl = local;                                     // inclusive scan inside the wavefront
-    for (int d = 1; d < 64; d <<= 1) { const uint64_t o = shfl_up_u64(incl, d); if (lane >= d) incl += o; }
-    if (lane == 63) sh16[wv] = incl;
-    if (t == 0) *sh_pick = -1;
-    __syncthreads();
-    if (wv == 0) {                                             // exclusive scan of the 16 wavefront totals
-        uint64_t v = lane < 16 ? sh16[lane] : 0, inc = v;
-        for (int d = 1; d < 16; d <<= 1) { const uint64_t o = shfl_up_u64(inc, d); if (lane >= d) inc += o; }
-        if (lane < 16) sh16[lane] = inc - v;
-        if (lane == 15) sh16[16] = inc;
+    uint64_t local = 0, incl = 0;
+    if (t < nt) {
+        for (int i = lo; i < hi; i += 4) {                      // loads first, four at a time
+            const float v0 = wb[i], v1 = i + 1 < hi ? wb[i + 1] : 0.0f, v2 = i + 2 < hi ? wb[i + 2] : 0.0f, v3 = i + 3 < hi ? wb[i + 3] : 0.0f;
+            local += (weight_fix_dev(v0) + weight_fix_dev(v1)) + (weight_fix_dev(v2) + weight_fix_dev(v3));
+        }
+            incl = wave_incl_scan_u64(local);
+        if (lane == 63) sh16[slot * 16 + wv] = incl;
     }
     __syncthreads();
-    const uint64_t total = sh16[16];
-    if (total != 0) {
-        const uint64_t r = mulhi64(r64, total);
-        const uint64_t in2 = sh16[wv] + incl, ex2 = in2 - local;
-        if (r >= ex2 && r < in2) {  // exactly one thread (local > 0)
-            uint64_t c = ex2;
-            int pick = -1;
-            for (int i = lo; i < hi; ++i) {
-                c += weight_fix(wb[i]);
-                if (c > r) { pick = i; break; }
+    if (t < nt) {
+        const uint64_t tv = lane < nw ? sh16[slot * 16 + lane] : 0;
+        const uint64_t tinc = wave_incl_scan_u64(tv);           // lanes 0..nw-1: inclusive scan of the wavefront totals
+        const uint64_t total = readlane_u64(tinc, nw - 1);
+        if (total == 0) { if (t == 0) sh_pick[slot] = -1; }
+        else {
+            const uint64_t r = mulhi64(r64, total);
+            const uint64_t in2 = readlane_u64(tinc - tv, wv) + incl, ex2 = in2 - local;
+            if (r >= ex2 && r < in2) {                          // exactly one thread (its local > 0)
+                uint64_t c = ex2;
+                int pick = -1;
+                for (int i = lo; i < hi && pick < 0; i += 4) {
+                    const float v0 = wb[i], v1 = i + 1 < hi ? wb[i + 1] : 0.0f, v2 = i + 2 < hi ? wb[i + 2] : 0.0f, v3 = i + 3 < hi ? wb[i + 3] : 0.0f;
+                    const uint64_t c0 = c + weight_fix_dev(v0), c1 = c0 + weight_fix_dev(v1), c2 = c1 + weight_fix_dev(v2), c3 = c2 + weight_fix_dev(v3);
+                    pick = c0 > r ? i : (c1 > r ? i + 1 : (c2 > r ? i + 2 : (c3 > r ? i + 3 : -1)));
+                    c = c3;
+                }
+                sh_pick[slot] = pick;
             }
-            *sh_pick = pick;
         }
     }
     __syncthreads();
-    const int pick = *sh_pick;
-    __syncthreads();   // sh16 / sh_pick are reused by the next draw
-    return pick;
+    return sh_pick[slot];
 }
 
 // one workgroup per attempt
 __global__ __launch_bounds__(1024) void draw_kernel(const float* __restrict__ w, size_t stride, int S, uint64_t seed,
                                                     uint64_t first_attempt, uint64_t k, const uint64_t* __restrict__ r_explicit,
                                                     int slot, int32_t* __restrict__ bidx, int32_t* __restrict__ fail) {
-    __shared__ uint64_t sh16[17];
-    __shared__ int sh_pick;
+    __shared__ uint64_t sh16[32];
+    __shared__ int sh_pick[2];
     const int b = blockIdx.x;
     if (fail[b]) return;
     const uint64_t r64 = r_explicit ? r_explicit[b] : rng64(seed, first_attempt + (uint64_t)b, k);
-    const int pick = draw_block_fast(w + (size_t)b * stride, S, r64, sh16, &sh_pick);
+    const int pick = draw_block_fast(w + (size_t)b * stride, S, r64, sh16, sh_pick, 0);
     if (threadIdx.x == 0) {
         bidx[b * 4 + slot] = pick;
         if (pick < 0) fail[b] = 1;
     }
+}
+
+// self-check of weight_fix_dev against the double formula, 2^32 patterns: one thread per 256 consecutive patterns
+__global__ __launch_bounds__(256) void weight_fix_check_kernel(unsigned int* __restrict__ counts) {
+    const uint32_t first = (blockIdx.x * 256u + threadIdx.x) << 8;
+    unsigned bad = 0;
+    for (uint32_t k = 0; k < 256; ++k) {
+        const float w = __uint_as_float(first + k);
+        uint64_t ref = 0;
+        if (w > 0.0f) {
+            const double s = (double)w * 4294967296.0;
+            ref = s >= 1.8446744073709552e19 ? 0xFFFFFFFFFFFFFFFFull : (uint64_t)s;
+        }
+        bad += (weight_fix_dev(w) != ref || weight_fix(w) != ref) ? 1u : 0u;
+    }
+    if (bad) atomicAdd(&counts[0], bad);
 }
 
 // self-check of the filter on the context's own scene: pair (i, j) of every thread with both evaluations
@@ -243,15 +334,14 @@ __global__ __launch_bounds__(256) void ppf_filter_check_kernel(PassArgs a, uint6
     if (i == j) return;
     const float4 p1 = a.spos[i], n1 = a.snrm[i], p2 = a.spos[j], n2 = a.snrm[j];
     const V3 P1 = mk3(p1.x, p1.y, p1.z), N1 = mk3(n1.x, n1.y, n1.z), P2 = mk3(p2.x, p2.y, p2.z), N2 = mk3(n2.x, n2.y, n2.z);
-    int Kf[4], Ke[4], bb;
-    ppf_compute_device(P1, N1, P2, N2, a.ix.tr, a.ix.rot, Kf);
+    bool certain;
+    const uint32_t kf = ppf_key_fast(a.ix, P1, N1, P2, N2, &certain);
+    int Ke[4];
     ppf_compute(P1, N1, P2, N2, a.ix.tr, a.ix.rot, Ke);
-    const V3 u = P1 - P2;
-    const bool certain = ppf_angle_filtered(norm3(cross3(N1, u)), dot3(N1, u), a.ix.rot, &bb) && ppf_angle_filtered(norm3(cross3(N2, u)), dot3(N2, u), a.ix.rot, &bb) &&
-                         ppf_angle_filtered(norm3(cross3(N1, N2)), dot3(N1, N2), a.ix.rot, &bb);
+    const uint32_t ke = ppf_pack_or_none(a.ix, Ke);
     atomicAdd(&counts[0], 1u);
     if (!certain) atomicAdd(&counts[1], 1u);
-    if (Kf[0] != Ke[0] || Kf[1] != Ke[1] || Kf[2] != Ke[2] || Kf[3] != Ke[3]) atomicAdd(&counts[2], 1u);
+    if (certain && kf != ke) atomicAdd(&counts[2], 1u);          // a pair the filter called certain and got wrong
 }
 
 // ---- host helpers ------------------------------------------------------------------------------
@@ -387,10 +477,33 @@ static int carve(stocs_ctx* c, int nB, SampleBuffers* sb) {
     return STOCS_OK;
 }
 
+// Distance component of the key in terms of the squared length.  With v = int(|u| * 1000) (rgbd.cpp:103) the bin index is
+// kd = floor((v - b + tr) / tr), b = ceil(tr / 2); a key exists only for kd * tr > 5 and kd < nD, i.e. v_lo <= v < v_hi.
+// sqrt (correctly rounded) and the float product are monotone, so that is sq_lo <= |u|^2 < sq_hi for two floats found by
+// bisection with the very float operations of the kernels (stocs_sqrtf, one float multiply).
+static void set_distance_thresholds(IndexView* ix) {
+    const int tr = ix->tr, b = (tr + 1) / 2;
+    const long long v_lo = (long long)(5 / tr + 1) * tr + b - tr, v_hi_full = (long long)ix->nD * tr + b - tr;
+    const long long v_hi = std::min<long long>(v_hi_full, 1 << 20);
+    ix->far_certain = v_hi_full <= (1 << 20) ? 1 : 0;
+    auto first_sq = [](float target) {   // smallest non-negative float q with sqrt(q) * 1000 >= target (+inf when there is none)
+        auto pred = [target](uint32_t bits) { float q; memcpy(&q, &bits, 4); return stocs_sqrtf(q) * 1000.0f >= target; };
+        uint32_t lo = 0, hi = 0x7F800000u;   // +0 .. +inf: the bit patterns of the non-negative floats are ordered
+        if (pred(lo)) return 0.0f;
+        while (hi - lo > 1) { const uint32_t mid = lo + (hi - lo) / 2; if (pred(mid)) hi = mid; else lo = mid; }
+        float q; memcpy(&q, &hi, 4);
+        return q;
+    };
+    ix->sq_lo = first_sq((float)v_lo);
+    ix->sq_hi = v_hi > v_lo ? first_sq((float)v_hi) : ix->sq_lo;
+}
+
 static PassArgs pass_args(const stocs_ctx* c) {
     PassArgs a;
     a.spos = c->d_spos; a.snrm = c->d_snrmw; a.S = c->nS;
     a.ix.bits = c->index.d_exists; a.ix.tr = c->index.tr; a.ix.rot = c->index.rot; a.ix.NA = c->index.NA; a.ix.nD = c->index.nD;
+    a.ix.sq_lo = 0.0f; a.ix.sq_hi = 0.0f; a.ix.far_certain = 1;
+    if (a.ix.tr > 0) set_distance_thresholds(&a.ix);
     a.plane_threshold = c->prm.plane_threshold; a.min_distance_base = c->prm.min_distance_base;
     a.ang_dot_hi = c->thr.ang_dot_hi; a.ang_dot_lo = c->thr.ang_dot_lo;
     return a;
@@ -469,6 +582,17 @@ static int sample_class(stocs_ctx* c, uint64_t seed, int first_attempt, int nB, 
 // the integers d2 (distinct integers below 2^20 have distinct float square roots).
 // ---------------------------------------------------------------------------------------------------------------
 #define INST_MAX_NODES 16384
+// the whole per-point working state of an attempt (weights 4 B + survivor index 2 B per point) lives in LDS next to the
+// union-find parents up to this many scene points; larger scenes keep it in device memory (same code, other pointers)
+#define INST_LDS_POINTS 16000
+
+// two passable runs of consecutive image rows that touch in the 8-neighbourhood (unclipped): the edges of the run graph,
+// built once per edge map.  g = run in `row`, g + dh = run in row + 1; [gs, ge) / [hs, he) their columns.
+struct RunPair {
+    uint32_t g;
+    uint16_t dh, row;
+    uint16_t gs, ge, hs, he;
+};
 
 struct InstanceArgs {
     PassArgs pa;
@@ -477,25 +601,30 @@ struct InstanceArgs {
     const int32_t* pt_run;      // run holding the point's pixel, -1 when the pixel is not passable
     const uint16_t* run_s; const uint16_t* run_e;   // [start, end) columns of the passable runs, row by row
     const uint32_t* row_off;    // H + 1
+    const RunPair* pairs;       // touching runs of rows (r, r + 1), row by row
+    const uint32_t* pair_off;   // H + 1: pairs of rows (r, r + 1) start at pair_off[r]
     int H, W, Sw;               // Sw = words per point bitset
     float* cls;                 // current class probabilities (decay in place, Q8)
     uint8_t* prev_in; uint8_t* label;
     uint32_t* maskbits;         // 256 x Sw
     uint32_t* segbits;          // Sw: `segment` of the last attempt
     uint32_t* parent_g;         // union-find parents when the disc holds more than INST_MAX_NODES runs (+ 1)
-    float* w;                   // S weights
+    float* w;                   // S weights (device-memory variant only)
+    int32_t* sv;                // S survivor indices (device-memory variant only)
+    int draw_per_thread;        // weights per thread the draws aim at
     unsigned long long* stamps; // STOCS_DEBUG_TIMING only: cycles per stage, summed over the attempts (else NULL)
-    int32_t* sv; float* wc;     // survivors of pass 1 inside the mask (scene indices, weights), compacted in scene order
     float4* spos_w; float4* snrm_w;   // the scene arrays whose .w the LCP adds: refreshed with the decayed prior at the end
     BaseOut* res;
 };
 
-__device__ __forceinline__ uint32_t uf_find(uint32_t* parent, uint32_t x) {
+template <class P>
+__device__ __forceinline__ uint32_t uf_find(P parent, uint32_t x) {
     uint32_t p = parent[x];
     while (p != x) { const uint32_t g = parent[p]; parent[x] = g; x = p; p = g; }   // path halving; races only ever shorten paths
     return x;
 }
-__device__ __forceinline__ void uf_unite(uint32_t* parent, uint32_t a, uint32_t b) {
+template <class P>
+__device__ __forceinline__ void uf_unite(P parent, uint32_t a, uint32_t b) {
     for (;;) {
         a = uf_find(parent, a); b = uf_find(parent, b);
         if (a == b) return;
@@ -510,88 +639,199 @@ __device__ __forceinline__ int half_width(int rem) {
     while ((h + 1) * (h + 1) < rem) ++h;
     return h;
 }
+// columns [s, e) of a run of row r clipped to the open disc d2 < maxd2 around (r0, c0); empty when *cs >= *ce
+__device__ __forceinline__ void clip_run(int s, int e, int r, int r0, int c0, int maxd2, int* cs, int* ce) {
+    const int dr = r - r0, rem = maxd2 - dr * dr;
+    if (rem <= 0) { *cs = 0; *ce = 0; return; }
+    const int hw = half_width(rem);
+    *cs = max(s, c0 - hw);
+    *ce = min(e, c0 + hw + 1);
+}
 
-// connected component of the seed: after this call a point whose run r satisfies in_mask_run(r) is inside the mask
+// connected component of the seed (rgbd.cpp:334-366): the run pairs of the rows inside the disc are clipped and united when
+// the clipped intervals still touch; the seed pixel (node `nodes`) touches every clipped run that meets its 3x3
+// neighbourhood.  Afterwards a point is inside the mask when its run has the seed's root.
 template <class ParentPtr>
 __device__ void flood_fill_runs(const InstanceArgs& A, ParentPtr parent, int r0, int c0, int maxd2, int rlo, int rhi, uint32_t base, uint32_t nodes) {
-    const int t = threadIdx.x;
-    for (uint32_t k = t; k <= nodes; k += blockDim.x) parent[k] = k;   // node `nodes` is the seed pixel itself
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const uint32_t p0 = A.pair_off[rlo], p1 = A.pair_off[rhi];
+    for (uint32_t k = t; k <= nodes; k += 1024) parent[k] = k;
     __syncthreads();
-    // clipped interval of run g (global index) in row r: empty when cs >= ce
-    auto clip = [&](uint32_t g, int r, int* cs, int* ce) {
-        const int dr = r - r0, rem = maxd2 - dr * dr;
-        if (rem <= 0) { *cs = 0; *ce = 0; return; }
-        const int hw = half_width(rem);
-        *cs = max((int)A.run_s[g], c0 - hw);
-        *ce = min((int)A.run_e[g], c0 + hw + 1);
-    };
-    for (int r = rlo + (int)(t >> 6); r <= rhi; r += (int)(blockDim.x >> 6)) {   // one wavefront per row pair (r, r + 1)
-        const uint32_t a0 = A.row_off[r], a1 = A.row_off[r + 1], b1 = (r < rhi) ? A.row_off[r + 2] : a1;
-        for (uint32_t g = a0 + (t & 63); g < a1; g += 64) {
-            int cs, ce;
-            clip(g, r, &cs, &ce);
+    for (uint32_t pb = p0; pb < p1; pb += 4096) {
+        uint4 raw[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const uint32_t p = pb + k * 1024 + t; raw[k] = make_uint4(0, 0, 0, 0); if (p < p1) raw[k] = ((const uint4*)A.pairs)[p]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t p = pb + k * 1024 + t;
+            if (p >= p1) continue;
+            const uint32_t g = raw[k].x;
+            const int dh = (int)(raw[k].y & 0xFFFFu), row = (int)(raw[k].y >> 16);
+            int cs, ce, ds, de;
+            clip_run((int)(raw[k].z & 0xFFFFu), (int)(raw[k].z >> 16), row, r0, c0, maxd2, &cs, &ce);
             if (cs >= ce) continue;
-            // the seed pixel touches every clipped run that meets its 3x3 neighbourhood
-            if (r >= r0 - 1 && r <= r0 + 1 && cs < c0 + 2 && ce > c0 - 1) uf_unite(parent, g - base, nodes);
-            for (uint32_t h = a1; h < b1; ++h) {           // runs of the next row, in column order
-                if ((int)A.run_s[h] >= ce + 1) break;
-                int ds, de;
-                clip(h, r + 1, &ds, &de);
-                if (ds < de && ds < ce + 1 && de > cs - 1) uf_unite(parent, g - base, h - base);   // 8-neighbourhood: overlap widened by one
+            clip_run((int)(raw[k].w & 0xFFFFu), (int)(raw[k].w >> 16), row + 1, r0, c0, maxd2, &ds, &de);
+            if (ds < de && ds < ce + 1 && de > cs - 1) uf_unite(parent, g - base, g + (uint32_t)dh - base);   // 8-neighbourhood: overlap widened by one
+        }
+    }
+    if (wv < 3) {                                              // one wavefront per row of the seed's 3x3 neighbourhood
+        const int r = r0 - 1 + wv;
+        if (r >= rlo && r <= rhi) {
+            const uint32_t a0 = A.row_off[r], a1 = A.row_off[r + 1];
+            for (uint32_t g = a0 + lane; g < a1; g += 64) {
+                int cs, ce;
+                clip_run((int)A.run_s[g], (int)A.run_e[g], r, r0, c0, maxd2, &cs, &ce);
+                if (cs < ce && cs < c0 + 2 && ce > c0 - 1) uf_unite(parent, g - base, nodes);
             }
         }
     }
     __syncthreads();
 }
 
+__device__ __noinline__ void finalize_one_wave_call(const float4* spos, int b0, int b1, int b2, int b3, int fail, BaseOut* o) {
+    const int32_t bidx[4] = {b0, b1, b2, b3};
+    finalize_one_wave(spos, bidx, fail, o);
+}
+
+template <bool WLDS> struct InstTypes { typedef int32_t sv_t; };
+template <> struct InstTypes<true> { typedef uint16_t sv_t; };
+
+// Every loop over the scene points handles 4 points per thread with the loads of all four issued before the first use:
+// the kernel is one workgroup, so memory latency is not hidden by other workgroups -- it is paid once per stage instead
+// of once per point.
+template <bool WLDS>
 __global__ __launch_bounds__(1024) void instance_attempts_kernel(InstanceArgs A, uint64_t seed, int first_attempt, int n_attempts, float dispersion) {
-    __shared__ uint64_t sh16[17];
-    __shared__ int sh_pick;
-    __shared__ int sh_max;
-    __shared__ int sh_cnt[17];
-    __shared__ uint32_t parent_l[INST_MAX_NODES + 1];
-    const int t = threadIdx.x, S = A.pa.S, lane = t & 63, wv = t >> 6;
-    int32_t* sv = A.sv;       // survivors of pass 1 inside the mask, compacted in scene order
-    float* wc = A.wc;         // their weights
+    typedef typename InstTypes<WLDS>::sv_t sv_t;
+    extern __shared__ __align__(16) unsigned char inst_dyn[];
+    __shared__ uint64_t sh16[32];
+    __shared__ int sh_pick[2];
+    __shared__ int sh_max, sh_nunc;
+    __shared__ int sh_cnt[64], sh_cex[65];
+    uint32_t* parent_l = (uint32_t*)inst_dyn;                               // INST_MAX_NODES + 1
+    const int S = A.pa.S;
+    const size_t o_w = ((size_t)(INST_MAX_NODES + 1) * 4 + 15) & ~(size_t)15;
+    float* w = WLDS ? (float*)(inst_dyn + o_w) : A.w;                       // weights; after the compaction the survivors' weights
+    sv_t* sv = WLDS ? (sv_t*)(inst_dyn + o_w + (((size_t)S * 4 + 15) & ~(size_t)15)) : (sv_t*)A.sv;   // survivors of pass 1 inside the mask, in scene order
+    const float4* spos = A.pa.spos;
+    const float4* snrm = A.pa.snrm;
     unsigned long long tprev = A.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-#define INST_STAMP(k) if (A.stamps && t == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); A.stamps[k] += now_ - tprev; tprev = now_; }
+    // the thread index is made opaque at the start of every stage: otherwise the compiler hoists per-thread addresses of
+    // every array out of the attempt loop, and a hundred registers of them spill to scratch around every stage
+#define INST_THREAD() int t = threadIdx.x; asm volatile("" : "+v"(t)); const int lane = t & 63, wv = t >> 6; (void)lane; (void)wv;
+    // (debug) the stage clocks are summed in scalar registers and written once at the end: a read-modify-write of device
+    // memory per stamp would cost more than most stages
+    unsigned long long acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0, acc4 = 0, acc5 = 0, acc6 = 0, acc7 = 0;
+#define INST_STAMP(k) if (A.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc##k += now_ - tprev; tprev = now_; }
     for (int a = 0; a < n_attempts; ++a) {
         const int attempt = first_attempt + a, base_num = attempt + 1;
         BaseOut* out = A.res + a;
         // ---- weights: compounding decay of the prior inside the previous segment, edge pixels pruned (stocs.cpp:572-584) ----
-        for (int i = t; i < S; i += 1024) {
-            float c = A.cls[i];
-            if (A.prev_in[i]) { c = dispersion * c; A.cls[i] = c; }
-            A.w[i] = A.edge_pt[i] ? 0.0f : c;
+        {
+        INST_THREAD()
+        for (int i0 = 0; i0 < S; i0 += 4096) {
+            float c[4]; uint8_t pin[4], ep[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * 1024 + t;
+                c[k] = 0.0f; pin[k] = 0; ep[k] = 0;
+                if (i < S) { c[k] = A.cls[i]; pin[k] = A.prev_in[i]; ep[k] = A.edge_pt[i]; }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * 1024 + t;
+                if (i >= S) continue;
+                float ck = c[k];
+                if (pin[k]) { ck = dispersion * ck; A.cls[i] = ck; }
+                w[i] = ep[k] ? 0.0f : ck;
+            }
         }
-        if (t == 0) sh_max = 0;
+        if (t == 0) { sh_max = 0; sh_nunc = 0; }
+        }
         __syncthreads();
         INST_STAMP(0)
         int32_t bidx[4] = {-1, -1, -1, -1};
         int fail = 0;
-        bidx[0] = draw_block_fast(A.w, S, rng64(seed, (uint64_t)attempt, 0), sh16, &sh_pick);
+        bidx[0] = draw_block_fast(w, S, rng64(seed, (uint64_t)attempt, 0), sh16, sh_pick, 0, A.draw_per_thread);
         INST_STAMP(1)
         if (bidx[0] < 0) {   // "FAILED SAMPLING": no base, no mask, previous_segment stays (stocs.cpp:586-589)
-            if (t == 0) { for (int k = 0; k < 4; ++k) out->ids[k] = -1; out->inv[0] = out->inv[1] = 0; out->valid = 0; out->pad = 0; }
+            if (threadIdx.x == 0) { for (int k = 0; k < 4; ++k) out->ids[k] = -1; out->inv[0] = out->inv[1] = 0; out->valid = 0; out->pad = 0; }
             __syncthreads();
             continue;
         }
         const int b1 = bidx[0];
         const int2 sp = A.pix[b1];
-        // ---- pass 1 + the largest pixel distance of a survivor (stocs.cpp:596-618) ----
-        int my_max = 0;
-        for (int i = t; i < S; i += 1024) {
-            float wi = A.w[i];
-            if (wi != 0.0f && pass_zeroes<1>(A.pa, b1, -1, -1, i)) { wi = 0.0f; A.w[i] = 0.0f; }
-            if (wi != 0.0f) { const int2 p = A.pix[i]; const int dr = sp.x - p.x, dc = sp.y - p.y; my_max = max(my_max, dr * dr + dc * dc); }
+        const int lab = A.label[b1];
+        // ---- pass 1 (stocs.cpp:596-609) + the largest pixel distance of a survivor (:610-618) ----
+        {
+            INST_THREAD()
+            const float4 pc4 = spos[b1], nc4 = snrm[b1];
+            const V3 pc = mk3(pc4.x, pc4.y, pc4.z), nc = mk3(nc4.x, nc4.y, nc4.z);
+            int my_max = 0;
+            // stage A, distance alone (the first component of the key, rgbd.cpp:103): a point farther from P1 than the
+            // longest model pair (or within 5 mm) has no key whatever its angles; the others are listed in `sv`
+            for (int i0 = 0; i0 < S; i0 += 4096) {
+                float wi[4]; float4 P[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + k * 1024 + t;
+                    wi[k] = (i < S) ? w[i] : 0.0f;
+                    P[k] = make_float4(0, 0, 0, 0);
+                    if (wi[k] != 0.0f) P[k] = spos[i];
+                }
+                bool cand[4];
+                unsigned long long cm[4];
+                int n_here = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + k * 1024 + t;
+                    cand[k] = false;
+                    if (wi[k] != 0.0f) {
+                        cand[k] = i != b1 && ppf_distance_may_have_key(A.pa.ix, pc - mk3(P[k].x, P[k].y, P[k].z));
+                        if (!cand[k]) w[i] = 0.0f;
+                    }
+                    cm[k] = __ballot(cand[k]);
+                    n_here += __popcll(cm[k]);
+                }
+                int base_pos = 0;                                             // one atomic per wavefront for its (up to) 256 points
+                if (lane == 0 && n_here) base_pos = atomicAdd(&sh_nunc, n_here);
+                base_pos = __builtin_amdgcn_readfirstlane(base_pos);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (cand[k]) sv[base_pos + __popcll(cm[k] & ((1ull << lane) - 1ull))] = (sv_t)(i0 + k * 1024 + t);
+                    base_pos += __popcll(cm[k]);
+                }
+            }
+            __syncthreads();
+            // stage B, the angles of the listed points (two per thread and turn, loads first)
+            const int n_cand = sh_nunc;
+            if (A.stamps && threadIdx.x == 0) { A.stamps[8] += (unsigned long long)n_cand; A.stamps[10] += __builtin_amdgcn_s_memtime() - tprev; }
+            for (int j0 = 0; j0 < n_cand; j0 += 2048) {
+                int ii[2]; float4 P[2], N[2]; int2 px[2]; uint32_t key[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int j = j0 + k * 1024 + t;
+                    ii[k] = -1; P[k] = make_float4(0, 0, 0, 0); N[k] = P[k]; px[k] = make_int2(0, 0);
+                    if (j < n_cand) { ii[k] = (int)sv[j]; P[k] = spos[ii[k]]; N[k] = snrm[ii[k]]; px[k] = A.pix[ii[k]]; }
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    key[k] = PPF_NO_KEY;
+                    if (ii[k] >= 0) key[k] = ppf_key_device(A.pa.ix, pc, nc, mk3(P[k].x, P[k].y, P[k].z), mk3(N[k].x, N[k].y, N[k].z));
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    if (ii[k] < 0) continue;
+                    if (!ppf_key_present(A.pa.ix, key[k])) w[ii[k]] = 0.0f;
+                    else { const int dr = sp.x - px[k].x, dc = sp.y - px[k].y; my_max = max(my_max, dr * dr + dc * dc); }
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) my_max = max(my_max, __shfl_xor(my_max, off, 64));
+            if (lane == 0 && my_max) atomicMax(&sh_max, my_max);
         }
-        for (int off = 32; off > 0; off >>= 1) my_max = max(my_max, __shfl_xor(my_max, off, 64));
-        if (lane == 0 && my_max) atomicMax(&sh_max, my_max);
         __syncthreads();
         INST_STAMP(2)
         const int maxd2 = sh_max;
         // ---- the mask: an earlier attempt's when the seed pixel is already labelled, else a new flood fill (rgbd.cpp:314-367) ----
-        const int lab = A.label[b1];
         const int rad = maxd2 > 0 ? half_width(maxd2) : 0;
         const int rlo = max(0, sp.x - rad), rhi = min(A.H - 1, sp.x + rad);
         const uint32_t base = A.row_off[rlo], nodes = A.row_off[rhi + 1] - base;
@@ -604,73 +844,113 @@ __global__ __launch_bounds__(1024) void instance_attempts_kernel(InstanceArgs A,
         }
         INST_STAMP(3)
         // ---- bookkeeping per scene point: mask membership, previous_segment, labels, and the survivors inside the mask
-        //      (`segment`, stocs.cpp:628-638) compacted in scene order: points 2..4 are drawn among them alone ----
+        //      (`segment`, stocs.cpp:628-638) compacted in scene order (in place: position <= index): points 2..4 are
+        //      drawn among them alone ----
         int n_surv = 0;
-        for (int i0 = 0; i0 < S; i0 += 1024) {    // whole wavefronts: the bitset words are ballots
-            const int i = i0 + t;
-            bool in = false;
-            float wi = 0.0f;
-            if (i < S) {
-                wi = A.w[i];
-                if (lab != 0) in = (A.maskbits[(size_t)lab * A.Sw + (i >> 5)] >> (i & 31)) & 1u;
-                else {
-                    const int2 p = A.pix[i];
-                    const int dr = p.x - sp.x, dc = p.y - sp.y;
-                    if (dr == 0 && dc == 0) in = true;                       // the seed pixel is always part of its mask
-                    else if (dr * dr + dc * dc < maxd2) {
-                        const int g = A.pt_run[i];
-                        if (g >= 0) in = (in_lds ? uf_find(parent_l, (uint32_t)g - base) : uf_find(A.parent_g, (uint32_t)g - base)) == root_s;
-                    }
+        {
+        INST_THREAD()
+        for (int i0 = 0; i0 < S; i0 += 4096) {
+            float wi[4]; int2 px[4]; int run[4]; uint32_t mw[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * 1024 + t;
+                wi[k] = 0.0f; run[k] = -1; mw[k] = 0; px[k] = make_int2(0, 0);
+                if (i < S) {
+                    wi[k] = w[i];
+                    if (lab != 0) mw[k] = A.maskbits[(size_t)lab * A.Sw + (i >> 5)];
+                    else { px[k] = A.pix[i]; run[k] = A.pt_run[i]; }
                 }
-                A.prev_in[i] = in ? 1 : 0;                                   // segmentation_mask.copyTo(previous_segment), stocs.cpp:626
-                if (lab == 0 && in) A.label[i] = (uint8_t)base_num;          // segmentation_buffer = base_num over the new mask
-                if (!in) wi = 0.0f;
             }
-            const bool keep = wi != 0.0f;
-            const unsigned long long mb = __ballot(in), sb = __ballot(keep);
-            if (lane == 0) {
-                const int wd = (i0 >> 5) + 2 * wv;
-                if (wd < A.Sw) {
-                    A.maskbits[(size_t)base_num * A.Sw + wd] = (uint32_t)mb;     // seg_mask_<base_num>.png, whichever mask it is
-                    A.segbits[wd] = (uint32_t)sb;
-                    A.maskbits[(size_t)base_num * A.Sw + wd + 1] = (uint32_t)(mb >> 32); A.segbits[wd + 1] = (uint32_t)(sb >> 32);
+            unsigned long long sbal[4];
+            bool keep[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                                     // whole wavefronts: the bitset words are ballots
+                const int i = i0 + k * 1024 + t;
+                bool in = false;
+                if (i < S) {
+                    if (lab != 0) in = (mw[k] >> (i & 31)) & 1u;
+                    else {
+                        const int dr = px[k].x - sp.x, dc = px[k].y - sp.y;
+                        if (dr == 0 && dc == 0) in = true;                    // the seed pixel is always part of its mask
+                        else if (dr * dr + dc * dc < maxd2 && run[k] >= 0)
+                            in = (in_lds ? uf_find(parent_l, (uint32_t)run[k] - base) : uf_find(A.parent_g, (uint32_t)run[k] - base)) == root_s;
+                    }
+                    A.prev_in[i] = in ? 1 : 0;                                // segmentation_mask.copyTo(previous_segment), stocs.cpp:626
+                    if (lab == 0 && in) A.label[i] = (uint8_t)base_num;       // segmentation_buffer = base_num over the new mask
                 }
-                sh_cnt[wv] = __popcll(sb);
+                keep[k] = in && wi[k] != 0.0f;
+                const unsigned long long mb = __ballot(in);
+                sbal[k] = __ballot(keep[k]);
+                if (lane == 0) {
+                    const int wd = ((i0 + k * 1024) >> 5) + 2 * wv;
+                    if (wd < A.Sw) {
+                        A.maskbits[(size_t)base_num * A.Sw + wd] = (uint32_t)mb;   // seg_mask_<base_num>.png, whichever mask it is
+                        A.segbits[wd] = (uint32_t)sbal[k];
+                        A.maskbits[(size_t)base_num * A.Sw + wd + 1] = (uint32_t)(mb >> 32); A.segbits[wd + 1] = (uint32_t)(sbal[k] >> 32);
+                    }
+                    sh_cnt[k * 16 + wv] = __popcll(sbal[k]);                   // scene order inside the block of 4096: k, wavefront, lane
+                }
             }
             __syncthreads();
-            int before = n_surv;                                              // order-preserving compaction
-            for (int k = 0; k < wv; ++k) before += sh_cnt[k];
-            int all = 0;
-            for (int k = 0; k < 16; ++k) all += sh_cnt[k];
-            if (keep) { const int pos = before + __popcll(sb & ((1ull << lane) - 1ull)); sv[pos] = i; wc[pos] = wi; }
-            n_surv += all;
+            if (wv == 0) {
+                const int v = sh_cnt[lane];
+                int inc = v;
+                for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+                sh_cex[lane] = inc - v;
+                if (lane == 63) sh_cex[64] = inc;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (keep[k]) {
+                    const int pos = n_surv + sh_cex[k * 16 + wv] + __popcll(sbal[k] & ((1ull << lane) - 1ull));
+                    sv[pos] = (sv_t)(i0 + k * 1024 + t); w[pos] = wi[k];
+                }
+            n_surv += sh_cex[64];
             __syncthreads();
         }
+        }
         INST_STAMP(4)
+        if (A.stamps && threadIdx.x == 0) A.stamps[9] += (unsigned long long)n_surv;
         // ---- points 2..4 (stocs.cpp:640-751 = the class-mode passes) over the survivors ----
         for (int k = 1; k < 4 && !fail; ++k) {
-            const int pos = draw_block_fast(wc, n_surv, rng64(seed, (uint64_t)attempt, (uint64_t)k), sh16, &sh_pick);
+            INST_THREAD()
+            const int pos = draw_block_fast(w, n_surv, rng64(seed, (uint64_t)attempt, (uint64_t)k), sh16, sh_pick, k & 1, A.draw_per_thread);
             if (pos < 0) { fail = 1; break; }
-            bidx[k] = sv[pos];
+            bidx[k] = (int32_t)sv[pos];
             if (k < 3) {
                 for (int j = t; j < n_surv; j += 1024) {
-                    if (wc[j] == 0.0f) continue;                              // already zero: nothing to decide
-                    const int i = sv[j];
+                    if (w[j] == 0.0f) continue;                               // already zero: nothing to decide
+                    const int i = (int)sv[j];
                     const bool z = (k == 1) ? pass_zeroes<2>(A.pa, bidx[0], bidx[1], -1, i) : pass_zeroes<3>(A.pa, bidx[0], bidx[1], bidx[2], i);
-                    if (z) wc[j] = 0.0f;
+                    if (z) w[j] = 0.0f;
                 }
                 __syncthreads();
             }
         }
         INST_STAMP(5)
-        if (t < 64) finalize_one_wave(A.pa.spos, bidx, fail, out);
+        // the four points as drawn; their ordering (try_sampled_base) waits for the end of the kernel
+        if (threadIdx.x == 0) { for (int k = 0; k < 4; ++k) out->ids[k] = bidx[k]; out->inv[0] = out->inv[1] = 0; out->valid = fail ? 0 : 1; out->pad = 0; }
         __syncthreads();
         INST_STAMP(6)
     }
+    // ---- ordered base + invariants of every attempt (stocs.cpp:224-268): nothing above depends on them, so the attempts
+    //      are finalised side by side, one wavefront each ----
+    for (int a = (int)(threadIdx.x >> 6); a < n_attempts; a += 16) {
+        BaseOut* o = A.res + a;
+        const int b0 = o->ids[0], b1 = o->ids[1], b2 = o->ids[2], b3 = o->ids[3], fl = o->valid ? 0 : 1;
+        finalize_one_wave_call(A.pa.spos, b0, b1, b2, b3, fl, o);
+    }
+    INST_STAMP(7)
+    if (A.stamps && threadIdx.x == 0) {
+        A.stamps[0] += acc0; A.stamps[1] += acc1; A.stamps[2] += acc2; A.stamps[3] += acc3;
+        A.stamps[4] += acc4; A.stamps[5] += acc5; A.stamps[6] += acc6; A.stamps[7] += acc7;
+    }
 #undef INST_STAMP
     // the LCP adds class_probability_, which this sampling decays in place (Q8): refresh the scene arrays it reads
-    for (int i = t; i < S; i += 1024) { const float c = A.cls[i]; A.spos_w[i].w = c; A.snrm_w[i].w = c; }
+    for (int i = threadIdx.x; i < S; i += 1024) { const float c = A.cls[i]; A.spos_w[i].w = c; A.snrm_w[i].w = c; }
 }
+
 
 static int refresh_class_prob_on_device(stocs_ctx* c) {
     // the LCP adds class_probability_, which instance-mode sampling decays in place (Q8)
@@ -693,7 +973,8 @@ struct InstanceState {
     uint16_t* d_run_s = NULL; uint16_t* d_run_e = NULL; uint32_t* d_row_off = NULL;
     int32_t* d_pt_run = NULL; uint8_t* d_edge_pt = NULL; uint8_t* d_prev_in = NULL; uint8_t* d_label = NULL;
     float* d_cls = NULL; uint32_t* d_maskbits = NULL; uint32_t* d_segbits = NULL; uint32_t* d_parent = NULL;
-    int32_t* d_sv = NULL; float* d_wc = NULL;
+    int32_t* d_sv = NULL; float* d_w = NULL;
+    RunPair* d_pairs = NULL; uint32_t* d_pair_off = NULL;
     size_t n_runs = 0;
     std::vector<uint32_t> h_segbits;
 };
@@ -727,6 +1008,24 @@ static int prepare_instance_state(stocs_ctx* c) {
         }
     }
     row_off[H] = (uint32_t)rs.size();
+    // the run graph: runs of consecutive rows whose pixels touch in the 8-neighbourhood (columns [s, e): s_h <= e_g and e_h >= s_g)
+    std::vector<RunPair> pairs;
+    std::vector<uint32_t> pair_off((size_t)H + 1, 0);
+    for (int r = 0; r < H; ++r) {
+        pair_off[r] = (uint32_t)pairs.size();
+        if (r + 1 >= H) continue;
+        const uint32_t a0 = row_off[r], a1 = row_off[r + 1], b1 = row_off[r + 2];
+        uint32_t h0 = a1;
+        for (uint32_t g = a0; g < a1; ++g) {
+            while (h0 < b1 && re[h0] < rs[g]) ++h0;
+            for (uint32_t h = h0; h < b1 && rs[h] <= re[g]; ++h) {
+                RunPair q;
+                q.g = g; q.dh = (uint16_t)(h - g); q.row = (uint16_t)r; q.gs = rs[g]; q.ge = re[g]; q.hs = rs[h]; q.he = re[h];
+                pairs.push_back(q);
+            }
+        }
+    }
+    pair_off[H] = (uint32_t)pairs.size();
     std::vector<int32_t> pt_run(S, -1);
     std::vector<uint8_t> edge_pt(S, 0);
     for (int i = 0; i < S; ++i) {
@@ -744,7 +1043,8 @@ static int prepare_instance_state(stocs_ctx* c) {
     const size_t nr = std::max<size_t>(rs.size(), 1);
     const size_t o_rs = 0, o_re = o_rs + al(nr * 2), o_ro = o_re + al(nr * 2), o_pr = o_ro + al(((size_t)H + 1) * 4), o_ep = o_pr + al((size_t)S * 4),
                  o_pi = o_ep + al(S), o_lb = o_pi + al(S), o_cl = o_lb + al(S), o_mb = o_cl + al((size_t)S * 4), o_sb = o_mb + al((size_t)256 * Sw * 4),
-                 o_pa = o_sb + al((size_t)Sw * 4), o_sv = o_pa + al((nr + 1) * 4), o_wc = o_sv + al((size_t)S * 4), total = o_wc + al((size_t)S * 4);
+                 o_pa = o_sb + al((size_t)Sw * 4), o_sv = o_pa + al((nr + 1) * 4), o_wc = o_sv + al((size_t)S * 4), o_pp = o_wc + al((size_t)S * 4),
+                 o_po = o_pp + al(std::max<size_t>(pairs.size(), 1) * sizeof(RunPair)), total = o_po + al(((size_t)H + 1) * 4);
     if (I->mem_bytes < total) {
         if (I->d_mem) { STOCS_HIP_CHECK(hipStreamSynchronize(c->stream)); (void)hipFree(I->d_mem); I->d_mem = NULL; I->mem_bytes = 0; }
         STOCS_HIP_CHECK(dev_malloc((void**)&I->d_mem, total + total / 4));
@@ -754,13 +1054,16 @@ static int prepare_instance_state(stocs_ctx* c) {
     I->d_run_s = (uint16_t*)(m + o_rs); I->d_run_e = (uint16_t*)(m + o_re); I->d_row_off = (uint32_t*)(m + o_ro); I->d_pt_run = (int32_t*)(m + o_pr);
     I->d_edge_pt = (uint8_t*)(m + o_ep); I->d_prev_in = (uint8_t*)(m + o_pi); I->d_label = (uint8_t*)(m + o_lb); I->d_cls = (float*)(m + o_cl);
     I->d_maskbits = (uint32_t*)(m + o_mb); I->d_segbits = (uint32_t*)(m + o_sb); I->d_parent = (uint32_t*)(m + o_pa);
-    I->d_sv = (int32_t*)(m + o_sv); I->d_wc = (float*)(m + o_wc);
+    I->d_sv = (int32_t*)(m + o_sv); I->d_w = (float*)(m + o_wc);
+    I->d_pairs = (RunPair*)(m + o_pp); I->d_pair_off = (uint32_t*)(m + o_po);
     I->S = S; I->Sw = Sw; I->n_runs = rs.size();
     hipStream_t st = c->stream;
     if (!rs.empty()) {
         STOCS_HIP_CHECK(hipMemcpyAsync(I->d_run_s, rs.data(), rs.size() * 2, hipMemcpyHostToDevice, st));
         STOCS_HIP_CHECK(hipMemcpyAsync(I->d_run_e, re.data(), re.size() * 2, hipMemcpyHostToDevice, st));
     }
+    if (!pairs.empty()) STOCS_HIP_CHECK(hipMemcpyAsync(I->d_pairs, pairs.data(), pairs.size() * sizeof(RunPair), hipMemcpyHostToDevice, st));
+    STOCS_HIP_CHECK(hipMemcpyAsync(I->d_pair_off, pair_off.data(), ((size_t)H + 1) * 4, hipMemcpyHostToDevice, st));
     STOCS_HIP_CHECK(hipMemcpyAsync(I->d_row_off, row_off.data(), ((size_t)H + 1) * 4, hipMemcpyHostToDevice, st));
     STOCS_HIP_CHECK(hipMemcpyAsync(I->d_pt_run, pt_run.data(), (size_t)S * 4, hipMemcpyHostToDevice, st));
     STOCS_HIP_CHECK(hipMemcpyAsync(I->d_edge_pt, edge_pt.data(), S, hipMemcpyHostToDevice, st));
@@ -798,13 +1101,25 @@ static int sample_instance(stocs_ctx* c, uint64_t seed, int first_attempt, int n
     InstanceArgs A;
     A.pa = pass_args(c);
     A.pix = c->d_spix; A.edge_pt = I->d_edge_pt; A.pt_run = I->d_pt_run; A.run_s = I->d_run_s; A.run_e = I->d_run_e; A.row_off = I->d_row_off;
+    A.pairs = I->d_pairs; A.pair_off = I->d_pair_off;
+    A.draw_per_thread = 2;   // measured on the packed frame (3 415 points, ~290 survivors): 1..4 within 2 %, 8 and 16 slower
+    if (const char* e = getenv("STOCS_DRAW_PER_THREAD")) A.draw_per_thread = std::max(1, atoi(e));
     A.H = c->prm.image_height; A.W = c->prm.image_width; A.Sw = I->Sw;
     A.cls = I->d_cls; A.prev_in = I->d_prev_in; A.label = I->d_label; A.maskbits = I->d_maskbits; A.segbits = I->d_segbits; A.parent_g = I->d_parent;
     const bool dbg = getenv("STOCS_DEBUG_TIMING") != NULL;
     A.stamps = NULL;
-    if (dbg) { A.stamps = (unsigned long long*)I->d_parent; STOCS_HIP_CHECK(hipMemsetAsync(I->d_parent, 0, 64, c->stream)); }   // parent_g is idle for small discs
-    A.w = sb.w; A.sv = I->d_sv; A.wc = I->d_wc; A.spos_w = c->d_spos; A.snrm_w = c->d_snrmw; A.res = sb.res;
-    hipLaunchKernelGGL(instance_attempts_kernel, dim3(1), dim3(1024), 0, c->stream, A, seed, first_attempt, nB, dispersion);
+    if (dbg) { A.stamps = (unsigned long long*)I->d_parent; STOCS_HIP_CHECK(hipMemsetAsync(I->d_parent, 0, 128, c->stream)); }   // parent_g is idle for small discs
+    A.w = I->d_w; A.sv = I->d_sv; A.spos_w = c->d_spos; A.snrm_w = c->d_snrmw; A.res = sb.res;
+    // parents, and up to INST_LDS_POINTS points' weights + survivor indices, in LDS (<= 160 KB per workgroup on gfx950)
+    const size_t lds_parent = ((size_t)(INST_MAX_NODES + 1) * 4 + 15) & ~(size_t)15;
+    const bool wlds = c->nS <= INST_LDS_POINTS && !getenv("STOCS_INSTANCE_NO_LDS");
+    const size_t lds = lds_parent + (wlds ? ((((size_t)c->nS * 4 + 15) & ~(size_t)15) + (size_t)c->nS * 2 + 16) : 0);
+    {
+        const void* fn = wlds ? (const void*)instance_attempts_kernel<true> : (const void*)instance_attempts_kernel<false>;
+        STOCS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+    }
+    if (wlds) hipLaunchKernelGGL(instance_attempts_kernel<true>, dim3(1), dim3(1024), lds, c->stream, A, seed, first_attempt, nB, dispersion);
+    else hipLaunchKernelGGL(instance_attempts_kernel<false>, dim3(1), dim3(1024), lds, c->stream, A, seed, first_attempt, nB, dispersion);
     STOCS_HIP_CHECK(hipGetLastError());
     std::vector<BaseOut> res((size_t)nB);
     I->h_segbits.assign((size_t)I->Sw, 0);
@@ -813,11 +1128,13 @@ static int sample_instance(stocs_ctx* c, uint64_t seed, int first_attempt, int n
     STOCS_HIP_CHECK(hipMemcpyAsync(I->h_segbits.data(), I->d_segbits, (size_t)I->Sw * 4, hipMemcpyDeviceToHost, c->stream));
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
     if (dbg) {
-        unsigned long long st[8];
-        STOCS_HIP_CHECK(hipMemcpy(st, I->d_parent, 64, hipMemcpyDeviceToHost));
+        unsigned long long st[16];
+        STOCS_HIP_CHECK(hipMemcpy(st, I->d_parent, 128, hipMemcpyDeviceToHost));
         const double per = 1.0 / std::max(nB, 1);
-        fprintf(stderr, "[stocs instance] %d attempts, shader cycles per attempt (s_memtime): weights %.0f | draw0 %.0f | pass1+maxdist %.0f | flood fill %.0f | bookkeeping+compaction %.0f | points 2-4 %.0f | finalize %.0f\n",
-                nB, st[0] * per, st[1] * per, st[2] * per, st[3] * per, st[4] * per, st[5] * per, st[6] * per);
+        fprintf(stderr, "[stocs instance] %d attempts, shader cycles per attempt (s_memtime): weights %.0f | draw0 %.0f | pass1+maxdist %.0f | flood fill %.0f | bookkeeping+compaction %.0f | points 2-4 %.0f | record %.0f | ordered bases (once, /attempt) %.0f\n",
+                nB, st[0] * per, st[1] * per, st[2] * per, st[3] * per, st[4] * per, st[5] * per, st[6] * per, st[7] * per);
+        fprintf(stderr, "[stocs instance] per attempt: %.0f of %d points within key distance of point 1 (stage A of pass 1: %.0f cycles), %.0f survivors inside the mask\n",
+                st[8] * per, c->nS, st[10] * per, st[9] * per);
     }
     c->last_segment.clear();
     if (nB > 0 && res[(size_t)nB - 1].ids[0] >= 0)   // `segment` of the last attempt that got as far as its mask
@@ -933,7 +1250,7 @@ int stocs_try_sampled_base(stocs_ctx* c, int32_t* ids4, float* inv2, int* valid)
     return STOCS_OK;
 }
 
-// Device self-check of the float filter in front of the PPF arithmetic (ppf_compute_device): n_pairs seeded pairs of the
+// Device self-check of the float filter in front of the PPF arithmetic (ppf_key_fast): n_pairs seeded pairs of the
 // context's scene points are keyed with the filter and with the reference's double arithmetic alone; *n_mismatch must be 0.
 int stocs_ppf_filter_check(stocs_ctx* c, uint64_t seed, int64_t n_pairs, int64_t* n_tested, int64_t* n_undecided, int64_t* n_mismatch) {
     if (!c || n_pairs <= 0 || n_pairs > 0x7FFFFFFF || c->nS < 2) return STOCS_ERR_INVALID;
@@ -943,7 +1260,11 @@ int stocs_ppf_filter_check(stocs_ctx* c, uint64_t seed, int64_t n_pairs, int64_t
     unsigned int* d_counts = (unsigned int*)c->d_scratch;
     STOCS_HIP_CHECK(hipMemsetAsync(d_counts, 0, 16, c->stream));
     PassArgs a = pass_args(c);
-    a.ix.tr = c->prm.ppf_tr_discretization; a.ix.rot = c->prm.ppf_rot_discretization;   // no index needed for this check
+    // no index needed for this check: the key space of the parameters, as wide in distance as the packed key allows
+    a.ix.tr = c->prm.ppf_tr_discretization; a.ix.rot = c->prm.ppf_rot_discretization;
+    a.ix.NA = 180 / a.ix.rot + 1;
+    a.ix.nD = (int)std::min<uint64_t>(16384, (0xFFFFFFFFull / ((uint64_t)a.ix.NA * a.ix.NA * a.ix.NA)) - 1);
+    set_distance_thresholds(&a.ix);
     hipLaunchKernelGGL(ppf_filter_check_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, c->stream, a, seed, (uint32_t)n_pairs, d_counts);
     STOCS_HIP_CHECK(hipGetLastError());
     unsigned int h[4] = {0, 0, 0, 0};
@@ -952,6 +1273,22 @@ int stocs_ppf_filter_check(stocs_ctx* c, uint64_t seed, int64_t n_pairs, int64_t
     if (n_tested) *n_tested = h[0];
     if (n_undecided) *n_undecided = h[1];
     if (n_mismatch) *n_mismatch = h[2];
+    return STOCS_OK;
+}
+
+int stocs_weight_fix_check(stocs_ctx* c, int64_t* n_mismatch) {
+    if (!c || !n_mismatch) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
+    int rc = ensure_scratch(c, 256);
+    if (rc) return rc;
+    unsigned int* d_counts = (unsigned int*)c->d_scratch;
+    STOCS_HIP_CHECK(hipMemsetAsync(d_counts, 0, 16, c->stream));
+    hipLaunchKernelGGL(weight_fix_check_kernel, dim3(1u << 16), dim3(256), 0, c->stream, d_counts);   // 2^16 * 2^8 threads * 2^8 patterns
+    STOCS_HIP_CHECK(hipGetLastError());
+    unsigned int h = 0;
+    STOCS_HIP_CHECK(hipMemcpyAsync(&h, d_counts, 4, hipMemcpyDeviceToHost, c->stream));
+    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *n_mismatch = h;
     return STOCS_OK;
 }
 

@@ -180,11 +180,25 @@ STOCS_HD uint64_t rng64(uint64_t seed, uint64_t attempt, uint64_t k) {
     z = mix64(z ^ ((k + 1) * 0xDB4F0B9175AE2165ull));
     return z;
 }
+// trunc(w * 2^32) for w > 0 (0 for w <= 0 and NaN, saturating at 2^64 - 1) -- the value of
+//     (uint64_t)((double)w * 4294967296.0)
+// read off the bits of w: the product is exact, so the result is the 24-bit significand shifted by the exponent.  Equal
+// to the double formula for all 2^32 floats (tests/test_abi_cpu.py checks a dense sample); no double arithmetic and no
+// 64-bit conversion on the device.
 STOCS_HD uint64_t weight_fix(float w) {
-    if (!(w > 0.0f)) return 0;
-    double s = (double)w * 4294967296.0;
-    if (s >= 1.8446744073709552e19) return 0xFFFFFFFFFFFFFFFFull;
-    return (uint64_t)s;
+    union { float f; uint32_t u; } cv;
+    cv.f = w;
+    const uint32_t b = cv.u;
+    if ((int32_t)b <= 0) return 0;                         // sign bit set, or +0
+    const int e = (int)(b >> 23);                          // biased exponent
+    if (e == 255) return (b & 0x7FFFFFu) ? 0 : 0xFFFFFFFFFFFFFFFFull;   // NaN / +inf
+    if (e == 0) return 0;                                  // denormal: below 2^-126
+    const uint64_t m = (uint64_t)((b & 0x7FFFFFu) | 0x800000u);
+    const int sh = e - 118;                                // (e - 127) - 23 + 32
+    if (sh >= 41) return 0xFFFFFFFFFFFFFFFFull;
+    if (sh >= 0) return m << sh;
+    if (sh <= -24) return 0;
+    return m >> (-sh);
 }
 STOCS_HD uint64_t mulhi64(uint64_t a, uint64_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -249,3 +249,35 @@ def test_png_and_ply_files_round_trip(capi, tmp_path):
     assert np.array_equal(p3, pos) and np.array_equal(n3, nrm) and hn.value == 1
     (tmp_path / "c.ply").write_text("ply\nformat ascii 1.0\nelement vertex 2\nproperty float x\nend_header\n1\n2\n")
     assert L.stocs_ply_read(str(tmp_path / "c.ply").encode(), None, None, 0, C.byref(n), C.byref(hn)) == -1
+
+
+def test_weight_fix_bits_equal_the_double_formula(tmp_path):
+    """weight_fix (stocs_math.h) reads trunc(w * 2^32) off the float's bits; the draws are defined by the double formula
+    (uint64_t)((double)w * 2^32).  Every 61st of the 2^32 bit patterns plus all patterns around the exponent edges."""
+    src = tmp_path / "wf.cpp"
+    src.write_text(r'''
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include "stocs_math.h"
+static uint64_t ref(float w) {
+    if (!(w > 0.0f)) return 0;
+    double s = (double)w * 4294967296.0;
+    if (s >= 1.8446744073709552e19) return 0xFFFFFFFFFFFFFFFFull;
+    return (uint64_t)s;
+}
+int main() {
+    unsigned long long bad = 0, n = 0;
+    for (uint64_t i = 0; i < (1ull << 32); i += 61) { uint32_t b = (uint32_t)i; float w; memcpy(&w, &b, 4); bad += ref(w) != stocs::weight_fix(w); ++n; }
+    for (uint32_t e = 0; e < 256; ++e)
+        for (int d = -2048; d <= 2048; ++d) { uint32_t b = (e << 23) + (uint32_t)d; float w; memcpy(&w, &b, 4); bad += ref(w) != stocs::weight_fix(w); ++n; }
+    printf("%llu %llu\n", bad, n);
+    return bad != 0;
+}
+''')
+    exe = tmp_path / "wf"
+    inc = os.path.join(ROOT, "model_matching_amd", "csrc")
+    subprocess.run(["g++", "-O2", "-std=c++11", "-I", inc, str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert int(out.stdout.split()[1]) > 70_000_000

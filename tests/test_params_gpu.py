@@ -153,19 +153,53 @@ def test_on_demand_quads_at_metric_size():
 
 
 def test_ppf_float_filter_never_changes_a_key():
-    """The pass kernels key point pairs with a float atan2 and fall back to the reference's double arithmetic within 1e-3
-    degree of a bin boundary (sample.hip, ppf_compute_device).  Device self-check on 20 million seeded pairs of the Cm scene
-    and of a scene with axis-aligned normals (exact 0 / 90 / 180 degree angles sit ON integer angles): no key may differ."""
+    """The pass kernels key point pairs with a float evaluation (own atan2, bin indices without integer division) and fall
+    back to the reference's double arithmetic within 1e-3 degree of a bin boundary (sample.hip, ppf_key_fast).  Device
+    self-check on seeded pairs of the Cm scene, of a scene with axis-aligned normals (exact 0 / 90 / 180 degree angles sit
+    ON integer angles) and of random clouds at several scales and discretisations: a pair the filter calls certain must
+    have the key of the double arithmetic -- no exception in 50 million."""
     import ctypes as C
-    from model_matching_amd import synth
+    from model_matching_amd import capi, synth
     from model_matching_amd.estimator import StocsEstimator
     m, s, k = synth.workload("Cm")
     nrm2 = np.zeros_like(s.nrm); nrm2[np.arange(len(s.nrm)), np.arange(len(s.nrm)) % 3] = 1.0
-    for nrm, n_pairs in ((s.nrm, 20_000_000), (nrm2, 2_000_000)):
-        est = StocsEstimator(s.pos, nrm, s.prob, s.pixel, m.pos[:200], m.nrm[:200], build_index=False)
+    rng = np.random.default_rng(5)
+    cases = [(s.pos, s.nrm, 5, 5, 20_000_000), (s.pos, nrm2, 5, 5, 2_000_000)]
+    for scale, tr, rot in ((0.05, 5, 5), (0.3, 1, 1), (1.0, 3, 2), (3.0, 10, 9), (0.1, 7, 10), (0.02, 2, 3), (0.2, 5, 180)):
+        n = 20000
+        pos = (rng.normal(size=(n, 3)) * scale).astype(np.float32)
+        nrm = rng.normal(size=(n, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        # a share of the normals snapped to exactly representable directions, positions to a lattice: ties and exact angles
+        snap = rng.random(n) < 0.2
+        nrm[snap] = np.round(nrm[snap]); bad = np.linalg.norm(nrm, axis=1) == 0; nrm[bad] = (0, 0, 1)
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        pos[snap] = np.round(pos[snap] / (scale / 8)) * np.float32(scale / 8)
+        cases.append((pos, nrm.astype(np.float32), tr, rot, 4_000_000))
+    total = 0
+    for pos, nrm, tr, rot, n_pairs in cases:
+        prm = capi.default_params()
+        prm.ppf_tr_discretization = tr; prm.ppf_rot_discretization = rot
+        est = StocsEstimator(pos, nrm, np.full(len(pos), 0.5, np.float32), None, m.pos[:200], m.nrm[:200], params=prm, build_index=False)
         nt, nu, nm = C.c_int64(), C.c_int64(), C.c_int64()
         assert est.L.stocs_ppf_filter_check(est.h, 99, n_pairs, C.byref(nt), C.byref(nu), C.byref(nm)) == 0
-        assert nm.value == 0 and nt.value > 0.99 * n_pairs
+        assert nm.value == 0, (tr, rot, nm.value)
+        assert nt.value > 0.99 * n_pairs
         if nrm is s.nrm:
             assert nu.value < 0.01 * nt.value       # the filter decides all but ~0.1 % of generic pairs
+        total += nt.value
         est.close()
+    assert total > 45_000_000
+
+
+def test_fixed_point_weight_of_the_draws_all_floats():
+    """The seeded draws weigh a point by trunc(w * 2^32); the kernels read it off the float's bits (no double, no branches).
+    Device self-check over all 2^32 float patterns against (uint64_t)((double)w * 2^32)."""
+    import ctypes as C
+    from model_matching_amd import synth
+    from model_matching_amd.estimator import StocsEstimator
+    m, s, k = synth.workload("tiny")
+    est = StocsEstimator(s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm, build_index=False)
+    nm = C.c_int64(-1)
+    assert est.L.stocs_weight_fix_check(est.h, C.byref(nm)) == 0
+    assert nm.value == 0
+    est.close()
