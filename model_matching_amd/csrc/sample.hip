@@ -615,6 +615,11 @@ struct InstanceArgs {
     unsigned long long* stamps; // STOCS_DEBUG_TIMING only: cycles per stage, summed over the attempts (else NULL)
     float4* spos_w; float4* snrm_w;   // the scene arrays whose .w the LCP adds: refreshed with the decayed prior at the end
     BaseOut* res;
+    // hand-over from the workgroup that runs point 1 + mask of every attempt to the one that runs points 2..4 (below)
+    int4* q_hdr;                // per attempt: survivors, point 1, 1 when the attempt got as far as its mask
+    int32_t* q_sv; float* q_w;  // per attempt S slots: the survivors (scene index, weight)
+    unsigned int* q_flag;       // per attempt: 1 once the slot is complete
+    unsigned int* q_err;        // set when the second workgroup gave up waiting
 };
 
 template <class P>
@@ -697,8 +702,17 @@ template <bool WLDS> struct InstTypes { typedef int32_t sv_t; };
 template <> struct InstTypes<true> { typedef uint16_t sv_t; };
 
 // Every loop over the scene points handles 4 points per thread with the loads of all four issued before the first use:
-// the kernel is one workgroup, so memory latency is not hidden by other workgroups -- it is paid once per stage instead
+// the stages run in one workgroup, so memory latency is not hidden by other workgroups -- it is paid once per stage instead
 // of once per point.
+//
+// TWO workgroups share the attempts as a pipeline.  What makes the attempts sequential is the image-space state (the
+// decayed prior, previous_segment, the segmentation buffer): it is complete once an attempt has its mask.  Points 2..4 of
+// an attempt (stocs.cpp:640-751) read that attempt's survivors only and write nothing a later attempt reads.  So the
+// first workgroup of the grid runs weights -> point 1 -> pass 1 -> mask -> bookkeeping of every attempt and hands the
+// survivors over through device memory (slot + release flag); the last workgroup of the grid picks the slots up (acquire),
+// draws points 2..4 and orders the bases.  The grid is 9 workgroups of which 7 exit at once: workgroups are dealt to the
+// 8 XCDs in turn, so workgroups 0 and 8 normally share an XCD and its L2 (correctness does not depend on it).  The second
+// workgroup bounds its wait, so a failure of the first cannot hang the device.
 template <bool WLDS>
 __global__ __launch_bounds__(1024) void instance_attempts_kernel(InstanceArgs A, uint64_t seed, int first_attempt, int n_attempts, float dispersion) {
     typedef typename InstTypes<WLDS>::sv_t sv_t;
@@ -714,6 +728,8 @@ __global__ __launch_bounds__(1024) void instance_attempts_kernel(InstanceArgs A,
     sv_t* sv = WLDS ? (sv_t*)(inst_dyn + o_w + (((size_t)S * 4 + 15) & ~(size_t)15)) : (sv_t*)A.sv;   // survivors of pass 1 inside the mask, in scene order
     const float4* spos = A.pa.spos;
     const float4* snrm = A.pa.snrm;
+    if (blockIdx.x != 0 && blockIdx.x + 1 != gridDim.x) return;            // the workgroups in between only steer the placement
+    const bool first_role = blockIdx.x == 0;
     unsigned long long tprev = A.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     // the thread index is made opaque at the start of every stage: otherwise the compiler hoists per-thread addresses of
     // every array out of the attempt loop, and a hundred registers of them spill to scratch around every stage
@@ -722,9 +738,9 @@ __global__ __launch_bounds__(1024) void instance_attempts_kernel(InstanceArgs A,
     // memory per stamp would cost more than most stages
     unsigned long long acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0, acc4 = 0, acc5 = 0, acc6 = 0, acc7 = 0;
 #define INST_STAMP(k) if (A.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc##k += now_ - tprev; tprev = now_; }
+    if (first_role) {
     for (int a = 0; a < n_attempts; ++a) {
         const int attempt = first_attempt + a, base_num = attempt + 1;
-        BaseOut* out = A.res + a;
         // ---- weights: compounding decay of the prior inside the previous segment, edge pixels pruned (stocs.cpp:572-584) ----
         {
         INST_THREAD()
@@ -748,14 +764,14 @@ __global__ __launch_bounds__(1024) void instance_attempts_kernel(InstanceArgs A,
         if (t == 0) { sh_max = 0; sh_nunc = 0; }
         }
         __syncthreads();
+        // every store to the slot of the previous attempt has completed (the barrier waits for them): publish it
+        if (a > 0 && threadIdx.x == 0) __hip_atomic_store(A.q_flag + (a - 1), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         INST_STAMP(0)
         int32_t bidx[4] = {-1, -1, -1, -1};
-        int fail = 0;
         bidx[0] = draw_block_fast(w, S, rng64(seed, (uint64_t)attempt, 0), sh16, sh_pick, 0, A.draw_per_thread);
         INST_STAMP(1)
         if (bidx[0] < 0) {   // "FAILED SAMPLING": no base, no mask, previous_segment stays (stocs.cpp:586-589)
-            if (threadIdx.x == 0) { for (int k = 0; k < 4; ++k) out->ids[k] = -1; out->inv[0] = out->inv[1] = 0; out->valid = 0; out->pad = 0; }
-            __syncthreads();
+            if (threadIdx.x == 0) A.q_hdr[a] = make_int4(0, -1, 0, 0);
             continue;
         }
         const int b1 = bidx[0];
@@ -910,45 +926,94 @@ __global__ __launch_bounds__(1024) void instance_attempts_kernel(InstanceArgs A,
             __syncthreads();
         }
         }
+        // ---- hand the survivors over (published at the next barrier that follows these stores) ----
+        {
+            INST_THREAD()
+            for (int j = t; j < n_surv; j += 1024) { A.q_sv[(size_t)a * S + j] = (int32_t)sv[j]; A.q_w[(size_t)a * S + j] = w[j]; }
+            if (t == 0) A.q_hdr[a] = make_int4(n_surv, b1, 1, 0);
+        }
         INST_STAMP(4)
         if (A.stamps && threadIdx.x == 0) A.stamps[9] += (unsigned long long)n_surv;
-        // ---- points 2..4 (stocs.cpp:640-751 = the class-mode passes) over the survivors ----
+    }
+    __syncthreads();
+    if (n_attempts > 0 && threadIdx.x == 0) __hip_atomic_store(A.q_flag + (n_attempts - 1), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (A.stamps && threadIdx.x == 0) { A.stamps[0] += acc0; A.stamps[1] += acc1; A.stamps[2] += acc2; A.stamps[3] += acc3; A.stamps[4] += acc4; }
+    // the LCP adds class_probability_, which this sampling decays in place (Q8): refresh the scene arrays it reads
+    for (int i = threadIdx.x; i < S; i += 1024) { const float c = A.cls[i]; A.spos_w[i].w = c; A.snrm_w[i].w = c; }
+    return;
+    }
+
+    // ================= second workgroup: points 2..4 (stocs.cpp:640-751 = the class-mode passes) over the survivors =================
+    __shared__ int sh_abort;
+    if (threadIdx.x == 0) sh_abort = 0;
+    __syncthreads();
+    for (int a = 0; a < n_attempts; ++a) {
+        const int attempt = first_attempt + a;
+        BaseOut* out = A.res + a;
+        if (threadIdx.x == 0) {                                               // bounded wait for the slot (a few seconds at the outside)
+            unsigned spins = 0;
+            while (__hip_atomic_load(A.q_flag + a, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                __builtin_amdgcn_s_sleep(16);
+                if (++spins > (1u << 21)) { sh_abort = 1; break; }
+            }
+        }
+        __syncthreads();
+        if (sh_abort) {                                                       // the same in every thread
+            if (threadIdx.x == 0) {
+                *A.q_err = 1u;
+                for (int r = a; r < n_attempts; ++r) { BaseOut* o = A.res + r; for (int k = 0; k < 4; ++k) o->ids[k] = -1; o->inv[0] = o->inv[1] = 0; o->valid = 0; o->pad = 0; }
+            }
+            break;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                    // every thread reads the slot behind the flag
+        INST_STAMP(5)
+        const int4 hdr = A.q_hdr[a];
+        int32_t bidx[4] = {hdr.y, -1, -1, -1};
+        int fail = hdr.z ? 0 : 1;
+        const int n_surv = hdr.x;
+        float* wq = w;
+        sv_t* svq = sv;
+        if (!fail) {
+            INST_THREAD()
+            if (WLDS) {
+                for (int j = t; j < n_surv; j += 1024) { w[j] = A.q_w[(size_t)a * S + j]; sv[j] = (sv_t)A.q_sv[(size_t)a * S + j]; }
+                __syncthreads();
+            } else {                                                          // large scenes: work on the slot itself
+                wq = A.q_w + (size_t)a * S;
+                svq = (sv_t*)(A.q_sv + (size_t)a * S);
+            }
+        }
         for (int k = 1; k < 4 && !fail; ++k) {
             INST_THREAD()
-            const int pos = draw_block_fast(w, n_surv, rng64(seed, (uint64_t)attempt, (uint64_t)k), sh16, sh_pick, k & 1, A.draw_per_thread);
+            const int pos = draw_block_fast(wq, n_surv, rng64(seed, (uint64_t)attempt, (uint64_t)k), sh16, sh_pick, k & 1, A.draw_per_thread);
             if (pos < 0) { fail = 1; break; }
-            bidx[k] = (int32_t)sv[pos];
+            bidx[k] = (int32_t)svq[pos];
             if (k < 3) {
                 for (int j = t; j < n_surv; j += 1024) {
-                    if (w[j] == 0.0f) continue;                               // already zero: nothing to decide
-                    const int i = (int)sv[j];
+                    if (wq[j] == 0.0f) continue;                              // already zero: nothing to decide
+                    const int i = (int)svq[j];
                     const bool z = (k == 1) ? pass_zeroes<2>(A.pa, bidx[0], bidx[1], -1, i) : pass_zeroes<3>(A.pa, bidx[0], bidx[1], bidx[2], i);
-                    if (z) w[j] = 0.0f;
+                    if (z) wq[j] = 0.0f;
                 }
                 __syncthreads();
             }
         }
-        INST_STAMP(5)
         // the four points as drawn; their ordering (try_sampled_base) waits for the end of the kernel
         if (threadIdx.x == 0) { for (int k = 0; k < 4; ++k) out->ids[k] = bidx[k]; out->inv[0] = out->inv[1] = 0; out->valid = fail ? 0 : 1; out->pad = 0; }
         __syncthreads();
         INST_STAMP(6)
     }
-    // ---- ordered base + invariants of every attempt (stocs.cpp:224-268): nothing above depends on them, so the attempts
-    //      are finalised side by side, one wavefront each ----
-    for (int a = (int)(threadIdx.x >> 6); a < n_attempts; a += 16) {
-        BaseOut* o = A.res + a;
-        const int b0 = o->ids[0], b1 = o->ids[1], b2 = o->ids[2], b3 = o->ids[3], fl = o->valid ? 0 : 1;
-        finalize_one_wave_call(A.pa.spos, b0, b1, b2, b3, fl, o);
-    }
+    __syncthreads();
+    // ---- ordered base + invariants of every attempt (stocs.cpp:224-268), side by side, one wavefront each ----
+    if (!sh_abort)
+        for (int a = (int)(threadIdx.x >> 6); a < n_attempts; a += 16) {
+            BaseOut* o = A.res + a;
+            const int b0 = o->ids[0], b1 = o->ids[1], b2 = o->ids[2], b3 = o->ids[3], fl = o->valid ? 0 : 1;
+            finalize_one_wave_call(A.pa.spos, b0, b1, b2, b3, fl, o);
+        }
     INST_STAMP(7)
-    if (A.stamps && threadIdx.x == 0) {
-        A.stamps[0] += acc0; A.stamps[1] += acc1; A.stamps[2] += acc2; A.stamps[3] += acc3;
-        A.stamps[4] += acc4; A.stamps[5] += acc5; A.stamps[6] += acc6; A.stamps[7] += acc7;
-    }
+    if (A.stamps && threadIdx.x == 0) { A.stamps[5] += acc5; A.stamps[6] += acc6; A.stamps[7] += acc7; }
 #undef INST_STAMP
-    // the LCP adds class_probability_, which this sampling decays in place (Q8): refresh the scene arrays it reads
-    for (int i = threadIdx.x; i < S; i += 1024) { const float c = A.cls[i]; A.spos_w[i].w = c; A.snrm_w[i].w = c; }
 }
 
 
@@ -975,6 +1040,7 @@ struct InstanceState {
     float* d_cls = NULL; uint32_t* d_maskbits = NULL; uint32_t* d_segbits = NULL; uint32_t* d_parent = NULL;
     int32_t* d_sv = NULL; float* d_w = NULL;
     RunPair* d_pairs = NULL; uint32_t* d_pair_off = NULL;
+    char* d_queue = NULL; size_t queue_bytes = 0;   // hand-over slots between the two workgroups (grown on demand)
     size_t n_runs = 0;
     std::vector<uint32_t> h_segbits;
 };
@@ -983,6 +1049,7 @@ static void free_instance_state(stocs_ctx* c) {
     InstanceState* I = (InstanceState*)c->inst;
     if (!I) return;
     if (I->d_mem) (void)hipFree(I->d_mem);
+    if (I->d_queue) (void)hipFree(I->d_queue);
     delete I;
     c->inst = NULL;
 }
@@ -1110,6 +1177,23 @@ static int sample_instance(stocs_ctx* c, uint64_t seed, int first_attempt, int n
     A.stamps = NULL;
     if (dbg) { A.stamps = (unsigned long long*)I->d_parent; STOCS_HIP_CHECK(hipMemsetAsync(I->d_parent, 0, 128, c->stream)); }   // parent_g is idle for small discs
     A.w = I->d_w; A.sv = I->d_sv; A.spos_w = c->d_spos; A.snrm_w = c->d_snrmw; A.res = sb.res;
+    // hand-over slots of the attempts: header, S (index, weight) pairs, flag; one error word
+    {
+        auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const size_t nq = (size_t)std::max(nB, 1), Sq = (size_t)c->nS;
+        const size_t o_hdr = 0, o_flag = o_hdr + al(nq * 16), o_err = o_flag + al(nq * 4), o_sv = o_err + 256, o_w = o_sv + al(nq * Sq * 4), total = o_w + al(nq * Sq * 4);
+        if (I->queue_bytes < total) {
+            if (I->d_queue) { STOCS_HIP_CHECK(hipStreamSynchronize(c->stream)); (void)hipFree(I->d_queue); I->d_queue = NULL; I->queue_bytes = 0; }
+            // sized for a whole trial of this scene at once (<= 254 attempts), so that a caller asking attempt by attempt allocates once
+            const size_t full = o_w - o_sv > 0 ? 256 + al(254 * 16) + al(254 * 4) + 2 * al((size_t)254 * Sq * 4) : total;
+            const size_t want = std::max(total, std::min<size_t>(full, (size_t)1 << 30));
+            STOCS_HIP_CHECK(dev_malloc((void**)&I->d_queue, want));
+            I->queue_bytes = want;
+        }
+        A.q_hdr = (int4*)(I->d_queue + o_hdr); A.q_flag = (unsigned int*)(I->d_queue + o_flag); A.q_err = (unsigned int*)(I->d_queue + o_err);
+        A.q_sv = (int32_t*)(I->d_queue + o_sv); A.q_w = (float*)(I->d_queue + o_w);
+        STOCS_HIP_CHECK(hipMemsetAsync(I->d_queue + o_flag, 0, o_sv - o_flag, c->stream));   // flags and the error word
+    }
     // parents, and up to INST_LDS_POINTS points' weights + survivor indices, in LDS (<= 160 KB per workgroup on gfx950)
     const size_t lds_parent = ((size_t)(INST_MAX_NODES + 1) * 4 + 15) & ~(size_t)15;
     const bool wlds = c->nS <= INST_LDS_POINTS && !getenv("STOCS_INSTANCE_NO_LDS");
@@ -1118,20 +1202,24 @@ static int sample_instance(stocs_ctx* c, uint64_t seed, int first_attempt, int n
         const void* fn = wlds ? (const void*)instance_attempts_kernel<true> : (const void*)instance_attempts_kernel<false>;
         STOCS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
     }
-    if (wlds) hipLaunchKernelGGL(instance_attempts_kernel<true>, dim3(1), dim3(1024), lds, c->stream, A, seed, first_attempt, nB, dispersion);
-    else hipLaunchKernelGGL(instance_attempts_kernel<false>, dim3(1), dim3(1024), lds, c->stream, A, seed, first_attempt, nB, dispersion);
+    // 9 workgroups: the first and the last do the work and normally land on the same XCD (see the kernel)
+    if (wlds) hipLaunchKernelGGL(instance_attempts_kernel<true>, dim3(9), dim3(1024), lds, c->stream, A, seed, first_attempt, nB, dispersion);
+    else hipLaunchKernelGGL(instance_attempts_kernel<false>, dim3(9), dim3(1024), lds, c->stream, A, seed, first_attempt, nB, dispersion);
     STOCS_HIP_CHECK(hipGetLastError());
     std::vector<BaseOut> res((size_t)nB);
     I->h_segbits.assign((size_t)I->Sw, 0);
     STOCS_HIP_CHECK(hipMemcpyAsync(res.data(), sb.res, (size_t)nB * sizeof(BaseOut), hipMemcpyDeviceToHost, c->stream));
     STOCS_HIP_CHECK(hipMemcpyAsync(c->h_sprob.data(), I->d_cls, (size_t)c->nS * 4, hipMemcpyDeviceToHost, c->stream));   // the decayed prior (Q8)
     STOCS_HIP_CHECK(hipMemcpyAsync(I->h_segbits.data(), I->d_segbits, (size_t)I->Sw * 4, hipMemcpyDeviceToHost, c->stream));
+    unsigned int q_err = 0;
+    STOCS_HIP_CHECK(hipMemcpyAsync(&q_err, A.q_err, 4, hipMemcpyDeviceToHost, c->stream));
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (q_err) { set_error("instance-mode sampling: the second workgroup gave up waiting for the first"); return STOCS_ERR_HIP; }
     if (dbg) {
         unsigned long long st[16];
         STOCS_HIP_CHECK(hipMemcpy(st, I->d_parent, 128, hipMemcpyDeviceToHost));
         const double per = 1.0 / std::max(nB, 1);
-        fprintf(stderr, "[stocs instance] %d attempts, shader cycles per attempt (s_memtime): weights %.0f | draw0 %.0f | pass1+maxdist %.0f | flood fill %.0f | bookkeeping+compaction %.0f | points 2-4 %.0f | record %.0f | ordered bases (once, /attempt) %.0f\n",
+        fprintf(stderr, "[stocs instance] %d attempts, shader cycles per attempt (s_memtime).  first workgroup: weights + publish %.0f | draw 1 %.0f | pass 1 + max distance %.0f | flood fill %.0f | bookkeeping + compaction + hand-over %.0f.  second workgroup: waiting %.0f | points 2-4 %.0f | ordered bases (once, /attempt) %.0f\n",
                 nB, st[0] * per, st[1] * per, st[2] * per, st[3] * per, st[4] * per, st[5] * per, st[6] * per, st[7] * per);
         fprintf(stderr, "[stocs instance] per attempt: %.0f of %d points within key distance of point 1 (stage A of pass 1: %.0f cycles), %.0f survivors inside the mask\n",
                 st[8] * per, c->nS, st[10] * per, st[9] * per);
