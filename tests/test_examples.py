@@ -116,3 +116,40 @@ def test_instance_mode_per_call_segment_equals_oracle(oracle_lib):
         n_seg += len(so)
     assert n_seg > 100
     est.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["device_memory_working_set", "speckled_edge_map", "both"])
+def test_instance_mode_fallback_paths_equal_oracle(variant, oracle_lib, monkeypatch):
+    """The paths the example frame does not reach by itself: the per-attempt working set in device memory instead of LDS
+    (scenes beyond 16 000 points; forced here with STOCS_INSTANCE_NO_LDS) and union-find parents in device memory (a disc
+    holding more than 16 384 passable runs: a heavily speckled edge map).  Bases, validity and `segment` against the oracle."""
+    from model_matching_amd.estimator import StocsEstimator
+    d = _load("packed_dove")
+    args = (d["scene_pos"], d["scene_nrm"], d["scene_prob"], d["scene_pixel"], d["model_pos"], d["model_nrm"])
+    edge = np.ascontiguousarray(d["edge_map"]).copy()
+    if variant != "device_memory_working_set":
+        rng = np.random.default_rng(17)
+        speck = rng.random(edge.shape) < 0.25                     # a quarter of the pixels neither edge nor passable: ~50 000 runs
+        edge[speck & (edge == 255)] = 128
+        runs = int(((edge[:, 1:] == 255) & (edge[:, :-1] != 255)).sum() + (edge[:, 0] == 255).sum())
+        assert runs > 3 * 16384
+    if variant != "speckled_edge_map":
+        monkeypatch.setenv("STOCS_INSTANCE_NO_LDS", "1")
+    est = StocsEstimator(*args, build_index=True)
+    orc = oracle_lib.Oracle(*args)
+    est.set_edge_map(edge); orc.set_edge_map(edge)
+    seed, n = 5, 40
+    valid, ids, inv = est.sample_bases(seed, n, mode=1, dispersion=0.9)
+    seg_gpu = est.get_segment()
+    n_ok = 0
+    for a in range(n):
+        ok, oi, ov = orc.sample_instance_base(seed, a, 0.9, a + 1)
+        assert ok == bool(valid[a]), a
+        if ok:
+            assert np.array_equal(oi, ids[a]) and np.array_equal(ov, inv[a]), a
+            n_ok += 1
+    assert np.array_equal(seg_gpu, orc.get_segment())
+    if variant == "device_memory_working_set":
+        assert n_ok >= 3
+    est.close()
