@@ -23,7 +23,7 @@
 namespace stocs {
 
 struct M3 { float m[3][3]; };
-__device__ __forceinline__ M3 mul33(const M3& A, const M3& B) {
+STOCS_HD M3 mul33(const M3& A, const M3& B) {
     M3 C;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -32,7 +32,7 @@ __device__ __forceinline__ M3 mul33(const M3& A, const M3& B) {
             C.m[i][j] = A.m[i][0] * B.m[0][j] + (A.m[i][1] * B.m[1][j] + A.m[i][2] * B.m[2][j]);
     return C;
 }
-__device__ __forceinline__ V3 mul3v(const M3& A, V3 v) {
+STOCS_HD V3 mul3v(const M3& A, V3 v) {
     return mk3(A.m[0][0] * v.x + (A.m[0][1] * v.y + A.m[0][2] * v.z),
                A.m[1][0] * v.x + (A.m[1][1] * v.y + A.m[1][2] * v.z),
                A.m[2][0] * v.x + (A.m[2][1] * v.y + A.m[2][2] * v.z));
@@ -41,15 +41,10 @@ __device__ __forceinline__ V3 ld3(const float4* a, int i) { float4 v = a[i]; ret
 
 struct XformJob { int32_t s[4]; int32_t q[4]; };  // scene base ids, model quad ids
 
-__global__ __launch_bounds__(256) void rigid_transform_kernel(const float4* __restrict__ spos, const float4* __restrict__ mpos,
-                                                              const XformJob* __restrict__ jobs, int n, V3 cscene, V3 cmodel,
-                                                              float* __restrict__ T_out, float* __restrict__ P_out,
-                                                              int32_t* __restrict__ ok_out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const XformJob job = jobs[j];
-    const V3 p0 = ld3(spos, job.s[0]), p1 = ld3(spos, job.s[1]), p2 = ld3(spos, job.s[2]);
-    const V3 q0 = ld3(mpos, job.q[0]), q1 = ld3(mpos, job.q[1]), q2 = ld3(mpos, job.q[2]);
+// One candidate: the arithmetic of ComputeRigidTransformation + get_rigid_transform_from_congruent_pair on three point
+// pairs.  Host and device run this same function (IEEE float operations in a fixed order, sqrt the only non-trivial one),
+// so a candidate computed by the per-call entry point on the host equals the batched kernel's bit for bit.
+STOCS_HD int rigid_transform_one(V3 p0, V3 p1, V3 p2, V3 q0, V3 q1, V3 q2, V3 cscene, V3 cmodel, float* T, float* P) {
     const V3 centroid1 = ((p0 + p1) + p2) / 3.0f;  // stocs.cpp:885
     const V3 centroid2 = ((q0 + q1) + q2) / 3.0f;  // stocs.cpp:907-909
     int ok = 1;
@@ -95,8 +90,6 @@ __global__ __launch_bounds__(256) void rigid_transform_kernel(const float4* __re
     const V3 t = centroid1 + mul3v(R, -centroid2);
     // camera-frame translation (stocs.cpp:925-933); rot*scale of computeRotationScaling == linear part
     const V3 tc = (centroid1 + cscene) - mul3v(R, centroid2 + cmodel);
-    float* T = T_out + (size_t)j * 16;
-    float* P = P_out + (size_t)j * 16;
 #pragma unroll
     for (int col = 0; col < 3; ++col) {
 #pragma unroll
@@ -105,6 +98,27 @@ __global__ __launch_bounds__(256) void rigid_transform_kernel(const float4* __re
     }
     T[12] = t.x; T[13] = t.y; T[14] = t.z; T[15] = 1.0f;
     P[12] = tc.x; P[13] = tc.y; P[14] = tc.z; P[15] = 1.0f;
+    return ok;
+}
+
+__global__ __launch_bounds__(256) void rigid_transform_kernel(const float4* __restrict__ spos, const float4* __restrict__ mpos,
+                                                              const XformJob* __restrict__ jobs, int n, V3 cscene, V3 cmodel,
+                                                              float* __restrict__ T_out, float* __restrict__ P_out,
+                                                              int32_t* __restrict__ ok_out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const XformJob job = jobs[j];
+    const V3 p0 = ld3(spos, job.s[0]), p1 = ld3(spos, job.s[1]), p2 = ld3(spos, job.s[2]);
+    const V3 q0 = ld3(mpos, job.q[0]), q1 = ld3(mpos, job.q[1]), q2 = ld3(mpos, job.q[2]);
+    float T[16], P[16];
+    const int ok = rigid_transform_one(p0, p1, p2, q0, q1, q2, cscene, cmodel, T, P);
+    float4* To = (float4*)(T_out + (size_t)j * 16);
+    float4* Po = (float4*)(P_out + (size_t)j * 16);
+#pragma unroll
+    for (int col = 0; col < 4; ++col) {
+        To[col] = make_float4(T[col * 4], T[col * 4 + 1], T[col * 4 + 2], T[col * 4 + 3]);
+        Po[col] = make_float4(P[col * 4], P[col * 4 + 1], P[col * 4 + 2], P[col * 4 + 3]);
+    }
     ok_out[j] = ok;
 }
 
@@ -157,15 +171,13 @@ int stocs_rigid_transform(stocs_ctx* c, const int32_t* ids4, const int32_t* quad
     DeviceGuard dev_guard(c->device);
     for (int k = 0; k < 4; ++k)
         if (ids4[k] < 0 || ids4[k] >= c->nS || quad4[k] < 0 || quad4[k] >= c->nM) { set_error("index out of range"); return STOCS_ERR_INVALID; }
-    std::vector<XformJob> jobs(1);
-    for (int k = 0; k < 4; ++k) { jobs[0].s[k] = ids4[k]; jobs[0].q[k] = quad4[k]; }
-    std::vector<float> T, P;
-    std::vector<int32_t> o;
-    int rc = run_jobs(c, jobs, T, P, o);
-    if (rc) return rc;
-    if (T16) memcpy(T16, T.data(), 64);
-    if (pose16) memcpy(pose16, P.data(), 64);
-    *ok = o[0];
+    // on the host, from the context's own copies of the centred clouds: the reference's caller asks for one candidate per
+    // call, up to 200 per base (stocs_match_one_object.cpp:120-147) -- a device round trip each would cost 35 us
+    float T[16], P[16];
+    *ok = rigid_transform_one(c->h_spos[ids4[0]], c->h_spos[ids4[1]], c->h_spos[ids4[2]], c->h_mpos[quad4[0]], c->h_mpos[quad4[1]], c->h_mpos[quad4[2]],
+                              c->centroid_scene, c->centroid_model, T, P);
+    if (T16) memcpy(T16, T, 64);
+    if (pose16) memcpy(pose16, P, 64);
     return STOCS_OK;
 }
 
