@@ -300,7 +300,7 @@ public:
         ingest(depth.data(), prob.data(), has_edge ? edge.data() : NULL, camera_intrinsics, read_depth_scale, write_depth_scale, voxel_size, dst_scene_location);
     }
 
-    void set_seed(uint64_t seed) { seed_ = seed; attempt_ = 0; }
+    void set_seed(uint64_t seed) { seed_ = seed; attempt_ = 0; la_n_ = 0; la_in_ctx_ = false; }
     // not in the reference (one estimator per scene there): the next frame against the same model; the model
     // clouds and the PPF index are kept, everything derived from the old scene is dropped
     void set_scene(const SceneCloud& scene) {
@@ -309,7 +309,7 @@ public:
                                            scene_.pixel.empty() ? NULL : scene_.pixel.data(), scene_.size());
         if (rc != STOCS_OK) throw std::runtime_error(std::string("stocs_ctx_set_scene: ") + stocs_last_error());
         if (!scene_.edge_map.empty()) stocs_set_edge_map(ctx_, scene_.edge_map.data());
-        attempt_ = 0; best_lcp = 0; best_index = -1;
+        attempt_ = 0; best_lcp = 0; best_index = -1; la_n_ = 0; la_in_ctx_ = false;
         all_transforms.clear(); all_pose.clear(); all_pose_store_.clear(); batched_ = false;
     }
     bool has_edge_map() const { return !scene_.edge_map.empty(); }
@@ -342,9 +342,20 @@ public:
         const int32_t ids[4] = {base_indices[0], base_indices[1], base_indices[2], base_indices[3]};
         const float inv[2] = {invariant1, invariant2};
         int64_t total = 0, n = 0;
-        if (stocs_set_bases(ctx_, 1, ids, inv) != STOCS_OK || stocs_find_congruent_all(ctx_, &total) != STOCS_OK) return false;
+        int slot = lookahead_slot(ids, inv);
+        if (slot >= 0) {                // one of the bases the facade sampled ahead: one search for all of them, then only read-backs
+            if (!la_congruent_done_) {
+                if (stocs_find_congruent_all(ctx_, &total) != STOCS_OK) return false;
+                la_congruent_done_ = true;
+            }
+            if (stocs_get_quads(ctx_, slot, NULL, 0, &total) != STOCS_OK) return false;
+        } else {
+            la_in_ctx_ = false;
+            slot = 0;
+            if (stocs_set_bases(ctx_, 1, ids, inv) != STOCS_OK || stocs_find_congruent_all(ctx_, &total) != STOCS_OK) return false;
+        }
         std::vector<int32_t> q((size_t)total * 4 + 4);
-        if (stocs_get_quads(ctx_, 0, q.data(), total, &n) != STOCS_OK) return false;
+        if (stocs_get_quads(ctx_, slot, q.data(), total, &n) != STOCS_OK) return false;
         for (int64_t i = 0; i < n; ++i) quadrilaterals->emplace_back(q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]);
         return quadrilaterals->size() != 0;
     }
@@ -429,6 +440,7 @@ public:
     // n attempts of sample_class_base / sample_instance_base (by the presence of the edge map, :90); valid bases are kept
     int sample_bases(int n_attempts, float dispersion) {
         base_ids_.assign((size_t)n_attempts * 4, -1); base_inv_.assign((size_t)n_attempts * 2, 0.0f); base_valid_.assign((size_t)n_attempts, 0);
+        la_n_ = 0; la_in_ctx_ = false;
         if (stocs_clear_bases(ctx_) != STOCS_OK) return 0;
         if (stocs_sample_bases(ctx_, has_edge_map() ? 1 : 0, seed_, 0, n_attempts, dispersion, base_ids_.data(), base_inv_.data(), base_valid_.data()) != STOCS_OK) return 0;
         return stocs_num_bases(ctx_);
@@ -449,6 +461,7 @@ public:
 protected:
     void reset_members(const std::string& dbg, int w, int h, float dist, int tr, int rot, float edge_thr, float class_thr) {
         ctx_ = NULL; best_lcp = 0; best_index = -1; seed_ = 0; attempt_ = 0; batched_ = false; fetched_ = false; n_batched_ = 0;
+        la_n_ = 0; la_first_ = 0; la_seed_ = 0; la_cursor_ = 0; la_in_ctx_ = false; la_congruent_done_ = false; la_mode_ = 0; la_nvalid_ = 0;
         debug_location = dbg; image_width = w; image_height = h; distance_threshold = dist; ppf_tr_discretization = tr;
         ppf_rot_discretization = rot; edge_threshold = edge_thr; class_threshold = class_thr;
     }
@@ -488,16 +501,61 @@ protected:
         if (!scene_.edge_map.empty()) stocs_set_edge_map(ctx_, scene_.edge_map.data());
         std::cout << "|S|: " << scene_.size() << std::endl;   // stocs.cpp:970
     }
+    // One attempt of the reference's one-per-call loop.  Class mode: the attempts do not depend on each other (every base
+    // starts from the prior, stocs.cpp:372-381; attempt a is seeded by (seed, a)), so the facade draws a block of them in one
+    // GPU pass and serves the calls from the block -- the results are those of one call per attempt.  Instance mode is
+    // sequential state (and decays the class probabilities the LCP reads, Q8): one attempt per call, nothing ahead of the caller.
     bool sample_one(int mode, float dispersion, std::vector<int>& base_indices, float& invariant1, float& invariant2) {
         int32_t ids[4] = {-1, -1, -1, -1};
         float inv[2] = {0, 0};
         int32_t valid = 0;
-        if (stocs_sample_bases(ctx_, mode, seed_, attempt_++, 1, dispersion, ids, inv, &valid) != STOCS_OK) return false;
+        if (mode == 0) {
+            if (!(la_mode_ == 0 && la_n_ > 0 && la_seed_ == seed_ && attempt_ >= la_first_ && attempt_ < la_first_ + la_n_)) {
+                la_n_ = 0; la_in_ctx_ = false; la_congruent_done_ = false;
+                la_ids_.assign((size_t)kLookahead * 4, -1); la_inv_.assign((size_t)kLookahead * 2, 0.0f); la_valid_.assign((size_t)kLookahead, 0);
+                if (stocs_clear_bases(ctx_) != STOCS_OK ||
+                    stocs_sample_bases(ctx_, 0, seed_, attempt_, kLookahead, 0.0f, la_ids_.data(), la_inv_.data(), la_valid_.data()) != STOCS_OK)
+                    return false;
+                la_first_ = attempt_; la_n_ = kLookahead; la_seed_ = seed_; la_in_ctx_ = true; la_cursor_ = 0; la_mode_ = 0;
+                la_slot_of_.assign((size_t)kLookahead, -1);                  // base slot in the context of every valid attempt
+                int slot = 0;
+                for (int k = 0; k < kLookahead; ++k) if (la_valid_[(size_t)k]) la_slot_of_[(size_t)k] = slot++;
+            }
+            const size_t k = (size_t)(attempt_ - la_first_);
+            for (int j = 0; j < 4; ++j) ids[j] = la_ids_[4 * k + (size_t)j];
+            inv[0] = la_inv_[2 * k]; inv[1] = la_inv_[2 * k + 1];
+            valid = la_valid_[k];
+            ++attempt_;
+        } else {
+            // nothing is drawn ahead; but the context keeps the valid bases in attempt order, so the facade remembers which
+            // slot each one got -- find_congruent_sets_on_model then searches once for all of them
+            if (attempt_ == 0 || la_mode_ != 1) {
+                la_ids_.clear(); la_inv_.clear(); la_valid_.clear(); la_slot_of_.clear();
+                la_n_ = 0; la_nvalid_ = 0; la_cursor_ = 0; la_mode_ = 1;
+                la_in_ctx_ = stocs_clear_bases(ctx_) == STOCS_OK;
+            }
+            if (stocs_sample_bases(ctx_, mode, seed_, attempt_++, 1, dispersion, ids, inv, &valid) != STOCS_OK) { la_in_ctx_ = false; return false; }
+            la_ids_.insert(la_ids_.end(), ids, ids + 4); la_inv_.insert(la_inv_.end(), inv, inv + 2); la_valid_.push_back(valid);
+            la_slot_of_.push_back(valid ? la_nvalid_++ : -1);
+            ++la_n_;
+            la_congruent_done_ = false;                                      // the base set grew: an earlier search does not cover it
+        }
         if (base_indices.size() < 4) base_indices.resize(4);
         for (int k = 0; k < 4; ++k) base_indices[(size_t)k] = ids[k];
         invariant1 = inv[0];
         invariant2 = inv[1];
         return valid != 0;
+    }
+    // slot in the context's base set of a base the look-ahead block sampled (so that its congruent sets come out of ONE
+    // search over all the block's bases), or -1
+    int lookahead_slot(const int32_t* ids, const float* inv) {
+        if (!la_in_ctx_ || la_n_ <= 0) return -1;
+        for (int step = 0; step < la_n_; ++step) {                           // the caller walks the bases in order: found at the cursor
+            const size_t k = (size_t)((la_cursor_ + step) % la_n_);
+            if (la_slot_of_[k] < 0) continue;
+            if (std::memcmp(&la_ids_[4 * k], ids, 16) == 0 && std::memcmp(&la_inv_[2 * k], inv, 8) == 0) { la_cursor_ = (int)k; return la_slot_of_[k]; }
+        }
+        return -1;
     }
     // candidates of make_transforms -> all_transforms / all_pose, on demand
     void fetch_batched() {
@@ -567,6 +625,14 @@ protected:
     int attempt_;
     bool batched_, fetched_;
     int n_batched_;
+    // look-ahead block of class-mode attempts / the instance-mode attempts made so far (sample_one)
+    enum { kLookahead = 100 };           // the reference's number_of_bases (stocs_match_one_object.cpp:16)
+    std::vector<int32_t> la_ids_, la_valid_;
+    std::vector<float> la_inv_;
+    std::vector<int> la_slot_of_;
+    uint64_t la_seed_;
+    int la_first_, la_n_, la_cursor_, la_mode_, la_nvalid_;
+    bool la_in_ctx_, la_congruent_done_;
 };
 
 // reference stocs.hpp:182-191 / stocs.cpp:28-84: raw model PLY -> normals (radius), flipped, voxel grid, scale -> model_search
