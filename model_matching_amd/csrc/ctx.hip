@@ -177,22 +177,34 @@ static int load_scene(stocs_ctx* c, const float* sp, const float* sn, const floa
     cs = cs / (float)nS;
     for (int i = 0; i < nS; ++i) c->h_spos[i] = c->h_spos[i] - cs;
     c->centroid_scene = cs;
-    if (c->d_spos) { (void)hipFree(c->d_spos); c->d_spos = NULL; }
-    if (c->d_snrmw) { (void)hipFree(c->d_snrmw); c->d_snrmw = NULL; }
-    if (c->d_spix) { (void)hipFree(c->d_spix); c->d_spix = NULL; }
     free_grid(c);
     int rc = STOCS_OK;
     {
-        std::vector<float4> a(std::max(nS, 1)), b(std::max(nS, 1));
-        std::vector<int2> px(std::max(nS, 1));
+        // one slab, grown only when a frame has more points than any before it: a camera stream does no hipMalloc / hipFree
+        // per frame (hipFree alone synchronises the whole device), and one copy moves the three arrays
+        const size_t n = (size_t)std::max(nS, 1);
+        if (n > c->scene_cap) {
+            STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+            if (c->d_scene_mem) { (void)hipFree(c->d_scene_mem); c->d_scene_mem = NULL; c->scene_cap = 0; }
+            const size_t cap = n + n / 4 + 256;
+            STOCS_HIP_CHECK(dev_malloc((void**)&c->d_scene_mem, cap * 40));
+            c->scene_cap = cap;
+        }
+        c->d_spos = (float4*)c->d_scene_mem;
+        c->d_snrmw = (float4*)(c->d_scene_mem + c->scene_cap * 16);
+        c->d_spix = (int2*)(c->d_scene_mem + c->scene_cap * 32);
+        std::vector<float4> ab(2 * n);
+        std::vector<int2> px(n);
         for (int i = 0; i < nS; ++i) {
-            a[i] = make_float4(c->h_spos[i].x, c->h_spos[i].y, c->h_spos[i].z, c->h_sprob[i]);
-            b[i] = make_float4(c->h_snrm[i].x, c->h_snrm[i].y, c->h_snrm[i].z, c->h_sprob[i]);
+            ab[i] = make_float4(c->h_spos[i].x, c->h_spos[i].y, c->h_spos[i].z, c->h_sprob[i]);
+            ab[n + i] = make_float4(c->h_snrm[i].x, c->h_snrm[i].y, c->h_snrm[i].z, c->h_sprob[i]);
             px[i] = make_int2(c->h_spix[2 * i], c->h_spix[2 * i + 1]);
         }
-        if (!rc) rc = upload(&c->d_spos, a.data(), a.size());
-        if (!rc) rc = upload(&c->d_snrmw, b.data(), b.size());
-        if (!rc) rc = upload(&c->d_spix, px.data(), px.size());
+        // stream-ordered behind whatever still reads the old frame; the pageable sources are staged before the calls return
+        STOCS_HIP_CHECK(hipMemcpyAsync(c->d_spos, ab.data(), n * 16, hipMemcpyHostToDevice, c->stream));
+        STOCS_HIP_CHECK(hipMemcpyAsync(c->d_snrmw, ab.data() + n, n * 16, hipMemcpyHostToDevice, c->stream));
+        STOCS_HIP_CHECK(hipMemcpyAsync(c->d_spix, px.data(), n * 8, hipMemcpyHostToDevice, c->stream));
+        STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
     if (!rc) rc = build_grid(c);
     // per-trial state belongs to the old scene
@@ -279,7 +291,7 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     c->d_order = NULL; c->order_bytes = 0;
     memset(&c->grid, 0, sizeof(c->grid));
     c->d_spos = c->d_snrmw = c->d_mpos = c->d_mnrm = c->d_munit = c->d_mpos_raw = c->d_mpos_s = c->d_mnrm_s = NULL;
-    c->d_spix = NULL; c->d_mperm = NULL;
+    c->d_spix = NULL; c->d_mperm = NULL; c->d_scene_mem = NULL; c->scene_cap = 0;
     c->stream = NULL; c->own_stream = NULL; c->aux_stream = NULL;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
@@ -366,7 +378,7 @@ int stocs_ctx_destroy(stocs_ctx* c) {
     if (!c) return STOCS_OK;
     DeviceGuard dev_guard(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->d_spos, c->d_snrmw, c->d_spix, c->d_mpos, c->d_mnrm, c->d_munit, c->d_mpos_raw, c->d_mpos_s,
+    void* ptrs[] = {c->d_scene_mem, c->d_mpos, c->d_mnrm, c->d_munit, c->d_mpos_raw, c->d_mpos_s,
                     c->d_mnrm_s, c->d_mperm, c->index.d_bucket_start,
                     c->index.d_pairs, c->index.d_exists, c->d_scratch, c->d_best, c->d_cand, c->d_order};
     stocs_internal_free_congruent(c);

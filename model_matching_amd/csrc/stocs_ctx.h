@@ -173,6 +173,7 @@ struct stocs_ctx {
     std::vector<int32_t> h_mperm;     // Morton order of the model used by the LCP kernel
 
     // device clouds
+    char* d_scene_mem; size_t scene_cap;   // one grow-only slab for the three scene arrays below (a new frame reuses it)
     float4* d_spos;    // xyz + class prob
     float4* d_snrmw;   // unit normal + class prob weight (what LCP adds, stocs.cpp:1033)
     int2* d_spix;
