@@ -105,8 +105,9 @@ __global__ __launch_bounds__(256) void depth_normals_kernel(const float4* __rest
 }
 
 // pcl::VoxelGrid leaf coordinates floor(p / leaf) (relative to the minimum added on the host)
-__global__ __launch_bounds__(256) void leaf_coords_kernel(const float4* __restrict__ P, int n, double inv_leaf, int3* __restrict__ ijk) {
+__global__ __launch_bounds__(256) void leaf_coords_kernel(const float4* __restrict__ P, int n, double inv_leaf, int3* __restrict__ ijk, int* __restrict__ mm) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < 6) mm[threadIdx.x] = threadIdx.x < 3 ? INT_MAX : INT_MIN;   // for minmax_i3_kernel, which runs after this one
     if (idx >= n) return;
     const float4 p = P[idx];
     ijk[idx] = make_int3((int)floor((double)p.x * inv_leaf), (int)floor((double)p.y * inv_leaf), (int)floor((double)p.z * inv_leaf));
@@ -138,11 +139,17 @@ __global__ __launch_bounds__(256) void seg_start_kernel(const uint32_t* __restri
 #define STOCS_LONG_LEAF 192
 __global__ __launch_bounds__(256) void centroid_kernel(const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ ids, int nv,
                                                        const float4* __restrict__ P, const float4* __restrict__ extra, float4* __restrict__ cen,
-                                                       float4* __restrict__ ext, uint32_t* __restrict__ long_list, uint32_t* __restrict__ n_long) {
+                                                       float4* __restrict__ ext, uint32_t* __restrict__ long_list, uint32_t* __restrict__ n_long,
+                                                       double* __restrict__ long_acc, uint32_t* __restrict__ long_done) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nv) return;
     const uint32_t e0 = seg_start[s], e1 = seg_start[s + 1];
-    if (e1 - e0 > STOCS_LONG_LEAF) { long_list[atomicAdd(n_long, 1u)] = (uint32_t)s; return; }
+    if (e1 - e0 > STOCS_LONG_LEAF) {
+        const uint32_t j = atomicAdd(n_long, 1u);
+        long_list[j] = (uint32_t)s;
+        long_done[j] = 0;
+        return;
+    }
     double sx = 0, sy = 0, sz = 0, ex = 0, ey = 0, ez = 0;
     for (uint32_t e = e0; e < e1; ++e) {
         const float4 p = P[ids[e]];
@@ -153,31 +160,51 @@ __global__ __launch_bounds__(256) void centroid_kernel(const uint32_t* __restric
     cen[s] = make_float4((float)(sx / cnt), (float)(sy / cnt), (float)(sz / cnt), 0.f);
     if (extra) ext[s] = make_float4((float)(ex / cnt), (float)(ey / cnt), (float)(ez / cnt), 0.f);
 }
-// one workgroup per queued leaf: strided partial sums, then a fixed tree (deterministic, whatever order the queue has)
+// Queued leaves (the leaf of the invalid pixels at the origin holds a third of a frame): every workgroup takes a strided
+// share of every queued leaf and writes its partial sums; the workgroup that arrives last adds the partial sums in
+// workgroup order and writes the centroid -- a fixed summation tree whatever the arrival order (deterministic), and equal
+// to the sequential sum whenever that is exact in double (points of one 5 mm leaf: always, short of denormal coordinates).
+#define STOCS_LONG_GROUPS 64
 __global__ __launch_bounds__(256) void centroid_long_kernel(const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ ids,
                                                             const float4* __restrict__ P, const float4* __restrict__ extra, float4* __restrict__ cen,
                                                             float4* __restrict__ ext, const uint32_t* __restrict__ long_list,
-                                                            const uint32_t* __restrict__ n_long) {
-    __shared__ double sh[6][256];
-    for (uint32_t j = blockIdx.x; j < *n_long; j += gridDim.x) {
+                                                            const uint32_t* __restrict__ n_long, double* __restrict__ long_acc,
+                                                            uint32_t* __restrict__ long_done) {
+    __shared__ double sh[6][4];
+    __shared__ uint32_t sh_last;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint32_t j = 0; j < *n_long; ++j) {
         const uint32_t s = long_list[j];
         const uint32_t e0 = seg_start[s], e1 = seg_start[s + 1];
         double v[6] = {0, 0, 0, 0, 0, 0};
-        for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) {
+        for (uint32_t e = e0 + blockIdx.x * 256 + threadIdx.x; e < e1; e += gridDim.x * 256) {
             const float4 p = P[ids[e]];
             v[0] += p.x; v[1] += p.y; v[2] += p.z;
             if (extra) { const float4 q = extra[ids[e]]; v[3] += q.x; v[4] += q.y; v[5] += q.z; }
         }
-        for (int k = 0; k < 6; ++k) sh[k][threadIdx.x] = v[k];
-        __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if ((int)threadIdx.x < off) for (int k = 0; k < 6; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + off];
-            __syncthreads();
+        for (int k = 0; k < 6; ++k) {
+            for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+            if (lane == 0) sh[k][wv] = v[k];
         }
-        if (threadIdx.x == 0) {
+        __syncthreads();
+        if (threadIdx.x < 6)
+            __hip_atomic_store(&long_acc[(6 * (size_t)j + threadIdx.x) * STOCS_LONG_GROUPS + blockIdx.x],
+                               (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) sh_last = atomicAdd(&long_done[j], 1u) == gridDim.x - 1 ? 1u : 0u;
+        __syncthreads();
+        if (sh_last && threadIdx.x == 0) {
+            __threadfence();
             const double cnt = (double)(e1 - e0);
-            cen[s] = make_float4((float)(sh[0][0] / cnt), (float)(sh[1][0] / cnt), (float)(sh[2][0] / cnt), 0.f);
-            if (extra) ext[s] = make_float4((float)(sh[3][0] / cnt), (float)(sh[4][0] / cnt), (float)(sh[5][0] / cnt), 0.f);
+            double a[6];
+            for (int k = 0; k < 6; ++k) {
+                a[k] = 0.0;
+                for (unsigned g = 0; g < gridDim.x; ++g)
+                    a[k] += __hip_atomic_load(&long_acc[(6 * (size_t)j + k) * STOCS_LONG_GROUPS + g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            cen[s] = make_float4((float)(a[0] / cnt), (float)(a[1] / cnt), (float)(a[2] / cnt), 0.f);
+            if (extra) ext[s] = make_float4((float)(a[3] / cnt), (float)(a[4] / cnt), (float)(a[5] / cnt), 0.f);
         }
         __syncthreads();
     }
@@ -304,25 +331,19 @@ struct Buf {   // typed view of workspace memory
 };
 
 // min / max of int3 or of the xyz of float4 over n elements -> out[0..5] (single workgroup; n is a few 10^5)
-__global__ __launch_bounds__(1024) void minmax_i3_kernel(const int3* __restrict__ v, int n, int* __restrict__ out) {
-    __shared__ int sh[6][1024];
+// out[0..2] = min, out[3..5] = max of the leaf coordinates (initialised by leaf_coords_kernel): strided partial results,
+// wavefront reductions, one atomic per wavefront and component
+__global__ __launch_bounds__(256) void minmax_i3_kernel(const int3* __restrict__ v, int n, int* __restrict__ out) {
     int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
-    for (int i = threadIdx.x; i < n; i += 1024) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int3 c = v[i];
         mn[0] = min(mn[0], c.x); mn[1] = min(mn[1], c.y); mn[2] = min(mn[2], c.z);
         mx[0] = max(mx[0], c.x); mx[1] = max(mx[1], c.y); mx[2] = max(mx[2], c.z);
     }
-    for (int k = 0; k < 3; ++k) { sh[k][threadIdx.x] = mn[k]; sh[3 + k][threadIdx.x] = mx[k]; }
-    __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off)
-            for (int k = 0; k < 3; ++k) {
-                sh[k][threadIdx.x] = min(sh[k][threadIdx.x], sh[k][threadIdx.x + off]);
-                sh[3 + k][threadIdx.x] = max(sh[3 + k][threadIdx.x], sh[3 + k][threadIdx.x + off]);
-            }
-        __syncthreads();
-    }
-    if (threadIdx.x < 6) out[threadIdx.x] = sh[threadIdx.x][0];
+    for (int k = 0; k < 3; ++k)
+        for (int off = 32; off > 0; off >>= 1) { mn[k] = min(mn[k], __shfl_xor(mn[k], off, 64)); mx[k] = max(mx[k], __shfl_xor(mx[k], off, 64)); }
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 3; ++k) { atomicMin(&out[k], mn[k]); atomicMax(&out[3 + k], mx[k]); }
 }
 __global__ __launch_bounds__(1024) void minmax_f4_kernel(const float4* __restrict__ v, int n, float* __restrict__ out) {
     __shared__ float sh[6][1024];
@@ -377,8 +398,8 @@ static int voxel_grid_device(const float4* dP, const float4* dExtra, int n, doub
         (rc = seg.alloc(n)) || (rc = mm.alloc(8)))
         return rc;
     const dim3 g((unsigned)((n + 255) / 256));
-    hipLaunchKernelGGL(leaf_coords_kernel, g, dim3(256), 0, st, dP, n, 1.0 / leaf, ijk.p);
-    hipLaunchKernelGGL(minmax_i3_kernel, dim3(1), dim3(1024), 0, st, ijk.p, n, mm.p);
+    hipLaunchKernelGGL(leaf_coords_kernel, g, dim3(256), 0, st, dP, n, 1.0 / leaf, ijk.p, mm.p);
+    hipLaunchKernelGGL(minmax_i3_kernel, dim3(std::min<unsigned>(g.x, 256u)), dim3(256), 0, st, ijk.p, n, mm.p);
     int h6[6];
     STOCS_HIP_CHECK(hipMemcpyAsync(h6, mm.p, sizeof(h6), hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
@@ -400,13 +421,18 @@ static int voxel_grid_device(const float4* dP, const float4* dExtra, int n, doub
     STOCS_HIP_CHECK(hipMemcpyAsync(&last_head, head.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
     const int nv = (int)(last_seg + last_head);
-    Buf<uint32_t> seg_start, long_list, n_long;
-    if ((rc = cen.alloc(nv)) || (rc = ext.alloc(nv)) || (rc = seg_start.alloc((size_t)nv + 1)) || (rc = long_list.alloc(nv)) || (rc = n_long.alloc(2))) return rc;
+    Buf<uint32_t> seg_start, long_list, n_long, long_done;
+    Buf<double> long_acc;
+    const size_t max_long = (size_t)n / STOCS_LONG_LEAF + 1;   // leaves with more than STOCS_LONG_LEAF points each
+    if ((rc = cen.alloc(nv)) || (rc = ext.alloc(nv)) || (rc = seg_start.alloc((size_t)nv + 1)) || (rc = long_list.alloc(nv)) || (rc = n_long.alloc(2)) ||
+        (rc = long_acc.alloc(6 * STOCS_LONG_GROUPS * max_long)) || (rc = long_done.alloc(max_long)))
+        return rc;
     hipLaunchKernelGGL(seg_start_kernel, g, dim3(256), 0, st, head.p, seg.p, n, nv, seg_start.p);
     hipLaunchKernelGGL(zero_u32x2_kernel, dim3(1), dim3(256), 0, st, n_long.p, n_long.p + 1, (size_t)1);
     hipLaunchKernelGGL(centroid_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, seg_start.p, ids_s.p, nv, dP, dExtra, cen.p, ext.p, long_list.p,
-                       n_long.p);
-    hipLaunchKernelGGL(centroid_long_kernel, dim3(256), dim3(256), 0, st, seg_start.p, ids_s.p, dP, dExtra, cen.p, ext.p, long_list.p, n_long.p);
+                       n_long.p, long_acc.p, long_done.p);
+    hipLaunchKernelGGL(centroid_long_kernel, dim3(STOCS_LONG_GROUPS), dim3(256), 0, st, seg_start.p, ids_s.p, dP, dExtra, cen.p, ext.p, long_list.p, n_long.p, long_acc.p,
+                       long_done.p);
     STOCS_HIP_CHECK(hipGetLastError());
     *n_out = nv;
     return STOCS_OK;
