@@ -110,7 +110,7 @@ template <class KeyT>
 __global__ __launch_bounds__(256) void p_records_kernel(const KeyT* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t totP, int cell_bits,
                                                         long long NC, const BaseJob* __restrict__ jobs, const float4* __restrict__ munit,
                                                         const float4* __restrict__ mpos, float nepsilon, float4* __restrict__ prec,
-                                                        uint32_t* __restrict__ cfirst, uint32_t* __restrict__ cend) {
+                                                        uint16_t* __restrict__ pdc, uint32_t* __restrict__ cfirst, uint32_t* __restrict__ cend) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= totP) return;
     const KeyT key = keys[e];
@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void p_records_kernel(const KeyT* __restrict__
         if (nc >= 0 && nc < 343) dc = nc;
     }
     prec[e] = make_float4(ip.x, ip.y, ip.z, __int_as_float(dc));
+    if (pdc) pdc[e] = (uint16_t)dc;
     if (!cfirst || pc == cmask) return;
     const bool first = (e == 0) || keys[e - 1] != key;
     const bool last = (e + 1 == totP) || keys[e + 1] != key;
@@ -141,6 +142,7 @@ struct JoinArgs {
     const float4* munit; const float4* mpos;
     const KeyT* qkeys; const uint32_t* qvals; uint32_t totQ;   // Q entries in (base, cell, index position) order
     const KeyT* pkeys; const uint32_t* pvals; const float4* prec;
+    const uint16_t* pdc;   // direction cells alone when the distance gate of stocs.cpp:854 cannot fail inside a position cell (else NULL)
     const uint32_t* cfirst; const uint32_t* cend; long long NC;
     float nepsilon, half_inv_neps, dist_thr;
     int id_bits, cell_bits;
@@ -238,6 +240,22 @@ __device__ __forceinline__ uint32_t join_one(const JoinArgs<KeyT>& A, uint32_t i
             local++;
         }
     };
+    if (MODE == 0 && A.pdc) {
+        // Counting with the gate out of the way: ||e_Q - e_P||^2 <= epsilon (squared metres against metres, Q1) holds for ANY
+        // two points of one position cell -- the cell edge is below 2 epsilon, so the squared diagonal is below 12 epsilon^2,
+        // and the host enables this path only when that is comfortably below epsilon -- so an entry matches iff its direction
+        // cell is in the cone's set: 2 bytes per entry instead of 16, eight entries per load.
+        const uint16_t* dcs = A.pdc;
+        auto hit = [&](uint32_t dc) { return dc < 343u && ((my[dc >> 5] >> (dc & 31)) & 1u) ? 1u : 0u; };
+        uint32_t k = lo;
+        for (; k < hi && (k & 7u); ++k) local += hit(dcs[k]);
+        for (; k + 8 <= hi; k += 8) {
+            const uint4 v = *(const uint4*)(dcs + k);
+            local += hit(v.x & 0xFFFFu) + hit(v.x >> 16) + hit(v.y & 0xFFFFu) + hit(v.y >> 16) + hit(v.z & 0xFFFFu) + hit(v.z >> 16) + hit(v.w & 0xFFFFu) + hit(v.w >> 16);
+        }
+        for (; k < hi; ++k) local += hit(dcs[k]);
+        return local;
+    }
     uint32_t k = lo;
     for (; k + 4 <= hi; k += 4) {
         const float4 r0 = A.prec[k], r1 = A.prec[k + 1], r2 = A.prec[k + 2], r3 = A.prec[k + 3];
@@ -431,6 +449,8 @@ struct CongruentState {
     DevBuf<uint32_t> d_qoff, d_pvals, d_qvals, d_cfirst, d_cend;
     DevBuf<char> d_pkeys, d_qkeys;   // KeyT arrays (uint32_t, or uint64_t when wide)
     DevBuf<float4> d_prec;
+    DevBuf<uint16_t> d_pdc;
+    bool close_cells = false;     // the distance gate cannot fail inside a position cell: count on direction cells alone
     DevBuf<unsigned long long> d_qoffe;
     DevBuf<int32_t> d_bids;
     DevBuf<unsigned int> d_err;   // picks resolve_picks_kernel could not resolve (internal consistency check)
@@ -444,7 +464,7 @@ struct CongruentState {
         JoinArgs<KeyT> A;
         A.jobs = d_jobs.p; A.q_off = d_qoff.p; A.nB = nB; A.munit = c->d_munit; A.mpos = c->d_mpos;
         A.qkeys = (const KeyT*)d_qkeys.p; A.qvals = d_qvals.p; A.totQ = totQ;
-        A.pkeys = (const KeyT*)d_pkeys.p; A.pvals = d_pvals.p; A.prec = d_prec.p;
+        A.pkeys = (const KeyT*)d_pkeys.p; A.pvals = d_pvals.p; A.prec = d_prec.p; A.pdc = close_cells ? d_pdc.p : NULL;
         A.cfirst = use_table ? d_cfirst.p : NULL; A.cend = use_table ? d_cend.p : NULL; A.NC = NC;
         A.nepsilon = nepsilon; A.half_inv_neps = half_inv_neps; A.dist_thr = c->prm.distance_threshold; A.id_bits = id_bits; A.cell_bits = cell_bits;
         return A;
@@ -547,7 +567,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const std::vector<Segment
     if ((rc = d_up.alloc(up_bytes)) ||
         (rc = d_pk_raw.alloc(totP)) || (rc = d_pv_raw.alloc(totP)) || (rc = d_qk_raw.alloc(totQ)) || (rc = d_qv_raw.alloc(totQ)) ||
         (rc = S->d_pkeys.alloc(totP * sizeof(KeyT))) || (rc = S->d_pvals.alloc(totP)) || (rc = S->d_qkeys.alloc(totQ * sizeof(KeyT))) || (rc = S->d_qvals.alloc(totQ)) ||
-        (rc = S->d_prec.alloc(totP)))
+        (rc = S->d_prec.alloc(totP)) || (rc = S->d_pdc.alloc(((size_t)totP + 15) & ~(size_t)7)))
         return rc;
     {
         char* h = (char*)S->h_stage;
@@ -572,7 +592,11 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const std::vector<Segment
     // the context's auxiliary stream next to the P side (a radix pass of 7 M pairs moves ~1.8 TB/s: two of them share the chip)
     const unsigned end_bit = (unsigned)(S->cell_bits + S->base_bits);
     size_t tb1 = 0, tb2 = 0;
-    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb1, d_pk_raw.p, (KeyT*)S->d_pkeys.p, d_pv_raw.p, S->d_pvals.p, totP, 0, end_bit, st));
+    // P side with the run table: sorted by position cell ALONE.  The gather emits base after base and the sort is stable, so
+    // inside a cell the entries stay grouped by base, in index order inside a base: the runs of (base, cell) are contiguous
+    // all the same, the table finds them wherever they are, and 15 bits are two radix passes where 22 are three.
+    const unsigned end_bit_p = S->use_table ? (unsigned)S->cell_bits : end_bit;
+    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb1, d_pk_raw.p, (KeyT*)S->d_pkeys.p, d_pv_raw.p, S->d_pvals.p, totP, 0, end_bit_p, st));
     STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb2, d_qk_raw.p, (KeyT*)S->d_qkeys.p, d_qv_raw.p, S->d_qvals.p, totQ, 0, end_bit, st));
     DevBuf<char> d_tmp2;
     if ((rc = d_tmp.alloc(tb1)) || (rc = d_tmp2.alloc(tb2))) return rc;
@@ -589,14 +613,15 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const std::vector<Segment
                        S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p);
     STOCS_HIP_CHECK(hipGetLastError());
     // one stable sort per list: (base, position cell); inside a cell the entries keep the index order of the gather
-    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_tmp.p, tb1, d_pk_raw.p, (KeyT*)S->d_pkeys.p, d_pv_raw.p, S->d_pvals.p, totP, 0, end_bit, st));
+    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_tmp.p, tb1, d_pk_raw.p, (KeyT*)S->d_pkeys.p, d_pv_raw.p, S->d_pvals.p, totP, 0, end_bit_p, st));
     if (S->use_table) {
         const size_t ncell = (size_t)(S->NC * nB);
         if ((rc = S->d_cfirst.alloc(ncell)) || (rc = S->d_cend.alloc(ncell))) return rc;
         hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, S->d_cfirst.p, ncell, S->d_cend.p);
     }
     hipLaunchKernelGGL(p_records_kernel<KeyT>, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, (const KeyT*)S->d_pkeys.p, S->d_pvals.p, (uint32_t)totP,
-                       S->cell_bits, S->NC, S->d_jobs.p, c->d_munit, c->d_mpos, S->nepsilon, S->d_prec.p, S->use_table ? S->d_cfirst.p : (uint32_t*)NULL,
+                       S->cell_bits, S->NC, S->d_jobs.p, c->d_munit, c->d_mpos, S->nepsilon, S->d_prec.p, S->close_cells ? S->d_pdc.p : (uint16_t*)NULL,
+                       S->use_table ? S->d_cfirst.p : (uint32_t*)NULL,
                        S->use_table ? S->d_cend.p : (uint32_t*)NULL);
     STOCS_HIP_CHECK(hipGetLastError());
     if (sq != st) STOCS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_join, 0));   // the join needs both sides
@@ -770,6 +795,11 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     S->nB = nB; S->totP = (uint32_t)totP; S->totQ = (uint32_t)totQ; S->nepsilon = nepsilon;
     S->half_inv_neps = (float)(0.5 / (double)nepsilon);
     S->NC = NC; S->use_table = use_table; S->wide = wide;
+    {   // two points of one position cell are at most a cell diagonal apart (cell edge = ratio / egSize < 2 epsilon); the
+        // float roundings of the two world-space points and of the unit-cube coordinates are far below the 1e-5 m allowed for
+        const double cell_world = (double)c->ratio / (double)egSize, diag2 = 3.0 * (cell_world * 1.001 + 1e-5) * (cell_world * 1.001 + 1e-5);
+        S->close_cells = diag2 < 0.999 * (double)c->prm.distance_threshold && !getenv("STOCS_CONGRUENT_DISTANCE_GATE");
+    }
     S->id_bits = id_bits; S->base_bits = base_bits; S->cell_bits = cell_bits;
     int rc = wide ? count_pass<uint64_t>(c, S, psegs, qsegs, jobs, q_off, dbg, tprev) : count_pass<uint32_t>(c, S, psegs, qsegs, jobs, q_off, dbg, tprev);
     if (rc) return rc;

@@ -163,6 +163,27 @@ def test_wide_key_path_of_the_pair_lists(setup, monkeypatch):
         slot += 1
 
 
+def test_distance_gate_path_of_the_count(setup, monkeypatch):
+    """The count pass normally tests direction cells alone: inside one position cell the gate of stocs.cpp:854 (squared
+    metres against epsilon, Q1) cannot fail while 12 epsilon^2 < epsilon.  The general path -- the gate evaluated per
+    (Q, P) test, what a distance threshold beyond 1/12 m would need -- is forced here and must count the same sets."""
+    m, s, est, orc = setup
+    est.L.stocs_clear_bases(est.h)
+    valid, ids, inv = est.sample_bases(77, 24)
+    n_fast = est.find_congruent_all()
+    sizes_fast = [len(est.get_quads(k)) for k in range(int(valid.sum()))]
+    monkeypatch.setenv("STOCS_CONGRUENT_DISTANCE_GATE", "1")
+    n_gate = est.find_congruent_all()
+    assert n_gate == n_fast and n_fast > 0
+    slot = 0
+    for a in range(24):
+        if not valid[a]:
+            continue
+        qo = orc.find_congruent(ids[a], float(inv[a][0]), float(inv[a][1]))
+        assert len(qo) == sizes_fast[slot] and np.array_equal(est.get_quads(slot), qo)
+        slot += 1
+
+
 def test_full_run_equals_oracle_and_recovers_pose(setup, oracle_lib):
     """run_stocs_estimation (stocs_match_one_object.cpp:51-185), class mode, seeded."""
     m, s, est, orc = setup
