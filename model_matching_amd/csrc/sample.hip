@@ -709,9 +709,10 @@ template <> struct InstTypes<true> { typedef uint16_t sv_t; };
 // decayed prior, previous_segment, the segmentation buffer): it is complete once an attempt has its mask.  Points 2..4 of
 // an attempt (stocs.cpp:640-751) read that attempt's survivors only and write nothing a later attempt reads.  So the
 // first workgroup of the grid runs weights -> point 1 -> pass 1 -> mask -> bookkeeping of every attempt and hands the
-// survivors over through device memory (slot + release flag); the last workgroup of the grid picks the slots up (acquire),
-// draws points 2..4 and orders the bases.  The grid is 9 workgroups of which 7 exit at once: workgroups are dealt to the
-// 8 XCDs in turn, so workgroups 0 and 8 normally share an XCD and its L2 (correctness does not depend on it).  The second
+// survivors over through device memory (slot + agent-scope release flag); the second workgroup picks the slots up
+// (acquire), draws points 2..4 and orders the bases.  The two normally sit on neighbouring XCDs with separate L2s;
+// placing them on one XCD (a grid of 9 with 7 idle workgroups, since workgroups are dealt to the XCDs in turn) was
+// measured and made no difference (1.81 against 1.82 ms per 100 attempts), so the grid is just the two.  The second
 // workgroup bounds its wait, so a failure of the first cannot hang the device.
 template <bool WLDS>
 __global__ __launch_bounds__(1024) void instance_attempts_kernel(InstanceArgs A, uint64_t seed, int first_attempt, int n_attempts, float dispersion) {
@@ -728,7 +729,7 @@ __global__ __launch_bounds__(1024) void instance_attempts_kernel(InstanceArgs A,
     sv_t* sv = WLDS ? (sv_t*)(inst_dyn + o_w + (((size_t)S * 4 + 15) & ~(size_t)15)) : (sv_t*)A.sv;   // survivors of pass 1 inside the mask, in scene order
     const float4* spos = A.pa.spos;
     const float4* snrm = A.pa.snrm;
-    if (blockIdx.x != 0 && blockIdx.x + 1 != gridDim.x) return;            // the workgroups in between only steer the placement
+    if (blockIdx.x != 0 && blockIdx.x + 1 != gridDim.x) return;            // (placement experiments launch idle workgroups in between)
     const bool first_role = blockIdx.x == 0;
     unsigned long long tprev = A.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     // the thread index is made opaque at the start of every stage: otherwise the compiler hoists per-thread addresses of
@@ -1202,9 +1203,10 @@ static int sample_instance(stocs_ctx* c, uint64_t seed, int first_attempt, int n
         const void* fn = wlds ? (const void*)instance_attempts_kernel<true> : (const void*)instance_attempts_kernel<false>;
         STOCS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
     }
-    // 9 workgroups: the first and the last do the work and normally land on the same XCD (see the kernel)
-    if (wlds) hipLaunchKernelGGL(instance_attempts_kernel<true>, dim3(9), dim3(1024), lds, c->stream, A, seed, first_attempt, nB, dispersion);
-    else hipLaunchKernelGGL(instance_attempts_kernel<false>, dim3(9), dim3(1024), lds, c->stream, A, seed, first_attempt, nB, dispersion);
+    unsigned n_wg = 2;
+    if (const char* e = getenv("STOCS_INSTANCE_GRID")) n_wg = (unsigned)std::max(2, atoi(e));   // 9: both working workgroups on one XCD (A/B of the placement)
+    if (wlds) hipLaunchKernelGGL(instance_attempts_kernel<true>, dim3(n_wg), dim3(1024), lds, c->stream, A, seed, first_attempt, nB, dispersion);
+    else hipLaunchKernelGGL(instance_attempts_kernel<false>, dim3(n_wg), dim3(1024), lds, c->stream, A, seed, first_attempt, nB, dispersion);
     STOCS_HIP_CHECK(hipGetLastError());
     std::vector<BaseOut> res((size_t)nB);
     I->h_segbits.assign((size_t)I->Sw, 0);
