@@ -8,16 +8,16 @@
 //
 // Class mode: all attempts are independent (every attempt restarts from the class prior,
 // stocs.cpp:373-381), so the whole batch of attempts runs as seven launches: draw, pass 1, draw,
-// pass 2, draw, pass 3, draw.  A pass is one thread per (attempt, scene point): the PPF of
-// (base point, point) -- three double-precision atan2, see stocs_math.h -- one bit test in the
-// dilated existence bitmap of the model index (replaces std::map::find), the geometric tests, and
-// a 4-byte weight write; reads are coalesced float4 loads of the scene SoA.  A draw is one
-// 1024-thread workgroup per attempt: 2^32 fixed-point weights, block scan, binary choice of the
-// owning chunk, i.e. an exact, order-independent replacement of std::discrete_distribution with a
-// counter-based RNG (documented divergence Q6).
+// pass 2, draw, pass 3, draw.  A pass is one thread per (attempt, scene point): the PPF key of
+// (base point, point) -- a float filter in front of the reference's double atan2 arithmetic, see
+// ppf_key_fast below -- one bit test in the dilated existence bitmap of the model index (replaces
+// std::map::find), the geometric tests, and a 4-byte weight write; reads are coalesced float4 loads
+// of the scene SoA.  A draw is one 1024-thread workgroup per attempt: 2^32 fixed-point weights,
+// wavefront scans, i.e. an exact, order-independent replacement of std::discrete_distribution with
+// a counter-based RNG (documented divergence Q6).
 // Instance mode is sequential across attempts by construction (compounding prior decay and the
-// previous segment, stocs.cpp:572-580,626): one persistent workgroup runs all its attempts on the device,
-// image-space flood fill included (instance_attempts_kernel below); the host only reads the results.
+// previous segment, stocs.cpp:572-580,626): one kernel of two pipelined workgroups runs all its attempts
+// on the device, image-space flood fill included (instance_attempts_kernel below); the host only reads the results.
 #include <math.h>
 #include <string.h>
 #include <time.h>

@@ -136,30 +136,6 @@ __global__ __launch_bounds__(256) void compact_candidates_kernel(const float4* _
     base_out[d] = job_base[j];
 }
 
-static int run_jobs(stocs_ctx* c, const std::vector<XformJob>& jobs, std::vector<float>& T, std::vector<float>& P,
-                    std::vector<int32_t>& ok) {
-    const size_t n = jobs.size();
-    T.resize(n * 16); P.resize(n * 16); ok.resize(n);
-    if (n == 0) return STOCS_OK;
-    const size_t jb = ((n * sizeof(XformJob) + 255) / 256) * 256, tb = n * 64, ob = ((n * 4 + 255) / 256) * 256;
-    int rc = ensure_scratch(c, jb + 2 * tb + ob);
-    if (rc) return rc;
-    char* base = (char*)c->d_scratch;
-    XformJob* dJ = (XformJob*)base;
-    float* dT = (float*)(base + jb);
-    float* dP = (float*)(base + jb + tb);
-    int32_t* dO = (int32_t*)(base + jb + 2 * tb);
-    STOCS_HIP_CHECK(hipMemcpyAsync(dJ, jobs.data(), n * sizeof(XformJob), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(rigid_transform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_spos, c->d_mpos,
-                       dJ, (int)n, c->centroid_scene, c->centroid_model, dT, dP, dO);
-    STOCS_HIP_CHECK(hipGetLastError());
-    STOCS_HIP_CHECK(hipMemcpyAsync(T.data(), dT, tb, hipMemcpyDeviceToHost, c->stream));
-    STOCS_HIP_CHECK(hipMemcpyAsync(P.data(), dP, tb, hipMemcpyDeviceToHost, c->stream));
-    STOCS_HIP_CHECK(hipMemcpyAsync(ok.data(), dO, n * 4, hipMemcpyDeviceToHost, c->stream));
-    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
-    return STOCS_OK;
-}
-
 }  // namespace stocs
 
 using namespace stocs;
