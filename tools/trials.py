@@ -66,7 +66,14 @@ def main():
     if mode:
         for est in ests:
             est.set_edge_map(d["edge_map"])
+    # one untimed trial per context sizes its arenas (the only device allocations a context ever makes), as a serving
+    # process would have done long before the trials that count
     for est in ests:
+        est.reset_trial()
+        est.sample_bases(args.seed + 10**6, args.bases, mode=mode, dispersion=0.9)
+        est.find_congruent_all()
+        est.make_transforms(args.max_sets, args.seed + 10**6)
+        est.compute_best_transform()
         est.sync()
     setup_s = time.perf_counter() - t_setup
     if world > 1:
