@@ -339,7 +339,9 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coop_kernel(LcpArgs a, const flo
 // SPLIT: the WPB wavefronts of a workgroup share ONE candidate and take its 64-point steps round-robin (a trial's ~8 000
 // candidates are a single round of wavefronts on the chip, and four times as many, four times shorter wavefronts finish
 // it sooner; big batches lose nothing); the partial sums are integers, so the score is the same bit for bit.
-template <bool DETAIL, int UNR, bool SORTQ = false, int PIPE = 4, bool IDX = true, int WPB = 4, bool FLAT = false, bool SPLIT = false>
+// TILE (tools build, A/B only): the WPB candidates of a workgroup read the model points from a 256-point tile staged in LDS
+// (one global load per point and workgroup instead of one per wavefront), at the price of a workgroup barrier per tile.
+template <bool DETAIL, int UNR, bool SORTQ = false, int PIPE = 4, bool IDX = true, int WPB = 4, bool FLAT = false, bool SPLIT = false, bool TILE = false>
 __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
                                                         int n, int32_t* __restrict__ hit_out, uint8_t* __restrict__ cnt_out) {
     __shared__ float4 qt[WPB][128];     // qx, qy, qz, bits(list offset)
@@ -352,9 +354,9 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
     const int sub = lane & 7, grp = lane >> 3;
     const int w = threadIdx.x >> 6;
     const int cand = SPLIT ? lcp_candidate(a, n, 0, 1) : lcp_candidate(a, n, w, WPB);
-    if (cand < 0) return;   // SPLIT: the whole workgroup leaves together
+    if (cand < 0 && !TILE) return;   // SPLIT: the whole workgroup leaves together; TILE: the wavefront stays for the barriers
     const int first = SPLIT ? 64 * w : 0, stride = SPLIT ? 64 * WPB : 64;
-    const float* T = T16 + (size_t)cand * 16;
+    const float* T = T16 + (size_t)(cand < 0 ? 0 : cand) * 16;
     const float t0 = T[0], t1 = T[1], t2 = T[2], t4 = T[4], t5 = T[5], t6 = T[6], t8 = T[8], t9 = T[9], t10 = T[10],
                 t12 = T[12], t13 = T[13], t14 = T[14];
     unsigned long long acc = 0ull;
@@ -452,16 +454,10 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
         __builtin_amdgcn_wave_barrier();
     };
 
-    // the model point of the NEXT step is requested one step ahead (takes one of the three dependent
-    // loads of the look-up chain off the critical path)
-    float4 p_next = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (first + lane < a.M) p_next = a.mpos[first + lane];
-    for (int base = first; base < a.M; base += stride) {
-        const int i = base + lane;
+    // one 64-point step of this wavefront's candidate: model point p of slot i
+    auto step = [&](const int i, const float4 p) {
         float qx = 0.f, qy = 0.f, qz = 0.f;
         uint32_t off = 0, cnt = 0;
-        const float4 p = p_next;
-        if (i + stride < a.M) p_next = a.mpos[i + stride];
         if (i < a.M) {
             qx = ((t0 * p.x + t4 * p.y) + t8 * p.z) + t12;
             qy = ((t1 * p.x + t5 * p.y) + t9 * p.z) + t13;
@@ -510,6 +506,34 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
                 head += 64;
             }
         }
+    };
+    if (TILE) {
+        __shared__ float4 tile[2][64 * WPB];
+        const int tid = threadIdx.x;
+        tile[0][tid] = tid < a.M ? a.mpos[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+        int buf = 0;
+        for (int tbase = 0; tbase < a.M; tbase += 64 * WPB) {
+            const int nxt = tbase + 64 * WPB + tid;                  // the next tile is requested before this one is worked on
+            const float4 gn = nxt < a.M ? a.mpos[nxt] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cand >= 0)
+                for (int s = 0; s < WPB && tbase + 64 * s < a.M; ++s) step(tbase + 64 * s + lane, tile[buf][64 * s + lane]);
+            tile[buf ^ 1][tid] = gn;
+            __syncthreads();
+            buf ^= 1;
+        }
+        if (cand < 0) return;
+    } else {
+    // the model point of the NEXT step is requested one step ahead (takes one of the three dependent
+    // loads of the look-up chain off the critical path)
+    float4 p_next = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (first + lane < a.M) p_next = a.mpos[first + lane];
+    for (int base = first; base < a.M; base += stride) {
+        const int i = base + lane;
+        const float4 p = p_next;
+        if (i + stride < a.M) p_next = a.mpos[i + stride];
+        step(i, p);
+    }
     }
     if (tail - head > 0) process(tail - head);
     acc = lcp_wave_sum(acc);
@@ -593,7 +617,7 @@ __global__ __launch_bounds__(256) void order_keys_kernel(const float* __restrict
 static bool lcp_variant_selectable(int v) {
     if (v == 99 || v == 0 || v == 15 || v == 24 || v == 31) return true;
 #ifdef STOCS_TOOLS_BUILD
-    static const int extra[] = {1, 9, 16, 17, 20, 25, 26, 27, 28, 30, 32, 33, 40, 44};
+    static const int extra[] = {1, 9, 16, 17, 20, 25, 26, 27, 28, 30, 32, 33, 40, 44, 45, 46};
     for (size_t i = 0; i < sizeof(extra) / sizeof(extra[0]); ++i) if (extra[i] == v) return true;
 #endif
     return false;
@@ -691,6 +715,9 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
             // waves per workgroup (the kernel has no workgroup-wide barrier): 16 / 8 / 4 / 2 / 1 -> 1.83 / 1.62 / 1.51 / 1.51 / 1.475 ms at Cm
             case 40: hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 4, true, 8>), dim3((n + 7) / 8), dim3(512), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); break;
             case 44: STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 4, true, 4>); break;
+            // model tile shared through LDS by the four candidates of a workgroup (45), next to the same workgroup shape without it (46)
+            case 45: if (a.flat) STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 4, true, 4, true, false, true>); else STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 4, true, 4, false, false, true>); break;
+            case 46: if (a.flat) STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 4, true, 4, true>); else STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 4, true, 4>); break;
 #endif
             default: {  // 24
                 const bool flat = a.flat && c->lcp_flat;
