@@ -377,7 +377,7 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
 int stocs_ctx_destroy(stocs_ctx* c) {
     if (!c) return STOCS_OK;
     DeviceGuard dev_guard(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_scene_mem, c->d_mpos, c->d_mnrm, c->d_munit, c->d_mpos_raw, c->d_mpos_s,
                     c->d_mnrm_s, c->d_mperm, c->index.d_bucket_start,
                     c->index.d_pairs, c->index.d_exists, c->d_scratch, c->d_best, c->d_cand, c->d_order};
@@ -385,13 +385,13 @@ int stocs_ctx_destroy(stocs_ctx* c) {
     stocs_internal_free_instance(c);
     c->grid_mem.destroy(); c->grid_ws.destroy();
     if (c->h_pin) (void)hipHostFree(c->h_pin);
-    for (void* p : ptrs) if (p) hipFree(p);
-    hipEventDestroy(c->ev0);
-    hipEventDestroy(c->ev1);
-    hipEventDestroy(c->ev_fork);
-    hipEventDestroy(c->ev_join);
-    if (c->aux_stream) { hipStreamSynchronize(c->aux_stream); hipStreamDestroy(c->aux_stream); }
-    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    (void)hipEventDestroy(c->ev0);
+    (void)hipEventDestroy(c->ev1);
+    (void)hipEventDestroy(c->ev_fork);
+    (void)hipEventDestroy(c->ev_join);
+    if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return STOCS_OK;
 }
