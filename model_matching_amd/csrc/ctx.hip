@@ -164,6 +164,14 @@ static int load_scene(stocs_ctx* c, const float* sp, const float* sn, const floa
                 return STOCS_ERR_INVALID;
             }
     }
+    const bool dbg_t = getenv("STOCS_DEBUG_TIMING") != NULL;
+    struct timespec ts_a; clock_gettime(CLOCK_MONOTONIC, &ts_a);
+    auto lap = [&](const char* what) {
+        if (!dbg_t) return;
+        struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
+        fprintf(stderr, "[stocs scene] %-22s %8.3f ms\n", what, (t.tv_sec - ts_a.tv_sec) * 1e3 + (t.tv_nsec - ts_a.tv_nsec) * 1e-6);
+        ts_a = t;
+    };
     c->nS = nS;
     c->h_spos.resize(nS); c->h_snrm.resize(nS); c->h_sprob.assign(sprob, sprob + nS); c->h_sprob0 = c->h_sprob; c->h_spix.assign((size_t)2 * nS, 0);
     for (int i = 0; i < nS; ++i) {
@@ -178,6 +186,7 @@ static int load_scene(stocs_ctx* c, const float* sp, const float* sn, const floa
     for (int i = 0; i < nS; ++i) c->h_spos[i] = c->h_spos[i] - cs;
     c->centroid_scene = cs;
     free_grid(c);
+    lap("host copies + centroid");
     int rc = STOCS_OK;
     {
         // one slab, grown only when a frame has more points than any before it: a camera stream does no hipMalloc / hipFree
@@ -206,7 +215,9 @@ static int load_scene(stocs_ctx* c, const float* sp, const float* sn, const floa
         STOCS_HIP_CHECK(hipMemcpyAsync(c->d_spix, px.data(), n * 8, hipMemcpyHostToDevice, c->stream));
         STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
+    lap("upload");
     if (!rc) rc = build_grid(c);
+    lap("grid");
     // per-trial state belongs to the old scene
     c->bases.clear(); c->quad_off.clear(); clear_candidates(c);
     c->best_lcp = 0; c->best_index = -1;
