@@ -953,7 +953,9 @@ __global__ __launch_bounds__(1024) void instance_attempts_kernel(InstanceArgs A,
         BaseOut* out = A.res + a;
         if (threadIdx.x == 0) {                                               // bounded wait for the slot (a few seconds at the outside)
             unsigned spins = 0;
-            while (__hip_atomic_load(A.q_flag + a, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            // relaxed polls (a coherent read of the one flag word); the acquire is the fence every thread executes behind the
+            // barrier below -- an acquire per poll would invalidate this XCD's L2 a million times a second under whoever shares it
+            while (__hip_atomic_load(A.q_flag + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                 __builtin_amdgcn_s_sleep(16);
                 if (++spins > (1u << 21)) { sh_abort = 1; break; }
             }
