@@ -3,16 +3,17 @@
 // src/stocs.cpp:1006-1041) and the kd-tree query it calls per model point
 // (reference include/super4pcs/accelerators/kdtree.h:394-459).
 //
-// Mapping: one 64-lane wavefront per candidate transform; the shipped kernels run one wavefront per workgroup
-// (they have no workgroup-wide barrier; 1 / 2 / 4 / 8 / 16 waves per workgroup were measured).
-// The 3x4 transform is wave-uniform (scalar loads -> SGPRs).  Lane l walks the Morton-sorted model
-// points l, l+64, ...: coalesced 16-byte loads, and the 64 queries of one step fall into a handful
-// of neighbouring grid cells, so the brick/cell/list gathers of a wave share cache lines.
-// Per query: transform the point, locate its cell (top -> brick -> cell word), scan that cell's
+// Mapping: one candidate transform per workgroup of four wavefronts, which take the candidate's 64-point steps in turn and
+// add their integer partial sums through LDS at the end (the only barrier); small models run one wavefront per candidate.
+// Several candidates per workgroup, and a model tile shared through LDS, were measured and lost.
+// The 3x4 transform is wave-uniform (scalar loads -> SGPRs).  A lane takes one Morton-sorted model
+// point per step: coalesced 16-byte loads, and the 64 queries of one step fall into a handful
+// of neighbouring grid cells, so the cell/list gathers of a wave share cache lines.
+// Per query: transform the point, locate its cell (one word of the flat cell table, or top -> brick -> cell word), scan that cell's
 // candidate list (every scene point within epsilon of the cell box) for the nearest point with
-// d^2 <= epsilon^2, then the 30-degree normal test as an exact threshold on the dot product, and a
-// wave butterfly reduction of the class-probability weights.  No atomics: results are run-to-run
-// deterministic.
+// d^2 <= epsilon^2, then the 30-degree normal test as an exact threshold on the dot product, and an
+// integer (2^32 fixed-point) sum of the class-probability weights.  No atomics: results are run-to-run
+// deterministic and do not depend on the batch or on how the points are split over wavefronts.
 //
 // Roofline: HBM-read model, algorithmic bytes 68 + 52*|M| per pose.
 #include <stdlib.h>
