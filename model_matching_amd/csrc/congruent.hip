@@ -14,13 +14,15 @@
 //      scalars, exactly the reference's values);
 //   2. gather_key_kernel: the P and Q pair lists of all bases straight out of the device index, each entry with its
 //      32-bit key (base, position cell of its intersection point);
-//   3. ONE 3-pass rocPRIM radix sort per list replaces the pointer grid: a base's P entries and Q entries grouped by
-//      position cell, inside a cell in index order (the sort is stable);
-//   4. p_records_kernel: per P entry a 16-byte record (world-space intersection point, direction cell) and the
-//      per-(base, cell) run table;
-//   5. join, one lane per Q pair in (base, cell) order -- the lanes of a wavefront share P runs and read them
-//      coalesced: cone -> direction-cell bitset in LDS (filtered exact arithmetic, cone_cells.h), one pass over the P
-//      run of the query's cell, |e_Q - e_P|^2 <= epsilon (sic, Q1).  Only the COUNT pass runs here (+ an exclusive scan);
+//   3. ONE stable rocPRIM radix sort per list replaces the pointer grid: the Q entries by (base, position cell) in three
+//      passes; the P entries by position cell alone in two -- the gather is base-major, so the entries of a (base, cell)
+//      stay together, in index order, and the run table finds them;
+//   4. p_records_kernel: per P entry a 16-byte record (world-space intersection point, direction cell), the direction
+//      cell alone as 2 bytes, and the per-(base, cell) run table;
+//   5. join, one lane per Q pair in (base, cell) order: cone -> direction-cell bitset in LDS (filtered exact arithmetic,
+//      cone_cells.h), one pass over the P run of the query's cell, |e_Q - e_P|^2 <= epsilon (sic, Q1) -- a gate that cannot
+//      fail inside one position cell while 12 epsilon^2 < epsilon, in which case the count reads the direction cells
+//      alone.  Only the COUNT pass runs here (+ an exclusive scan);
 //   6. quads are produced on demand: a base with fewer than the per-base maximum is materialised and
 //      radix-sorted into the order of the reference's std::set<pair<P index, Q index>>; a base with
 //      more is only ever sampled, and each sampled rank is resolved by re-running the join of the one Q
