@@ -250,6 +250,15 @@ class StocsEstimator:
     def score_device(self, dT, n, dL):
         capi.check(self.L.stocs_score_transforms_device(self.h, dT, n, dL))
 
+    def get_scene(self):
+        """The scene as the context holds it (stocs_get_scene): centred positions, unit normals, CURRENT class
+        probabilities (instance-mode sampling decays them, Q8), pixels."""
+        pos = np.zeros((self.nS, 3), np.float32); nrm = np.zeros((self.nS, 3), np.float32)
+        prob = np.zeros(self.nS, np.float32); pix = np.zeros((self.nS, 2), np.int32)
+        capi.check(self.L.stocs_get_scene(self.h, pos.ctypes.data_as(capi._fp), nrm.ctypes.data_as(capi._fp), prob.ctypes.data_as(capi._fp),
+                                          pix.ctypes.data_as(capi._ip)))
+        return pos, nrm, prob, pix
+
     def get_segment(self):
         """`segment` of the last instance-mode attempt (stocs_get_segment): scene indices."""
         n = C.c_int(0)

@@ -252,6 +252,45 @@ def test_instance_mode_equals_oracle(oracle_lib):
     assert (orc.scene_class_prob() < s.prob - 1e-6).any()
 
 
+@pytest.mark.parametrize("kind", ["all_edges", "no_edges", "in_between_values", "checkerboard", "one_open_pixel_per_point"])
+def test_instance_mode_degenerate_edge_maps(kind, oracle_lib):
+    """Edge maps at the corners of the flood fill (rgbd.cpp:334-366) and of prune_edge_pixels (stocs.cpp:521-535): every
+    pixel an edge (all weights pruned: every attempt fails at the first draw), no edge at all (one run per row, the disc
+    alone bounds the mask), only in-between values (neither pruned nor passable: masks of one pixel), a checkerboard
+    (diagonal 8-connectivity only, 153 600 runs), passable pixels only under the scene points.  Bases, validity, `segment`
+    and the decayed class probabilities against the oracle."""
+    from model_matching_amd import synth
+    from model_matching_amd.estimator import StocsEstimator
+    m, s, k = synth.workload("tiny")
+    H, W = 480, 640
+    if kind == "all_edges":
+        edge = np.zeros((H, W), np.uint8)
+    elif kind == "no_edges":
+        edge = np.full((H, W), 255, np.uint8)
+    elif kind == "in_between_values":
+        edge = np.full((H, W), 128, np.uint8)
+    elif kind == "checkerboard":
+        edge = np.where((np.add.outer(np.arange(H), np.arange(W)) & 1) == 0, 255, 100).astype(np.uint8)
+    else:
+        edge = np.full((H, W), 60, np.uint8)
+        edge[s.pixel[:, 0], s.pixel[:, 1]] = 255
+    est = StocsEstimator(s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm, build_index=True)
+    orc = oracle_lib.Oracle(s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm, build_index=True)
+    est.set_edge_map(edge); orc.set_edge_map(edge)
+    seed, n = 5, 12
+    valid, ids, inv = est.sample_bases(seed, n, mode=1, dispersion=0.9)
+    for a in range(n):
+        ok, oi, ov = orc.sample_instance_base(seed, a, 0.9, a + 1)
+        assert ok == bool(valid[a]), (kind, a)
+        if ok:
+            assert np.array_equal(oi, ids[a]) and np.array_equal(ov, inv[a]), (kind, a)
+    assert np.array_equal(est.get_segment(), orc.get_segment())
+    assert np.array_equal(est.get_scene()[2], orc.scene_class_prob())       # the decay of the prior (Q8), attempt after attempt
+    if kind == "all_edges":
+        assert not valid.any()
+    est.close()
+
+
 def test_index_file_round_trip(setup, tmp_path):
     """stocs_index_save / stocs_index_load (flat CSR file replacing the Boost archive of rgbd.cpp:156-177)."""
     from model_matching_amd import capi, synth
