@@ -147,6 +147,22 @@ def test_reference_command_line_on_the_example_data(name, tmp_path, oracle_lib):
         assert abs(lcp2 - ro.best_lcp) < 0.02 and lcp2 > 0.05            # another subset of the big bases' sets: a pose of the same quality
 
 
+@pytest.mark.gpu
+def test_facade_batching_is_invisible_to_a_per_call_caller(tmp_path):
+    """tests/cpp/facade_percall_check.cpp: the look-ahead block of class-mode attempts, the one congruent search for all
+    sampled bases and the per-base fallback give exactly what one C-ABI call per reference call gives (second context):
+    130 attempts across the block boundary, searches out of order, a foreign base in between, sampling and searching
+    interleaved."""
+    from model_matching_amd import synth, cloudio
+    m, s, k = synth.workload("tiny")
+    cloudio.write_stcl(tmp_path / "scene.stcl", s.pos, s.nrm, s.prob, s.pixel)
+    cloudio.write_stcl(tmp_path / "model.stcl", m.pos, m.nrm)
+    exe = os.path.join(ROOT, "model_matching_amd", "apps", "facade_percall_check")
+    r = subprocess.run([exe, str(tmp_path / "scene.stcl"), str(tmp_path / "model.stcl")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "mismatches 0" in r.stdout
+
+
 def test_stocs_single_fails_loudly_without_gpu(tmp_path):
     import torch
     if torch.cuda.is_available():
