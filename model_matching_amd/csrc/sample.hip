@@ -544,7 +544,7 @@ static int upload_class_prob(stocs_ctx* c, const SampleBuffers& sb) {
     return STOCS_OK;
 }
 
-static int sample_class(stocs_ctx* c, uint64_t seed, int first_attempt, int nB, int32_t* ids, float* inv, int32_t* valid) {
+static int sample_class_multi(stocs_ctx* c, uint64_t seed, int first_attempt, int nB, int32_t* ids, float* inv, int32_t* valid) {
     SampleBuffers sb;
     int rc = carve(c, nB, &sb);
     if (rc) return rc;
@@ -1019,6 +1019,200 @@ __global__ __launch_bounds__(1024) void instance_attempts_kernel(InstanceArgs A,
 #undef INST_STAMP
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Class mode (stocs.cpp:363-519) in ONE launch: one 1024-thread workgroup per attempt (the attempts are independent) runs
+// weights -> point 1 -> pass 1 -> compaction of the surviving weights -> points 2..4 with their passes over the survivors
+// alone -> ordered base, with the attempt's weights in LDS.  The same stages as the instance kernel without the image-space
+// ones.  A zero weight never changes a draw (the prefix sums are the same and the first index whose inclusive prefix
+// exceeds r is a non-zero one), so drawing among the compacted survivors equals drawing among all points.
+// Replaces nine launches (init, 4 x draw, 3 x pass, finalize) whose passes each walked every scene point of every attempt.
+// ---------------------------------------------------------------------------------------------------------------
+struct ClassArgs {
+    PassArgs pa;
+    const float* cls;           // class probabilities (the prior every attempt starts from, stocs.cpp:372-381)
+    int draw_per_thread;
+    float* w_g; int32_t* sv_g;  // n_attempts x S each: the working set of scenes too large for LDS
+    BaseOut* res;
+};
+
+template <bool WLDS>
+__global__ __launch_bounds__(1024) void class_attempts_kernel(ClassArgs A, uint64_t seed, int first_attempt, int n_attempts) {
+    typedef typename InstTypes<WLDS>::sv_t sv_t;
+    extern __shared__ __align__(16) unsigned char cls_dyn[];
+    __shared__ uint64_t sh16[32];
+    __shared__ int sh_pick[2];
+    __shared__ int sh_ncand;
+    __shared__ int sh_cnt[64], sh_cex[65];
+    const int a = blockIdx.x;
+    if (a >= n_attempts) return;
+    const int S = A.pa.S, attempt = first_attempt + a;
+    float* w = WLDS ? (float*)cls_dyn : A.w_g + (size_t)a * S;
+    sv_t* sv = WLDS ? (sv_t*)(cls_dyn + (((size_t)S * 4 + 15) & ~(size_t)15)) : (sv_t*)(A.sv_g + (size_t)a * S);
+    const float4* spos = A.pa.spos;
+    const float4* snrm = A.pa.snrm;
+    BaseOut* out = A.res + a;
+    int32_t bidx[4] = {-1, -1, -1, -1};
+    int fail = 0;
+#define CLS_THREAD() int t = threadIdx.x; asm volatile("" : "+v"(t)); const int lane = t & 63, wv = t >> 6; (void)lane; (void)wv;
+    // ---- "every base will start from the prior" (stocs.cpp:372-381) ----
+    {
+        CLS_THREAD()
+        for (int i = t; i < S; i += 1024) w[i] = A.cls[i];
+        if (t == 0) sh_ncand = 0;
+    }
+    __syncthreads();
+    bidx[0] = draw_block_fast(w, S, rng64(seed, (uint64_t)attempt, 0), sh16, sh_pick, 0, A.draw_per_thread);
+    if (bidx[0] < 0) fail = 1;   // "FAILED SAMPLING:: Zero probability returned" (:386-389); the same in every thread
+    int n_surv = 0;
+    if (!fail) {
+        // ---- pass 1 (stocs.cpp:395-407), distance first: only the points that can have a key at all get their angles ----
+        const int b1 = bidx[0];
+        const float4 pc4 = spos[b1], nc4 = snrm[b1];
+        const V3 pc = mk3(pc4.x, pc4.y, pc4.z), nc = mk3(nc4.x, nc4.y, nc4.z);
+        {
+            CLS_THREAD()
+            for (int i0 = 0; i0 < S; i0 += 4096) {
+                float wi[4]; float4 P[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + k * 1024 + t;
+                    wi[k] = (i < S) ? w[i] : 0.0f;
+                    P[k] = make_float4(0, 0, 0, 0);
+                    if (wi[k] != 0.0f) P[k] = spos[i];
+                }
+                bool cand[4];
+                unsigned long long cm[4];
+                int n_here = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + k * 1024 + t;
+                    cand[k] = false;
+                    if (wi[k] != 0.0f) {
+                        cand[k] = i != b1 && ppf_distance_may_have_key(A.pa.ix, pc - mk3(P[k].x, P[k].y, P[k].z));
+                        if (!cand[k]) w[i] = 0.0f;
+                    }
+                    cm[k] = __ballot(cand[k]);
+                    n_here += __popcll(cm[k]);
+                }
+                int base_pos = 0;
+                if (lane == 0 && n_here) base_pos = atomicAdd(&sh_ncand, n_here);
+                base_pos = __builtin_amdgcn_readfirstlane(base_pos);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (cand[k]) sv[base_pos + __popcll(cm[k] & ((1ull << lane) - 1ull))] = (sv_t)(i0 + k * 1024 + t);
+                    base_pos += __popcll(cm[k]);
+                }
+            }
+        }
+        __syncthreads();
+        {
+            CLS_THREAD()
+            const int n_cand = sh_ncand;
+            for (int j0 = 0; j0 < n_cand; j0 += 2048) {
+                int ii[2]; float4 P[2], N[2]; uint32_t key[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int j = j0 + k * 1024 + t;
+                    ii[k] = -1; P[k] = make_float4(0, 0, 0, 0); N[k] = P[k];
+                    if (j < n_cand) { ii[k] = (int)sv[j]; P[k] = spos[ii[k]]; N[k] = snrm[ii[k]]; }
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    key[k] = PPF_NO_KEY;
+                    if (ii[k] >= 0) key[k] = ppf_key_device(A.pa.ix, pc, nc, mk3(P[k].x, P[k].y, P[k].z), mk3(N[k].x, N[k].y, N[k].z));
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (ii[k] >= 0 && !ppf_key_present(A.pa.ix, key[k])) w[ii[k]] = 0.0f;
+            }
+        }
+        __syncthreads();
+        // ---- the surviving weights compacted in scene order, in place (position <= index) ----
+        {
+            CLS_THREAD()
+            for (int i0 = 0; i0 < S; i0 += 4096) {
+                float wi[4];
+                unsigned long long sbal[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + k * 1024 + t;
+                    wi[k] = (i < S) ? w[i] : 0.0f;
+                    sbal[k] = __ballot(wi[k] != 0.0f);
+                    if (lane == 0) sh_cnt[k * 16 + wv] = __popcll(sbal[k]);
+                }
+                __syncthreads();
+                if (wv == 0) {
+                    const int v = sh_cnt[lane];
+                    int inc = v;
+                    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+                    sh_cex[lane] = inc - v;
+                    if (lane == 63) sh_cex[64] = inc;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (wi[k] != 0.0f) {
+                        const int pos = n_surv + sh_cex[k * 16 + wv] + __popcll(sbal[k] & ((1ull << lane) - 1ull));
+                        sv[pos] = (sv_t)(i0 + k * 1024 + t); w[pos] = wi[k];
+                    }
+                n_surv += sh_cex[64];
+                __syncthreads();
+            }
+        }
+        // ---- points 2..4 (stocs.cpp:410-505) over the survivors ----
+        for (int k = 1; k < 4 && !fail; ++k) {
+            CLS_THREAD()
+            const int pos = draw_block_fast(w, n_surv, rng64(seed, (uint64_t)attempt, (uint64_t)k), sh16, sh_pick, k & 1, A.draw_per_thread);
+            if (pos < 0) { fail = 1; break; }
+            bidx[k] = (int32_t)sv[pos];
+            if (k < 3) {
+                for (int j = t; j < n_surv; j += 1024) {
+                    if (w[j] == 0.0f) continue;                               // already zero: nothing to decide
+                    const int i = (int)sv[j];
+                    const bool z = (k == 1) ? pass_zeroes<2>(A.pa, bidx[0], bidx[1], -1, i) : pass_zeroes<3>(A.pa, bidx[0], bidx[1], bidx[2], i);
+                    if (z) w[j] = 0.0f;
+                }
+                __syncthreads();
+            }
+        }
+    }
+#undef CLS_THREAD
+    if (threadIdx.x < 64) finalize_one_wave_call(A.pa.spos, bidx[0], bidx[1], bidx[2], bidx[3], fail, out);
+}
+
+// class mode through the one-launch kernel; scenes beyond the LDS working set keep it in device memory (same code)
+static int sample_class(stocs_ctx* c, uint64_t seed, int first_attempt, int nB, int32_t* ids, float* inv, int32_t* valid) {
+    if (getenv("STOCS_CLASS_MULTI_KERNEL")) return sample_class_multi(c, seed, first_attempt, nB, ids, inv, valid);   // the nine-launch form (A/B)
+    const size_t S = (size_t)c->nS;
+    const bool wlds = S <= 26000 && !getenv("STOCS_INSTANCE_NO_LDS");        // 6 bytes per point of the 160 KB
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t b_res = al((size_t)nB * sizeof(BaseOut)), b_cls = al(S * 4), b_w = wlds ? 0 : al((size_t)nB * S * 4), b_sv = wlds ? 0 : al((size_t)nB * S * 4);
+    int rc = ensure_scratch(c, b_res + b_cls + b_w + b_sv);
+    if (rc) return rc;
+    char* p = (char*)c->d_scratch;
+    ClassArgs A;
+    A.pa = pass_args(c);
+    A.res = (BaseOut*)p; p += b_res;
+    float* d_cls = (float*)p; p += b_cls;
+    A.cls = d_cls;
+    A.w_g = (float*)p; p += b_w;
+    A.sv_g = (int32_t*)p;
+    A.draw_per_thread = 2;
+    STOCS_HIP_CHECK(hipMemcpyAsync(d_cls, c->h_sprob.data(), S * 4, hipMemcpyHostToDevice, c->stream));
+    const size_t lds = wlds ? ((S * 4 + 15) & ~(size_t)15) + S * 2 + 16 : 0;
+    if (wlds) {
+        STOCS_HIP_CHECK(hipFuncSetAttribute((const void*)class_attempts_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+        hipLaunchKernelGGL(class_attempts_kernel<true>, dim3((unsigned)nB), dim3(1024), lds, c->stream, A, seed, first_attempt, nB);
+    } else {
+        hipLaunchKernelGGL(class_attempts_kernel<false>, dim3((unsigned)nB), dim3(1024), 0, c->stream, A, seed, first_attempt, nB);
+    }
+    STOCS_HIP_CHECK(hipGetLastError());
+    std::vector<BaseOut> res((size_t)nB);
+    STOCS_HIP_CHECK(hipMemcpyAsync(res.data(), A.res, (size_t)nB * sizeof(BaseOut), hipMemcpyDeviceToHost, c->stream));
+    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return record_bases(c, nB, res.data(), ids, inv, valid);
+}
 
 static int refresh_class_prob_on_device(stocs_ctx* c) {
     // the LCP adds class_probability_, which instance-mode sampling decays in place (Q8)

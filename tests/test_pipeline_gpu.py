@@ -83,7 +83,15 @@ def test_draw_equals_oracle(setup, oracle_lib):
     assert est.draw(z, 12345) == -1
 
 
-def test_class_bases_equal_oracle(setup):
+@pytest.mark.parametrize("path", ["one_launch_lds", "one_launch_device_memory", "nine_launches"])
+def test_class_bases_equal_oracle(setup, path, monkeypatch):
+    """sample_class_base (stocs.cpp:363-519): the one-launch kernel with the attempt's weights in LDS (the default up to
+    26 000 scene points), the same kernel on device memory (larger scenes; forced here), and the nine-launch form kept for
+    A/B -- bases and invariants bit for bit against the oracle."""
+    if path == "one_launch_device_memory":
+        monkeypatch.setenv("STOCS_INSTANCE_NO_LDS", "1")
+    if path == "nine_launches":
+        monkeypatch.setenv("STOCS_CLASS_MULTI_KERNEL", "1")
     m, s, est, orc = setup
     seed, n = 4242, 40
     valid, ids, inv = est.sample_bases(seed, n)
