@@ -597,7 +597,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const std::vector<Segment
     // P side with the run table: sorted by position cell ALONE.  The gather emits base after base and the sort is stable, so
     // inside a cell the entries stay grouped by base, in index order inside a base: the runs of (base, cell) are contiguous
     // all the same, the table finds them wherever they are, and 15 bits are two radix passes where 22 are three.
-    const unsigned end_bit_p = S->use_table ? (unsigned)S->cell_bits : end_bit;
+    const unsigned end_bit_p = (S->use_table && !getenv("STOCS_CONGRUENT_P_FULLSORT")) ? (unsigned)S->cell_bits : end_bit;
     STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb1, d_pk_raw.p, (KeyT*)S->d_pkeys.p, d_pv_raw.p, S->d_pvals.p, totP, 0, end_bit_p, st));
     STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb2, d_qk_raw.p, (KeyT*)S->d_qkeys.p, d_qv_raw.p, S->d_qvals.p, totQ, 0, end_bit, st));
     DevBuf<char> d_tmp2;
