@@ -269,8 +269,8 @@ __device__ __forceinline__ uint32_t join_one(const JoinArgs<KeyT>& A, uint32_t i
 
 // workgroup prologue of the join kernels: cone tables of the first JOIN_LDS_BASES bases of the workgroup's entries
 template <class KeyT>
-__device__ __forceinline__ uint32_t join_stage_tables(const JoinArgs<KeyT>& A, JoinLds& lds) {
-    const uint32_t i0 = blockIdx.x * blockDim.x;
+__device__ __forceinline__ uint32_t join_stage_tables(const JoinArgs<KeyT>& A, JoinLds& lds, uint32_t i0 = 0xFFFFFFFFu) {
+    if (i0 == 0xFFFFFFFFu) i0 = blockIdx.x * blockDim.x;
     const uint32_t b0 = (uint32_t)(A.qkeys[i0] >> A.cell_bits);   // i0 < totQ for every launched workgroup
     for (int t = threadIdx.x; t < JOIN_LDS_BASES * STOCS_MAX_CONE; t += blockDim.x) {
         const uint32_t b = b0 + (uint32_t)(t / STOCS_MAX_CONE);
@@ -299,15 +299,18 @@ __global__ __launch_bounds__(256) void join_count_kernel(JoinArgs<KeyT> A, unsig
     qcnt[i] = join_one<0>(A, i, lds, b0, (uint64_t*)NULL);
 }
 
-// fill pass for the bases whose out_base is not ~0: destinations from the exclusive scan of the counts (no atomics);
-// Q entries without matches leave at once, so materialising a few small bases costs one sweep over the offsets
+// fill pass for the bases whose out_base is not ~0: destinations from the exclusive scan of the counts (no atomics).
+// `blocks` lists, per workgroup, the (first, end) Q entries it takes: only the Q ranges of the selected bases are walked
+// (a trial materialises a handful of small bases out of a hundred: the sweep over all Q entries was 50 us at Cm).
 template <class KeyT>
 __global__ __launch_bounds__(256) void join_fill_kernel(JoinArgs<KeyT> A, const unsigned long long* __restrict__ qoffe,
-                                                        const unsigned long long* __restrict__ out_base, uint64_t* __restrict__ quads) {
+                                                        const unsigned long long* __restrict__ out_base, uint64_t* __restrict__ quads,
+                                                        const uint2* __restrict__ blocks) {
     __shared__ JoinLds lds;
-    const uint32_t b0 = join_stage_tables(A, lds);
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A.totQ) return;
+    const uint2 range = blocks[blockIdx.x];
+    const uint32_t b0 = join_stage_tables(A, lds, range.x);
+    const uint32_t i = range.x + threadIdx.x;
+    if (i >= range.y) return;
     const uint32_t b = (uint32_t)(A.qkeys[i] >> A.cell_bits);
     const unsigned long long ob = out_base[b];
     if (ob == ~0ull) return;
@@ -459,6 +462,8 @@ struct CongruentState {
     // host sources of asynchronous uploads issued by materialise / make_jobs: kept here so that they outlive the copy
     // (those calls return without synchronising; the caller's own synchronisation point comes before the next reuse)
     std::vector<unsigned long long> h_out_base, h_off;
+    std::vector<uint32_t> h_qoff;          // Q range of every base (host copy of d_qoff)
+    std::vector<uint2> h_blocks;           // workgroup -> Q range of the last materialise
     void* h_stage = NULL;         // pinned staging of the per-trial tables (one upload per trial)
     size_t stage_bytes = 0;
     template <class KeyT>
@@ -490,11 +495,18 @@ static int materialise_t(stocs_ctx* c, CongruentState* S, const std::vector<char
     if (tot == 0) return STOCS_OK;
     if (tot > (1ull << 31)) { set_error("%llu congruent quads requested at once: more than 2^31, refusing to materialise them", tot); return STOCS_ERR_CAPACITY; }
     hipStream_t st = c->stream;
-    DevBuf<unsigned long long> d_ob; DevBuf<uint64_t> d_raw; DevBuf<char> d_tmp;
+    DevBuf<unsigned long long> d_ob; DevBuf<uint64_t> d_raw; DevBuf<char> d_tmp; DevBuf<uint2> d_blocks;
+    std::vector<uint2>& blocks = S->h_blocks;
+    blocks.clear();
+    for (int b = 0; b < nB; ++b)
+        if (sel[b] && c->quad_off[b + 1] > c->quad_off[b])
+            for (uint32_t i0 = S->h_qoff[b]; i0 < S->h_qoff[b + 1]; i0 += 256) blocks.push_back(make_uint2(i0, std::min(i0 + 256u, S->h_qoff[b + 1])));
     int rc;
-    if ((rc = d_ob.alloc(nB)) || (rc = d_raw.alloc(tot)) || (rc = out->alloc(tot))) return rc;
+    if ((rc = d_ob.alloc(nB)) || (rc = d_raw.alloc(tot)) || (rc = out->alloc(tot)) || (rc = d_blocks.alloc(std::max<size_t>(blocks.size(), 1)))) return rc;
     STOCS_HIP_CHECK(hipMemcpyAsync(d_ob.p, out_base.data(), 8 * (size_t)nB, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(join_fill_kernel<KeyT>, dim3((unsigned)((S->totQ + 255) / 256)), dim3(256), 0, st, S->args<KeyT>(c), S->d_qoffe.p, d_ob.p, d_raw.p);
+    STOCS_HIP_CHECK(hipMemcpyAsync(d_blocks.p, blocks.data(), sizeof(uint2) * blocks.size(), hipMemcpyHostToDevice, st));
+    if (!blocks.empty())
+        hipLaunchKernelGGL(join_fill_kernel<KeyT>, dim3((unsigned)blocks.size()), dim3(256), 0, st, S->args<KeyT>(c), S->d_qoffe.p, d_ob.p, d_raw.p, d_blocks.p);
     STOCS_HIP_CHECK(hipGetLastError());
     size_t tmp = 0;
     const unsigned end_bit = (unsigned)(4 * S->id_bits + S->base_bits);
@@ -577,6 +589,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const std::vector<Segment
         memcpy(h + o_pseg, psegs.data(), sizeof(Segment) * psegs.size());
         memcpy(h + o_qseg, qsegs.data(), sizeof(Segment) * qsegs.size());
         memcpy(h + o_qoff, q_off.data(), 4 * (size_t)(nB + 1));
+        S->h_qoff = q_off;
         int32_t* bids = (int32_t*)(h + o_bids);
         for (int b = 0; b < nB; ++b) for (int k = 0; k < 4; ++k) bids[4 * b + k] = c->bases[b].ids[k];
         memset(h + o_err, 0, 256);
