@@ -1030,8 +1030,7 @@ __global__ __launch_bounds__(1024) void instance_attempts_kernel(InstanceArgs A,
 // ---------------------------------------------------------------------------------------------------------------
 struct ClassArgs {
     PassArgs pa;
-    const float* cls;           // class probabilities (the prior every attempt starts from, stocs.cpp:372-381)
-    int draw_per_thread;
+    int draw_per_thread;        // (the prior every attempt starts from, stocs.cpp:372-381, is the .w of the scene positions)
     float* w_g; int32_t* sv_g;  // n_attempts x S each: the working set of scenes too large for LDS
     BaseOut* res;
 };
@@ -1058,7 +1057,7 @@ __global__ __launch_bounds__(1024) void class_attempts_kernel(ClassArgs A, uint6
     // ---- "every base will start from the prior" (stocs.cpp:372-381) ----
     {
         CLS_THREAD()
-        for (int i = t; i < S; i += 1024) w[i] = A.cls[i];
+        for (int i = t; i < S; i += 1024) w[i] = spos[i].w;             // the class probability travels with the scene arrays (what the LCP adds, Q8)
         if (t == 0) sh_ncand = 0;
     }
     __syncthreads();
@@ -1187,19 +1186,16 @@ static int sample_class(stocs_ctx* c, uint64_t seed, int first_attempt, int nB, 
     const size_t S = (size_t)c->nS;
     const bool wlds = S <= 26000 && !getenv("STOCS_INSTANCE_NO_LDS");        // 6 bytes per point of the 160 KB
     auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-    const size_t b_res = al((size_t)nB * sizeof(BaseOut)), b_cls = al(S * 4), b_w = wlds ? 0 : al((size_t)nB * S * 4), b_sv = wlds ? 0 : al((size_t)nB * S * 4);
-    int rc = ensure_scratch(c, b_res + b_cls + b_w + b_sv);
+    const size_t b_res = al((size_t)nB * sizeof(BaseOut)), b_w = wlds ? 0 : al((size_t)nB * S * 4), b_sv = wlds ? 0 : al((size_t)nB * S * 4);
+    int rc = ensure_scratch(c, b_res + b_w + b_sv);
     if (rc) return rc;
     char* p = (char*)c->d_scratch;
     ClassArgs A;
     A.pa = pass_args(c);
     A.res = (BaseOut*)p; p += b_res;
-    float* d_cls = (float*)p; p += b_cls;
-    A.cls = d_cls;
     A.w_g = (float*)p; p += b_w;
     A.sv_g = (int32_t*)p;
     A.draw_per_thread = 2;
-    STOCS_HIP_CHECK(hipMemcpyAsync(d_cls, c->h_sprob.data(), S * 4, hipMemcpyHostToDevice, c->stream));
     const size_t lds = wlds ? ((S * 4 + 15) & ~(size_t)15) + S * 2 + 16 : 0;
     if (wlds) {
         STOCS_HIP_CHECK(hipFuncSetAttribute((const void*)class_attempts_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
