@@ -1033,6 +1033,7 @@ struct ClassArgs {
     int draw_per_thread;        // (the prior every attempt starts from, stocs.cpp:372-381, is the .w of the scene positions)
     float* w_g; int32_t* sv_g;  // n_attempts x S each: the working set of scenes too large for LDS
     BaseOut* res;
+    unsigned long long* stamps; // STOCS_DEBUG_TIMING only: cycles per stage of the first workgroup (else NULL)
 };
 
 template <bool WLDS>
@@ -1054,14 +1055,24 @@ __global__ __launch_bounds__(1024) void class_attempts_kernel(ClassArgs A, uint6
     int32_t bidx[4] = {-1, -1, -1, -1};
     int fail = 0;
 #define CLS_THREAD() int t = threadIdx.x; asm volatile("" : "+v"(t)); const int lane = t & 63, wv = t >> 6; (void)lane; (void)wv;
+    unsigned long long tprev = A.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+#define CLS_STAMP(k) if (A.stamps && blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); A.stamps[k] = now_ - tprev; tprev = now_; }
     // ---- "every base will start from the prior" (stocs.cpp:372-381) ----
     {
         CLS_THREAD()
-        for (int i = t; i < S; i += 1024) w[i] = spos[i].w;             // the class probability travels with the scene arrays (what the LCP adds, Q8)
+        for (int i0 = 0; i0 < S; i0 += 8192) {                          // the class probability travels with the scene arrays (what the LCP adds, Q8)
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int i = i0 + k * 1024 + t; v[k] = i < S ? spos[i].w : 0.0f; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int i = i0 + k * 1024 + t; if (i < S) w[i] = v[k]; }
+        }
         if (t == 0) sh_ncand = 0;
     }
     __syncthreads();
+    CLS_STAMP(0)
     bidx[0] = draw_block_fast(w, S, rng64(seed, (uint64_t)attempt, 0), sh16, sh_pick, 0, A.draw_per_thread);
+    CLS_STAMP(1)
     if (bidx[0] < 0) fail = 1;   // "FAILED SAMPLING:: Zero probability returned" (:386-389); the same in every thread
     int n_surv = 0;
     if (!fail) {
@@ -1105,9 +1116,11 @@ __global__ __launch_bounds__(1024) void class_attempts_kernel(ClassArgs A, uint6
             }
         }
         __syncthreads();
+        CLS_STAMP(2)
         {
             CLS_THREAD()
             const int n_cand = sh_ncand;
+            if (A.stamps && blockIdx.x == 0 && t == 0) A.stamps[8] = (unsigned long long)n_cand;
             for (int j0 = 0; j0 < n_cand; j0 += 2048) {
                 int ii[2]; float4 P[2], N[2]; uint32_t key[2];
 #pragma unroll
@@ -1127,6 +1140,7 @@ __global__ __launch_bounds__(1024) void class_attempts_kernel(ClassArgs A, uint6
             }
         }
         __syncthreads();
+        CLS_STAMP(3)
         // ---- the surviving weights compacted in scene order, in place (position <= index) ----
         {
             CLS_THREAD()
@@ -1159,6 +1173,8 @@ __global__ __launch_bounds__(1024) void class_attempts_kernel(ClassArgs A, uint6
                 __syncthreads();
             }
         }
+        CLS_STAMP(4)
+        if (A.stamps && blockIdx.x == 0 && threadIdx.x == 0) A.stamps[9] = (unsigned long long)n_surv;
         // ---- points 2..4 (stocs.cpp:410-505) over the survivors ----
         for (int k = 1; k < 4 && !fail; ++k) {
             CLS_THREAD()
@@ -1177,7 +1193,10 @@ __global__ __launch_bounds__(1024) void class_attempts_kernel(ClassArgs A, uint6
         }
     }
 #undef CLS_THREAD
+    CLS_STAMP(5)
     if (threadIdx.x < 64) finalize_one_wave_call(A.pa.spos, bidx[0], bidx[1], bidx[2], bidx[3], fail, out);
+    CLS_STAMP(6)
+#undef CLS_STAMP
 }
 
 // class mode through the one-launch kernel; scenes beyond the LDS working set keep it in device memory (same code)
@@ -1196,6 +1215,16 @@ static int sample_class(stocs_ctx* c, uint64_t seed, int first_attempt, int nB, 
     A.w_g = (float*)p; p += b_w;
     A.sv_g = (int32_t*)p;
     A.draw_per_thread = 2;
+    const bool dbg = getenv("STOCS_DEBUG_TIMING") != NULL;
+    A.stamps = NULL;
+    if (dbg) {   // behind everything else in the scratch area
+        rc = ensure_scratch(c, b_res + b_w + b_sv + 256);
+        if (rc) return rc;
+        p = (char*)c->d_scratch;
+        A.res = (BaseOut*)p; A.w_g = (float*)(p + b_res); A.sv_g = (int32_t*)(p + b_res + b_w);
+        A.stamps = (unsigned long long*)(p + b_res + b_w + b_sv);
+        STOCS_HIP_CHECK(hipMemsetAsync(A.stamps, 0, 128, c->stream));
+    }
     const size_t lds = wlds ? ((S * 4 + 15) & ~(size_t)15) + S * 2 + 16 : 0;
     if (wlds) {
         STOCS_HIP_CHECK(hipFuncSetAttribute((const void*)class_attempts_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
@@ -1207,6 +1236,12 @@ static int sample_class(stocs_ctx* c, uint64_t seed, int first_attempt, int nB, 
     std::vector<BaseOut> res((size_t)nB);
     STOCS_HIP_CHECK(hipMemcpyAsync(res.data(), A.res, (size_t)nB * sizeof(BaseOut), hipMemcpyDeviceToHost, c->stream));
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (dbg) {
+        unsigned long long st[16];
+        STOCS_HIP_CHECK(hipMemcpy(st, A.stamps, 128, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[stocs class] first attempt, shader cycles: prior %llu | draw 1 %llu | pass 1 distances %llu (%llu of %d in range) | pass 1 angles %llu | compaction %llu (%llu survivors) | points 2-4 %llu | ordered base %llu\n",
+                st[0], st[1], st[2], st[8], c->nS, st[3], st[4], st[9], st[5], st[6]);
+    }
     return record_bases(c, nB, res.data(), ids, inv, valid);
 }
 
