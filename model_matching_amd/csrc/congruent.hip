@@ -60,6 +60,90 @@ struct Segment { uint32_t src, len, dst, base; };
 
 __device__ __forceinline__ V3 ld3c(const float4* a, int i) { const float4 v = a[i]; return mk3(v.x, v.y, v.z); }
 
+// ---- planning of the lookups on the device (what plan_lookup of ppf_index.hip does per key on the host) ----
+// Totals and array sizes of a trial's pair lists, read back by the host (the only thing it needs before it can size the sorts)
+struct PlanOut { unsigned long long totP, totQ; uint32_t n_pseg, n_qseg, overflow, pad; };
+
+// One 64-lane workgroup per (base, list): the PPF key of the base's point pair (stocs.cpp:771-772, the reference's double
+// arithmetic), its 128 probes of the bucket table in ASCENDING key order -- F = K - o with o0 in {-tr, 0}, ok in
+// {-2 rot, -rot, 0, rot}, rgbd.cpp:130-137 read from the query side -- two per lane, then lane 0 merges adjacent buckets
+// into ranges exactly as plan_lookup does: the gathered list is in index order.
+__global__ __launch_bounds__(64) void plan_ranges_kernel(const uint32_t* __restrict__ bucket_start, int tr, int rot, int NA, int nD,
+                                                         const int32_t* __restrict__ bids, const float4* __restrict__ spos, const float4* __restrict__ snrm,
+                                                         int nB, uint2* __restrict__ ranges, uint32_t* __restrict__ n_ranges, uint32_t* __restrict__ totals) {
+    __shared__ uint32_t ss[128], se[128];
+    const int b = blockIdx.x, list = blockIdx.y, lane = threadIdx.x;
+    const int i0 = bids[4 * b + 2 * list], i1 = bids[4 * b + 2 * list + 1];
+    int K[4];
+    ppf_compute(ld3c(spos, i0), ld3c(snrm, i0), ld3c(spos, i1), ld3c(snrm, i1), tr, rot, K);
+    const bool valid = !(K[0] <= 5 || K[1] < 0 || K[2] < 0 || K[3] < 0) && !(K[0] % tr || K[1] % rot || K[2] % rot || K[3] % rot);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int p = lane + 64 * h;                              // probe number in visiting order: a, then F1, F2, F3 ascending
+        const int a = p >> 6, bi = (p >> 4) & 3, ci = (p >> 2) & 3, di = p & 3;
+        const int F0 = K[0] + a * tr, F1 = K[1] + (bi - 1) * rot, F2 = K[2] + (ci - 1) * rot, F3 = K[3] + (di - 1) * rot;
+        uint32_t s0 = 0, e0 = 0;
+        if (valid && F1 >= 0 && F2 >= 0 && F3 >= 0) {
+            const int fd = F0 / tr, f1 = F1 / rot, f2 = F2 / rot, f3 = F3 / rot;
+            if (fd < nD && f1 < NA && f2 < NA && f3 < NA) {
+                const uint32_t key = ppf_pack(fd, f1, f2, f3, NA);
+                s0 = bucket_start[key]; e0 = bucket_start[key + 1];
+                if (e0 <= s0) { s0 = 0; e0 = 0; }
+            }
+        }
+        ss[p] = s0; se[p] = e0;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        uint2* out = ranges + ((size_t)list * nB + b) * 128;
+        uint32_t n = 0, total = 0, cs = 0, ce = 0;
+        for (int p = 0; p < 128; ++p) {
+            const uint32_t s0 = ss[p], e0 = se[p];
+            if (e0 <= s0) continue;
+            total += e0 - s0;
+            if (n && ce == s0) ce = e0;
+            else { if (n) out[n - 1] = make_uint2(cs, ce); cs = s0; ce = e0; ++n; }
+        }
+        if (n) out[n - 1] = make_uint2(cs, ce);
+        n_ranges[(size_t)list * nB + b] = n;
+        totals[(size_t)list * nB + b] = total;
+    }
+}
+
+// One workgroup: offsets of every base in the gathered lists (a base without P pairs or without Q pairs gets neither,
+// stocs.cpp:788), the segment arrays the gather walks, the list offsets patched into the base jobs, the totals for the host.
+__global__ __launch_bounds__(256) void plan_offsets_kernel(int nB, const uint2* __restrict__ ranges, uint32_t* __restrict__ n_ranges, const uint32_t* __restrict__ totals,
+                                                           BaseJob* __restrict__ jobs, Segment* __restrict__ psegs, Segment* __restrict__ qsegs,
+                                                           uint32_t* __restrict__ p_off, uint32_t* __restrict__ q_off, uint32_t* __restrict__ sp_off,
+                                                           uint32_t* __restrict__ sq_off, PlanOut* __restrict__ out, unsigned int* __restrict__ err) {
+    if (threadIdx.x == 0) {
+        unsigned long long totP = 0, totQ = 0;
+        uint32_t nsp = 0, nsq = 0, overflow = 0;
+        for (int b = 0; b < nB; ++b) {
+            uint32_t np = totals[b], nq = totals[nB + b];
+            if (np == 0 || nq == 0) { np = 0; nq = 0; n_ranges[b] = 0; n_ranges[nB + b] = 0; }
+            p_off[b] = (uint32_t)totP; q_off[b] = (uint32_t)totQ; sp_off[b] = nsp; sq_off[b] = nsq;
+            jobs[b].p_off = (uint32_t)totP; jobs[b].p_len = np; jobs[b].q_off = (uint32_t)totQ; jobs[b].q_len = nq;
+            totP += np; totQ += nq; nsp += n_ranges[b]; nsq += n_ranges[nB + b];
+            if (totP >= 0xFFFF0000ull || totQ >= 0xFFFF0000ull) overflow = 1;
+        }
+        p_off[nB] = (uint32_t)totP; q_off[nB] = (uint32_t)totQ;
+        out->totP = totP; out->totQ = totQ; out->n_pseg = nsp; out->n_qseg = nsq; out->overflow = overflow; out->pad = 0;
+        for (int k = 0; k < 64; ++k) err[k] = 0;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nB; b += blockDim.x) {
+#pragma unroll
+        for (int list = 0; list < 2; ++list) {
+            const uint2* r = ranges + ((size_t)list * nB + b) * 128;
+            Segment* sg = (list ? qsegs + sq_off[b] : psegs + sp_off[b]);
+            uint32_t d = list ? q_off[b] : p_off[b];
+            const uint32_t n = n_ranges[(size_t)list * nB + b];
+            for (uint32_t k = 0; k < n; ++k) { Segment v = {r[k].x, r[k].y - r[k].x, d, (uint32_t)b}; sg[k] = v; d += v.len; }
+        }
+    }
+}
+
 // normalset.h:97-104 + utils.h:139-148: int truncation of coord/epsilon, x fastest
 // (cell = 1 / eg with eg a power of two, normalset.h:117-119: dividing by it and multiplying by eg are the same float)
 __device__ __forceinline__ int64_t index_pos(V3 p, float cell, int eg) {
@@ -466,6 +550,8 @@ struct CongruentState {
     std::vector<uint2> h_blocks;           // workgroup -> Q range of the last materialise
     void* h_stage = NULL;         // pinned staging of the per-trial tables (one upload per trial)
     size_t stage_bytes = 0;
+    char* d_plan = NULL;          // persistent planning buffer: jobs, base ids, ranges, segments, offsets (outside the arenas:
+    size_t plan_bytes = 0;        // it is written before the trial's sizes -- and with them the arena's -- are known)
     template <class KeyT>
     JoinArgs<KeyT> args(const stocs_ctx* c) const {
         JoinArgs<KeyT> A;
@@ -557,50 +643,32 @@ static double now_s() {
     if (dbg) { (void)hipStreamSynchronize(c->stream); const double t_ = now_s(); fprintf(stderr, "[stocs congruent] %-18s %8.3f ms\n", label, (t_ - tprev) * 1e3); tprev = t_; }
 
 // device part of stocs_find_congruent_all for one key width
+// the per-trial tables of a planned trial, all in the context's persistent planning buffer (device)
+struct PlanDev {
+    BaseJob* jobs; Segment* psegs; Segment* qsegs; uint32_t* q_off; uint32_t* p_off; int32_t* bids; unsigned int* err;
+    int n_pseg, n_qseg;
+};
+
 template <class KeyT>
-static int count_pass(stocs_ctx* c, CongruentState* S, const std::vector<Segment>& psegs, const std::vector<Segment>& qsegs, const std::vector<BaseJob>& jobs,
-                      const std::vector<uint32_t>& q_off, bool dbg, double& tprev) {
+static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool dbg, double& tprev) {
     const int nB = S->nB;
     const size_t totP = S->totP, totQ = S->totQ;
     hipStream_t st = c->stream;
     DevBuf<KeyT> d_pk_raw, d_qk_raw;
     DevBuf<uint32_t> d_pv_raw, d_qv_raw;
-    DevBuf<char> d_tmp, d_up;
+    DevBuf<char> d_tmp;
     int rc;
-    // the per-trial tables travel in ONE copy from pinned memory: jobs | P segments | Q segments | q_off | base ids | error word
-    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t o_jobs = 0, o_pseg = o_jobs + al(sizeof(BaseJob) * nB), o_qseg = o_pseg + al(sizeof(Segment) * psegs.size()),
-                 o_qoff = o_qseg + al(sizeof(Segment) * qsegs.size()), o_bids = o_qoff + al(4 * (size_t)(nB + 1)), o_err = o_bids + al(16 * (size_t)nB),
-                 up_bytes = o_err + 256;
-    if (S->stage_bytes < up_bytes) {
-        if (S->h_stage) (void)hipHostFree(S->h_stage);
-        S->h_stage = NULL; S->stage_bytes = 0;
-        STOCS_HIP_CHECK(hipHostMalloc(&S->h_stage, 2 * up_bytes, hipHostMallocDefault));
-        S->stage_bytes = 2 * up_bytes;
-    }
-    if ((rc = d_up.alloc(up_bytes)) ||
-        (rc = d_pk_raw.alloc(totP)) || (rc = d_pv_raw.alloc(totP)) || (rc = d_qk_raw.alloc(totQ)) || (rc = d_qv_raw.alloc(totQ)) ||
+    if ((rc = d_pk_raw.alloc(totP)) || (rc = d_pv_raw.alloc(totP)) || (rc = d_qk_raw.alloc(totQ)) || (rc = d_qv_raw.alloc(totQ)) ||
         (rc = S->d_pkeys.alloc(totP * sizeof(KeyT))) || (rc = S->d_pvals.alloc(totP)) || (rc = S->d_qkeys.alloc(totQ * sizeof(KeyT))) || (rc = S->d_qvals.alloc(totQ)) ||
         (rc = S->d_prec.alloc(totP)) || (rc = S->d_pdc.alloc(((size_t)totP + 15) & ~(size_t)7)))
         return rc;
-    {
-        char* h = (char*)S->h_stage;
-        memcpy(h + o_jobs, jobs.data(), sizeof(BaseJob) * nB);
-        memcpy(h + o_pseg, psegs.data(), sizeof(Segment) * psegs.size());
-        memcpy(h + o_qseg, qsegs.data(), sizeof(Segment) * qsegs.size());
-        memcpy(h + o_qoff, q_off.data(), 4 * (size_t)(nB + 1));
-        S->h_qoff = q_off;
-        int32_t* bids = (int32_t*)(h + o_bids);
-        for (int b = 0; b < nB; ++b) for (int k = 0; k < 4; ++k) bids[4 * b + k] = c->bases[b].ids[k];
-        memset(h + o_err, 0, 256);
-        STOCS_HIP_CHECK(hipMemcpyAsync(d_up.p, h, up_bytes, hipMemcpyHostToDevice, st));
-    }
-    S->d_jobs.p = (BaseJob*)(d_up.p + o_jobs);
-    const Segment* d_psegs = (const Segment*)(d_up.p + o_pseg);
-    const Segment* d_qsegs = (const Segment*)(d_up.p + o_qseg);
-    S->d_qoff.p = (uint32_t*)(d_up.p + o_qoff);
-    S->d_bids.p = (int32_t*)(d_up.p + o_bids);
-    S->d_err.p = (unsigned int*)(d_up.p + o_err);
+    S->d_jobs.p = plan.jobs;
+    const Segment* d_psegs = plan.psegs;
+    const Segment* d_qsegs = plan.qsegs;
+    S->d_qoff.p = plan.q_off;
+    S->d_bids.p = plan.bids;
+    S->d_err.p = plan.err;
+    const int n_pseg = plan.n_pseg, n_qseg = plan.n_qseg;
     const PpfIndex& ix = c->index;
     const long long cell_limit = S->use_table ? S->NC : ((long long)1 << 31);
     // The P side (gather, sort, records) and the Q side (gather, sort) are independent until the join: the Q side runs on
@@ -620,11 +688,11 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const std::vector<Segment
         STOCS_HIP_CHECK(hipEventRecord(c->ev_fork, st));          // the upload above is on st
         STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_fork, 0));
     }
-    hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totQ + 255) / 256)), dim3(256), 0, sq, ix.d_pairs, d_qsegs, (int)qsegs.size(), (uint32_t)totQ,
+    hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totQ + 255) / 256)), dim3(256), 0, sq, ix.d_pairs, d_qsegs, n_qseg, (uint32_t)totQ,
                        S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p);
     STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_tmp2.p, tb2, d_qk_raw.p, (KeyT*)S->d_qkeys.p, d_qv_raw.p, S->d_qvals.p, totQ, 0, end_bit, sq));
     if (sq != st) STOCS_HIP_CHECK(hipEventRecord(c->ev_join, sq));
-    hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, ix.d_pairs, d_psegs, (int)psegs.size(), (uint32_t)totP,
+    hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, ix.d_pairs, d_psegs, n_pseg, (uint32_t)totP,
                        S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p);
     STOCS_HIP_CHECK(hipGetLastError());
     // one stable sort per list: (base, position cell); inside a cell the entries keep the index order of the gather
@@ -675,6 +743,7 @@ void stocs_internal_free_congruent(stocs_ctx* c) {   // stocs_ctx_destroy: nothi
         CongruentState* S = (CongruentState*)c->cong;
         S->arena_state.destroy(); S->arena_tmp.destroy();
         if (S->h_stage) (void)hipHostFree(S->h_stage);
+        if (S->d_plan) (void)hipFree(S->d_plan);
         delete S;
         c->cong = NULL;
     }
@@ -735,58 +804,121 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     if (nB >= (1 << 20)) { set_error("too many bases"); return STOCS_ERR_INVALID; }
     const PpfIndex& ix = c->index;
 
-    // ---- host preparation per base ----
+    // ---- per base: the job record (invariants, cone table), then the plan of its two lookups ----
     std::vector<BaseJob> jobs(nB);
-    std::vector<Segment> psegs, qsegs;
-    std::vector<uint32_t> q_off(nB + 1, 0);
     const float eps_unit = c->prm.distance_threshold / c->ratio;  // getNormalizedEpsilon, pairCreationFunctor.h:141-143
     const int gridDepth = (int)(-log2f(eps_unit));                // normalset.h:117
     const int egSize = (int)pow(2.0, (double)gridDepth);          // :118
     const float cell = 1.f / egSize;                               // :119
     const float nepsilon = (float)((double)(1.0f / 7.0f) + 0.00001);  // normalset.h:86
-    uint64_t totP = 0, totQ = 0;
-    std::vector<std::pair<uint32_t, uint32_t> > pr, qr;
-    // the two PPF keys of every base first, touching the index's bucket table ahead of the planning loop: a lookup probes
-    // 32 lines of a ~10 MB host array, and the host would otherwise wait for them one after the other
-    std::vector<int> keys8((size_t)nB * 8);
-    for (int b = 0; b < nB; ++b) {
-        const BaseRec& B = c->bases[b];
-        int* K1 = &keys8[(size_t)b * 8];
-        int* K2 = K1 + 4;
-        ppf_compute(c->h_spos[B.ids[0]], c->h_snrm[B.ids[0]], c->h_spos[B.ids[1]], c->h_snrm[B.ids[1]], ix.tr, ix.rot, K1);  // stocs.cpp:771
-        ppf_compute(c->h_spos[B.ids[2]], c->h_snrm[B.ids[2]], c->h_spos[B.ids[3]], c->h_snrm[B.ids[3]], ix.tr, ix.rot, K2);  // stocs.cpp:772
-        prefetch_lookup(ix, K1);
-        prefetch_lookup(ix, K2);
-    }
-    if (dbg) { const double t_ = now_s(); fprintf(stderr, "[stocs congruent] %-18s %8.3f ms\n", "keys+prefetch", (t_ - tprev) * 1e3); tprev = t_; }
     for (int b = 0; b < nB; ++b) {
         const BaseRec& B = c->bases[b];
         BaseJob& J = jobs[b];
         memset(&J, 0, sizeof(J));
         J.inv1 = B.inv1; J.inv2 = B.inv2;
         J.cell = cell; J.egSize = egSize;
-        const int* K1 = &keys8[(size_t)b * 8];
-        const int* K2 = K1 + 4;
-        plan_lookup(ix, K1, &pr);
-        plan_lookup(ix, K2, &qr);
-        uint64_t np = 0, nq = 0;
-        for (size_t r = 0; r < pr.size(); ++r) np += pr[r].second - pr[r].first;
-        for (size_t r = 0; r < qr.size(); ++r) nq += qr[r].second - qr[r].first;
-        if (np == 0 || nq == 0) { np = 0; nq = 0; pr.clear(); qr.clear(); }  // stocs.cpp:788
-        J.p_off = (uint32_t)totP; J.p_len = (uint32_t)np; J.q_off = (uint32_t)totQ; J.q_len = (uint32_t)nq;
-        uint32_t d = (uint32_t)totP;
-        for (size_t r = 0; r < pr.size(); ++r) { Segment s = {pr[r].first, pr[r].second - pr[r].first, d, (uint32_t)b}; psegs.push_back(s); d += s.len; }
-        d = (uint32_t)totQ;
-        for (size_t r = 0; r < qr.size(); ++r) { Segment s = {qr[r].first, qr[r].second - qr[r].first, d, (uint32_t)b}; qsegs.push_back(s); d += s.len; }
-        q_off[b] = (uint32_t)totQ;
-        totP += np; totQ += nq;
-        if (totP >= 0xFFFF0000ull || totQ >= 0xFFFF0000ull) { set_error("pair lists exceed 2^32 entries"); return STOCS_ERR_CAPACITY; }
         J.cos_alpha = dot3(normalized3(c->h_spos[B.ids[1]] - c->h_spos[B.ids[0]]), normalized3(c->h_spos[B.ids[3]] - c->h_spos[B.ids[2]]));  // stocs.cpp:801-803
         fill_cone_table(&J);
     }
-    q_off[nB] = (uint32_t)totQ;
-    STOCS_TICK("host prep")
-    if (dbg) fprintf(stderr, "[stocs congruent] totP %llu totQ %llu segs %zu %zu\n", (unsigned long long)totP, (unsigned long long)totQ, psegs.size(), qsegs.size());
+    // the planning buffer: jobs | base ids | error words | ranges | range counts | totals | P segments | Q segments | p_off | q_off |
+    // segment offsets | result.  A lookup is at most 128 ranges, so every array has a bound that depends on nB alone.
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t nb = (size_t)nB;
+    const size_t o_jobs = 0, o_bids = o_jobs + al(sizeof(BaseJob) * nb), o_err = o_bids + al(16 * nb), o_rng = o_err + 256, o_nr = o_rng + al(2 * nb * 128 * 8),
+                 o_tot = o_nr + al(2 * nb * 4), o_pseg = o_tot + al(2 * nb * 4), o_qseg = o_pseg + al(nb * 128 * sizeof(Segment)),
+                 o_poff = o_qseg + al(nb * 128 * sizeof(Segment)), o_qoff = o_poff + al((nb + 1) * 4), o_spo = o_qoff + al((nb + 1) * 4), o_sqo = o_spo + al(nb * 4),
+                 o_out = o_sqo + al(nb * 4), plan_bytes = o_out + 256, up_bytes = o_err + 256;
+    if (S->plan_bytes < plan_bytes) {
+        if (S->d_plan) (void)hipFree(S->d_plan);
+        S->d_plan = NULL; S->plan_bytes = 0;
+        STOCS_HIP_CHECK(dev_malloc((void**)&S->d_plan, 2 * plan_bytes));
+        S->plan_bytes = 2 * plan_bytes;
+    }
+    const size_t host_plan_bytes = o_out;   // the host-planned form stages everything up to the result block
+    if (S->stage_bytes < host_plan_bytes) {
+        if (S->h_stage) (void)hipHostFree(S->h_stage);
+        S->h_stage = NULL; S->stage_bytes = 0;
+        STOCS_HIP_CHECK(hipHostMalloc(&S->h_stage, 2 * host_plan_bytes, hipHostMallocDefault));
+        S->stage_bytes = 2 * host_plan_bytes;
+    }
+    char* h = (char*)S->h_stage;
+    char* dpl = S->d_plan;
+    PlanDev plan;
+    plan.jobs = (BaseJob*)(dpl + o_jobs); plan.bids = (int32_t*)(dpl + o_bids); plan.err = (unsigned int*)(dpl + o_err);
+    plan.psegs = (Segment*)(dpl + o_pseg); plan.qsegs = (Segment*)(dpl + o_qseg); plan.p_off = (uint32_t*)(dpl + o_poff); plan.q_off = (uint32_t*)(dpl + o_qoff);
+    plan.n_pseg = 0; plan.n_qseg = 0;
+    uint64_t totP = 0, totQ = 0;
+    std::vector<uint32_t>& q_off = S->h_qoff;
+    q_off.assign(nB + 1, 0);
+    {
+        int32_t* bids = (int32_t*)(h + o_bids);
+        for (int b = 0; b < nB; ++b) for (int k = 0; k < 4; ++k) bids[4 * b + k] = c->bases[b].ids[k];
+        memset(h + o_err, 0, 256);
+    }
+    if (nB <= 4096 && !getenv("STOCS_CONGRUENT_HOST_PLAN")) {
+        // on the device: 2 x nB small workgroups probe the bucket table, one workgroup lays the lists out; the host reads
+        // back four totals and the Q offsets (it sizes the sorts with them) -- 0.2 ms of host work per trial otherwise
+        memcpy(h + o_jobs, jobs.data(), sizeof(BaseJob) * nb);
+        STOCS_HIP_CHECK(hipMemcpyAsync(dpl, h, up_bytes, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(plan_ranges_kernel, dim3((unsigned)nB, 2), dim3(64), 0, c->stream, ix.d_bucket_start, ix.tr, ix.rot, ix.NA, ix.nD, plan.bids,
+                           (const float4*)c->d_spos, (const float4*)c->d_snrmw, nB, (uint2*)(dpl + o_rng), (uint32_t*)(dpl + o_nr), (uint32_t*)(dpl + o_tot));
+        hipLaunchKernelGGL(plan_offsets_kernel, dim3(1), dim3(256), 0, c->stream, nB, (const uint2*)(dpl + o_rng), (uint32_t*)(dpl + o_nr), (const uint32_t*)(dpl + o_tot),
+                           plan.jobs, plan.psegs, plan.qsegs, plan.p_off, plan.q_off, (uint32_t*)(dpl + o_spo), (uint32_t*)(dpl + o_sqo), (PlanOut*)(dpl + o_out), plan.err);
+        STOCS_HIP_CHECK(hipGetLastError());
+        PlanOut po;
+        STOCS_HIP_CHECK(hipMemcpyAsync(&po, dpl + o_out, sizeof(po), hipMemcpyDeviceToHost, c->stream));
+        STOCS_HIP_CHECK(hipMemcpyAsync(q_off.data(), plan.q_off, 4 * (nb + 1), hipMemcpyDeviceToHost, c->stream));
+        STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (po.overflow) { set_error("pair lists exceed 2^32 entries"); return STOCS_ERR_CAPACITY; }
+        totP = po.totP; totQ = po.totQ; plan.n_pseg = (int)po.n_pseg; plan.n_qseg = (int)po.n_qseg;
+        STOCS_TICK("plan (device)")
+    } else {
+        // on the host (kept for very many bases and for A/B): the same ranges from the host copy of the bucket table
+        std::vector<Segment> psegs, qsegs;
+        std::vector<std::pair<uint32_t, uint32_t> > pr, qr;
+        std::vector<int> keys8((size_t)nB * 8);
+        for (int b = 0; b < nB; ++b) {   // the keys first, touching the bucket table ahead of the planning loop
+            const BaseRec& B = c->bases[b];
+            int* K1 = &keys8[(size_t)b * 8];
+            int* K2 = K1 + 4;
+            ppf_compute(c->h_spos[B.ids[0]], c->h_snrm[B.ids[0]], c->h_spos[B.ids[1]], c->h_snrm[B.ids[1]], ix.tr, ix.rot, K1);  // stocs.cpp:771
+            ppf_compute(c->h_spos[B.ids[2]], c->h_snrm[B.ids[2]], c->h_spos[B.ids[3]], c->h_snrm[B.ids[3]], ix.tr, ix.rot, K2);  // stocs.cpp:772
+            prefetch_lookup(ix, K1);
+            prefetch_lookup(ix, K2);
+        }
+        for (int b = 0; b < nB; ++b) {
+            BaseJob& J = jobs[b];
+            const int* K1 = &keys8[(size_t)b * 8];
+            const int* K2 = K1 + 4;
+            plan_lookup(ix, K1, &pr);
+            plan_lookup(ix, K2, &qr);
+            uint64_t np = 0, nq = 0;
+            for (size_t r = 0; r < pr.size(); ++r) np += pr[r].second - pr[r].first;
+            for (size_t r = 0; r < qr.size(); ++r) nq += qr[r].second - qr[r].first;
+            if (np == 0 || nq == 0) { np = 0; nq = 0; pr.clear(); qr.clear(); }  // stocs.cpp:788
+            J.p_off = (uint32_t)totP; J.p_len = (uint32_t)np; J.q_off = (uint32_t)totQ; J.q_len = (uint32_t)nq;
+            uint32_t d = (uint32_t)totP;
+            for (size_t r = 0; r < pr.size(); ++r) { Segment sg = {pr[r].first, pr[r].second - pr[r].first, d, (uint32_t)b}; psegs.push_back(sg); d += sg.len; }
+            d = (uint32_t)totQ;
+            for (size_t r = 0; r < qr.size(); ++r) { Segment sg = {qr[r].first, qr[r].second - qr[r].first, d, (uint32_t)b}; qsegs.push_back(sg); d += sg.len; }
+            q_off[b] = (uint32_t)totQ;
+            totP += np; totQ += nq;
+            if (totP >= 0xFFFF0000ull || totQ >= 0xFFFF0000ull) { set_error("pair lists exceed 2^32 entries"); return STOCS_ERR_CAPACITY; }
+        }
+        q_off[nB] = (uint32_t)totQ;
+        if (psegs.size() > nb * 128 || qsegs.size() > nb * 128) { set_error("internal: more than 128 ranges per lookup"); return STOCS_ERR_STATE; }
+        memcpy(h + o_jobs, jobs.data(), sizeof(BaseJob) * nb);
+        memcpy(h + o_pseg, psegs.data(), sizeof(Segment) * psegs.size());
+        memcpy(h + o_qseg, qsegs.data(), sizeof(Segment) * qsegs.size());
+        memcpy(h + o_qoff, q_off.data(), 4 * (nb + 1));
+        STOCS_HIP_CHECK(hipMemcpyAsync(dpl, h, up_bytes, hipMemcpyHostToDevice, c->stream));
+        STOCS_HIP_CHECK(hipMemcpyAsync(dpl + o_pseg, h + o_pseg, sizeof(Segment) * psegs.size(), hipMemcpyHostToDevice, c->stream));
+        STOCS_HIP_CHECK(hipMemcpyAsync(dpl + o_qseg, h + o_qseg, sizeof(Segment) * qsegs.size(), hipMemcpyHostToDevice, c->stream));
+        STOCS_HIP_CHECK(hipMemcpyAsync(dpl + o_qoff, h + o_qoff, 4 * (nb + 1), hipMemcpyHostToDevice, c->stream));
+        plan.n_pseg = (int)psegs.size(); plan.n_qseg = (int)qsegs.size();
+        STOCS_TICK("plan (host)")
+    }
+    if (dbg) fprintf(stderr, "[stocs congruent] totP %llu totQ %llu segs %d %d\n", (unsigned long long)totP, (unsigned long long)totQ, plan.n_pseg, plan.n_qseg);
     if (totP == 0 || totQ == 0) return STOCS_OK;
 
     // ---- key layout ----
@@ -816,7 +948,7 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
         S->close_cells = diag2 < 0.999 * (double)c->prm.distance_threshold && !getenv("STOCS_CONGRUENT_DISTANCE_GATE");
     }
     S->id_bits = id_bits; S->base_bits = base_bits; S->cell_bits = cell_bits;
-    int rc = wide ? count_pass<uint64_t>(c, S, psegs, qsegs, jobs, q_off, dbg, tprev) : count_pass<uint32_t>(c, S, psegs, qsegs, jobs, q_off, dbg, tprev);
+    int rc = wide ? count_pass<uint64_t>(c, S, plan, dbg, tprev) : count_pass<uint32_t>(c, S, plan, dbg, tprev);
     if (rc) return rc;
     S->valid = true;
     c->quad_id_bits = id_bits;

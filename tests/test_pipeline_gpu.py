@@ -171,6 +171,29 @@ def test_wide_key_path_of_the_pair_lists(setup, monkeypatch):
         slot += 1
 
 
+def test_host_planned_lookups_equal_device_planned(setup, monkeypatch):
+    """The lookups of a trial (128 buckets per key merged into ranges, list offsets per base) are planned by two small
+    kernels; the host form (plan_lookup over the host copy of the bucket table, kept for very many bases) must lay out the
+    same lists: same counts, same quads in the same orders."""
+    m, s, est, orc = setup
+    est.L.stocs_clear_bases(est.h)
+    valid, ids, inv = est.sample_bases(123, 24)
+    n_dev = est.find_congruent_all()
+    sizes = [len(est.get_quads(k)) for k in range(int(valid.sum()))]
+    monkeypatch.setenv("STOCS_CONGRUENT_HOST_PLAN", "1")
+    assert est.find_congruent_all() == n_dev and n_dev > 0
+    slot = 0
+    for a in range(24):
+        if not valid[a]:
+            continue
+        qo = orc.find_congruent(ids[a], float(inv[a][0]), float(inv[a][1]))
+        assert len(qo) == sizes[slot] and np.array_equal(est.get_quads(slot), qo)
+        if len(qo):
+            so = orc.find_congruent_seq(ids[a], float(inv[a][0]), float(inv[a][1]))
+            assert np.array_equal(est.get_quads_at(slot, np.arange(len(so))), so)
+        slot += 1
+
+
 def test_distance_gate_path_of_the_count(setup, monkeypatch):
     """The count pass normally tests direction cells alone: inside one position cell the gate of stocs.cpp:854 (squared
     metres against epsilon, Q1) cannot fail while 12 epsilon^2 < epsilon.  The general path -- the gate evaluated per
