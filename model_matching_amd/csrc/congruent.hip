@@ -112,34 +112,47 @@ __global__ __launch_bounds__(64) void plan_ranges_kernel(const uint32_t* __restr
 
 // One workgroup: offsets of every base in the gathered lists (a base without P pairs or without Q pairs gets neither,
 // stocs.cpp:788), the segment arrays the gather walks, the list offsets patched into the base jobs, the totals for the host.
-__global__ __launch_bounds__(256) void plan_offsets_kernel(int nB, const uint2* __restrict__ ranges, uint32_t* __restrict__ n_ranges, const uint32_t* __restrict__ totals,
+// Counts are staged in LDS, scanned there by one thread (nB <= PLAN_MAX_BASES), and everything else is written in parallel.
+#define PLAN_MAX_BASES 2048
+__global__ __launch_bounds__(256) void plan_offsets_kernel(int nB, const uint2* __restrict__ ranges, const uint32_t* __restrict__ n_ranges, const uint32_t* __restrict__ totals,
                                                            BaseJob* __restrict__ jobs, Segment* __restrict__ psegs, Segment* __restrict__ qsegs,
-                                                           uint32_t* __restrict__ p_off, uint32_t* __restrict__ q_off, uint32_t* __restrict__ sp_off,
-                                                           uint32_t* __restrict__ sq_off, PlanOut* __restrict__ out, unsigned int* __restrict__ err) {
+                                                           uint32_t* __restrict__ p_off, uint32_t* __restrict__ q_off, PlanOut* __restrict__ out,
+                                                           unsigned int* __restrict__ err) {
+    __shared__ uint32_t s_np[PLAN_MAX_BASES], s_nq[PLAN_MAX_BASES], s_rp[PLAN_MAX_BASES], s_rq[PLAN_MAX_BASES];   // counts, then exclusive offsets
+    for (int b = threadIdx.x; b < nB; b += blockDim.x) {
+        uint32_t np = totals[b], nq = totals[nB + b], rp = n_ranges[b], rq = n_ranges[nB + b];
+        if (np == 0 || nq == 0) { np = 0; nq = 0; rp = 0; rq = 0; }
+        s_np[b] = np; s_nq[b] = nq; s_rp[b] = rp; s_rq[b] = rq;
+    }
+    if (threadIdx.x < 64) err[threadIdx.x] = 0;
+    __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long totP = 0, totQ = 0;
         uint32_t nsp = 0, nsq = 0, overflow = 0;
         for (int b = 0; b < nB; ++b) {
-            uint32_t np = totals[b], nq = totals[nB + b];
-            if (np == 0 || nq == 0) { np = 0; nq = 0; n_ranges[b] = 0; n_ranges[nB + b] = 0; }
-            p_off[b] = (uint32_t)totP; q_off[b] = (uint32_t)totQ; sp_off[b] = nsp; sq_off[b] = nsq;
-            jobs[b].p_off = (uint32_t)totP; jobs[b].p_len = np; jobs[b].q_off = (uint32_t)totQ; jobs[b].q_len = nq;
-            totP += np; totQ += nq; nsp += n_ranges[b]; nsq += n_ranges[nB + b];
+            const uint32_t np = s_np[b], nq = s_nq[b], rp = s_rp[b], rq = s_rq[b];
+            s_np[b] = (uint32_t)totP; s_nq[b] = (uint32_t)totQ; s_rp[b] = nsp; s_rq[b] = nsq;
+            totP += np; totQ += nq; nsp += rp; nsq += rq;
             if (totP >= 0xFFFF0000ull || totQ >= 0xFFFF0000ull) overflow = 1;
         }
         p_off[nB] = (uint32_t)totP; q_off[nB] = (uint32_t)totQ;
         out->totP = totP; out->totQ = totQ; out->n_pseg = nsp; out->n_qseg = nsq; out->overflow = overflow; out->pad = 0;
-        for (int k = 0; k < 64; ++k) err[k] = 0;
     }
     __syncthreads();
     for (int b = threadIdx.x; b < nB; b += blockDim.x) {
+        uint32_t np = totals[b], nq = totals[nB + b];
+        const bool none = np == 0 || nq == 0;
+        if (none) { np = 0; nq = 0; }
+        p_off[b] = s_np[b]; q_off[b] = s_nq[b];
+        jobs[b].p_off = s_np[b]; jobs[b].p_len = np; jobs[b].q_off = s_nq[b]; jobs[b].q_len = nq;
+        if (none) continue;
 #pragma unroll
         for (int list = 0; list < 2; ++list) {
             const uint2* r = ranges + ((size_t)list * nB + b) * 128;
-            Segment* sg = (list ? qsegs + sq_off[b] : psegs + sp_off[b]);
-            uint32_t d = list ? q_off[b] : p_off[b];
+            Segment* sg = list ? qsegs + s_rq[b] : psegs + s_rp[b];
+            uint32_t d = list ? s_nq[b] : s_np[b];
             const uint32_t n = n_ranges[(size_t)list * nB + b];
-            for (uint32_t k = 0; k < n; ++k) { Segment v = {r[k].x, r[k].y - r[k].x, d, (uint32_t)b}; sg[k] = v; d += v.len; }
+            for (uint32_t k = 0; k < n; ++k) { const uint2 v = r[k]; Segment o = {v.x, v.y - v.x, d, (uint32_t)b}; sg[k] = o; d += o.len; }
         }
     }
 }
@@ -855,15 +868,15 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
         for (int b = 0; b < nB; ++b) for (int k = 0; k < 4; ++k) bids[4 * b + k] = c->bases[b].ids[k];
         memset(h + o_err, 0, 256);
     }
-    if (nB <= 4096 && !getenv("STOCS_CONGRUENT_HOST_PLAN")) {
+    if (nB <= PLAN_MAX_BASES && !getenv("STOCS_CONGRUENT_HOST_PLAN")) {
         // on the device: 2 x nB small workgroups probe the bucket table, one workgroup lays the lists out; the host reads
         // back four totals and the Q offsets (it sizes the sorts with them) -- 0.2 ms of host work per trial otherwise
         memcpy(h + o_jobs, jobs.data(), sizeof(BaseJob) * nb);
         STOCS_HIP_CHECK(hipMemcpyAsync(dpl, h, up_bytes, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(plan_ranges_kernel, dim3((unsigned)nB, 2), dim3(64), 0, c->stream, ix.d_bucket_start, ix.tr, ix.rot, ix.NA, ix.nD, plan.bids,
                            (const float4*)c->d_spos, (const float4*)c->d_snrmw, nB, (uint2*)(dpl + o_rng), (uint32_t*)(dpl + o_nr), (uint32_t*)(dpl + o_tot));
-        hipLaunchKernelGGL(plan_offsets_kernel, dim3(1), dim3(256), 0, c->stream, nB, (const uint2*)(dpl + o_rng), (uint32_t*)(dpl + o_nr), (const uint32_t*)(dpl + o_tot),
-                           plan.jobs, plan.psegs, plan.qsegs, plan.p_off, plan.q_off, (uint32_t*)(dpl + o_spo), (uint32_t*)(dpl + o_sqo), (PlanOut*)(dpl + o_out), plan.err);
+        hipLaunchKernelGGL(plan_offsets_kernel, dim3(1), dim3(256), 0, c->stream, nB, (const uint2*)(dpl + o_rng), (const uint32_t*)(dpl + o_nr), (const uint32_t*)(dpl + o_tot),
+                           plan.jobs, plan.psegs, plan.qsegs, plan.p_off, plan.q_off, (PlanOut*)(dpl + o_out), plan.err);
         STOCS_HIP_CHECK(hipGetLastError());
         PlanOut po;
         STOCS_HIP_CHECK(hipMemcpyAsync(&po, dpl + o_out, sizeof(po), hipMemcpyDeviceToHost, c->stream));
