@@ -540,6 +540,10 @@ struct CongruentState {
     Arena arena_state;   // the buffers below + the temporaries of stocs_find_congruent_all; reset by that call
     Arena arena_tmp;     // temporaries of the calls that produce quads afterwards; reset by each of them
     bool valid = false;  // a count pass has completed and its buffers are intact
+    // quads of the small bases, materialised ahead of the picks that refer to them (stocs_internal_prepare_small)
+    bool small_ready = false, small_any = false;
+    DevBuf<uint64_t> d_small_sorted;
+    DevBuf<unsigned long long> d_small_soff;
     bool wide = false;   // 64-bit sort keys (only without the cell table: more than 32 bits of (base, cell))
     int nB = 0;
     uint32_t totP = 0, totQ = 0;
@@ -979,6 +983,7 @@ int stocs_get_quads(stocs_ctx* c, int slot, int32_t* quads4, int64_t cap, int64_
     if (!S || !S->valid) { set_error("stocs_get_quads: no congruent state (call stocs_find_congruent_all first)"); return STOCS_ERR_STATE; }
     { int rc0 = S->arena_tmp.reset(); if (rc0) return rc0; }
     tl_arena = &S->arena_tmp;
+    S->small_ready = false;
     const int64_t m = std::min<int64_t>(*n, cap);
     std::vector<uint64_t> q((size_t)std::max<int64_t>(m, 0));
     if (m > 0) {
@@ -1020,6 +1025,7 @@ int stocs_get_quads_at(stocs_ctx* c, int slot, const int64_t* ranks, int n, int3
     if (!S || !S->valid) { set_error("stocs_get_quads_at: no congruent state (call stocs_find_congruent_all first)"); return STOCS_ERR_STATE; }
     { int rc0 = S->arena_tmp.reset(); if (rc0) return rc0; }
     tl_arena = &S->arena_tmp;
+    S->small_ready = false;
     DevBuf<Pick> d_picks; DevBuf<uint64_t> d_keys;
     int rc;
     if ((rc = d_picks.alloc(n)) || (rc = d_keys.alloc(n))) return rc;
@@ -1052,32 +1058,63 @@ int stocs_get_quads_at(stocs_ctx* c, int slot, const int64_t* ranks, int n, int3
 // on the device.  Bases picked with sorted != 0 are materialised and sorted first (they are the small ones).
 // *d_unresolved_out: device counter of the picks the kernel could not resolve (0 while counts and join agree); the
 // caller reads it behind its own synchronisation point, this call does not wait for the device
-int stocs_internal_make_jobs(stocs_ctx* c, const int32_t* picks4_host, int n, void* d_jobs_out, const unsigned int** d_unresolved_out) {
-    if (d_unresolved_out) *d_unresolved_out = NULL;
-    if (n <= 0) return STOCS_OK;
+// First half of stocs_make_transforms' device work, launched BEFORE the host draws its picks: the bases with fewer quads than
+// the per-base maximum are materialised and sorted (they are used whole, in the std::set order).  Which bases those are
+// follows from the counts alone, so the fill + sort run while the host is busy with the seeded subsets of the large bases.
+int stocs_internal_prepare_small(stocs_ctx* c, int max_per_base) {
     CongruentState* S = (CongruentState*)c->cong;
     if (!S || !S->valid) { set_error("stocs_make_transforms: no congruent state (call stocs_find_congruent_all first)"); return STOCS_ERR_STATE; }
     { int rc0 = S->arena_tmp.reset(); if (rc0) return rc0; }
     tl_arena = &S->arena_tmp;
-    const Pick* picks = (const Pick*)picks4_host;
+    S->small_ready = true; S->small_any = false;
     std::vector<char> sel(S->nB, 0);
-    bool any_sorted = false;
-    for (int i = 0; i < n; ++i) if (picks[i].sorted) { sel[picks[i].base] = 1; any_sorted = true; }
-    DevBuf<uint64_t> d_sorted; DevBuf<unsigned long long> d_soff; DevBuf<Pick> d_picks;
+    for (int b = 0; b < S->nB; ++b) {
+        const unsigned long long nq = c->quad_off[b + 1] - c->quad_off[b];
+        if (nq > 0 && nq < (unsigned long long)max_per_base) { sel[b] = 1; S->small_any = true; }
+    }
+    if (!S->small_any) return STOCS_OK;
     std::vector<unsigned long long>& off = S->h_off;
     int rc;
-    if (any_sorted) {
-        if ((rc = materialise(c, S, sel, &d_sorted, &off)) || (rc = d_soff.alloc(off.size()))) return rc;
-        STOCS_HIP_CHECK(hipMemcpyAsync(d_soff.p, off.data(), 8 * off.size(), hipMemcpyHostToDevice, c->stream));
+    if ((rc = materialise(c, S, sel, &S->d_small_sorted, &off)) || (rc = S->d_small_soff.alloc(off.size()))) return rc;
+    STOCS_HIP_CHECK(hipMemcpyAsync(S->d_small_soff.p, off.data(), 8 * off.size(), hipMemcpyHostToDevice, c->stream));
+    return STOCS_OK;
+}
+
+int stocs_internal_make_jobs(stocs_ctx* c, const int32_t* picks4_host, int n, void* d_jobs_out, const unsigned int** d_unresolved_out) {
+    if (d_unresolved_out) *d_unresolved_out = NULL;
+    CongruentState* S = (CongruentState*)c->cong;
+    const bool prepared = S && S->small_ready;
+    if (S) S->small_ready = false;
+    if (n <= 0) return STOCS_OK;
+    if (!S || !S->valid) { set_error("stocs_make_transforms: no congruent state (call stocs_find_congruent_all first)"); return STOCS_ERR_STATE; }
+    const Pick* picks = (const Pick*)picks4_host;
+    const uint64_t* d_sorted = NULL; const unsigned long long* d_soff = NULL;
+    DevBuf<uint64_t> d_sorted_here; DevBuf<unsigned long long> d_soff_here; DevBuf<Pick> d_picks;
+    int rc;
+    if (prepared) {   // the temporaries of stocs_internal_prepare_small are still in the arena
+        tl_arena = &S->arena_tmp;
+        if (S->small_any) { d_sorted = S->d_small_sorted.p; d_soff = S->d_small_soff.p; }
+    } else {
+        { int rc0 = S->arena_tmp.reset(); if (rc0) return rc0; }
+        tl_arena = &S->arena_tmp;
+        std::vector<char> sel(S->nB, 0);
+        bool any_sorted = false;
+        for (int i = 0; i < n; ++i) if (picks[i].sorted) { sel[picks[i].base] = 1; any_sorted = true; }
+        std::vector<unsigned long long>& off = S->h_off;
+        if (any_sorted) {
+            if ((rc = materialise(c, S, sel, &d_sorted_here, &off)) || (rc = d_soff_here.alloc(off.size()))) return rc;
+            STOCS_HIP_CHECK(hipMemcpyAsync(d_soff_here.p, off.data(), 8 * off.size(), hipMemcpyHostToDevice, c->stream));
+            d_sorted = d_sorted_here.p; d_soff = d_soff_here.p;
+        }
     }
     if ((rc = d_picks.alloc(n))) return rc;
     STOCS_HIP_CHECK(hipMemcpyAsync(d_picks.p, picks, sizeof(Pick) * (size_t)n, hipMemcpyHostToDevice, c->stream));
     if (S->wide)
-        hipLaunchKernelGGL(resolve_picks_kernel<uint64_t>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, S->args<uint64_t>(c), S->d_qoffe.p, d_picks.p, n, d_sorted.p,
-                           d_soff.p, S->d_bids.p, (XformJobC*)d_jobs_out, (uint64_t*)NULL, S->d_err.p);
+        hipLaunchKernelGGL(resolve_picks_kernel<uint64_t>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, S->args<uint64_t>(c), S->d_qoffe.p, d_picks.p, n, d_sorted,
+                           d_soff, S->d_bids.p, (XformJobC*)d_jobs_out, (uint64_t*)NULL, S->d_err.p);
     else
-        hipLaunchKernelGGL(resolve_picks_kernel<uint32_t>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, S->args<uint32_t>(c), S->d_qoffe.p, d_picks.p, n, d_sorted.p,
-                           d_soff.p, S->d_bids.p, (XformJobC*)d_jobs_out, (uint64_t*)NULL, S->d_err.p);
+        hipLaunchKernelGGL(resolve_picks_kernel<uint32_t>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, S->args<uint32_t>(c), S->d_qoffe.p, d_picks.p, n, d_sorted,
+                           d_soff, S->d_bids.p, (XformJobC*)d_jobs_out, (uint64_t*)NULL, S->d_err.p);
     STOCS_HIP_CHECK(hipGetLastError());
     if (d_unresolved_out) *d_unresolved_out = S->d_err.p;
     return STOCS_OK;

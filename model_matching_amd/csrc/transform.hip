@@ -170,6 +170,8 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
         fprintf(stderr, "[stocs transforms] %-18s %8.3f ms\n", label, (t1.tv_sec - ts0.tv_sec) * 1e3 + (t1.tv_nsec - ts0.tv_nsec) * 1e-6);
         ts0 = t1;
     };
+    // the device starts on the small bases (used whole: materialised and sorted) while the host draws the subsets of the large ones
+    if (!c->bases.empty()) { const int rc0 = stocs_internal_prepare_small(c, max_per_base); if (rc0) return rc0; }
     // picks = (base, rank, job slot, sorted?) records; the quads themselves are produced on the device
     std::vector<int32_t> picks;
     std::vector<int> job_base;
