@@ -122,6 +122,16 @@ __global__ __launch_bounds__(256) void rigid_transform_kernel(const float4* __re
     ok_out[j] = ok;
 }
 
+// the winner's camera-frame pose next to its key: one copy and one synchronisation tell the host everything
+__global__ __launch_bounds__(64) void winner_pose_kernel(const unsigned long long* __restrict__ key, const float* __restrict__ P, int n, float* __restrict__ out18) {
+    const unsigned long long k = *key;
+    if (threadIdx.x == 0) { out18[0] = __uint_as_float((uint32_t)(k & 0xFFFFFFFFull)); out18[1] = __uint_as_float((uint32_t)(k >> 32)); }
+    if (threadIdx.x < 16) {
+        const uint32_t id = 0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull);
+        out18[2 + threadIdx.x] = (k && id < (uint32_t)n) ? P[(size_t)id * 16 + threadIdx.x] : 0.0f;
+    }
+}
+
 // accepted candidates (ok != 0) keep their pick order: destination = exclusive scan of the flags
 __global__ __launch_bounds__(256) void compact_candidates_kernel(const float4* __restrict__ T, const float4* __restrict__ P, const int32_t* __restrict__ ok,
                                                                  const int32_t* __restrict__ pos, const int32_t* __restrict__ job_base, int n,
@@ -317,16 +327,26 @@ int stocs_verify_all(stocs_ctx* c, float* best_lcp, int* best_idx, float* best_p
         // compute_best_transform (stocs.cpp:987-998: strict > from 0 => first maximum wins, Q18) as an integer max
         int rc = launch_lcp(c, cand_T(c), n, cand_lcp(c), NULL, NULL);
         if (rc) return rc;
-        uint64_t key = 0;
-        rc = stocs_best_device(c, cand_lcp(c), n, 0, &key);
+        if (!c->d_best) STOCS_HIP_CHECK(dev_malloc((void**)&c->d_best, 8));
+        rc = ensure_scratch(c, 256);
         if (rc) return rc;
+        rc = stocs_best_device_async(c, cand_lcp(c), n, 0, c->d_best);
+        if (rc) return rc;
+        float* d_out = (float*)c->d_scratch;   // the transform jobs of this trial are done with the scratch area
+        hipLaunchKernelGGL(winner_pose_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)c->d_best, (const float*)cand_P(c), n, d_out);
+        STOCS_HIP_CHECK(hipGetLastError());
+        float out18[18];
+        STOCS_HIP_CHECK(hipMemcpyAsync(out18, d_out, sizeof(out18), hipMemcpyDeviceToHost, c->stream));
+        STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        uint32_t lo, hi;
+        memcpy(&lo, &out18[0], 4); memcpy(&hi, &out18[1], 4);
+        const uint64_t key = ((uint64_t)hi << 32) | lo;
         c->cands_stale = true;   // the host mirror (if any) lacks the new scores
         if (key) {
             uint32_t id = 0;
             stocs_unpack_best(key, &c->best_lcp, &id);
             c->best_index = (int)id;
-            STOCS_HIP_CHECK(hipMemcpyAsync(pose, cand_P(c) + (size_t)id * 16, 64, hipMemcpyDeviceToHost, c->stream));
-            STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+            memcpy(pose, &out18[2], 64);
         }
     }
     if (best_lcp) *best_lcp = c->best_lcp;
