@@ -141,21 +141,32 @@ __global__ __launch_bounds__(256) void centroid_kernel(const uint32_t* __restric
                                                        const float4* __restrict__ P, const float4* __restrict__ extra, float4* __restrict__ cen,
                                                        float4* __restrict__ ext, uint32_t* __restrict__ long_list, uint32_t* __restrict__ n_long,
                                                        double* __restrict__ long_acc, uint32_t* __restrict__ long_done) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nv) return;
-    const uint32_t e0 = seg_start[s], e1 = seg_start[s + 1];
-    if (e1 - e0 > STOCS_LONG_LEAF) {
+    // eight lanes per leaf (a leaf holds ~15 points of a frame; one thread per leaf walked them as a chain of dependent gathers):
+    // strided partial sums in double, then a fixed xor tree -- the same value for every run, and the sequential sum's
+    // whenever that is exact (see centroid_long_kernel)
+    const int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, sub = threadIdx.x & 7;
+    const bool live = s < nv;
+    uint32_t e0 = 0, e1 = 0;
+    if (live) { e0 = seg_start[s]; e1 = seg_start[s + 1]; }
+    const bool is_long = live && e1 - e0 > STOCS_LONG_LEAF;
+    if (is_long && sub == 0) {
         const uint32_t j = atomicAdd(n_long, 1u);
         long_list[j] = (uint32_t)s;
         long_done[j] = 0;
-        return;
     }
     double sx = 0, sy = 0, sz = 0, ex = 0, ey = 0, ez = 0;
-    for (uint32_t e = e0; e < e1; ++e) {
-        const float4 p = P[ids[e]];
-        sx += p.x; sy += p.y; sz += p.z;
-        if (extra) { const float4 q = extra[ids[e]]; ex += q.x; ey += q.y; ez += q.z; }
+    if (live && !is_long)
+        for (uint32_t e = e0 + sub; e < e1; e += 8) {
+            const float4 p = P[ids[e]];
+            sx += p.x; sy += p.y; sz += p.z;
+            if (extra) { const float4 q = extra[ids[e]]; ex += q.x; ey += q.y; ez += q.z; }
+        }
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+        sx += __shfl_xor(sx, off, 64); sy += __shfl_xor(sy, off, 64); sz += __shfl_xor(sz, off, 64);
+        if (extra) { ex += __shfl_xor(ex, off, 64); ey += __shfl_xor(ey, off, 64); ez += __shfl_xor(ez, off, 64); }
     }
+    if (!live || is_long || sub != 0) return;
     const double cnt = (double)(e1 - e0);
     cen[s] = make_float4((float)(sx / cnt), (float)(sy / cnt), (float)(sz / cnt), 0.f);
     if (extra) ext[s] = make_float4((float)(ex / cnt), (float)(ey / cnt), (float)(ez / cnt), 0.f);
@@ -330,7 +341,6 @@ struct Buf {   // typed view of workspace memory
     int alloc(size_t n) { return tl_cur->take(n * sizeof(T), (void**)&p); }
 };
 
-// min / max of int3 or of the xyz of float4 over n elements -> out[0..5] (single workgroup; n is a few 10^5)
 // out[0..2] = min, out[3..5] = max of the leaf coordinates (initialised by leaf_coords_kernel): strided partial results,
 // wavefront reductions, one atomic per wavefront and component
 __global__ __launch_bounds__(256) void minmax_i3_kernel(const int3* __restrict__ v, int n, int* __restrict__ out) {
@@ -344,27 +354,6 @@ __global__ __launch_bounds__(256) void minmax_i3_kernel(const int3* __restrict__
         for (int off = 32; off > 0; off >>= 1) { mn[k] = min(mn[k], __shfl_xor(mn[k], off, 64)); mx[k] = max(mx[k], __shfl_xor(mx[k], off, 64)); }
     if ((threadIdx.x & 63) == 0)
         for (int k = 0; k < 3; ++k) { atomicMin(&out[k], mn[k]); atomicMax(&out[3 + k], mx[k]); }
-}
-__global__ __launch_bounds__(1024) void minmax_f4_kernel(const float4* __restrict__ v, int n, float* __restrict__ out) {
-    __shared__ float sh[6][1024];
-    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        const float4 c = v[i];
-        // (a < b ? a : b) keeps the host loop's std::min semantics: a NaN never replaces the running value
-        mn[0] = c.x < mn[0] ? c.x : mn[0]; mn[1] = c.y < mn[1] ? c.y : mn[1]; mn[2] = c.z < mn[2] ? c.z : mn[2];
-        mx[0] = c.x > mx[0] ? c.x : mx[0]; mx[1] = c.y > mx[1] ? c.y : mx[1]; mx[2] = c.z > mx[2] ? c.z : mx[2];
-    }
-    for (int k = 0; k < 3; ++k) { sh[k][threadIdx.x] = mn[k]; sh[3 + k][threadIdx.x] = mx[k]; }
-    __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off)
-            for (int k = 0; k < 3; ++k) {
-                sh[k][threadIdx.x] = fminf(sh[k][threadIdx.x], sh[k][threadIdx.x + off]);
-                sh[3 + k][threadIdx.x] = fmaxf(sh[3 + k][threadIdx.x], sh[3 + k][threadIdx.x + off]);
-            }
-        __syncthreads();
-    }
-    if (threadIdx.x < 6) out[threadIdx.x] = sh[threadIdx.x][0];
 }
 __global__ __launch_bounds__(256) void iota_kernel(uint32_t* __restrict__ a, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -389,7 +378,8 @@ __global__ __launch_bounds__(256) void scene_pack_kernel(const float4* __restric
 }
 
 // voxel grid on device points dP[n] (+ optional extra field); outputs device centroid arrays (workspace memory)
-static int voxel_grid_device(const float4* dP, const float4* dExtra, int n, double leaf, Buf<float4>& cen, Buf<float4>& ext, int* n_out, hipStream_t st) {
+static int voxel_grid_device(const float4* dP, const float4* dExtra, int n, double leaf, Buf<float4>& cen, Buf<float4>& ext, int* n_out, hipStream_t st,
+                             double* box6 = NULL) {   // box6: a box that holds every centroid (from the leaf bounds, a leaf of slack either side)
     *n_out = 0;
     if (n == 0) return STOCS_OK;
     Buf<int3> ijk; Buf<uint64_t> keys, keys_s; Buf<uint32_t> ids, ids_s, head, seg; Buf<char> tmp; Buf<int> mm;
@@ -404,6 +394,7 @@ static int voxel_grid_device(const float4* dP, const float4* dExtra, int n, doub
     STOCS_HIP_CHECK(hipMemcpyAsync(h6, mm.p, sizeof(h6), hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
     const int3 mn = make_int3(h6[0], h6[1], h6[2]), mx = make_int3(h6[3], h6[4], h6[5]);
+    if (box6) for (int k = 0; k < 3; ++k) { box6[k] = ((double)h6[k] - 1.0) * leaf; box6[3 + k] = ((double)h6[3 + k] + 2.0) * leaf; }
     const int3 dims = make_int3(mx.x - mn.x + 1, mx.y - mn.y + 1, mx.z - mn.z + 1);
     if ((double)dims.x * dims.y * dims.z > 9.0e18) { set_error("voxel grid: leaf size too small for the cloud extent"); return STOCS_ERR_INVALID; }
     hipLaunchKernelGGL(leaf_keys_kernel, g, dim3(256), 0, st, ijk.p, n, mn, dims, keys.p, ids.p);
@@ -429,7 +420,7 @@ static int voxel_grid_device(const float4* dP, const float4* dExtra, int n, doub
         return rc;
     hipLaunchKernelGGL(seg_start_kernel, g, dim3(256), 0, st, head.p, seg.p, n, nv, seg_start.p);
     hipLaunchKernelGGL(zero_u32x2_kernel, dim3(1), dim3(256), 0, st, n_long.p, n_long.p + 1, (size_t)1);
-    hipLaunchKernelGGL(centroid_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, seg_start.p, ids_s.p, nv, dP, dExtra, cen.p, ext.p, long_list.p,
+    hipLaunchKernelGGL(centroid_kernel, dim3((unsigned)(((size_t)nv * 8 + 255) / 256)), dim3(256), 0, st, seg_start.p, ids_s.p, nv, dP, dExtra, cen.p, ext.p, long_list.p,
                        n_long.p, long_acc.p, long_done.p);
     hipLaunchKernelGGL(centroid_long_kernel, dim3(STOCS_LONG_GROUPS), dim3(256), 0, st, seg_start.p, ids_s.p, dP, dExtra, cen.p, ext.p, long_list.p, n_long.p, long_acc.p,
                        long_done.p);
@@ -485,19 +476,16 @@ int stocs_ingest_scene(const stocs_camera* cam, const uint16_t* depth, const uin
     tick("upload+backproject+normals");
     Buf<float4> cen, ext;
     int nv = 0;
-    if ((rc = voxel_grid_device(dP.p, NULL, npx, (double)voxel_size, cen, ext, &nv, st))) return rc;   // rgbd.cpp:228-231
+    double box6[6] = {0, 0, 0, 0, 0, 0};
+    if ((rc = voxel_grid_device(dP.p, NULL, npx, (double)voxel_size, cen, ext, &nv, st, box6))) return rc;   // rgbd.cpp:228-231
     *n_out = 0;
     tick("voxel grid");
     if (nv == 0) { STOCS_HIP_CHECK(hipStreamSynchronize(st)); return STOCS_OK; }
     // radius outlier removal: radius 2*voxel + 5 mm, more than 10 points (itself included)   rgbd.cpp:233-237
     const double radius = 2.0 * (double)voxel_size + 0.005;
-    Buf<float> bb;
-    if ((rc = bb.alloc(8))) return rc;
-    hipLaunchKernelGGL(minmax_f4_kernel, dim3(1), dim3(1024), 0, st, cen.p, nv, bb.p);
-    float hbb[6];
-    STOCS_HIP_CHECK(hipMemcpyAsync(hbb, bb.p, sizeof(hbb), hipMemcpyDeviceToHost, st));
-    STOCS_HIP_CHECK(hipStreamSynchronize(st));
-    const double3 mn = make_double3(hbb[0], hbb[1], hbb[2]), mx = make_double3(hbb[3], hbb[4], hbb[5]);
+    // the search grid only has to hold every centroid (the counts do not depend on where its cells fall): its box comes from
+    // the leaf bounds the voxel grid already read back -- no reduction over the centroids, no synchronisation here
+    const double3 mn = make_double3(box6[0], box6[1], box6[2]), mx = make_double3(box6[3], box6[4], box6[5]);
     const int3 dims = make_int3((int)floor((mx.x - mn.x) / radius) + 1, (int)floor((mx.y - mn.y) / radius) + 1, (int)floor((mx.z - mn.z) / radius) + 1);
     const size_t ncell = (size_t)dims.x * dims.y * dims.z;
     if (ncell > ((size_t)1 << 28)) { set_error("scene extent too large for the outlier-removal grid"); return STOCS_ERR_INVALID; }
