@@ -112,15 +112,18 @@ __global__ __launch_bounds__(256) void leaf_coords_kernel(const float4* __restri
     const float4 p = P[idx];
     ijk[idx] = make_int3((int)floor((double)p.x * inv_leaf), (int)floor((double)p.y * inv_leaf), (int)floor((double)p.z * inv_leaf));
 }
-__global__ __launch_bounds__(256) void leaf_keys_kernel(const int3* __restrict__ ijk, int n, int3 mn, int3 dims, uint64_t* __restrict__ keys,
+// KeyT = uint32_t when the leaf grid has fewer than 2^32 cells (any camera frame): half the bytes through the sort
+template <class KeyT>
+__global__ __launch_bounds__(256) void leaf_keys_kernel(const int3* __restrict__ ijk, int n, int3 mn, int3 dims, KeyT* __restrict__ keys,
                                                         uint32_t* __restrict__ ids) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     const int3 c = ijk[idx];
-    keys[idx] = (uint64_t)(c.x - mn.x) + (uint64_t)(c.y - mn.y) * (uint64_t)dims.x + (uint64_t)(c.z - mn.z) * (uint64_t)dims.x * (uint64_t)dims.y;
+    keys[idx] = (KeyT)((uint64_t)(c.x - mn.x) + (uint64_t)(c.y - mn.y) * (uint64_t)dims.x + (uint64_t)(c.z - mn.z) * (uint64_t)dims.x * (uint64_t)dims.y);
     ids[idx] = (uint32_t)idx;
 }
-__global__ __launch_bounds__(256) void seg_heads_kernel(const uint64_t* __restrict__ keys, int n, uint32_t* __restrict__ head) {
+template <class KeyT>
+__global__ __launch_bounds__(256) void seg_heads_kernel(const KeyT* __restrict__ keys, int n, uint32_t* __restrict__ head) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     head[idx] = (idx == 0 || keys[idx] != keys[idx - 1]) ? 1u : 0u;
@@ -397,15 +400,24 @@ static int voxel_grid_device(const float4* dP, const float4* dExtra, int n, doub
     if (box6) for (int k = 0; k < 3; ++k) { box6[k] = ((double)h6[k] - 1.0) * leaf; box6[3 + k] = ((double)h6[3 + k] + 2.0) * leaf; }
     const int3 dims = make_int3(mx.x - mn.x + 1, mx.y - mn.y + 1, mx.z - mn.z + 1);
     if ((double)dims.x * dims.y * dims.z > 9.0e18) { set_error("voxel grid: leaf size too small for the cloud extent"); return STOCS_ERR_INVALID; }
-    hipLaunchKernelGGL(leaf_keys_kernel, g, dim3(256), 0, st, ijk.p, n, mn, dims, keys.p, ids.p);
-    size_t tb = 0, tb2 = 0;
-    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb, keys.p, keys_s.p, ids.p, ids_s.p, (size_t)n, 0, 64, st));   // stable
-    STOCS_HIP_CHECK(rocprim::exclusive_scan(NULL, tb2, head.p, seg.p, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
-    if ((rc = tmp.alloc(std::max(tb, tb2)))) return rc;
     int key_bits = 1;   // sort only the bits the keys can have
     while (key_bits < 64 && (double)(1ull << key_bits) < (double)dims.x * dims.y * dims.z) key_bits++;
-    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, tb, keys.p, keys_s.p, ids.p, ids_s.p, (size_t)n, 0, (unsigned)key_bits, st));
-    hipLaunchKernelGGL(seg_heads_kernel, g, dim3(256), 0, st, keys_s.p, n, head.p);
+    size_t tb = 0, tb2 = 0;
+    STOCS_HIP_CHECK(rocprim::exclusive_scan(NULL, tb2, head.p, seg.p, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
+    if (key_bits <= 32) {
+        uint32_t* k32 = (uint32_t*)keys.p; uint32_t* k32s = (uint32_t*)keys_s.p;
+        hipLaunchKernelGGL(leaf_keys_kernel<uint32_t>, g, dim3(256), 0, st, ijk.p, n, mn, dims, k32, ids.p);
+        STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb, k32, k32s, ids.p, ids_s.p, (size_t)n, 0, (unsigned)key_bits, st));   // stable
+        if ((rc = tmp.alloc(std::max(tb, tb2)))) return rc;
+        STOCS_HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, tb, k32, k32s, ids.p, ids_s.p, (size_t)n, 0, (unsigned)key_bits, st));
+        hipLaunchKernelGGL(seg_heads_kernel<uint32_t>, g, dim3(256), 0, st, k32s, n, head.p);
+    } else {
+        hipLaunchKernelGGL(leaf_keys_kernel<uint64_t>, g, dim3(256), 0, st, ijk.p, n, mn, dims, keys.p, ids.p);
+        STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb, keys.p, keys_s.p, ids.p, ids_s.p, (size_t)n, 0, (unsigned)key_bits, st));   // stable
+        if ((rc = tmp.alloc(std::max(tb, tb2)))) return rc;
+        STOCS_HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, tb, keys.p, keys_s.p, ids.p, ids_s.p, (size_t)n, 0, (unsigned)key_bits, st));
+        hipLaunchKernelGGL(seg_heads_kernel<uint64_t>, g, dim3(256), 0, st, keys_s.p, n, head.p);
+    }
     STOCS_HIP_CHECK(rocprim::exclusive_scan(tmp.p, tb2, head.p, seg.p, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
     uint32_t last_seg = 0, last_head = 0;
     STOCS_HIP_CHECK(hipMemcpyAsync(&last_seg, seg.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
