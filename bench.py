@@ -35,10 +35,14 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (roofline.traffic / binding become null)")
     args = ap.parse_args()
 
+    # --gpus N > 1 without a launcher around it: this process becomes the launcher of N rank children (before torch or the
+    # GPU runtime is loaded) and relays rank 0's JSON line; it never runs one rank under an N-GPU label
+    from model_matching_amd import dist as sdist
+    sdist.launch_ranks_if_needed(args.gpus, os.path.abspath(__file__), sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
 
     import torch
@@ -75,7 +79,6 @@ def main():
     dL = est.dev_alloc(kcand * 4)
     est.dev_upload(dT, T)
     lcp = np.zeros(kcand, np.float32)
-    from model_matching_amd import dist as sdist
 
     # All work of a step is enqueued on PyTorch's current HIP stream: LCP kernel, device arg-max into an
     # 8-byte torch tensor and (N > 1) the RCCL max all-reduce of that key -- no host round trip per step.
@@ -178,6 +181,7 @@ def main():
                              "The working set (scene grid + model, a few MB) is cache resident, so this fraction is not bounded by 1; "
                              "`traffic` is what HBM really moved and `binding` is the unit that does bound the kernel, both from counters of this run",
                      "traffic": traffic, "binding": binding,
+                     "traffic_over_algorithmic": (traffic / float(b_pose * kcand)) if traffic is not None else None,
                      "kernel": "lcp_coopq_kernel behind stocs_score_transforms_device (kernel_ms includes the ~50 us candidate ordering in front of it)",
                      "kernel_ms": k_ms, "kernel_timed_launches": reps,
                      "algorithmic_bytes_per_launch": b_pose * kcand,
@@ -225,7 +229,10 @@ def main():
                          "winner_rot_err_deg_vs_gt": rot_err, "winner_centroid_err_mm_vs_gt": tr_err, "winner_add_s_mm_vs_gt": add_s,
                          "sample_ms": (t1 - t0) * 1e3, "congruent_ms": (t2 - t1) * 1e3, "transforms_ms": (t3 - t2) * 1e3,
                          "verify_ms": (t4 - t3) * 1e3, "poses_per_s_phases_2_4": nc / max(t4 - t1, 1e-9),
-                         "device_allocations_during_trial": int(pe.L.stocs_device_alloc_count()) - n_alloc0})
+                         "device_allocations_during_trial": int(pe.L.stocs_device_alloc_count()) - n_alloc0,
+                         # host wall clock of the steps inside the three calls (always recorded by the library): a stalled run names its step
+                         "steps_ms": {name: [[lab, round(ms, 4)] for lab, ms in pe.last_call_timing(w)]
+                                      for w, name in ((0, "find_congruent_all"), (1, "make_transforms"), (2, "verify_all"))}})
         # per-frame cost of a new scene against the same model: scene upload + GPU grid build (the index is kept)
         t_set = []
         for r in range(4):

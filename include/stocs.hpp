@@ -30,9 +30,13 @@
 #include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <iostream>
+#include <map>
 #include <memory>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -386,8 +390,13 @@ public:
     void compute_best_transform() {
         if (batched_) {   // candidates live on the device (make_transforms): score + arg-max there, one round trip
             float pose[16];
-            stocs_verify_all(ctx_, &best_lcp, &best_index, pose);
             std::cout << "Transforms to verify: " << n_batched_ << std::endl;   // stocs.cpp:985
+            if (stocs_verify_all(ctx_, &best_lcp, &best_index, pose) != STOCS_OK) {
+                // the reference's error convention: text on stdout, "no pose" state, no exception from the hot path
+                std::cout << "compute_best_transform failed: " << stocs_last_error() << std::endl;
+                best_lcp = 0;
+                best_index = -1;
+            }
             std::cout << "best index: " << best_index << ", maximum score: " << best_lcp << std::endl;   // :1003
             fetched_ = false;
             return;

@@ -264,9 +264,16 @@ void* stocs_stream(stocs_ctx* ctx);          /* hipStream_t */
  * events on the context's stream; returns the average milliseconds per launch */
 int stocs_time_score_kernel(stocs_ctx* ctx, const void* d_T16, int n, void* d_lcp, int reps,
                             float* avg_ms);
-/* number of device allocations (hipMalloc) the library has made in this process so far.  A warm context -- one that has
- * run a trial of the current scene -- runs further trials without allocating: the difference across them is 0. */
+/* number of device (hipMalloc) and pinned-host (hipHostMalloc) allocations the library has made in this process so far.
+ * A warm context -- one that has run a trial of the current scene -- runs further trials without allocating: the
+ * difference across them is 0. */
 int64_t stocs_device_alloc_count(void);
+/* host wall clock, in milliseconds, of the steps of the context's LAST stocs_find_congruent_all (which = 0),
+ * stocs_make_transforms (1) or stocs_verify_all (2): always recorded (a few clock reads per call, no synchronisation of its
+ * own), so that a call that stalls -- tens of milliseconds instead of one -- names the step it stalled in.  Steps are host
+ * intervals between the call's existing synchronisation points: "wait for the device" steps hold the GPU work, the others
+ * host work and runtime calls.  labels[i] point to static strings.  STOCS_ERR_CAPACITY when cap is too small (*n is set). */
+int stocs_last_call_timing(const stocs_ctx* ctx, int which, const char** labels, double* ms, int cap, int* n);
 /* device memory helpers so that callers without a HIP binding (ctypes) can keep inputs resident */
 int stocs_dev_alloc(stocs_ctx* ctx, int64_t bytes, void** dptr);
 int stocs_dev_free(stocs_ctx* ctx, void* dptr);

@@ -93,6 +93,7 @@ SIGNATURES = {
     "stocs_trim": (C.c_int, []),
     "stocs_icp_point_to_plane": (C.c_int, [_fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_float, C.c_int, _fp, _intp]),
     "stocs_device_alloc_count": (C.c_int64, []),
+    "stocs_last_call_timing": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.c_int, _intp]),
     "stocs_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "stocs_set_stream": (C.c_int, [_vp, _vp]),
     "stocs_best_device_async": (C.c_int, [_vp, _vp, C.c_int, C.c_uint32, _vp]),

@@ -737,13 +737,15 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     if ((rc = d_tmp_scan.alloc(tmp_scan))) return rc;
     STOCS_HIP_CHECK(rocprim::exclusive_scan(d_tmp_scan.p, tmp_scan, d_qcnt.p, S->d_qoffe.p, 0ull, totQ + 1, rocprim::plus<unsigned long long>(), st));
     // per-base offsets = scan value at the first Q entry of each base
-    std::vector<unsigned long long> qoff_at(nB + 1);
+    unsigned long long* qoff_at = (unsigned long long*)((char*)c->h_pin + PIN_VAR);   // pinned (sized by the caller)
     DevBuf<unsigned long long> d_boff;
     if ((rc = d_boff.alloc(nB + 1))) return rc;
     hipLaunchKernelGGL(base_offsets_kernel, dim3((unsigned)((nB + 1 + 255) / 256)), dim3(256), 0, st, S->d_qoffe.p, S->d_qoff.p, nB + 1, d_boff.p);
     STOCS_HIP_CHECK(hipGetLastError());
-    STOCS_HIP_CHECK(hipMemcpyAsync(qoff_at.data(), d_boff.p, 8 * (size_t)(nB + 1), hipMemcpyDeviceToHost, st));
+    STOCS_HIP_CHECK(hipMemcpyAsync(qoff_at, d_boff.p, 8 * (size_t)(nB + 1), hipMemcpyDeviceToHost, st));
+    c->timing[0].lap("enqueue gather/sort/records/join/scan");
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
+    c->timing[0].lap("wait for the device (counts)");
     STOCS_TICK("join count+scan")
     for (int b = 0; b <= nB; ++b) c->quad_off[b] = qoff_at[b];
     return STOCS_OK;
@@ -804,6 +806,7 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     DeviceGuard dev_guard(c->device);
     const bool dbg = getenv("STOCS_DEBUG_TIMING") != NULL;
     double tprev = now_s();
+    c->timing[0].begin();
     if (!c->index.built) { set_error("stocs_find_congruent_all: PPF index not built"); return STOCS_ERR_STATE; }
     const int nB = (int)c->bases.size();
     if (!c->cong) c->cong = new CongruentState();
@@ -811,8 +814,12 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     S->valid = false;
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));   // the previous trial's buffers are about to be reused
     if (c->aux_stream) STOCS_HIP_CHECK(hipStreamSynchronize(c->aux_stream));   // (idle unless an earlier call failed half way)
+    c->timing[0].lap("entry synchronisation");
     { int rc0 = S->arena_state.reset(); if (rc0) return rc0; }
     tl_arena = &S->arena_state;
+    // pinned block for everything this call reads back: plan totals, Q offsets (4 B per base), per-base quad offsets (8 B)
+    { int rc0 = ensure_pinned(c, (size_t)PIN_VAR + 12 * ((size_t)nB + 1) + 256); if (rc0) return rc0; }
+    c->timing[0].lap("arena reset + pinned block");
     if (dbg) { const double t_ = now_s(); fprintf(stderr, "[stocs congruent] %-18s %8.3f ms\n", "sync+reset", (t_ - tprev) * 1e3); tprev = t_; }
     c->quad_off.assign(nB + 1, 0);
     c->quad_id_bits = 16;
@@ -855,9 +862,10 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     if (S->stage_bytes < host_plan_bytes) {
         if (S->h_stage) (void)hipHostFree(S->h_stage);
         S->h_stage = NULL; S->stage_bytes = 0;
-        STOCS_HIP_CHECK(hipHostMalloc(&S->h_stage, 2 * host_plan_bytes, hipHostMallocDefault));
+        STOCS_HIP_CHECK(pinned_malloc(&S->h_stage, 2 * host_plan_bytes));   // counted: a regrow inside a trial must show up
         S->stage_bytes = 2 * host_plan_bytes;
     }
+    c->timing[0].lap("host: jobs + cone tables + buffers");
     char* h = (char*)S->h_stage;
     char* dpl = S->d_plan;
     PlanDev plan;
@@ -882,10 +890,18 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
         hipLaunchKernelGGL(plan_offsets_kernel, dim3(1), dim3(256), 0, c->stream, nB, (const uint2*)(dpl + o_rng), (const uint32_t*)(dpl + o_nr), (const uint32_t*)(dpl + o_tot),
                            plan.jobs, plan.psegs, plan.qsegs, plan.p_off, plan.q_off, (PlanOut*)(dpl + o_out), plan.err);
         STOCS_HIP_CHECK(hipGetLastError());
-        PlanOut po;
-        STOCS_HIP_CHECK(hipMemcpyAsync(&po, dpl + o_out, sizeof(po), hipMemcpyDeviceToHost, c->stream));
-        STOCS_HIP_CHECK(hipMemcpyAsync(q_off.data(), plan.q_off, 4 * (nb + 1), hipMemcpyDeviceToHost, c->stream));
+        // read-backs land in the pinned block (a copy into pageable memory -- a stack variable, a std::vector -- takes the
+        // runtime's staging path): totals in the fixed slot, the Q offsets behind the per-base quad offsets of count_pass
+        static_assert(sizeof(PlanOut) <= 256, "PlanOut must fit its pinned slot");
+        PlanOut* po_pin = (PlanOut*)((char*)c->h_pin + PIN_CONGRUENT);
+        uint32_t* qoff_pin = (uint32_t*)((char*)c->h_pin + PIN_VAR + 8 * (nb + 1));
+        STOCS_HIP_CHECK(hipMemcpyAsync(po_pin, dpl + o_out, sizeof(PlanOut), hipMemcpyDeviceToHost, c->stream));
+        STOCS_HIP_CHECK(hipMemcpyAsync(qoff_pin, plan.q_off, 4 * (nb + 1), hipMemcpyDeviceToHost, c->stream));
+        c->timing[0].lap("enqueue plan upload + kernels + read-back");
         STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->timing[0].lap("wait for the device (plan)");
+        const PlanOut po = *po_pin;
+        memcpy(q_off.data(), qoff_pin, 4 * (nb + 1));
         if (po.overflow) { set_error("pair lists exceed 2^32 entries"); return STOCS_ERR_CAPACITY; }
         totP = po.totP; totQ = po.totQ; plan.n_pseg = (int)po.n_pseg; plan.n_qseg = (int)po.n_qseg;
         STOCS_TICK("plan (device)")
@@ -933,6 +949,7 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
         STOCS_HIP_CHECK(hipMemcpyAsync(dpl + o_qseg, h + o_qseg, sizeof(Segment) * qsegs.size(), hipMemcpyHostToDevice, c->stream));
         STOCS_HIP_CHECK(hipMemcpyAsync(dpl + o_qoff, h + o_qoff, 4 * (nb + 1), hipMemcpyHostToDevice, c->stream));
         plan.n_pseg = (int)psegs.size(); plan.n_qseg = (int)qsegs.size();
+        c->timing[0].lap("plan on the host + upload");
         STOCS_TICK("plan (host)")
     }
     if (dbg) fprintf(stderr, "[stocs congruent] totP %llu totQ %llu segs %d %d\n", (unsigned long long)totP, (unsigned long long)totQ, plan.n_pseg, plan.n_qseg);
@@ -956,6 +973,7 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
         int rc0 = S->arena_state.reserve((size_t)totP * (3 * kb + 8 + 16 + 8) + (size_t)totQ * (3 * kb + 8 + 16 + 8) + tables + ((size_t)48 << 20));
         if (rc0) return rc0;
     }
+    c->timing[0].lap("arena reserve");
     S->nB = nB; S->totP = (uint32_t)totP; S->totQ = (uint32_t)totQ; S->nepsilon = nepsilon;
     S->half_inv_neps = (float)(0.5 / (double)nepsilon);
     S->NC = NC; S->use_table = use_table; S->wide = wide;
@@ -1029,7 +1047,9 @@ int stocs_get_quads_at(stocs_ctx* c, int slot, const int64_t* ranks, int n, int3
     DevBuf<Pick> d_picks; DevBuf<uint64_t> d_keys;
     int rc;
     if ((rc = d_picks.alloc(n)) || (rc = d_keys.alloc(n))) return rc;
-    std::vector<uint64_t> keys(n);
+    if ((rc = ensure_pinned(c, (size_t)PIN_VAR + 8 * (size_t)n + 256))) return rc;
+    uint64_t* keys = (uint64_t*)((char*)c->h_pin + PIN_VAR);
+    unsigned int* n_err_pin = (unsigned int*)((char*)c->h_pin + PIN_CONGRUENT);
     STOCS_HIP_CHECK(hipMemcpyAsync(d_picks.p, picks.data(), sizeof(Pick) * (size_t)n, hipMemcpyHostToDevice, c->stream));
     if (S->wide)
         hipLaunchKernelGGL(resolve_picks_kernel<uint64_t>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, S->args<uint64_t>(c), S->d_qoffe.p, d_picks.p, n,
@@ -1038,10 +1058,10 @@ int stocs_get_quads_at(stocs_ctx* c, int slot, const int64_t* ranks, int n, int3
         hipLaunchKernelGGL(resolve_picks_kernel<uint32_t>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, S->args<uint32_t>(c), S->d_qoffe.p, d_picks.p, n,
                            (const uint64_t*)NULL, (const unsigned long long*)NULL, S->d_bids.p, (XformJobC*)NULL, d_keys.p, S->d_err.p);
     STOCS_HIP_CHECK(hipGetLastError());
-    unsigned int n_err = 0;
-    STOCS_HIP_CHECK(hipMemcpyAsync(keys.data(), d_keys.p, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    STOCS_HIP_CHECK(hipMemcpyAsync(&n_err, S->d_err.p, 4, hipMemcpyDeviceToHost, c->stream));
+    STOCS_HIP_CHECK(hipMemcpyAsync(keys, d_keys.p, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    STOCS_HIP_CHECK(hipMemcpyAsync(n_err_pin, S->d_err.p, 4, hipMemcpyDeviceToHost, c->stream));
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    const unsigned int n_err = *n_err_pin;
     if (n_err) { set_error("stocs_get_quads_at: %u ranks could not be resolved (internal inconsistency)", n_err); return STOCS_ERR_STATE; }
     const int bits = c->quad_id_bits;
     const uint64_t mask = (1ull << bits) - 1ull;

@@ -95,6 +95,15 @@ int ensure_scratch(stocs_ctx* c, size_t bytes) {
     return STOCS_OK;
 }
 
+int ensure_pinned(stocs_ctx* c, size_t bytes) {
+    if (c->pin_bytes >= bytes) return STOCS_OK;
+    if (c->h_pin) { (void)hipHostFree(c->h_pin); c->h_pin = NULL; c->pin_bytes = 0; }
+    const size_t cap = std::max<size_t>(2 * bytes, (size_t)64 << 10);
+    STOCS_HIP_CHECK(pinned_malloc(&c->h_pin, cap));
+    c->pin_bytes = cap;
+    return STOCS_OK;
+}
+
 static inline uint32_t part1by2(uint32_t x) {
     x &= 0x3ff;
     x = (x | (x << 16)) & 0x30000ff;
@@ -155,7 +164,7 @@ static int build_grid(stocs_ctx* c) {
 // Everything that depends on the scene cloud: host copies (kdtree_initialize / centroid_shift of the scene,
 // stocs.cpp:943-980), device clouds, the brick grid; per-trial state is reset.  Used by stocs_ctx_create and
 // stocs_ctx_set_scene (a new camera frame against the same model keeps the model clouds and the PPF index).
-static int load_scene(stocs_ctx* c, const float* sp, const float* sn, const float* sprob, const int32_t* spix, int nS) {
+static int load_scene_impl(stocs_ctx* c, const float* sp, const float* sn, const float* sprob, const int32_t* spix, int nS) {
     if (spix) {   // instance-mode sampling indexes the 2-D maps with these (sample.hip); refuse what would land outside them
         const int W = c->prm.image_width, H = c->prm.image_height;
         for (int i = 0; i < nS; ++i)
@@ -230,6 +239,25 @@ static int load_scene(stocs_ctx* c, const float* sp, const float* sn, const floa
     return rc;
 }
 
+// A failed load (allocation, copy or grid build) must not leave a context that still points at the previous frame's --
+// possibly freed -- device clouds: it becomes scene-less (nS = 0: sampling reports no bases, scoring refuses) until the
+// next successful stocs_ctx_set_scene.
+static int load_scene(stocs_ctx* c, const float* sp, const float* sn, const float* sprob, const int32_t* spix, int nS) {
+    const int rc = load_scene_impl(c, sp, sn, sprob, spix, nS);
+    if (rc != STOCS_OK) {
+        c->nS = 0;
+        c->h_spos.clear(); c->h_snrm.clear(); c->h_sprob.clear(); c->h_sprob0.clear(); c->h_spix.clear();
+        c->d_spos = NULL; c->d_snrmw = NULL; c->d_spix = NULL;
+        free_grid(c);
+        c->bases.clear(); c->quad_off.clear(); clear_candidates(c);
+        c->best_lcp = 0; c->best_index = -1;
+        stocs_internal_invalidate_congruent(c);
+        stocs_internal_invalidate_instance(c);
+        c->last_segment.clear();
+    }
+    return rc;
+}
+
 }  // namespace stocs
 
 using namespace stocs;
@@ -286,6 +314,7 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     c->nS = nS; c->nM = nM;
     c->d_scratch = NULL; c->scratch_bytes = 0;
     c->h_pin = NULL; c->pin_bytes = 0;
+    for (int k = 0; k < 3; ++k) c->timing[k].n = 0;
     c->index.built = false;
     c->index.d_bucket_start = NULL; c->index.d_pairs = NULL; c->index.d_exists = NULL;
     c->cong = NULL; c->quad_id_bits = 16;
@@ -485,6 +514,17 @@ int stocs_dev_download(stocs_ctx* c, void* host, const void* dptr, int64_t bytes
     STOCS_HIP_CHECK(hipMemcpyAsync(host, dptr, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
     return STOCS_OK;
+}
+
+int stocs_last_call_timing(const stocs_ctx* c, int which, const char** labels, double* ms, int cap, int* n) {
+    if (!c || which < 0 || which > 2 || !n || cap < 0) return STOCS_ERR_INVALID;
+    const CallTiming& t = c->timing[which];
+    *n = t.n;
+    for (int i = 0; i < t.n && i < cap; ++i) {
+        if (labels) labels[i] = t.label[i];
+        if (ms) ms[i] = t.ms[i];
+    }
+    return t.n > cap ? STOCS_ERR_CAPACITY : STOCS_OK;
 }
 
 int64_t stocs_device_alloc_count(void) { return (int64_t)__atomic_load_n(&g_dev_allocs, __ATOMIC_RELAXED); }

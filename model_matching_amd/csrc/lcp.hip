@@ -801,8 +801,11 @@ int stocs_best_device(stocs_ctx* c, const void* d_lcp, int n, uint32_t id_offset
         hipLaunchKernelGGL(best_kernel, dim3(blocks), dim3(256), 0, c->stream, (const float*)d_lcp, n, id_offset, c->d_best);
     }
     STOCS_HIP_CHECK(hipGetLastError());
-    STOCS_HIP_CHECK(hipMemcpyAsync(key, c->d_best, 8, hipMemcpyDeviceToHost, c->stream));
+    { int rc = ensure_pinned(c, PIN_VAR); if (rc) return rc; }
+    uint64_t* key_pin = (uint64_t*)((char*)c->h_pin + PIN_BEST);
+    STOCS_HIP_CHECK(hipMemcpyAsync(key_pin, c->d_best, 8, hipMemcpyDeviceToHost, c->stream));
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *key = *key_pin;
     return STOCS_OK;
 }
 

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <time.h>
 
 #include <algorithm>
 #include <memory>
@@ -36,6 +37,29 @@ inline hipError_t dev_malloc(void** p, size_t bytes) {
     return hipMalloc(p, bytes);
 }
 template <class T> inline hipError_t dev_malloc(T** p, size_t bytes) { return dev_malloc((void**)p, bytes); }
+// pinned host memory goes through the same counter: a hipHostMalloc / hipHostFree inside a trial is as much of a stall
+// as a hipMalloc, and stocs_device_alloc_count must see it
+inline hipError_t pinned_malloc(void** p, size_t bytes) {
+    __atomic_fetch_add(&g_dev_allocs, 1ull, __ATOMIC_RELAXED);
+    return hipHostMalloc(p, bytes, hipHostMallocDefault);
+}
+
+// Host wall clock of the steps of one entry point, always recorded (a handful of clock reads, no synchronisation of its
+// own): when a call takes 80 ms instead of 1, the record says which step it spent them in (stocs_last_call_timing).
+struct CallTiming {
+    enum { MAX_STEPS = 12 };
+    int n;
+    const char* label[MAX_STEPS];
+    double ms[MAX_STEPS];
+    double t_last;
+    static double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+    void begin() { n = 0; t_last = now_s(); }
+    void lap(const char* what) {
+        const double t = now_s();
+        if (n < MAX_STEPS) { label[n] = what; ms[n] = (t - t_last) * 1e3; ++n; }
+        t_last = t;
+    }
+};
 
 // Binds the calling thread to the context's device for the duration of an entry point and restores the
 // caller's device afterwards (a context may be driven from any thread, one thread at a time).
@@ -225,9 +249,11 @@ struct stocs_ctx {
 
     unsigned long long* d_best;   // 8-byte arg-max key
 
-    // pinned host staging of instance-mode sampling
+    // pinned host block for the small device-to-host read-backs of the entry points (totals, offsets, keys): a copy into
+    // pageable memory goes through the runtime's own staging and is one more thing that can stall (ensure_pinned grows it)
     void* h_pin;
     size_t pin_bytes;
+    stocs::CallTiming timing[3];   // last stocs_find_congruent_all / stocs_make_transforms / stocs_verify_all
 
     // scratch
     void* d_scratch;
@@ -241,6 +267,8 @@ inline float* cand_P(stocs_ctx* c) { return (float*)c->d_cand + (size_t)c->cand_
 inline float* cand_lcp(stocs_ctx* c) { return (float*)c->d_cand + (size_t)c->cand_cap * 32; }
 inline int32_t* cand_base(stocs_ctx* c) { return (int32_t*)((float*)c->d_cand + (size_t)c->cand_cap * 33); }
 int ensure_scratch(stocs_ctx* c, size_t bytes);
+int ensure_pinned(stocs_ctx* c, size_t bytes);   // c->h_pin of at least `bytes` (nothing may still be copying into the old block)
+enum { PIN_CONGRUENT = 0, PIN_TRANSFORMS = 256, PIN_VERIFY = 512, PIN_BEST = 768, PIN_VAR = 1024 };   // fixed slots, then the per-call variable part
 int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d_hit, uint8_t* d_counted);
 int build_ppf_index(stocs_ctx* c);
 int build_grid_gpu(stocs_ctx* c, int div, int dense);

@@ -173,6 +173,7 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
     if (c->quad_off.size() != c->bases.size() + 1) { set_error("stocs_make_transforms: call stocs_find_congruent_all first"); return STOCS_ERR_STATE; }
     const bool dbg = getenv("STOCS_DEBUG_TIMING") != NULL;
     struct timespec ts0; clock_gettime(CLOCK_MONOTONIC, &ts0);
+    c->timing[1].begin();
     auto tick = [&](const char* label) {
         if (!dbg) return;
         (void)hipStreamSynchronize(c->stream);
@@ -225,6 +226,7 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
         }
     }
     const size_t n = job_base.size();
+    c->timing[1].lap("small bases enqueued + host picks");
     tick("host picks");
     clear_candidates(c);
     c->best_lcp = 0; c->best_index = -1;
@@ -236,6 +238,7 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
         scan_tmp = ((scan_tmp + 255) / 256) * 256;
         int rc = ensure_scratch(c, jb + 2 * tb + 3 * ob + scan_tmp);
         if (rc) return rc;
+        if ((rc = ensure_pinned(c, PIN_VAR))) return rc;
         if ((size_t)c->cand_cap < n) {
             if (c->d_cand) { STOCS_HIP_CHECK(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_cand); c->d_cand = NULL; }
             c->cand_cap = (int)(n + n / 4 + 1024);
@@ -263,11 +266,15 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
         hipLaunchKernelGGL(compact_candidates_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float4*)dT, (const float4*)dP, dO, dPos, dB,
                            (int)n, (float4*)cand_T(c), (float4*)cand_P(c), cand_lcp(c), cand_base(c));
         STOCS_HIP_CHECK(hipGetLastError());
-        int32_t n_ok = 0;
-        unsigned int n_unresolved = 0;
-        STOCS_HIP_CHECK(hipMemcpyAsync(&n_ok, dPos + n, 4, hipMemcpyDeviceToHost, c->stream));
-        if (d_unresolved) STOCS_HIP_CHECK(hipMemcpyAsync(&n_unresolved, d_unresolved, 4, hipMemcpyDeviceToHost, c->stream));
+        int32_t* rb = (int32_t*)((char*)c->h_pin + PIN_TRANSFORMS);   // pinned read-back slot: accepted count, unresolved picks
+        rb[0] = 0; rb[1] = 0;
+        STOCS_HIP_CHECK(hipMemcpyAsync(&rb[0], dPos + n, 4, hipMemcpyDeviceToHost, c->stream));
+        if (d_unresolved) STOCS_HIP_CHECK(hipMemcpyAsync(&rb[1], d_unresolved, 4, hipMemcpyDeviceToHost, c->stream));
+        c->timing[1].lap("enqueue resolve/transform/compact");
         STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));   // the one synchronisation point of this call
+        c->timing[1].lap("wait for the device");
+        const int32_t n_ok = rb[0];
+        const unsigned int n_unresolved = (unsigned int)rb[1];
         if (n_unresolved) { set_error("stocs_make_transforms: %u picks could not be resolved (internal inconsistency)", n_unresolved); return STOCS_ERR_STATE; }
         c->n_cands = n_ok;
         c->cands_stale = n_ok > 0;
@@ -322,6 +329,7 @@ int stocs_verify_all(stocs_ctx* c, float* best_lcp, int* best_idx, float* best_p
     c->best_lcp = 0; c->best_index = -1;
     float pose[16];
     memset(pose, 0, sizeof(pose));
+    c->timing[2].begin();
     if (n > 0) {
         // scores and the arg-max stay on the device: one LCP launch over the resident transforms, then
         // compute_best_transform (stocs.cpp:987-998: strict > from 0 => first maximum wins, Q18) as an integer max
@@ -335,9 +343,12 @@ int stocs_verify_all(stocs_ctx* c, float* best_lcp, int* best_idx, float* best_p
         float* d_out = (float*)c->d_scratch;   // the transform jobs of this trial are done with the scratch area
         hipLaunchKernelGGL(winner_pose_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)c->d_best, (const float*)cand_P(c), n, d_out);
         STOCS_HIP_CHECK(hipGetLastError());
-        float out18[18];
-        STOCS_HIP_CHECK(hipMemcpyAsync(out18, d_out, sizeof(out18), hipMemcpyDeviceToHost, c->stream));
+        if ((rc = ensure_pinned(c, PIN_VAR))) return rc;
+        float* out18 = (float*)((char*)c->h_pin + PIN_VERIFY);   // pinned read-back slot (18 floats)
+        STOCS_HIP_CHECK(hipMemcpyAsync(out18, d_out, 18 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        c->timing[2].lap("enqueue score + arg-max + winner");
         STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->timing[2].lap("wait for the device");
         uint32_t lo, hi;
         memcpy(&lo, &out18[0], 4); memcpy(&hi, &out18[1], 4);
         const uint64_t key = ((uint64_t)hi << 32) | lo;

@@ -6,9 +6,33 @@ compute_best_transform (reference src/stocs.cpp:982-1004) across ranks: one 8-by
 of the packed (score, candidate id) key, then a 64-byte broadcast of the winner's pose."""
 from __future__ import annotations
 
+import os
+import socket
 import struct
+import subprocess
+import sys
 
 import numpy as np
+
+
+def launch_ranks_if_needed(n_ranks: int, script: str, argv) -> None:
+    """`script --gpus N` started as ONE plain process (no WORLD_SIZE in the environment) must not quietly run one rank and
+    label the result N GPUs.  Called before anything imports torch or touches the GPU: starts the N rank processes as
+    CHILDREN (python -m torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1), relays their output -- rank 0
+    prints the one JSON line -- and exits with their return code.  Never os.exec: on this pool a process must not replace
+    itself once a GPU runtime may be loaded.  Returns immediately for N <= 1 or inside a rank process."""
+    if n_ranks <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool: RCCL needs it across processes
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.stdout.flush()
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def shard_range(n: int, rank: int, world: int):

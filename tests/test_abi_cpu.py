@@ -204,6 +204,65 @@ int main() { Point3D p(1, 2, 3); p.set_normal(VectorType(0, 0, 2)); Quadrilatera
     assert "Enter scene path and object name as arguments!" in r.stdout
 
 
+def test_caller_gets_the_standard_headers_the_reference_headers_give(tmp_path):
+    """A caller of the reference includes ONLY <stocs.hpp> and <pose_clustering.hpp> (stocs_match_one_object.cpp:1-2) and
+    still uses std::ofstream (:173-174), struct stat (:89-90), system() (:207-208), std::chrono + micro (:80-105),
+    std::map and std::vector: the reference's headers hand those over transitively (point3d.hpp:4-7 <vector> <iostream>
+    <fstream> <array>; rgbd.hpp:4,23 <chrono> and the std::map of PPFMapType; OpenCV/PCL pull in <cstdlib> and
+    <sys/stat.h>).  The facade must hand over the same set.  This TU is written fresh: the 18-argument constructor of
+    stocs.hpp:18-30 and the pose-file write of stocs_match_one_object.cpp:171-180, at the reference's -std=c++11."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "caller.cpp"
+    src.write_text(r"""
+#include <stocs.hpp>
+#include <pose_clustering.hpp>
+static std::map<std::string, int> seen;
+static int write_pose(stocs::stocs_estimator& e, const std::string& file) {
+    auto start = std::chrono::high_resolution_clock::now();
+    e.compute_best_transform();
+    auto finish = std::chrono::high_resolution_clock::now();
+    long long us = std::chrono::duration_cast<micro>(finish - start).count();
+    std::cout << "verify took " << us << " microseconds" << std::endl;
+    PoseCandidate* best = e.get_best_pose();
+    if (best != NULL) {
+        std::ofstream out;
+        out.open(file, std::ofstream::out);
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 4; c++) out << best->transform(r, c) << (r == 2 && c == 3 ? "" : " ");
+        out << std::endl;
+        out.close();
+        return 0;
+    }
+    std::cout << "no pose found" << std::endl;
+    return 1;
+}
+int run(std::string scene, std::string object, PPFMapType& map) {
+    std::vector<float> k = {1066.778f, 312.986f, 1067.487f, 241.310f};
+    std::string edge = scene + "/probability_maps/edge.png";
+    struct stat buffer;
+    bool instance = stat(edge.c_str(), &buffer) == 0;
+    if (system(("mkdir -p " + scene + "/dbg").c_str()) != 0) return 2;
+    stocs::stocs_estimator e("models/" + object + "/model_search.ply", map, scene + "/rgb.png", scene + "/depth.png",
+                             scene + "/probability_maps/" + object + ".png", edge, scene + "/dbg", k, 640, 480,
+                             1 / 10000.0f, 1.0f, 0.005f, 0.005f, 5, 5, 0.0f, 0.10f);
+    seen[object] = instance ? 1 : 0;
+    std::array<int, 4> ids = {{0, 1, 2, 3}};
+    std::stringstream name;
+    name << scene << "/best_pose_candidate_" << object << ".txt";
+    return write_pose(e, name.str()) + ids[0];
+}
+int main() { return 0; }
+""")
+    r = subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # the reference's own callers, where the reference tree is present (this container; absent on the GPU box)
+    for caller in ("src/stocs_match_one_object.cpp", "src/model_preprocess.cpp"):
+        path = os.path.join("/root/reference", caller)
+        if os.path.exists(path):
+            r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-I", os.path.join(root, "include"), path], capture_output=True, text=True)
+            assert r.returncode == 0, caller + "\n" + r.stderr
+
+
 def test_png_and_ply_files_round_trip(capi, tmp_path):
     """stocs_png_read against PIL-written 8/16-bit images (every PNG row filter occurs in PIL's output), stocs_ply_write /
     stocs_ply_read round trip incl. binary_little_endian input, and the error paths."""

@@ -84,3 +84,38 @@ def test_two_rank_gloo_argmax(tmp_path, oracle_lib):
                           "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "DIST_OK" in out.stdout
+
+
+LAUNCHED = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    from model_matching_amd import dist as sd
+    n, outdir = int(sys.argv[1]), sys.argv[2]
+    sd.launch_ranks_if_needed(n, os.path.abspath(__file__), sys.argv[1:])   # parent: becomes the launcher and exits with the ranks' code
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        assert (dist.get_rank(), dist.get_world_size()) == (rank, world)
+        dist.barrier()
+        dist.destroy_process_group()
+    open(os.path.join(outdir, "rank_%%d_of_%%d" %% (rank, world)), "w").close()
+    if len(sys.argv) > 3 and sys.argv[3] == "fail" and rank == 1:
+        sys.exit(7)
+""")
+
+
+def test_gpus_n_without_a_launcher_starts_n_ranks(tmp_path):
+    """What bench.py / tools/trials.py do with `--gpus N` when nothing launched them as ranks: N rank children through
+    torch.distributed.run (not one rank under an N-GPU label), return code propagated; N = 1 stays one plain process."""
+    script = tmp_path / "launched.py"
+    script.write_text(LAUNCHED % ROOT)
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    for n, extra, want_rc0 in ((2, [], True), (1, [], True), (2, ["fail"], False)):
+        out = tmp_path / ("out_%d_%s" % (n, "".join(extra)))
+        out.mkdir()
+        r = subprocess.run([sys.executable, str(script), str(n), str(out)] + extra, capture_output=True, text=True, timeout=300, env=env)
+        assert (r.returncode == 0) == want_rc0, r.stderr[-2000:]
+        assert sorted(os.listdir(out)) == ["rank_%d_of_%d" % (k, n) for k in range(n)]

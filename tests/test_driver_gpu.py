@@ -203,6 +203,31 @@ def test_trial_sharding_tool_single_and_two_ranks():
 
 
 @pytest.mark.gpu
+def test_bench_gpus_2_without_a_launcher_runs_two_ranks():
+    """`python bench.py --gpus 2` as ONE plain process (no WORLD_SIZE) must start two rank processes itself and report them
+    (it used to run one rank and print n_gpus 1).  Both ranks share this box's one GPU over gloo (STOCS_BENCH_REHEARSAL=1):
+    a rehearsal of the launch path, not a measurement; tools/trials.py --gpus 2 takes the same path."""
+    import json, sys
+    env = dict(os.environ, PYTHONPATH=ROOT, STOCS_BENCH_REHEARSAL="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-pmc", "--no-cpu-baseline",
+                        "--no-pipeline", "--workload", "small"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rehearsal"] is True and out["distributed"]["world_size"] == 2 and out["distributed"]["backend"] == "gloo"
+    assert [x["rank"] for x in out["distributed"]["ranks"]] == [0, 1]
+    assert out["value"] > 0 and out["config"]["candidates_per_step_per_gpu"] == 2048
+    t = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trials.py"), "--gpus", "2", "--trials", "4", "--seed", "3"], capture_output=True, text=True,
+                       timeout=900, env=env, cwd=ROOT)
+    assert t.returncode == 0, t.stderr[-3000:]
+    rt = json.loads([l for l in t.stdout.splitlines() if l.startswith("{")][-1])
+    assert rt["n_gpus"] == 2 and rt["world_size"] == 2 and [x["rank"] for x in rt["ranks"]] == [0, 1]
+
+
+@pytest.mark.gpu
 def test_stocs_single_instance_mode_on_packed_dove(tmp_path):
     """edge map present -> the driver takes the sample_instance_base path (stocs_match_one_object.cpp:90)."""
     from model_matching_amd import cloudio

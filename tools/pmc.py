@@ -101,8 +101,13 @@ def derive(pmc, kernel_ms):
         d["l2_bw_frac_64B_128B"] = [lo / (kernel_ms * 1e-3) / L2_PEAK_BPS, hi / (kernel_ms * 1e-3) / L2_PEAK_BPS]
         if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum") is not None and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
             d["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    if d.get("hbm_bytes_per_launch") is not None and kernel_ms:
+        # what the L2s asked of the fabric (Infinity-Cache hits included: FETCH_SIZE counts the L2's memory-side requests) over
+        # the kernel time, against the HBM peak: a kernel whose lists do not stay in L2 is bound here, not in the CUs
+        d["hbm_fabric_bps"] = d["hbm_bytes_per_launch"] / (kernel_ms * 1e-3)
+        d["hbm_fabric_frac"] = d["hbm_fabric_bps"] / HBM_PEAK_BPS
     cand = {"valu_issue": d.get("valu_issue_frac"), "texture_addresser": d.get("ta_busy_frac"),
-            "l2_bandwidth": (d.get("l2_bw_frac_64B_128B") or [None, None])[1]}
+            "l2_bandwidth": (d.get("l2_bw_frac_64B_128B") or [None, None])[1], "hbm_fabric": d.get("hbm_fabric_frac")}
     cand = {k: v for k, v in cand.items() if v is not None}
     if cand:
         name = max(cand, key=cand.get)

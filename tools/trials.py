@@ -28,7 +28,12 @@ def main():
     ap.add_argument("--bases", type=int, default=100)
     ap.add_argument("--max-sets", type=int, default=200)
     ap.add_argument("--streams", type=int, default=1, help="trial streams in flight per GPU (one context + HIP stream + host thread each)")
+    ap.add_argument("--gpus", type=int, default=0, help="N > 1 without a launcher: start N rank processes (one per GPU) as children and relay their output")
     args = ap.parse_args()
+    from model_matching_amd import dist as sd
+    sd.launch_ranks_if_needed(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    if args.gpus and int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit("WORLD_SIZE=%s does not match --gpus %d" % (os.environ.get("WORLD_SIZE", "1"), args.gpus))
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     rehearsal = os.environ.get("STOCS_BENCH_REHEARSAL") == "1"
     import torch
@@ -39,7 +44,6 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo") if rehearsal else dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    from model_matching_amd import dist as sd
     from model_matching_amd.estimator import StocsEstimator
     if args.example.startswith("synth:"):
         from model_matching_amd import synth
