@@ -165,14 +165,6 @@ static int build_grid(stocs_ctx* c) {
 // stocs.cpp:943-980), device clouds, the brick grid; per-trial state is reset.  Used by stocs_ctx_create and
 // stocs_ctx_set_scene (a new camera frame against the same model keeps the model clouds and the PPF index).
 static int load_scene_impl(stocs_ctx* c, const float* sp, const float* sn, const float* sprob, const int32_t* spix, int nS) {
-    if (spix) {   // instance-mode sampling indexes the 2-D maps with these (sample.hip); refuse what would land outside them
-        const int W = c->prm.image_width, H = c->prm.image_height;
-        for (int i = 0; i < nS; ++i)
-            if (spix[2 * i] < 0 || spix[2 * i] >= H || spix[2 * i + 1] < 0 || spix[2 * i + 1] >= W) {
-                set_error("scene point %d has pixel (row %d, col %d) outside the %dx%d image of stocs_params", i, spix[2 * i], spix[2 * i + 1], W, H);
-                return STOCS_ERR_INVALID;
-            }
-    }
     const bool dbg_t = getenv("STOCS_DEBUG_TIMING") != NULL;
     struct timespec ts_a; clock_gettime(CLOCK_MONOTONIC, &ts_a);
     auto lap = [&](const char* what) {
@@ -243,6 +235,14 @@ static int load_scene_impl(stocs_ctx* c, const float* sp, const float* sn, const
 // possibly freed -- device clouds: it becomes scene-less (nS = 0: sampling reports no bases, scoring refuses) until the
 // next successful stocs_ctx_set_scene.
 static int load_scene(stocs_ctx* c, const float* sp, const float* sn, const float* sprob, const int32_t* spix, int nS) {
+    if (spix) {   // instance-mode sampling indexes the 2-D maps with these (sample.hip); refuse what would land outside them
+        const int W = c->prm.image_width, H = c->prm.image_height;   // (a refused frame changes nothing: the old scene stays)
+        for (int i = 0; i < nS; ++i)
+            if (spix[2 * i] < 0 || spix[2 * i] >= H || spix[2 * i + 1] < 0 || spix[2 * i + 1] >= W) {
+                set_error("scene point %d has pixel (row %d, col %d) outside the %dx%d image of stocs_params", i, spix[2 * i], spix[2 * i + 1], W, H);
+                return STOCS_ERR_INVALID;
+            }
+    }
     const int rc = load_scene_impl(c, sp, sn, sprob, spix, nS);
     if (rc != STOCS_OK) {
         c->nS = 0;

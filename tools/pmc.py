@@ -121,7 +121,7 @@ def main():
     if "--" not in sys.argv or len(sys.argv) < 5:
         raise SystemExit(__doc__)
     i = sys.argv.index("--")
-    kernel, outdir = sys.argv[1], sys.argv[2]
+    kernel, outdir = sys.argv[1], os.path.abspath(sys.argv[2])
     pmc = collect(kernel, sys.argv[i + 1:], outdir)
     print(json.dumps(pmc, indent=1))
 
