@@ -123,7 +123,7 @@ static int upload(T** dptr, const T* h, size_t n) {
 }
 
 static void free_grid(stocs_ctx* c) {   // the grid lives in c->grid_mem, which the next build resets
-    c->grid.d_top = NULL; c->grid.d_cells = NULL; c->grid.d_list = NULL; c->grid.d_chunk_r = NULL; c->grid.d_flat = NULL;
+    c->grid.d_top = NULL; c->grid.d_cells = NULL; c->grid.d_list = NULL; c->grid.d_chunk_r = NULL; c->grid.d_flat = NULL; c->grid.d_flatb = NULL;
 }
 
 // one build at cell edge eps / div; lists longer than 16 on average get the centre-sorted layout + chunk bounds

@@ -37,6 +37,8 @@ struct LcpArgs {
     const int32_t* top;
     const uint4* cells;
     const uint4* flat;    // cell words addressed by (cz*ny + cy)*nx + cx, or NULL (brick look-up through top / cells)
+    const uint4* flatb;   // the same with the cells of a 2x2x2 block in one 128-byte line (SceneGrid::d_flatb), or NULL
+    int nbx2, nby2;
     const float4* list;
     const float4* snrmw;  // scene unit normal + class-probability weight
     const float* chunk_r; // per 8-entry chunk: lower bound of |entry - cell centre| (dense scenes), else NULL
@@ -45,7 +47,15 @@ struct LcpArgs {
     float sq_eps, dot_lo;
     const int32_t* order;   // processing slot -> candidate (NULL: identity): candidates that land in the same part of the scene run together
     int xcd_blocks;         // != 0: workgroups of one XCD take a contiguous run of slots (each XCD has its own L2)
+#ifdef STOCS_TOOLS_BUILD
+    int ablate;             // measurement build only (STOCS_LCP_ABLATE): parts of the kernel switched off to price them; scores are then wrong
+#endif
 };
+#ifdef STOCS_TOOLS_BUILD
+#define STOCS_ABLATE(a, bit) (((a).ablate & (bit)) != 0)
+#else
+#define STOCS_ABLATE(a, bit) false
+#endif
 
 // workgroup -> first processing slot.  The hardware hands consecutive workgroups to the 8 XCDs round-robin; with
 // xcd_blocks the workgroups that land on one XCD take consecutive slot blocks, so an XCD's L2 sees one
@@ -172,6 +182,17 @@ __device__ __forceinline__ float dpp_f32(float v) {
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v) {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+
+// minimum of a squared distance over the 8 lanes of a query group.  Squared distances are non-negative and never NaN here
+// (a NaN distance fails `d <= best` and is never kept), so their bit patterns order like unsigned integers: an integer
+// minimum needs no NaN canonicalisation and takes its DPP operand directly -- 3 instructions instead of 10.
+__device__ __forceinline__ float group8_min_nonneg(float v) {
+    uint32_t u = __float_as_uint(v);
+    u = min(u, (uint32_t)__builtin_amdgcn_update_dpp((int)u, (int)u, DPP_QUAD_XOR1, 0xF, 0xF, false));
+    u = min(u, (uint32_t)__builtin_amdgcn_update_dpp((int)u, (int)u, DPP_QUAD_XOR2, 0xF, 0xF, false));
+    u = min(u, (uint32_t)__builtin_amdgcn_update_dpp((int)u, (int)u, DPP_HALF_MIRROR, 0xF, 0xF, false));
+    return __uint_as_float(u);
 }
 
 template <bool DETAIL, int UNR, bool MASK = true, bool EARLY = false, bool IDX = true, int WPB = 4, bool SPLIT = false>
@@ -342,7 +363,7 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coop_kernel(LcpArgs a, const flo
 // it sooner; big batches lose nothing); the partial sums are integers, so the score is the same bit for bit.
 // TILE (tools build, A/B only): the WPB candidates of a workgroup read the model points from a 256-point tile staged in LDS
 // (one global load per point and workgroup instead of one per wavefront), at the price of a workgroup barrier per tile.
-template <bool DETAIL, int UNR, bool SORTQ = false, int PIPE = 4, bool IDX = true, int WPB = 4, bool FLAT = false, bool SPLIT = false, bool TILE = false>
+template <bool DETAIL, int UNR, bool SORTQ = false, int PIPE = 4, bool IDX = true, int WPB = 4, int FLAT = 0, bool SPLIT = false, bool TILE = false>
 __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
                                                         int n, int32_t* __restrict__ hit_out, uint8_t* __restrict__ cnt_out) {
     __shared__ float4 qt[WPB][128];     // qx, qy, qz, bits(list offset)
@@ -367,15 +388,14 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
         // order the pending queries by list length (number of 128-byte chunks) so that the eight
         // groups of a step stream lists of similar length: a counting sort on <= 8 classes with ballots
         if (SORTQ) {
-            uint32_t cls = 8;
-            if (lane < nq) { const uint32_t nch = (qn[w][(head + lane) & 127] + 7u) >> 3; cls = nch < 8u ? nch - 1u : 7u; }
-            int pos = 0, basep = 0;
-#pragma unroll
-            for (uint32_t cidx = 0; cidx < 8; ++cidx) {
-                const unsigned long long mc = __ballot(cls == cidx);
-                if (cls == cidx) pos = basep + __popcll(mc & ((1ull << lane) - 1ull));
-                basep += __popcll(mc);
-            }
+            // (most lists are one or two lines: three classes -- one line, two, more -- keep the eight groups of a step on
+            //  lists of similar length at a third of the instructions of a sort over all lengths)
+            uint32_t cls = 3;
+            if (lane < nq) { const uint32_t nch = (qn[w][(head + lane) & 127] + 7u) >> 3; cls = nch <= 1u ? 0u : (nch == 2u ? 1u : 2u); }
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const unsigned long long m0 = __ballot(cls == 0u), m1 = __ballot(cls == 1u), m2 = __ballot(cls == 2u);
+            const int n0 = __popcll(m0), n1 = __popcll(m1);
+            const int pos = cls == 0u ? __popcll(m0 & below) : (cls == 1u ? n0 + __popcll(m1 & below) : n0 + n1 + __popcll(m2 & below));
             if (lane < nq) ord[w][pos] = (uint8_t)lane;
             __builtin_amdgcn_wave_barrier();
         }
@@ -392,7 +412,11 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
                 idxs[u] = (head + (SORTQ ? (int)ord[w][gact ? slot : 0] : slot)) & 127;
                 cs[u] = gact ? qn[w][idxs[u]] : 0u;
                 e0[u] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(-1));
-                if (cs[u]) e0[u] = a.list[(uint32_t)__float_as_int(qt[w][idxs[u]].w) + sub];
+                if (STOCS_ABLATE(a, 4)) {   // 4: no list loads (every survivor "hits" scene point 0 at distance 0)
+                    if (cs[u]) { const float4 qq0 = qt[w][idxs[u]]; e0[u] = make_float4(qq0.x, qq0.y, qq0.z, __int_as_float(0)); }
+                    cs[u] = cs[u] ? 1u : 0u;
+                }
+                else if (cs[u]) e0[u] = a.list[(uint32_t)__float_as_int(qt[w][idxs[u]].w) + sub];
             }
 #pragma unroll
             for (int u = 0; u < PIPE; ++u) {
@@ -420,9 +444,7 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
                         take_if_better<IDX>(d, __float_as_int(e[v].w), gd, gi);
                     }
                 }
-                float dm = fminf(gd, dpp_f32<DPP_QUAD_XOR1>(gd));
-                dm = fminf(dm, dpp_f32<DPP_QUAD_XOR2>(dm));
-                dm = fminf(dm, dpp_f32<DPP_HALF_MIRROR>(dm));
+                const float dm = group8_min_nonneg(gd);
                 int im = (gd == dm) ? gi : -1;
                 im = max(im, dpp_i32<DPP_QUAD_XOR1>(im));
                 im = max(im, dpp_i32<DPP_QUAD_XOR2>(im));
@@ -436,12 +458,13 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
             const int best = ri[w][idx];
             const uint32_t slot_i = qs[w][idx];
             bool counted = false;
-            if (best >= 0) {
-                const float4 nm = a.mnrm[slot_i];
+            if (best >= 0 && STOCS_ABLATE(a, 8)) { lcp_add(acc, 0.5f); }   // 8: no normal test
+            else if (best >= 0) {
+                const float4 nm = STOCS_ABLATE(a, 16) ? make_float4(0.f, 0.f, 1.f, 0.f) : a.mnrm[slot_i];   // 16: no model-normal gather
                 const float nx = t0 * nm.x + (t4 * nm.y + t8 * nm.z);
                 const float ny = t1 * nm.x + (t5 * nm.y + t9 * nm.z);
                 const float nz = t2 * nm.x + (t6 * nm.y + t10 * nm.z);
-                const float4 sn = a.snrmw[best];
+                const float4 sn = STOCS_ABLATE(a, 32) ? make_float4(nx, ny, nz, 0.5f) : a.snrmw[best];         // 32: no scene-normal gather
                 const float d = sn.x * nx + (sn.y * ny + sn.z * nz);
                 counted = (d >= a.dot_lo) && (d <= 1.0f);
                 if (counted) lcp_add(acc, sn.w);
@@ -472,9 +495,13 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
             if ((unsigned)cx < (unsigned)a.nx && (unsigned)cy < (unsigned)a.ny && (unsigned)cz < (unsigned)a.nz) {
                 const int sb = ((c4z & 3) << 4) | ((c4y & 3) << 2) | (c4x & 3);
                 if (FLAT) {   // one look-up: an empty cell is an all-zero word (count 0, mask 0)
-                    const uint4 cw = a.flat[(uint32_t)((cz * a.ny + cy) * a.nx + cx)];
+                    uint4 cw = make_uint4(0u, 0u, 0u, 0u);
+                    if (!STOCS_ABLATE(a, 1))   // 1: no cell-word look-up at all
+                        cw = FLAT == 1 ? a.flat[(uint32_t)((cz * a.ny + cy) * a.nx + cx)]
+                                       : a.flatb[(uint32_t)(((((cz >> 1) * a.nby2 + (cy >> 1)) * a.nbx2 + (cx >> 1)) << 3) | ((cz & 1) << 2) | ((cy & 1) << 1) | (cx & 1))];
                     const uint32_t mw = sb < 32 ? cw.z : cw.w;
                     off = cw.x; cnt = ((mw >> (sb & 31)) & 1u) ? cw.y : 0u;
+                    if (STOCS_ABLATE(a, 2)) cnt = cw.x == 0xFFFFFFF1u ? 1u : 0u;   // 2: look-up done, nobody survives
                 } else {
                     const int brick = a.top[((cz >> 3) * a.nby + (cy >> 3)) * a.nbx + (cx >> 3)];
                     if (brick >= 0) {
@@ -532,7 +559,8 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
     for (int base = first; base < a.M; base += stride) {
         const int i = base + lane;
         const float4 p = p_next;
-        if (i + stride < a.M) p_next = a.mpos[i + stride];
+        if (STOCS_ABLATE(a, 64)) p_next = make_float4(0.001f * (float)(i & 63), 0.0007f * (float)(i >> 6), 0.02f, 0.f);   // 64: no model-point loads
+        else if (i + stride < a.M) p_next = a.mpos[i + stride];
         step(i, p);
     }
     }
@@ -640,13 +668,16 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
     if (n <= 0) return STOCS_OK;
     LcpArgs a;
     a.mpos = c->d_mpos_s; a.mnrm = c->d_mnrm_s; a.mperm = c->d_mperm; a.M = c->nM;
-    a.top = c->grid.d_top; a.cells = c->grid.d_cells; a.flat = c->grid.d_flat; a.list = c->grid.d_list; a.snrmw = c->d_snrmw;
+    a.top = c->grid.d_top; a.cells = c->grid.d_cells; a.flat = c->grid.d_flat; a.flatb = c->grid.d_flatb; a.nbx2 = c->grid.nbx2; a.nby2 = c->grid.nby2; a.list = c->grid.d_list; a.snrmw = c->d_snrmw;
     a.ox = c->grid.ox; a.oy = c->grid.oy; a.oz = c->grid.oz; a.inv_h = c->grid.inv_h; a.inv_h4 = c->grid.inv_h * 4.0f; a.h = c->grid.h; a.chunk_r = c->grid.d_chunk_r;
     a.nx = c->grid.nx; a.ny = c->grid.ny; a.nz = c->grid.nz; a.nbx = c->grid.nbx; a.nby = c->grid.nby;
     a.sq_eps = c->prm.distance_threshold * c->prm.distance_threshold;  // sq_eps = epsilon*epsilon, stocs.cpp:1014
     a.dot_lo = c->thr.lcp_dot_lo;
     const int blocks = (n + 3) / 4;
     a.order = NULL; a.xcd_blocks = 0;
+#ifdef STOCS_TOOLS_BUILD
+    a.ablate = getenv("STOCS_LCP_ABLATE") ? atoi(getenv("STOCS_LCP_ABLATE")) : 0;
+#endif
     // big batches (the ordering costs ~50 us, the gain is ~10 % of a kernel time that grows with n * |M|): spatially ordered
     // processing; scores do not depend on it
     if (!d_hit && n >= 1024 && (double)n * (double)c->nM >= 1.5e8 && c->lcp_order) {
@@ -717,18 +748,19 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
             case 40: hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 4, true, 8>), dim3((n + 7) / 8), dim3(512), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); break;
             case 44: STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 4, true, 4>); break;
             // model tile shared through LDS by the four candidates of a workgroup (45), next to the same workgroup shape without it (46)
-            case 45: if (a.flat) STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 4, true, 4, true, false, true>); else STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 4, true, 4, false, false, true>); break;
-            case 46: if (a.flat) STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 4, true, 4, true>); else STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 4, true, 4>); break;
+            case 45: if (a.flat) STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 4, true, 4, 1, false, true>); else STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 4, true, 4, 0, false, true>); break;
+            case 46: if (a.flat) STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 4, true, 4, 1>); else STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 4, true, 4>); break;
 #endif
             default: {  // 24
-                const bool flat = a.flat && c->lcp_flat;
+                // the flat table the grid was built with (the option may have changed since): row-major, 2x2x2-blocked, or none
+                const int flat = !c->lcp_flat ? 0 : (a.flat ? 1 : (a.flatb ? 2 : 0));
                 // four wavefronts per candidate: a trial's ~8 000 candidates finish 40 % sooner (one round of long wavefronts
                 // becomes four rounds of short ones), 32 768 candidates 9 % sooner, 65 536 the same (tools/lcp_flat_ab.py)
                 const bool split = c->lcp_split && a.M >= 512;
-                if (split && flat) hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 4, true, 4, true, true>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
-                else if (split) hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 4, true, 4, false, true>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
-                else if (flat) hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 4, true, 1, true>), dim3(n), dim3(64), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
-                else hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 4, true, 1>), dim3(n), dim3(64), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
+#define STOCS_LCP_Q(FLATV, WPBV, SPLITV, GRID, BLOCK) hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 4, true, WPBV, FLATV, SPLITV>), dim3(GRID), dim3(BLOCK), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted)
+                if (split) { if (flat == 1) STOCS_LCP_Q(1, 4, true, n, 256); else if (flat == 2) STOCS_LCP_Q(2, 4, true, n, 256); else STOCS_LCP_Q(0, 4, true, n, 256); }
+                else { if (flat == 1) STOCS_LCP_Q(1, 1, false, n, 64); else if (flat == 2) STOCS_LCP_Q(2, 1, false, n, 64); else STOCS_LCP_Q(0, 1, false, n, 64); }
+#undef STOCS_LCP_Q
                 break;
             }
         }
@@ -839,9 +871,9 @@ int stocs_set_option(stocs_ctx* c, const char* key, int value) {
     }
     // 0 off, 1 spatial order, 2 + XCD-contiguous halves of the list, k > 2 + chunks of k consecutive slots per XCD
     if (!strcmp(key, "lcp_order") && value >= 0 && value <= 4096) { c->lcp_order = value; return STOCS_OK; }
-    // 0: brick look-ups only, 1: the flat cell table when the grid has one (takes effect for kernels launched afterwards;
-    // the table itself is built with the scene grid)
-    if (!strcmp(key, "lcp_flat") && (value == 0 || value == 1)) { c->lcp_flat = value; return STOCS_OK; }
+    // 0: brick look-ups only, 1: the flat cell table, 2: its 2x2x2-blocked layout (A/B).  The table is built with the scene grid
+    // (stocs_ctx_set_scene after changing the option); kernels launched afterwards use what the grid has
+    if (!strcmp(key, "lcp_flat") && value >= 0 && value <= 2) { c->lcp_flat = value; return STOCS_OK; }
     // 0: one wavefront per candidate, 1 (default): four wavefronts share a candidate's model points (same scores)
     if (!strcmp(key, "lcp_split") && (value == 0 || value == 1)) { c->lcp_split = value; return STOCS_OK; }
     set_error("stocs_set_option: unknown option or value");

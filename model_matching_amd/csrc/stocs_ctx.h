@@ -132,7 +132,11 @@ struct SceneGrid {
     double avg_list_len;   // entries per non-empty cell
     int32_t* d_top;      // nbx*nby*nbz -> brick id or -1
     uint4* d_flat;       // the same cell words addressed directly, (cz*ny + cy)*nx + cx, when the box is small enough (sparse
-                         // scenes, cell edge eps): saves the LCP kernel the dependent `top` look-up; else NULL
+                         // scenes, cell edge eps): saves the LCP kernel the dependent `top` look-up; else NULL (lcp_flat = 2 only)
+    uint4* d_flatb;      // the flat table with the cells of a 2 x 2 x 2 block next to each other (one 128-byte line per block): the cell
+                         // words a wavefront's 64 neighbouring queries need fall into fewer lines.  index = block * 8 + (z&1)<<2 | (y&1)<<1 | (x&1),
+                         // block = ((z>>1) * nby2 + (y>>1)) * nbx2 + (x>>1)
+    int nbx2, nby2;
     uint4* d_cells;      // n_bricks*512: (offset, count, sub-cell mask lo, hi); mask bit s set <=> some scene
                          // point lies within epsilon of sub-cell s (4x4x4 sub-cells, x fastest)
     float4* d_list;      // (x, y, z, bits(scene index))
@@ -215,7 +219,7 @@ struct stocs_ctx {
     int grid_div;   // cell edge = epsilon / grid_div
     int lcp_variant;   // -1: STOCS_LCP_VARIANT or automatic; else stocs_set_option("lcp_variant")
     int lcp_split;     // 1: four wavefronts share one candidate (default), 0: one wavefront per candidate
-    int lcp_flat;      // 1: build and use the flat cell table when it fits (default), 0: brick look-ups only
+    int lcp_flat;      // 1: build and use the flat cell table when it fits (default), 2: its 2x2x2-blocked layout (A/B), 0: brick look-ups only
     int lcp_order;     // 0: candidates in batch order; 1: spatially ordered processing of big batches; 2: + XCD-contiguous blocks
     void* d_order;     // keys / permutation / sort scratch of the ordering
     size_t order_bytes;

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Prices the parts of the LCP kernel by switching them off one at a time (measurement build only: libstocs_hip_tools.so,
+`make -C model_matching_amd/csrc tools`; the scores of an ablated run are wrong by design).  One context, the same resident
+batch, HIP events, interleaved rounds.  usage: python tools/lcp_ablate.py [Cm] [rounds] [candidates]"""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from model_matching_amd import capi, synth  # noqa: E402
+_tools_lib = os.path.join(os.path.dirname(capi.LIB_PATH), "libstocs_hip_tools.so")
+if not os.path.exists(_tools_lib):
+    raise SystemExit("build the measurement library first: make -C model_matching_amd/csrc tools")
+capi.LIB_PATH = _tools_lib
+from model_matching_amd.estimator import StocsEstimator  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "Cm"
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+m, s, k = synth.workload(name)
+if len(sys.argv) > 3 and int(sys.argv[3]) > 0:
+    k = int(sys.argv[3])
+est = StocsEstimator(s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm, build_index=False)
+cs, cm = est.get_scene_centroid().astype(np.float64), est.get_model_centroid().astype(np.float64)
+T = synth.make_candidates(synth.centred_gt(s.T_gt, cs, cm), k)
+dT, dL = est.dev_alloc(T.nbytes), est.dev_alloc(k * 4)
+est.dev_upload(dT, T)
+cases = [(0, "full kernel"), (32, "no scene-normal gather"), (16, "no model-normal gather"), (48, "no normal gathers"), (8, "no normal test at all"),
+         (4, "no list loads"), (4 | 8, "no list loads, no normal test"), (2, "cell look-up done, nobody survives"), (1, "no cell look-up, nobody survives"),
+         (1 | 64, "no cell look-up, no model-point loads (transform + bookkeeping only)"), (64, "no model-point loads")]
+times = {c: [] for c, _ in cases}
+for r in range(rounds):
+    for c, _ in cases:
+        os.environ["STOCS_LCP_ABLATE"] = str(c)
+        times[c].append(est.time_score_kernel(dT, k, dL, 10))
+print(json.dumps({"workload": name, "K": k, "cases": [{"ablate": c, "what": w, "ms_median": float(np.median(times[c])), "ms_all": times[c]} for c, w in cases]}, indent=1))

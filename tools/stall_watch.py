@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Runs N Cm trials on one warm context and prints, for every trial whose stocs_find_congruent_all / stocs_make_transforms /
+stocs_verify_all took more than 5x the median, the library's own step record of that call (stocs_last_call_timing) -- the
+80 ms stalls of rounds 1-2 were the same trial (seed 1234 + 3) both times.  usage: python tools/stall_watch.py [trials] [first seed]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from model_matching_amd import synth  # noqa: E402
+from model_matching_amd.estimator import StocsEstimator  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1234
+m, s, k = synth.workload("Cm")
+est = StocsEstimator(s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm, build_index=True)
+rows = []
+for r in range(n):
+    est.L.stocs_clear_bases(est.h)
+    a0 = int(est.L.stocs_device_alloc_count())
+    t0 = time.perf_counter(); valid, _, _ = est.sample_bases(seed0 + (r % 8), 100)
+    t1 = time.perf_counter(); nq = est.find_congruent_all()
+    t2 = time.perf_counter(); nc = est.make_transforms(200, seed0 + (r % 8))
+    t3 = time.perf_counter(); est.compute_best_transform()
+    t4 = time.perf_counter()
+    rows.append({"trial": r, "seed": seed0 + (r % 8), "bases": int(valid.sum()), "quads": int(nq), "candidates": int(nc),
+                 "ms": [(t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3], "allocs": int(est.L.stocs_device_alloc_count()) - a0,
+                 "steps": [est.last_call_timing(w) for w in range(3)]})
+warm = rows[8:]
+med = [float(np.median([x["ms"][i] for x in warm])) for i in range(4)]
+flag = [x for x in warm if any(x["ms"][i] > 5 * med[i] for i in range(1, 4))]
+print(json.dumps({"trials": n, "median_ms_sample_congruent_transforms_verify": med, "max_ms": [float(max(x["ms"][i] for x in warm)) for i in range(4)],
+                  "allocations_in_warm_trials": int(sum(x["allocs"] for x in warm)), "stalled_trials": flag,
+                  "example_steps_of_a_normal_trial": warm[0]["steps"]}, indent=1))
