@@ -272,7 +272,8 @@ int64_t stocs_device_alloc_count(void);
  * stocs_make_transforms (1) or stocs_verify_all (2): always recorded (a few clock reads per call, no synchronisation of its
  * own), so that a call that stalls -- tens of milliseconds instead of one -- names the step it stalled in.  Steps are host
  * intervals between the call's existing synchronisation points: "wait for the device" steps hold the GPU work, the others
- * host work and runtime calls.  labels[i] point to static strings.  STOCS_ERR_CAPACITY when cap is too small (*n is set). */
+ * host work and runtime calls; entries whose label starts with "device:" are HIP-event times of the kernel groups that
+ * wait covered.  At most 18 entries.  labels[i] point to static strings.  STOCS_ERR_CAPACITY when cap is too small (*n is set). */
 int stocs_last_call_timing(const stocs_ctx* ctx, int which, const char** labels, double* ms, int cap, int* n);
 /* device memory helpers so that callers without a HIP binding (ctypes) can keep inputs resident */
 int stocs_dev_alloc(stocs_ctx* ctx, int64_t bytes, void** dptr);

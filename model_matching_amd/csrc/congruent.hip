@@ -701,6 +701,9 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     DevBuf<char> d_tmp2;
     if ((rc = d_tmp.alloc(tb1)) || (rc = d_tmp2.alloc(tb2))) return rc;
     hipStream_t sq = c->aux_stream ? c->aux_stream : st;
+    // device-side clock of the groups below (HIP events on the streams they run on; read after the call's closing
+    // synchronisation): a call that takes 70 ms instead of 1 then says which group of kernels it spent them in
+    STOCS_HIP_CHECK(hipEventRecord(c->ev_t[0], st));
     if (sq != st) {
         STOCS_HIP_CHECK(hipEventRecord(c->ev_fork, st));          // the upload above is on st
         STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_fork, 0));
@@ -708,12 +711,14 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totQ + 255) / 256)), dim3(256), 0, sq, ix.d_pairs, d_qsegs, n_qseg, (uint32_t)totQ,
                        S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p);
     STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_tmp2.p, tb2, d_qk_raw.p, (KeyT*)S->d_qkeys.p, d_qv_raw.p, S->d_qvals.p, totQ, 0, end_bit, sq));
+    STOCS_HIP_CHECK(hipEventRecord(c->ev_t[1], sq));
     if (sq != st) STOCS_HIP_CHECK(hipEventRecord(c->ev_join, sq));
     hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, ix.d_pairs, d_psegs, n_pseg, (uint32_t)totP,
                        S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p);
     STOCS_HIP_CHECK(hipGetLastError());
     // one stable sort per list: (base, position cell); inside a cell the entries keep the index order of the gather
     STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_tmp.p, tb1, d_pk_raw.p, (KeyT*)S->d_pkeys.p, d_pv_raw.p, S->d_pvals.p, totP, 0, end_bit_p, st));
+    STOCS_HIP_CHECK(hipEventRecord(c->ev_t[2], st));
     if (S->use_table) {
         const size_t ncell = (size_t)(S->NC * nB);
         if ((rc = S->d_cfirst.alloc(ncell)) || (rc = S->d_cend.alloc(ncell))) return rc;
@@ -725,12 +730,14 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
                        S->use_table ? S->d_cend.p : (uint32_t*)NULL);
     STOCS_HIP_CHECK(hipGetLastError());
     if (sq != st) STOCS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_join, 0));   // the join needs both sides
+    STOCS_HIP_CHECK(hipEventRecord(c->ev_t[3], st));
     STOCS_TICK("gather+sort+records")
     // join: count pass + exclusive scan.  The quads themselves are produced on demand (materialise / resolve_picks_kernel)
     DevBuf<unsigned long long> d_qcnt;   // 64-bit: the total can exceed 2^32
     if ((rc = d_qcnt.alloc(totQ + 1)) || (rc = S->d_qoffe.alloc(totQ + 1))) return rc;
     hipLaunchKernelGGL(join_count_kernel<KeyT>, dim3((unsigned)((totQ + 255) / 256)), dim3(256), 0, st, S->args<KeyT>(c), d_qcnt.p);
     STOCS_HIP_CHECK(hipGetLastError());
+    STOCS_HIP_CHECK(hipEventRecord(c->ev_t[4], st));
     size_t tmp_scan = 0;
     STOCS_HIP_CHECK(rocprim::exclusive_scan(NULL, tmp_scan, d_qcnt.p, S->d_qoffe.p, 0ull, totQ + 1, rocprim::plus<unsigned long long>(), st));
     DevBuf<char> d_tmp_scan;
@@ -743,9 +750,22 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     hipLaunchKernelGGL(base_offsets_kernel, dim3((unsigned)((nB + 1 + 255) / 256)), dim3(256), 0, st, S->d_qoffe.p, S->d_qoff.p, nB + 1, d_boff.p);
     STOCS_HIP_CHECK(hipGetLastError());
     STOCS_HIP_CHECK(hipMemcpyAsync(qoff_at, d_boff.p, 8 * (size_t)(nB + 1), hipMemcpyDeviceToHost, st));
+    STOCS_HIP_CHECK(hipEventRecord(c->ev_t[5], st));
     c->timing[0].lap("enqueue gather/sort/records/join/scan");
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
     c->timing[0].lap("wait for the device (counts)");
+    {   // the device's own account of that wait (every event has completed: the stream is idle, the Q side was joined into it)
+        static const char* const what[5] = {"device: Q gather + sort (aux stream, from the fork)", "device: P gather + sort", "device: P records + wait for Q", "device: join count",
+                                            "device: scan + offsets + read-back"};
+        const int from[5] = {0, 0, 2, 3, 4}, to[5] = {1, 2, 3, 4, 5};
+        for (int k = 0; k < 5; ++k) {
+            float ms = -1.0f;
+            if (hipEventElapsedTime(&ms, c->ev_t[from[k]], c->ev_t[to[k]]) != hipSuccess) ms = -1.0f;
+            CallTiming& T = c->timing[0];
+            if (T.n < CallTiming::MAX_STEPS) { T.label[T.n] = what[k]; T.ms[T.n] = (double)ms; ++T.n; }
+        }
+        c->timing[0].t_last = CallTiming::now_s();
+    }
     STOCS_TICK("join count+scan")
     for (int b = 0; b <= nB; ++b) c->quad_off[b] = qoff_at[b];
     return STOCS_OK;

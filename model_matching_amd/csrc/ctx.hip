@@ -123,7 +123,7 @@ static int upload(T** dptr, const T* h, size_t n) {
 }
 
 static void free_grid(stocs_ctx* c) {   // the grid lives in c->grid_mem, which the next build resets
-    c->grid.d_top = NULL; c->grid.d_cells = NULL; c->grid.d_list = NULL; c->grid.d_chunk_r = NULL; c->grid.d_flat = NULL; c->grid.d_flatb = NULL;
+    c->grid.d_top = NULL; c->grid.d_cells = NULL; c->grid.d_list = NULL; c->grid.d_chunk_r = NULL; c->grid.d_flat = NULL;
 }
 
 // one build at cell edge eps / div; lists longer than 16 on average get the centre-sorted layout + chunk bounds
@@ -340,6 +340,8 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
         delete c;
         return STOCS_ERR_NO_DEVICE;
     }
+    for (int k = 0; k < 6; ++k)
+        if (hipEventCreate(&c->ev_t[k]) != hipSuccess) { set_error("event creation failed"); delete c; return STOCS_ERR_NO_DEVICE; }
     c->stream = c->own_stream;
     compute_thresholds(c->prm, &c->thr);
 
@@ -430,6 +432,7 @@ int stocs_ctx_destroy(stocs_ctx* c) {
     (void)hipEventDestroy(c->ev1);
     (void)hipEventDestroy(c->ev_fork);
     (void)hipEventDestroy(c->ev_join);
+    for (int k = 0; k < 6; ++k) (void)hipEventDestroy(c->ev_t[k]);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;

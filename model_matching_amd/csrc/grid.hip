@@ -119,12 +119,12 @@ __global__ __launch_bounds__(256) void cell_records_kernel(const uint64_t* __res
 }
 
 // padded length of every cell's list
-__global__ __launch_bounds__(256) void cell_padded_kernel(const uint32_t* __restrict__ cell_first, uint32_t n_cells, uint32_t n_inc,
+__global__ __launch_bounds__(256) void cell_padded_kernel(const uint32_t* __restrict__ cell_first, uint32_t n_cells, uint32_t n_inc, uint32_t pad,
                                                           uint32_t* __restrict__ padded, uint32_t* __restrict__ max_count) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_cells) return;
     const uint32_t cnt = (c + 1 < n_cells ? cell_first[c + 1] : n_inc) - cell_first[c];
-    padded[c] = (cnt + 7u) & ~7u;
+    padded[c] = (cnt + pad - 1u) & ~(pad - 1u);   // whole 128-byte lines: 8 entries of 16 bytes, or 16 of 8 bytes (dense scenes)
     atomicMax(max_count, cnt);
 }
 
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void cell_words_kernel(GridGeom G, int div, co
                                                          const uint32_t* __restrict__ cell_brick, const uint32_t* __restrict__ list_off,
                                                          uint32_t n_cells, uint32_t n_inc, const uint32_t* __restrict__ vals,
                                                          const float4* __restrict__ spos, int32_t* __restrict__ top, uint4* __restrict__ cells,
-                                                         uint4* __restrict__ flat, uint4* __restrict__ flatb, int nbx2, int nby2) {
+                                                         uint4* __restrict__ flat) {
     const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int s = threadIdx.x & 63;
     if (c >= n_cells) return;   // whole wavefront
@@ -185,13 +185,10 @@ __global__ __launch_bounds__(256) void cell_words_kernel(GridGeom G, int div, co
         top[brick] = (int32_t)b;   // every cell of the brick writes the same value
         const uint4 w = make_uint4(list_off[c], cnt, mlo, mhi);
         cells[(size_t)b * 512 + local] = w;
-        if (flat || flatb) {
+        if (flat) {
             const int bx = (int)(brick % (uint64_t)G.nbx), by = (int)((brick / (uint64_t)G.nbx) % (uint64_t)G.nby), bz = (int)(brick / ((uint64_t)G.nbx * (uint64_t)G.nby));
             const int cx = bx * 8 + (int)(local & 7), cy = by * 8 + (int)((local >> 3) & 7), cz = bz * 8 + (int)(local >> 6);
-            if (cx < G.n[0] && cy < G.n[1] && cz < G.n[2]) {
-                if (flat) flat[((size_t)cz * G.n[1] + cy) * G.n[0] + cx] = w;
-                if (flatb) flatb[((((size_t)(cz >> 1) * nby2 + (cy >> 1)) * nbx2 + (cx >> 1)) << 3) | (size_t)(((cz & 1) << 2) | ((cy & 1) << 1) | (cx & 1))] = w;
-            }
+            if (cx < G.n[0] && cy < G.n[1] && cz < G.n[2]) flat[((size_t)cz * G.n[1] + cy) * G.n[0] + cx] = w;
         }
     }
 }
@@ -269,7 +266,7 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense) {
     g.nbx = (n[0] + 7) / 8; g.nby = (n[1] + 7) / 8; g.nbz = (n[2] + 7) / 8;
     g.h = (float)h;
     g.n_bricks = 0; g.n_entries = 0; g.avg_list_len = 0;
-    g.d_top = NULL; g.d_cells = NULL; g.d_list = NULL; g.d_chunk_r = NULL; g.d_flat = NULL; g.d_flatb = NULL;
+    g.d_top = NULL; g.d_cells = NULL; g.d_list = NULL; g.d_chunk_r = NULL; g.d_flat = NULL;
     const int64_t n_top = (int64_t)g.nbx * g.nby * g.nbz;
     if (n_top > (int64_t)400 * 1000 * 1000) { set_error("scene extent too large for the brick grid"); return STOCS_ERR_INVALID; }
     int cell_bits = 1;
@@ -353,7 +350,7 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense) {
     hipLaunchKernelGGL(cell_records_kernel, dim3(grid_of(n_inc)), dim3(256), 0, st, d_keys_s, n_inc, qbits, d_cflag, d_cidx, d_bflag, d_bidx, d_cell_first,
                        d_cell_key, d_cell_brick);
     hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(256), 0, st, (int32_t*)d_max, (size_t)1, 0);
-    hipLaunchKernelGGL(cell_padded_kernel, dim3(grid_of(n_cells)), dim3(256), 0, st, d_cell_first, n_cells, (uint32_t)n_inc, d_padded, d_max);
+    hipLaunchKernelGGL(cell_padded_kernel, dim3(grid_of(n_cells)), dim3(256), 0, st, d_cell_first, n_cells, (uint32_t)n_inc, 8u, d_padded, d_max);
     hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(256), 0, st, (int32_t*)(d_padded + n_cells), (size_t)1, 0);
     STOCS_HIP_CHECK(rocprim::exclusive_scan(d_t32, t32, d_padded, d_list_off, 0u, (size_t)n_cells + 1, plus32, st));
     uint32_t tail[2] = {0, 0};
@@ -369,20 +366,14 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense) {
     hipLaunchKernelGGL(zero_cells_kernel, dim3(grid_of((size_t)n_bricks * 512)), dim3(256), 0, st, g.d_cells, (size_t)n_bricks * 512);
     {   // flat copy of the cell words for the sparse-scene kernel: one look-up per query instead of two dependent ones
         const size_t n_flat = (size_t)n[0] * n[1] * n[2];
-        if (!dense && div == 1 && c->lcp_flat == 1 && n_flat * sizeof(uint4) <= ((size_t)512 << 20)) {
+        if (!dense && div == 1 && c->lcp_flat && n_flat * sizeof(uint4) <= ((size_t)512 << 20)) {
             if ((rc = c->grid_mem.take(n_flat * sizeof(uint4), (void**)&g.d_flat))) return rc;
             hipLaunchKernelGGL(zero_cells_kernel, dim3(grid_of(n_flat)), dim3(256), 0, st, g.d_flat, n_flat);
-        }
-        g.nbx2 = (n[0] + 1) / 2; g.nby2 = (n[1] + 1) / 2;
-        const size_t n_flatb = (size_t)g.nbx2 * g.nby2 * ((n[2] + 1) / 2) * 8;
-        if (!dense && div == 1 && c->lcp_flat == 2 && n_flatb * sizeof(uint4) <= ((size_t)512 << 20)) {
-            if ((rc = c->grid_mem.take(n_flatb * sizeof(uint4), (void**)&g.d_flatb))) return rc;
-            hipLaunchKernelGGL(zero_cells_kernel, dim3(grid_of(n_flatb)), dim3(256), 0, st, g.d_flatb, n_flatb);
         }
     }
     hipLaunchKernelGGL(fill_list_kernel, dim3(grid_of(std::max<size_t>(n_list, 8))), dim3(256), 0, st, g.d_list, std::max<size_t>(n_list, 8));
     hipLaunchKernelGGL(cell_words_kernel, dim3((unsigned)((n_cells + 3) / 4)), dim3(256), 0, st, G, div, d_cell_first, d_cell_key, d_cell_brick, d_list_off, n_cells,
-                       (uint32_t)n_inc, d_vals_s, c->d_spos, g.d_top, g.d_cells, g.d_flat, g.d_flatb, g.nbx2, g.nby2);
+                       (uint32_t)n_inc, d_vals_s, c->d_spos, g.d_top, g.d_cells, g.d_flat);
     hipLaunchKernelGGL(list_fill_kernel, dim3(grid_of(n_inc)), dim3(256), 0, st, d_cflag, d_cidx, d_cell_first, d_list_off, d_vals_s, n_inc, c->d_spos, g.d_list);
     STOCS_HIP_CHECK(hipGetLastError());
     // ---- 5. dense scenes: chunk bounds ----

@@ -37,8 +37,6 @@ struct LcpArgs {
     const int32_t* top;
     const uint4* cells;
     const uint4* flat;    // cell words addressed by (cz*ny + cy)*nx + cx, or NULL (brick look-up through top / cells)
-    const uint4* flatb;   // the same with the cells of a 2x2x2 block in one 128-byte line (SceneGrid::d_flatb), or NULL
-    int nbx2, nby2;
     const float4* list;
     const float4* snrmw;  // scene unit normal + class-probability weight
     const float* chunk_r; // per 8-entry chunk: lower bound of |entry - cell centre| (dense scenes), else NULL
@@ -229,13 +227,15 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coop_kernel(LcpArgs a, const flo
             const float fx = floorf(ux), fy = floorf(uy), fz = floorf(uz);
             if (fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < (float)a.nx && fy < (float)a.ny && fz < (float)a.nz) {
                 const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
-                const int brick = a.top[((cz >> 3) * a.nby + (cy >> 3)) * a.nbx + (cx >> 3)];
+                const int brick = STOCS_ABLATE(a, 1) ? -1 : a.top[((cz >> 3) * a.nby + (cy >> 3)) * a.nbx + (cx >> 3)];   // 1: no look-ups at all
                 if (brick >= 0) {
-                    const uint4 cw = a.cells[(size_t)brick * 512 + (((cz & 7) << 6) | ((cy & 7) << 3) | (cx & 7))];
+                    uint4 cw = make_uint4(0u, 0u, 0u, 0u);
+                    if (!STOCS_ABLATE(a, 128)) cw = a.cells[(size_t)brick * 512 + (((cz & 7) << 6) | ((cy & 7) << 3) | (cx & 7))];   // 128: top table only
                     // sub-cell filter: no scene point within epsilon of this 1/4-cell => no neighbour possible
                     const int sb = ((int)((uz - fz) * 4.0f) << 4) | ((int)((uy - fy) * 4.0f) << 2) | (int)((ux - fx) * 4.0f);
                     const uint32_t mw = sb < 32 ? cw.z : cw.w;
                     off = cw.x; cnt = (!MASK || ((mw >> (sb & 31)) & 1u)) ? cw.y : 0u;
+                    if (STOCS_ABLATE(a, 2)) cnt = cw.x == 0xFFFFFFF1u ? 1u : 0u;   // 2: look-ups done, nobody survives
                     if (EARLY) {
                         const float ex = qx - (a.ox + ((float)cx + 0.5f) * a.h), ey = qy - (a.oy + ((float)cy + 0.5f) * a.h),
                                     ez = qz - (a.oz + ((float)cz + 0.5f) * a.h);
@@ -273,8 +273,9 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coop_kernel(LcpArgs a, const flo
                     const uint32_t chunk0 = (uint32_t)__float_as_int(qq.w) >> 3;
                     uint32_t nchunks = (c + 7u) >> 3;
                     float gb = a.sq_eps;   // best d^2 of the whole group so far
+                    if (STOCS_ABLATE(a, 4)) nchunks = min(nchunks, (uint32_t)UNR);   // 4: the first trip of every list only
                     for (uint32_t j = 0; __any(j < nchunks); j += UNR) {
-                        if (j < nchunks && j > 0 && a.chunk_r[chunk0 + j] - qcg > sqrtf(gb) + 2e-6f) nchunks = 0;
+                        if (j < nchunks && j > 0 && (STOCS_ABLATE(a, 256) ? 0.0f : a.chunk_r[chunk0 + j]) - qcg > sqrtf(gb) + 2e-6f) nchunks = 0;   // 256: no chunk bounds (scan everything)
                         float4 e[UNR];
 #pragma unroll
                         for (int u = 0; u < UNR; ++u) {
@@ -322,7 +323,8 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coop_kernel(LcpArgs a, const flo
             __builtin_amdgcn_wave_barrier();
         }
         bool counted = false;
-        if (best >= 0) {
+        if (best >= 0 && STOCS_ABLATE(a, 8)) lcp_add(acc, 0.5f);   // 8: no normal test
+        else if (best >= 0) {
             const float4 nm = a.mnrm[i];
             const float nx = t0 * nm.x + (t4 * nm.y + t8 * nm.z);
             const float ny = t1 * nm.x + (t5 * nm.y + t9 * nm.z);
@@ -363,10 +365,14 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coop_kernel(LcpArgs a, const flo
 // it sooner; big batches lose nothing); the partial sums are integers, so the score is the same bit for bit.
 // TILE (tools build, A/B only): the WPB candidates of a workgroup read the model points from a 256-point tile staged in LDS
 // (one global load per point and workgroup instead of one per wavefront), at the price of a workgroup barrier per tile.
-template <bool DETAIL, int UNR, bool SORTQ = false, int PIPE = 4, bool IDX = true, int WPB = 4, int FLAT = 0, bool SPLIT = false, bool TILE = false>
+// EARLY (dense scenes: lists sorted by distance from the cell centre, a lower bound of that distance per 8-entry line): a query
+// stops at the first line the triangle inequality rules out, as in variant 31 -- but fed from the queue, so that the first
+// lines of 32 queries are in flight together where variant 31 has the two lines of 8.
+template <bool DETAIL, int UNR, bool SORTQ = false, int PIPE = 4, bool IDX = true, int WPB = 4, int FLAT = 0, bool SPLIT = false, bool TILE = false, bool EARLY = false>
 __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
                                                         int n, int32_t* __restrict__ hit_out, uint8_t* __restrict__ cnt_out) {
     __shared__ float4 qt[WPB][128];     // qx, qy, qz, bits(list offset)
+    __shared__ float qcd[EARLY ? WPB : 1][EARLY ? 128 : 1];   // |query - cell centre| (EARLY)
     __shared__ uint32_t qn[WPB][128];   // list length
     __shared__ uint32_t qs[WPB][128];   // model slot (Morton order)
     __shared__ int ri[WPB][128];        // best scene index
@@ -430,6 +436,27 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
                     const float d = dx * dx + (dy * dy + dz * dz);
                     take_if_better<IDX>(d, __float_as_int(e0[u].w), gd, gi);
                 }
+                if (EARLY) {
+                    const float qcg = qcd[w][idxs[u]];
+                    const uint32_t chunk0 = (uint32_t)__float_as_int(qq.w) >> 3;
+                    uint32_t cc = c;   // entries still to be looked at (0 once the rest of the list is ruled out)
+                    for (uint32_t k = 8; __any(k < cc); k += 8 * UNR) {
+                        // |q - p| >= |p - centre| - |q - centre| > sqrt(best of the group) for every later p: stop
+                        if (k < cc && a.chunk_r[chunk0 + (k >> 3)] - qcg > sqrtf(group8_min_nonneg(gd)) + 2e-6f) cc = 0;
+                        float4 e[UNR];
+#pragma unroll
+                        for (int v = 0; v < UNR; ++v) {
+                            e[v] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(-1));
+                            if (k + 8 * v < cc) e[v] = lp[k + 8 * v];
+                        }
+#pragma unroll
+                        for (int v = 0; v < UNR; ++v) {
+                            const float dx = qq.x - e[v].x, dy = qq.y - e[v].y, dz = qq.z - e[v].z;
+                            const float d = dx * dx + (dy * dy + dz * dz);
+                            take_if_better<IDX>(d, __float_as_int(e[v].w), gd, gi);
+                        }
+                    }
+                } else
                 for (uint32_t k = 8; __any(k < c); k += 8 * UNR) {
                     float4 e[UNR];
 #pragma unroll
@@ -480,7 +507,7 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
 
     // one 64-point step of this wavefront's candidate: model point p of slot i
     auto step = [&](const int i, const float4 p) {
-        float qx = 0.f, qy = 0.f, qz = 0.f;
+        float qx = 0.f, qy = 0.f, qz = 0.f, qcentre = 0.f;
         uint32_t off = 0, cnt = 0;
         if (i < a.M) {
             qx = ((t0 * p.x + t4 * p.y) + t8 * p.z) + t12;
@@ -497,8 +524,7 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
                 if (FLAT) {   // one look-up: an empty cell is an all-zero word (count 0, mask 0)
                     uint4 cw = make_uint4(0u, 0u, 0u, 0u);
                     if (!STOCS_ABLATE(a, 1))   // 1: no cell-word look-up at all
-                        cw = FLAT == 1 ? a.flat[(uint32_t)((cz * a.ny + cy) * a.nx + cx)]
-                                       : a.flatb[(uint32_t)(((((cz >> 1) * a.nby2 + (cy >> 1)) * a.nbx2 + (cx >> 1)) << 3) | ((cz & 1) << 2) | ((cy & 1) << 1) | (cx & 1))];
+                        cw = a.flat[(uint32_t)((cz * a.ny + cy) * a.nx + cx)];
                     const uint32_t mw = sb < 32 ? cw.z : cw.w;
                     off = cw.x; cnt = ((mw >> (sb & 31)) & 1u) ? cw.y : 0u;
                     if (STOCS_ABLATE(a, 2)) cnt = cw.x == 0xFFFFFFF1u ? 1u : 0u;   // 2: look-up done, nobody survives
@@ -510,6 +536,10 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
                         off = cw.x; cnt = ((mw >> (sb & 31)) & 1u) ? cw.y : 0u;
                     }
                 }
+            }
+            if (EARLY && cnt) {
+                const float ex = qx - (a.ox + ((float)cx + 0.5f) * a.h), ey = qy - (a.oy + ((float)cy + 0.5f) * a.h), ez = qz - (a.oz + ((float)cz + 0.5f) * a.h);
+                qcentre = sqrtf(ex * ex + (ey * ey + ez * ez));
             }
             if (DETAIL && cnt == 0) {
                 const int orig = a.mperm[i];
@@ -526,6 +556,7 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
                 qt[w][sl] = make_float4(qx, qy, qz, __int_as_float((int)off));
                 qn[w][sl] = cnt;
                 qs[w][sl] = (uint32_t)i;
+                if (EARLY) qcd[w][sl] = qcentre;
             }
             tail += __popcll(mask);
             __builtin_amdgcn_wave_barrier();
@@ -644,9 +675,9 @@ __global__ __launch_bounds__(256) void order_keys_kernel(const float* __restrict
 // the reference's scores.  The other measured variants (profiles/r01_lcp_analysis.md) exist only in a tools build
 // (make tools -> libstocs_hip_tools.so, -DSTOCS_TOOLS_BUILD), which also honours the STOCS_LCP_VARIANT environment variable.
 static bool lcp_variant_selectable(int v) {
-    if (v == 99 || v == 0 || v == 15 || v == 24 || v == 31) return true;
+    if (v == 99 || v == 0 || v == 15 || v == 24 || v == 31 || v == 39) return true;
 #ifdef STOCS_TOOLS_BUILD
-    static const int extra[] = {1, 9, 16, 17, 20, 25, 26, 27, 28, 30, 32, 33, 40, 44, 45, 46};
+    static const int extra[] = {1, 9, 16, 17, 20, 25, 26, 27, 28, 30, 32, 33, 34, 35, 40, 41, 42, 43, 44, 45, 46};
     for (size_t i = 0; i < sizeof(extra) / sizeof(extra[0]); ++i) if (extra[i] == v) return true;
 #endif
     return false;
@@ -668,7 +699,7 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
     if (n <= 0) return STOCS_OK;
     LcpArgs a;
     a.mpos = c->d_mpos_s; a.mnrm = c->d_mnrm_s; a.mperm = c->d_mperm; a.M = c->nM;
-    a.top = c->grid.d_top; a.cells = c->grid.d_cells; a.flat = c->grid.d_flat; a.flatb = c->grid.d_flatb; a.nbx2 = c->grid.nbx2; a.nby2 = c->grid.nby2; a.list = c->grid.d_list; a.snrmw = c->d_snrmw;
+    a.top = c->grid.d_top; a.cells = c->grid.d_cells; a.flat = c->grid.d_flat; a.list = c->grid.d_list; a.snrmw = c->d_snrmw;
     a.ox = c->grid.ox; a.oy = c->grid.oy; a.oz = c->grid.oz; a.inv_h = c->grid.inv_h; a.inv_h4 = c->grid.inv_h * 4.0f; a.h = c->grid.h; a.chunk_r = c->grid.d_chunk_r;
     a.nx = c->grid.nx; a.ny = c->grid.ny; a.nz = c->grid.nz; a.nbx = c->grid.nbx; a.nby = c->grid.nby;
     a.sq_eps = c->prm.distance_threshold * c->prm.distance_threshold;  // sq_eps = epsilon*epsilon, stocs.cpp:1014
@@ -706,12 +737,14 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
     // instantiated with the order-independent tie rule may scan them
     const bool dense = c->grid.d_chunk_r != NULL;
     if (variant == 99)   // automatic; must not depend on the batch size (a candidate's score is batch-invariant)
-        variant = dense ? 31 : (c->grid.avg_list_len <= 10.0 ? 24 : 15);   // measured: tools/lcp_ab.py (Cm, C5)
-    if (dense && !(variant == 0 || variant == 16 || (variant >= 30 && variant <= 33))) variant = 31;
-    if (!dense && variant >= 30 && variant <= 33) variant = 24;
+        variant = dense ? 39 : (c->grid.avg_list_len <= 10.0 ? 24 : 15);   // measured: tools/lcp_ab.py (Cm, C5; profiles/r03_C5_lcp_ab.json)
+    const bool dense_only = (variant >= 30 && variant <= 35) || variant == 39 || (variant >= 41 && variant <= 43);   // kernels with the order-independent tie rule / early exit
+    if (dense && !(variant == 0 || variant == 16 || dense_only)) variant = 39;
+    if (!dense && dense_only) variant = 24;
 #define STOCS_LCP_LAUNCH(...) hipLaunchKernelGGL((__VA_ARGS__), dim3(blocks), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted)
     if (d_hit) {   // per-point detail (parity tests)
-        if (dense) STOCS_LCP_LAUNCH(lcp_coop_kernel<true, 2, true, true, false>);
+        if (dense && variant == 39) STOCS_LCP_LAUNCH(lcp_coopq_kernel<true, 1, true, 4, false, 4, 0, false, false, true>);
+        else if (dense) STOCS_LCP_LAUNCH(lcp_coop_kernel<true, 2, true, true, false>);
         else if (variant == 0) STOCS_LCP_LAUNCH(lcp_kernel<true, true>);
         else if (variant >= 20 && variant <= 28) STOCS_LCP_LAUNCH(lcp_coopq_kernel<true, 1, true, 4, true>);
         else STOCS_LCP_LAUNCH(lcp_coop_kernel<true, 1, true, false, true>);
@@ -723,6 +756,16 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
             case 30: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 1, true, true, false>); break;
             case 32: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 4, true, true, false>); break;
             case 33: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 2, true, true, false>); break;   // 31 with four waves per workgroup
+            case 34: hipLaunchKernelGGL((lcp_coop_kernel<false, 1, true, true, false, 4, true>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); break;   // 31 with one line per trip
+            case 35: hipLaunchKernelGGL((lcp_coop_kernel<false, 4, true, true, false, 4, true>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); break;   // 31 with four lines per trip
+#endif
+            case 39:   // queue-fed scan with early exit (16-byte lists)
+                hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 4, false, 4, 0, true, false, true>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
+                break;
+#ifdef STOCS_TOOLS_BUILD
+            case 41: hipLaunchKernelGGL((lcp_coopq_kernel<false, 2, true, 4, false, 4, 0, true, false, true>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); break;   // 39, two lines per trip after the first
+            case 42: hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 8, false, 4, 0, true, false, true>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); break;   // 39, eight first lines in flight
+            case 43: hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, false, 4, false, 4, 0, true, false, true>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); break;  // 39 without the ordering by list length
 #endif
             default:   // 31
                 // four wavefronts per candidate: C5 (16 384 candidates x 50 000 points) 11.6 -> 8.3 ms; eight: 8.1 ms, but 20 % slower at Cm
@@ -752,14 +795,13 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
             case 46: if (a.flat) STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 4, true, 4, 1>); else STOCS_LCP_LAUNCH(lcp_coopq_kernel<false, 1, true, 4, true, 4>); break;
 #endif
             default: {  // 24
-                // the flat table the grid was built with (the option may have changed since): row-major, 2x2x2-blocked, or none
-                const int flat = !c->lcp_flat ? 0 : (a.flat ? 1 : (a.flatb ? 2 : 0));
+                const int flat = (c->lcp_flat && a.flat) ? 1 : 0;
                 // four wavefronts per candidate: a trial's ~8 000 candidates finish 40 % sooner (one round of long wavefronts
                 // becomes four rounds of short ones), 32 768 candidates 9 % sooner, 65 536 the same (tools/lcp_flat_ab.py)
                 const bool split = c->lcp_split && a.M >= 512;
 #define STOCS_LCP_Q(FLATV, WPBV, SPLITV, GRID, BLOCK) hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 4, true, WPBV, FLATV, SPLITV>), dim3(GRID), dim3(BLOCK), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted)
-                if (split) { if (flat == 1) STOCS_LCP_Q(1, 4, true, n, 256); else if (flat == 2) STOCS_LCP_Q(2, 4, true, n, 256); else STOCS_LCP_Q(0, 4, true, n, 256); }
-                else { if (flat == 1) STOCS_LCP_Q(1, 1, false, n, 64); else if (flat == 2) STOCS_LCP_Q(2, 1, false, n, 64); else STOCS_LCP_Q(0, 1, false, n, 64); }
+                if (split) { if (flat) STOCS_LCP_Q(1, 4, true, n, 256); else STOCS_LCP_Q(0, 4, true, n, 256); }
+                else { if (flat) STOCS_LCP_Q(1, 1, false, n, 64); else STOCS_LCP_Q(0, 1, false, n, 64); }
 #undef STOCS_LCP_Q
                 break;
             }
@@ -865,15 +907,15 @@ int stocs_score_best_device(stocs_ctx* c, const void* d_T16, int n, void* d_lcp,
 int stocs_set_option(stocs_ctx* c, const char* key, int value) {
     if (!c || !key) return STOCS_ERR_INVALID;
     if (!strcmp(key, "lcp_variant")) {
-        if (!lcp_variant_selectable(value)) { set_error("stocs_set_option: lcp_variant %d is not part of this build (99 automatic, 0, 15, 24, 31)", value); return STOCS_ERR_INVALID; }
+        if (!lcp_variant_selectable(value)) { set_error("stocs_set_option: lcp_variant %d is not part of this build (99 automatic, 0, 15, 24, 31, 39)", value); return STOCS_ERR_INVALID; }
         c->lcp_variant = value;
         return STOCS_OK;
     }
     // 0 off, 1 spatial order, 2 + XCD-contiguous halves of the list, k > 2 + chunks of k consecutive slots per XCD
     if (!strcmp(key, "lcp_order") && value >= 0 && value <= 4096) { c->lcp_order = value; return STOCS_OK; }
-    // 0: brick look-ups only, 1: the flat cell table, 2: its 2x2x2-blocked layout (A/B).  The table is built with the scene grid
-    // (stocs_ctx_set_scene after changing the option); kernels launched afterwards use what the grid has
-    if (!strcmp(key, "lcp_flat") && value >= 0 && value <= 2) { c->lcp_flat = value; return STOCS_OK; }
+    // 0: brick look-ups only, 1: the flat cell table when the grid has one (takes effect for kernels launched afterwards;
+    // the table itself is built with the scene grid)
+    if (!strcmp(key, "lcp_flat") && (value == 0 || value == 1)) { c->lcp_flat = value; return STOCS_OK; }
     // 0: one wavefront per candidate, 1 (default): four wavefronts share a candidate's model points (same scores)
     if (!strcmp(key, "lcp_split") && (value == 0 || value == 1)) { c->lcp_split = value; return STOCS_OK; }
     set_error("stocs_set_option: unknown option or value");

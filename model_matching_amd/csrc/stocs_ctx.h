@@ -47,7 +47,7 @@ inline hipError_t pinned_malloc(void** p, size_t bytes) {
 // Host wall clock of the steps of one entry point, always recorded (a handful of clock reads, no synchronisation of its
 // own): when a call takes 80 ms instead of 1, the record says which step it spent them in (stocs_last_call_timing).
 struct CallTiming {
-    enum { MAX_STEPS = 12 };
+    enum { MAX_STEPS = 18 };
     int n;
     const char* label[MAX_STEPS];
     double ms[MAX_STEPS];
@@ -132,11 +132,7 @@ struct SceneGrid {
     double avg_list_len;   // entries per non-empty cell
     int32_t* d_top;      // nbx*nby*nbz -> brick id or -1
     uint4* d_flat;       // the same cell words addressed directly, (cz*ny + cy)*nx + cx, when the box is small enough (sparse
-                         // scenes, cell edge eps): saves the LCP kernel the dependent `top` look-up; else NULL (lcp_flat = 2 only)
-    uint4* d_flatb;      // the flat table with the cells of a 2 x 2 x 2 block next to each other (one 128-byte line per block): the cell
-                         // words a wavefront's 64 neighbouring queries need fall into fewer lines.  index = block * 8 + (z&1)<<2 | (y&1)<<1 | (x&1),
-                         // block = ((z>>1) * nby2 + (y>>1)) * nbx2 + (x>>1)
-    int nbx2, nby2;
+                         // scenes, cell edge eps): saves the LCP kernel the dependent `top` look-up; else NULL
     uint4* d_cells;      // n_bricks*512: (offset, count, sub-cell mask lo, hi); mask bit s set <=> some scene
                          // point lies within epsilon of sub-cell s (4x4x4 sub-cells, x fastest)
     float4* d_list;      // (x, y, z, bits(scene index))
@@ -188,6 +184,7 @@ struct stocs_ctx {
     hipStream_t own_stream;   // created with the context; `stream` may point to a caller's stream instead
     hipStream_t aux_stream;   // second stream of the context for work that is independent of `stream` until an event joins it
     hipEvent_t ev0, ev1, ev_fork, ev_join;
+    hipEvent_t ev_t[6];   // timing events around the device groups of stocs_find_congruent_all (always recorded; read after the call's own sync)
     int nS, nM;
     stocs::Thresholds thr;
 
@@ -219,7 +216,7 @@ struct stocs_ctx {
     int grid_div;   // cell edge = epsilon / grid_div
     int lcp_variant;   // -1: STOCS_LCP_VARIANT or automatic; else stocs_set_option("lcp_variant")
     int lcp_split;     // 1: four wavefronts share one candidate (default), 0: one wavefront per candidate
-    int lcp_flat;      // 1: build and use the flat cell table when it fits (default), 2: its 2x2x2-blocked layout (A/B), 0: brick look-ups only
+    int lcp_flat;      // 1: build and use the flat cell table when it fits (default), 0: brick look-ups only
     int lcp_order;     // 0: candidates in batch order; 1: spatially ordered processing of big batches; 2: + XCD-contiguous blocks
     void* d_order;     // keys / permutation / sort scratch of the ordering
     size_t order_bytes;

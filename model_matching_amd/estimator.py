@@ -302,10 +302,10 @@ class StocsEstimator:
     def last_call_timing(self, which):
         """[(step, milliseconds)] of the last find_congruent_all (0), make_transforms (1) or compute_best_transform (2):
         host wall clock between the call's own synchronisation points, always recorded by the library."""
-        labels = (C.c_char_p * 12)()
-        ms = (C.c_double * 12)()
+        labels = (C.c_char_p * 18)()
+        ms = (C.c_double * 18)()
         n = C.c_int(0)
-        capi.check(self.L.stocs_last_call_timing(self.h, which, labels, ms, 12, C.byref(n)))
+        capi.check(self.L.stocs_last_call_timing(self.h, which, labels, ms, 18, C.byref(n)))
         return [(labels[i].decode(), float(ms[i])) for i in range(n.value)]
 
     def time_score_kernel(self, dT, n, dL, reps):

@@ -236,7 +236,7 @@ def test_dense_scene_and_all_scan_variants(oracle_lib):
     assert np.abs(got - ref).max() <= LCP_TOL and got.max() > 0.05
     best = int(np.argmax(ref))
     ho, co = orc.lcp_detail(T[best])
-    for v in (0, 31, 15, 24):     # on a dense (centre-sorted) grid 15 and 24 map to the default
+    for v in (0, 31, 39, 15, 24):     # 39: queue-fed scan with early exit (the default here); on a dense (centre-sorted) grid 15 and 24 map to it
         est.set_option("lcp_variant", v)
         gv = est.score_transforms(T)
         assert np.abs(gv - ref).max() <= LCP_TOL, v

@@ -26,9 +26,13 @@ cs, cm = est.get_scene_centroid().astype(np.float64), est.get_model_centroid().a
 T = synth.make_candidates(synth.centred_gt(s.T_gt, cs, cm), k)
 dT, dL = est.dev_alloc(T.nbytes), est.dev_alloc(k * 4)
 est.dev_upload(dT, T)
+dense_cases = [(0, "full kernel"), (8, "no normal test"), (256, "no chunk bounds: every list scanned to its end"), (4, "only the first trip (two lines) of every list"),
+               (2, "cell words read, nobody survives"), (128, "top table only (no cell words), nobody survives"), (1, "no look-ups at all")]
 cases = [(0, "full kernel"), (32, "no scene-normal gather"), (16, "no model-normal gather"), (48, "no normal gathers"), (8, "no normal test at all"),
          (4, "no list loads"), (4 | 8, "no list loads, no normal test"), (2, "cell look-up done, nobody survives"), (1, "no cell look-up, nobody survives"),
          (1 | 64, "no cell look-up, no model-point loads (transform + bookkeeping only)"), (64, "no model-point loads")]
+if name in ("C5", "dense"):
+    cases = dense_cases
 times = {c: [] for c, _ in cases}
 for r in range(rounds):
     for c, _ in cases:

@@ -15,23 +15,25 @@ from model_matching_amd.estimator import StocsEstimator  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1234
+period = int(sys.argv[3]) if len(sys.argv) > 3 else 8      # trials cycle through this many seeds (0: every trial its own seed)
 m, s, k = synth.workload("Cm")
 est = StocsEstimator(s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm, build_index=True)
 rows = []
 for r in range(n):
     est.L.stocs_clear_bases(est.h)
     a0 = int(est.L.stocs_device_alloc_count())
-    t0 = time.perf_counter(); valid, _, _ = est.sample_bases(seed0 + (r % 8), 100)
+    t0 = time.perf_counter(); valid, _, _ = est.sample_bases(seed0 + (r % period if period else r), 100)
     t1 = time.perf_counter(); nq = est.find_congruent_all()
-    t2 = time.perf_counter(); nc = est.make_transforms(200, seed0 + (r % 8))
+    t2 = time.perf_counter(); nc = est.make_transforms(200, seed0 + (r % period if period else r))
     t3 = time.perf_counter(); est.compute_best_transform()
     t4 = time.perf_counter()
-    rows.append({"trial": r, "seed": seed0 + (r % 8), "bases": int(valid.sum()), "quads": int(nq), "candidates": int(nc),
+    rows.append({"trial": r, "seed": seed0 + (r % period if period else r), "bases": int(valid.sum()), "quads": int(nq), "candidates": int(nc),
                  "ms": [(t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3], "allocs": int(est.L.stocs_device_alloc_count()) - a0,
                  "steps": [est.last_call_timing(w) for w in range(3)]})
-warm = rows[8:]
+warm = rows[(period or 2):]
 med = [float(np.median([x["ms"][i] for x in warm])) for i in range(4)]
 flag = [x for x in warm if any(x["ms"][i] > 5 * med[i] for i in range(1, 4))]
 print(json.dumps({"trials": n, "median_ms_sample_congruent_transforms_verify": med, "max_ms": [float(max(x["ms"][i] for x in warm)) for i in range(4)],
                   "allocations_in_warm_trials": int(sum(x["allocs"] for x in warm)), "stalled_trials": flag,
-                  "example_steps_of_a_normal_trial": warm[0]["steps"]}, indent=1))
+                  "example_steps_of_a_normal_trial": warm[0]["steps"],
+                  "all_trials_seed_quads_congruent_ms": [[x["seed"], x["quads"], round(x["ms"][1], 3)] for x in rows]}, indent=1))
