@@ -232,6 +232,16 @@ __global__ __launch_bounds__(256) void chunk_bounds_kernel(GridGeom G, const uin
     }
 }
 
+// dense scenes with cell edges below epsilon (the sub-cell masks are all ones there): the z word of a cell takes a lower bound of
+// the distance from the cell centre to its nearest listed point (= the bound of the list's first chunk).  A query at distance t
+// from the centre has no neighbour within epsilon when bound - t > epsilon, and the scan kernel then never touches the list.
+__global__ __launch_bounds__(256) void cell_nearest_kernel(const uint64_t* __restrict__ cell_key, const uint32_t* __restrict__ cell_brick, const uint32_t* __restrict__ list_off,
+                                                           uint32_t n_cells, const float* __restrict__ chunk_r, uint4* __restrict__ cells) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cells) return;
+    cells[(size_t)cell_brick[c] * 512 + (uint32_t)(cell_key[c] & 511)].z = __float_as_uint(chunk_r[list_off[c] >> 3]);
+}
+
 struct Tmp {   // temporaries of one build: the context's workspace arena (no hipMalloc / hipFree in steady state)
     Arena* ws;
     template <class T>
@@ -265,7 +275,7 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense) {
     g.nx = n[0]; g.ny = n[1]; g.nz = n[2];
     g.nbx = (n[0] + 7) / 8; g.nby = (n[1] + 7) / 8; g.nbz = (n[2] + 7) / 8;
     g.h = (float)h;
-    g.n_bricks = 0; g.n_entries = 0; g.avg_list_len = 0;
+    g.n_bricks = 0; g.n_entries = 0; g.avg_list_len = 0; g.has_nearest = false;
     g.d_top = NULL; g.d_cells = NULL; g.d_list = NULL; g.d_chunk_r = NULL; g.d_flat = NULL;
     const int64_t n_top = (int64_t)g.nbx * g.nby * g.nbz;
     if (n_top > (int64_t)400 * 1000 * 1000) { set_error("scene extent too large for the brick grid"); return STOCS_ERR_INVALID; }
@@ -382,6 +392,9 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense) {
         hipLaunchKernelGGL(fill_i32_kernel, dim3(grid_of(n_list / 8)), dim3(256), 0, st, (int32_t*)g.d_chunk_r, n_list / 8, 0);
         hipLaunchKernelGGL(chunk_bounds_kernel, dim3(grid_of(n_cells)), dim3(256), 0, st, G, d_cell_first, d_cell_key, d_list_off, n_cells, (uint32_t)n_inc,
                            g.d_list, g.d_chunk_r);
+        g.has_nearest = div > 1;
+        if (g.has_nearest)
+            hipLaunchKernelGGL(cell_nearest_kernel, dim3(grid_of(n_cells)), dim3(256), 0, st, d_cell_key, d_cell_brick, d_list_off, n_cells, g.d_chunk_r, g.d_cells);
         STOCS_HIP_CHECK(hipGetLastError());
     }
     STOCS_HIP_CHECK(hipStreamSynchronize(st));

@@ -42,7 +42,8 @@ struct LcpArgs {
     const float* chunk_r; // per 8-entry chunk: lower bound of |entry - cell centre| (dense scenes), else NULL
     float ox, oy, oz, inv_h, inv_h4, h;
     int nx, ny, nz, nbx, nby;
-    float sq_eps, dot_lo;
+    float sq_eps, dot_lo, eps;
+    int has_nearest;        // the z word of a dense grid's cell is a lower bound of |cell centre - nearest listed point| (SceneGrid::has_nearest)
     const int32_t* order;   // processing slot -> candidate (NULL: identity): candidates that land in the same part of the scene run together
     int xcd_blocks;         // != 0: workgroups of one XCD take a contiguous run of slots (each XCD has its own L2)
 #ifdef STOCS_TOOLS_BUILD
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coop_kernel(LcpArgs a, const flo
                     if (!STOCS_ABLATE(a, 128)) cw = a.cells[(size_t)brick * 512 + (((cz & 7) << 6) | ((cy & 7) << 3) | (cx & 7))];   // 128: top table only
                     // sub-cell filter: no scene point within epsilon of this 1/4-cell => no neighbour possible
                     const int sb = ((int)((uz - fz) * 4.0f) << 4) | ((int)((uy - fy) * 4.0f) << 2) | (int)((ux - fx) * 4.0f);
-                    const uint32_t mw = sb < 32 ? cw.z : cw.w;
+                    const uint32_t mw = a.has_nearest ? 0xFFFFFFFFu : (sb < 32 ? cw.z : cw.w);   // (has_nearest: no mask on this grid, z holds a distance)
                     off = cw.x; cnt = (!MASK || ((mw >> (sb & 31)) & 1u)) ? cw.y : 0u;
                     if (STOCS_ABLATE(a, 2)) cnt = cw.x == 0xFFFFFFF1u ? 1u : 0u;   // 2: look-ups done, nobody survives
                     if (EARLY) {
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
 
     // one 64-point step of this wavefront's candidate: model point p of slot i
     auto step = [&](const int i, const float4 p) {
-        float qx = 0.f, qy = 0.f, qz = 0.f, qcentre = 0.f;
+        float qx = 0.f, qy = 0.f, qz = 0.f, qcentre = 0.f, nearest = 0.f;
         uint32_t off = 0, cnt = 0;
         if (i < a.M) {
             qx = ((t0 * p.x + t4 * p.y) + t8 * p.z) + t12;
@@ -532,14 +533,17 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
                     const int brick = a.top[((cz >> 3) * a.nby + (cy >> 3)) * a.nbx + (cx >> 3)];
                     if (brick >= 0) {
                         const uint4 cw = a.cells[(uint32_t)brick * 512u + (uint32_t)(((cz & 7) << 6) | ((cy & 7) << 3) | (cx & 7))];
-                        const uint32_t mw = sb < 32 ? cw.z : cw.w;
-                        off = cw.x; cnt = ((mw >> (sb & 31)) & 1u) ? cw.y : 0u;
+                        if (EARLY && a.has_nearest) { off = cw.x; cnt = cw.y; nearest = __uint_as_float(cw.z); }   // no mask on these grids: z = distance bound
+                        else { const uint32_t mw = a.has_nearest ? 0xFFFFFFFFu : (sb < 32 ? cw.z : cw.w); off = cw.x; cnt = ((mw >> (sb & 31)) & 1u) ? cw.y : 0u; }
                     }
                 }
             }
             if (EARLY && cnt) {
                 const float ex = qx - (a.ox + ((float)cx + 0.5f) * a.h), ey = qy - (a.oy + ((float)cy + 0.5f) * a.h), ez = qz - (a.oz + ((float)cz + 0.5f) * a.h);
                 qcentre = sqrtf(ex * ex + (ey * ey + ez * ez));
+                // every listed point is at least `nearest` from the cell centre, hence at least nearest - |q - centre| from the query:
+                // beyond epsilon the list is not worth a look
+                if (a.has_nearest && nearest - qcentre > a.eps + 2e-6f) cnt = 0;
             }
             if (DETAIL && cnt == 0) {
                 const int orig = a.mperm[i];
@@ -704,6 +708,8 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
     a.nx = c->grid.nx; a.ny = c->grid.ny; a.nz = c->grid.nz; a.nbx = c->grid.nbx; a.nby = c->grid.nby;
     a.sq_eps = c->prm.distance_threshold * c->prm.distance_threshold;  // sq_eps = epsilon*epsilon, stocs.cpp:1014
     a.dot_lo = c->thr.lcp_dot_lo;
+    a.eps = c->prm.distance_threshold;
+    a.has_nearest = c->grid.has_nearest ? 1 : 0;
     const int blocks = (n + 3) / 4;
     a.order = NULL; a.xcd_blocks = 0;
 #ifdef STOCS_TOOLS_BUILD

@@ -139,6 +139,8 @@ struct SceneGrid {
     float* d_chunk_r;    // dense scenes only: lists sorted by distance from the cell centre; per 8-entry chunk a
                          // lower bound of that distance (early exit by the triangle inequality); else NULL
     float h;             // cell edge
+    bool has_nearest;    // dense grids with cell edges below epsilon: the z word of a cell is a lower bound of the distance from the
+                         // cell centre to the nearest listed point (the sub-cell mask it replaces is all ones there)
 };
 
 // Model PPF index on the device: every ordered pair stored once under its own quantised key F

@@ -31,9 +31,15 @@ dense_cases = [(0, "full kernel"), (8, "no normal test"), (256, "no chunk bounds
 cases = [(0, "full kernel"), (32, "no scene-normal gather"), (16, "no model-normal gather"), (48, "no normal gathers"), (8, "no normal test at all"),
          (4, "no list loads"), (4 | 8, "no list loads, no normal test"), (2, "cell look-up done, nobody survives"), (1, "no cell look-up, nobody survives"),
          (1 | 64, "no cell look-up, no model-point loads (transform + bookkeeping only)"), (64, "no model-point loads")]
-if name in ("C5", "dense"):
-    cases = dense_cases
+if name in ("C5", "dense"):   # the dense default is the queue kernel with early exit: its switches are those of the Cm list
+    cases = [(0, "full kernel"), (48, "no normal gathers"), (8, "no normal test at all"), (4, "no list loads"), (4 | 8, "no list loads, no normal test"),
+             (2, "cell look-up done, nobody survives"), (1, "no cell look-up, nobody survives")]
+    if len(sys.argv) > 4 and sys.argv[4] == "v31":
+        cases = dense_cases
+        est_variant = 31
 times = {c: [] for c, _ in cases}
+if "est_variant" in globals():
+    est.set_option("lcp_variant", est_variant)
 for r in range(rounds):
     for c, _ in cases:
         os.environ["STOCS_LCP_ABLATE"] = str(c)
