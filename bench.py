@@ -86,8 +86,8 @@ def main():
     key = torch.zeros(1, dtype=torch.int64, device="cuda")
 
     def step():
-        est.score_device(dT, kcand, dL)                                   # the metric kernel
-        est.best_device_async(dL, kcand, rank * kcand, key.data_ptr())   # first maximum wins (stocs.cpp:994)
+        # the metric kernel; its epilogue takes compute_best_transform's arg-max (first maximum wins, stocs.cpp:994) into `key`
+        est.score_best_device_async(dT, kcand, dL, rank * kcand, key.data_ptr())
         if world > 1 and not rehearsal:
             dist.all_reduce(key, op=dist.ReduceOp.MAX)                    # 8 bytes over xGMI
         elif world > 1:

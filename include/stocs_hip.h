@@ -169,8 +169,12 @@ int stocs_score_transforms(stocs_ctx* ctx, const float* T16_centred_host, int n,
 /* device-resident variant: d_T16 and d_lcp are device pointers on the context's device; the call is
  * asynchronous on the context's stream (use stocs_sync) */
 int stocs_score_transforms_device(stocs_ctx* ctx, const void* d_T16, int n, void* d_lcp);
-/* score + device arg-max in one call (one host round trip): key as stocs_best_device */
+/* score + device arg-max in one call (one host round trip): key as stocs_best_device.  The arg-max is taken in the epilogue of
+ * the scoring kernel (one 64-bit atomic max per candidate: order independent), not by a second kernel */
 int stocs_score_best_device(stocs_ctx* ctx, const void* d_T16, int n, void* d_lcp, uint32_t id_offset, uint64_t* key);
+/* the same without any host synchronisation: scores into d_lcp, the packed key of the first maximum (0: no positive score) into
+ * the 8 bytes at d_key8 (device memory), everything on the context's stream -- what bench.py times per step */
+int stocs_score_best_device_async(stocs_ctx* ctx, const void* d_T16, int n, void* d_lcp, uint32_t id_offset, void* d_key8);
 /* per model point: index of the matched scene point (-1 none) and whether it was counted */
 int stocs_lcp_detail(stocs_ctx* ctx, const float* T16_centred_host, int32_t* hit, uint8_t* counted);
 /* compute_best_transform (stocs.cpp:982-1004): score every stored candidate, arg-max with first

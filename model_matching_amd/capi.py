@@ -97,6 +97,7 @@ SIGNATURES = {
     "stocs_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "stocs_set_stream": (C.c_int, [_vp, _vp]),
     "stocs_best_device_async": (C.c_int, [_vp, _vp, C.c_int, C.c_uint32, _vp]),
+    "stocs_score_best_device_async": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_uint32, _vp]),
     "stocs_sync": (C.c_int, [_vp]),
     "stocs_stream": (_vp, [_vp]),
     "stocs_time_score_kernel": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _fp]),

@@ -46,6 +46,8 @@ struct LcpArgs {
     int has_nearest;        // the z word of a dense grid's cell is a lower bound of |cell centre - nearest listed point| (SceneGrid::has_nearest)
     const int32_t* order;   // processing slot -> candidate (NULL: identity): candidates that land in the same part of the scene run together
     int xcd_blocks;         // != 0: workgroups of one XCD take a contiguous run of slots (each XCD has its own L2)
+    unsigned long long* best;   // != NULL: compute_best_transform in the kernel's epilogue -- every candidate's packed (score, ~id) key joins an
+    uint32_t id_offset;         // atomic max on this word (integer max: order independent), id = id_offset + candidate
 #ifdef STOCS_TOOLS_BUILD
     int ablate;             // measurement build only (STOCS_LCP_ABLATE): parts of the kernel switched off to price them; scores are then wrong
 #endif
@@ -95,6 +97,14 @@ __device__ __forceinline__ unsigned long long lcp_wave_sum(unsigned long long ac
 }
 __device__ __forceinline__ float lcp_finish(unsigned long long total, int M) {
     return (float)((double)total * (1.0 / 4294967296.0) / (double)M);
+}
+// the candidate's score, and -- when the caller wants the arg-max with it -- its key of compute_best_transform (stocs.cpp:987-998:
+// larger score wins, lower id wins ties, scores that are not positive never win): one atomic per candidate, no second kernel
+__device__ __forceinline__ void lcp_store(const LcpArgs& a, float* __restrict__ out, int cand, unsigned long long total) {
+    const float s = lcp_finish(total, a.M);
+    out[cand] = s;
+    if (a.best && s > 0.0f)
+        atomicMax(a.best, ((unsigned long long)__float_as_uint(s) << 32) | (unsigned long long)(0xFFFFFFFFu - (a.id_offset + (uint32_t)cand)));
 }
 
 // candidate update: inclusive radius (kdtree.h:424), ties -> larger scene index.  When a list is stored in
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(256) void lcp_kernel(LcpArgs a, const float* __rest
     }
     // fixed-shape butterfly: deterministic
     acc = lcp_wave_sum(acc);
-    if (lane == 0) out[cand] = lcp_finish(acc, a.M);
+    if (lane == 0) lcp_store(a, out, cand, acc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -349,9 +359,9 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coop_kernel(LcpArgs a, const flo
             unsigned long long total = 0;
 #pragma unroll
             for (int k = 0; k < WPB; ++k) total += part[k];
-            out[cand] = lcp_finish(total, a.M);
+            lcp_store(a, out, cand, total);
         }
-    } else if (lane == 0) out[cand] = lcp_finish(acc, a.M);
+    } else if (lane == 0) lcp_store(a, out, cand, acc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -608,9 +618,9 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
             unsigned long long total = 0;
 #pragma unroll
             for (int k = 0; k < WPB; ++k) total += part[k];
-            out[cand] = lcp_finish(total, a.M);
+            lcp_store(a, out, cand, total);
         }
-    } else if (lane == 0) out[cand] = lcp_finish(acc, a.M);
+    } else if (lane == 0) lcp_store(a, out, cand, acc);
 }
 
 // compute_best_transform (stocs.cpp:982-1004) on the device: max of the packed (score, ~id) keys --
@@ -663,8 +673,9 @@ __device__ __forceinline__ uint32_t spread10(uint32_t x) {
     return x;
 }
 __global__ __launch_bounds__(256) void order_keys_kernel(const float* __restrict__ T16, int n, float ox, float oy, float oz, float sx, float sy, float sz,
-                                                         uint32_t* __restrict__ keys, int32_t* __restrict__ vals) {
+                                                         uint32_t* __restrict__ keys, int32_t* __restrict__ vals, unsigned long long* __restrict__ best) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && best) *best = 0ull;   // the arg-max word of the launch that follows (saves a fill kernel of its own)
     if (i >= n) return;
     const float* T = T16 + (size_t)i * 16;
     const float qx = fminf(fmaxf((T[12] - ox) * sx, 0.0f), 255.0f), qy = fminf(fmaxf((T[13] - oy) * sy, 0.0f), 255.0f),
@@ -699,9 +710,11 @@ static int lcp_variant() {
 #endif
 }
 
-int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d_hit, uint8_t* d_counted) {
-    if (n <= 0) return STOCS_OK;
+int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d_hit, uint8_t* d_counted, unsigned long long* d_best8, uint32_t id_offset) {
+    if (n <= 0) { if (d_best8) STOCS_HIP_CHECK(hipMemsetAsync(d_best8, 0, 8, c->stream)); return STOCS_OK; }
+    bool best_zeroed = false;
     LcpArgs a;
+    a.best = d_best8; a.id_offset = id_offset;
     a.mpos = c->d_mpos_s; a.mnrm = c->d_mnrm_s; a.mperm = c->d_mperm; a.M = c->nM;
     a.top = c->grid.d_top; a.cells = c->grid.d_cells; a.flat = c->grid.d_flat; a.list = c->grid.d_list; a.snrmw = c->d_snrmw;
     a.ox = c->grid.ox; a.oy = c->grid.oy; a.oz = c->grid.oz; a.inv_h = c->grid.inv_h; a.inv_h4 = c->grid.inv_h * 4.0f; a.h = c->grid.h; a.chunk_r = c->grid.d_chunk_r;
@@ -733,11 +746,13 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
         void* tmp = p + 4 * kb;
         const float sx = 256.0f / ((float)c->grid.nx * c->grid.h), sy = 256.0f / ((float)c->grid.ny * c->grid.h), sz = 256.0f / ((float)c->grid.nz * c->grid.h);
         hipLaunchKernelGGL(order_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_T16, n, c->grid.ox, c->grid.oy, c->grid.oz, sx, sy, sz,
-                           keys, vals);
+                           keys, vals, d_best8);
+        best_zeroed = true;
         STOCS_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tb, keys, keys_s, vals, order, (size_t)n, 0, 24, c->stream));
         a.order = order;
         a.xcd_blocks = c->lcp_order >= 2 ? (c->lcp_order == 2 ? 1 : c->lcp_order) : 0;
     }
+    if (d_best8 && !best_zeroed) STOCS_HIP_CHECK(hipMemsetAsync(d_best8, 0, 8, c->stream));
     int variant = c->lcp_variant >= 0 ? c->lcp_variant : lcp_variant();
     // dense grids keep their lists sorted by distance from the cell centre (not by index): only kernels
     // instantiated with the order-independent tie rule may scan them
@@ -827,7 +842,7 @@ extern "C" {
 int stocs_score_transforms_device(stocs_ctx* c, const void* d_T16, int n, void* d_lcp) {
     if (!c || n < 0 || (n && (!d_T16 || !d_lcp))) return STOCS_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
-    return launch_lcp(c, (const float*)d_T16, n, (float*)d_lcp, NULL, NULL);
+    return launch_lcp(c, (const float*)d_T16, n, (float*)d_lcp, NULL, NULL, NULL, 0);
 }
 
 int stocs_score_transforms(stocs_ctx* c, const float* T_host, int n, float* lcp_host) {
@@ -840,7 +855,7 @@ int stocs_score_transforms(stocs_ctx* c, const float* T_host, int n, float* lcp_
     float* dT = (float*)c->d_scratch;
     float* dL = (float*)((char*)c->d_scratch + ((tb + 255) / 256) * 256);
     STOCS_HIP_CHECK(hipMemcpyAsync(dT, T_host, tb, hipMemcpyHostToDevice, c->stream));
-    rc = launch_lcp(c, dT, n, dL, NULL, NULL);
+    rc = launch_lcp(c, dT, n, dL, NULL, NULL, NULL, 0);
     if (rc) return rc;
     STOCS_HIP_CHECK(hipMemcpyAsync(lcp_host, dL, lb, hipMemcpyDeviceToHost, c->stream));
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -859,7 +874,7 @@ int stocs_lcp_detail(stocs_ctx* c, const float* T_host, int32_t* hit, uint8_t* c
     int32_t* dH = (int32_t*)(base + 512);
     uint8_t* dC = (uint8_t*)(base + 512 + ((M * 4 + 255) / 256) * 256);
     STOCS_HIP_CHECK(hipMemcpyAsync(dT, T_host, 64, hipMemcpyHostToDevice, c->stream));
-    rc = launch_lcp(c, dT, 1, dL, dH, dC);
+    rc = launch_lcp(c, dT, 1, dL, dH, dC, NULL, 0);
     if (rc) return rc;
     STOCS_HIP_CHECK(hipMemcpyAsync(hit, dH, M * 4, hipMemcpyDeviceToHost, c->stream));
     STOCS_HIP_CHECK(hipMemcpyAsync(counted, dC, M, hipMemcpyDeviceToHost, c->stream));
@@ -904,10 +919,24 @@ int stocs_best_device_async(stocs_ctx* c, const void* d_lcp, int n, uint32_t id_
     return STOCS_OK;
 }
 
+int stocs_score_best_device_async(stocs_ctx* c, const void* d_T16, int n, void* d_lcp, uint32_t id_offset, void* d_key8) {
+    if (!c || !d_key8 || n < 0 || (n && (!d_T16 || !d_lcp))) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
+    return launch_lcp(c, (const float*)d_T16, n, (float*)d_lcp, NULL, NULL, (unsigned long long*)d_key8, id_offset);
+}
+
 int stocs_score_best_device(stocs_ctx* c, const void* d_T16, int n, void* d_lcp, uint32_t id_offset, uint64_t* key) {
-    int rc = stocs_score_transforms_device(c, d_T16, n, d_lcp);
+    if (!c || !key) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
+    if (!c->d_best) STOCS_HIP_CHECK(dev_malloc((void**)&c->d_best, 8));
+    int rc = stocs_score_best_device_async(c, d_T16, n, d_lcp, id_offset, c->d_best);
     if (rc) return rc;
-    return stocs_best_device(c, d_lcp, n, id_offset, key);
+    if ((rc = ensure_pinned(c, PIN_VAR))) return rc;
+    uint64_t* key_pin = (uint64_t*)((char*)c->h_pin + PIN_BEST);
+    STOCS_HIP_CHECK(hipMemcpyAsync(key_pin, c->d_best, 8, hipMemcpyDeviceToHost, c->stream));
+    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *key = *key_pin;
+    return STOCS_OK;
 }
 
 int stocs_set_option(stocs_ctx* c, const char* key, int value) {
@@ -933,7 +962,7 @@ int stocs_time_score_kernel(stocs_ctx* c, const void* d_T16, int n, void* d_lcp,
     DeviceGuard dev_guard(c->device);
     STOCS_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
     for (int r = 0; r < reps; ++r) {
-        int rc = launch_lcp(c, (const float*)d_T16, n, (float*)d_lcp, NULL, NULL);
+        int rc = launch_lcp(c, (const float*)d_T16, n, (float*)d_lcp, NULL, NULL, NULL, 0);
         if (rc) return rc;
     }
     STOCS_HIP_CHECK(hipEventRecord(c->ev1, c->stream));

@@ -272,7 +272,8 @@ inline int32_t* cand_base(stocs_ctx* c) { return (int32_t*)((float*)c->d_cand + 
 int ensure_scratch(stocs_ctx* c, size_t bytes);
 int ensure_pinned(stocs_ctx* c, size_t bytes);   // c->h_pin of at least `bytes` (nothing may still be copying into the old block)
 enum { PIN_CONGRUENT = 0, PIN_TRANSFORMS = 256, PIN_VERIFY = 512, PIN_BEST = 768, PIN_VAR = 1024 };   // fixed slots, then the per-call variable part
-int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d_hit, uint8_t* d_counted);
+// d_best8 != NULL: the kernel's epilogue also takes the arg-max of compute_best_transform over the batch into that word (zeroed in front)
+int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d_hit, uint8_t* d_counted, unsigned long long* d_best8, uint32_t id_offset);
 int build_ppf_index(stocs_ctx* c);
 int build_grid_gpu(stocs_ctx* c, int div, int dense);
 extern "C" int stocs_internal_make_jobs(stocs_ctx* c, const int32_t* picks4_host, int n, void* d_jobs_out, const unsigned int** d_unresolved_out);

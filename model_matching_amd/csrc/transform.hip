@@ -333,12 +333,10 @@ int stocs_verify_all(stocs_ctx* c, float* best_lcp, int* best_idx, float* best_p
     if (n > 0) {
         // scores and the arg-max stay on the device: one LCP launch over the resident transforms, then
         // compute_best_transform (stocs.cpp:987-998: strict > from 0 => first maximum wins, Q18) as an integer max
-        int rc = launch_lcp(c, cand_T(c), n, cand_lcp(c), NULL, NULL);
-        if (rc) return rc;
         if (!c->d_best) STOCS_HIP_CHECK(dev_malloc((void**)&c->d_best, 8));
-        rc = ensure_scratch(c, 256);
+        int rc = launch_lcp(c, cand_T(c), n, cand_lcp(c), NULL, NULL, c->d_best, 0);   // scores + the arg-max key in one launch
         if (rc) return rc;
-        rc = stocs_best_device_async(c, cand_lcp(c), n, 0, c->d_best);
+        rc = ensure_scratch(c, 256);
         if (rc) return rc;
         float* d_out = (float*)c->d_scratch;   // the transform jobs of this trial are done with the scratch area
         hipLaunchKernelGGL(winner_pose_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)c->d_best, (const float*)cand_P(c), n, d_out);

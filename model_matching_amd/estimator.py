@@ -293,6 +293,10 @@ class StocsEstimator:
     def set_stream(self, hip_stream):
         capi.check(self.L.stocs_set_stream(self.h, C.c_void_p(hip_stream)))
 
+    def score_best_device_async(self, dT, n, dL, id_offset, d_key8):
+        """Scores + arg-max key in ONE launch (the arg-max is the scoring kernel's epilogue), nothing synchronised."""
+        capi.check(self.L.stocs_score_best_device_async(self.h, dT, n, dL, id_offset, C.c_void_p(d_key8)))
+
     def best_device_async(self, dL, n, id_offset, d_key8):
         capi.check(self.L.stocs_best_device_async(self.h, dL, n, id_offset, C.c_void_p(d_key8)))
 

@@ -136,9 +136,19 @@ def test_metric_batch_all_65536_candidates_equal_oracle(oracle_lib):
     dT, dL = est.dev_alloc(T.nbytes), est.dev_alloc(k * 4)
     est.dev_upload(dT, T)
     est.score_device(dT, k, dL)
-    bl, bi, _ = est.best_device(dL, k, 0)
+    bl, bi, key_two_kernels = est.best_device(dL, k, 0)
     assert bi == int(np.argmax(got)) and bl == float(got[bi])
-    est.dev_free(dT); est.dev_free(dL)
+    # the arg-max taken in the scoring kernel's epilogue (what bench.py times per step): the same key, the same scores
+    dK = est.dev_alloc(8)
+    est.score_best_device_async(dT, k, dL, 0, dK.value)
+    kb = np.zeros(1, np.uint64); again = np.zeros(k, np.float32)
+    est.dev_download(dK, kb); est.dev_download(dL, again)
+    assert int(kb[0]) == key_two_kernels and np.array_equal(again, got)
+    est.score_best_device_async(dT, k, dL, 7 * k, dK.value)          # global ids of rank 7 of a sharded run
+    est.dev_download(dK, kb)
+    from model_matching_amd import dist as sd
+    assert sd.unpack_best(int(kb[0])) == (float(got[bi]), 7 * k + bi)
+    est.dev_free(dT); est.dev_free(dL); est.dev_free(dK)
 
 
 def test_config5_200k_scene_50k_model(oracle_lib):

@@ -453,6 +453,21 @@ def test_repeated_trials_on_one_context_equal_fresh_contexts():
         ref = trial(fresh, 1234 + r)
         fresh.close()
         assert ref[:5] == reused[r][:5] and np.array_equal(ref[5], reused[r][5]), r
+    # the step record of the last calls (stocs_last_call_timing): always there, host steps between the calls' own
+    # synchronisation points plus the device's event times of the kernel groups -- what names the step when a call stalls
+    import time
+    est.L.stocs_clear_bases(est.h)
+    est.sample_bases(1234, 100)
+    t0 = time.perf_counter(); est.find_congruent_all(); wall_ms = (time.perf_counter() - t0) * 1e3
+    steps = est.last_call_timing(0)
+    host = [(k, v) for k, v in steps if not k.startswith("device:")]
+    dev = [(k, v) for k, v in steps if k.startswith("device:")]
+    assert len(host) >= 6 and len(dev) == 5 and all(v >= 0 for _, v in steps)
+    assert any("wait for the device" in k for k, _ in host)
+    assert 0.5 * wall_ms <= sum(v for _, v in host) <= wall_ms * 1.05 + 0.05       # the host steps account for the call
+    assert sum(v for k, v in dev if "Q gather" not in k) <= wall_ms                 # the device groups ran inside it
+    est.make_transforms(200, 1234); est.compute_best_transform()
+    assert len(est.last_call_timing(1)) >= 2 and len(est.last_call_timing(2)) == 2
     est.close()
 
 
