@@ -16,6 +16,13 @@ import os
 import sys
 import time
 
+# The host-side bookkeeping around the trials is a few tiny numpy calls: keep the BLAS / OpenMP pools to one thread.  On the GPU boxes
+# the process sees 256 CPUs but its cgroup has a quota of 16; OpenBLAS sizes its pool by the former, its spinning workers exhaust the
+# latter, and the kernel then freezes the whole process for the rest of a 100 ms period -- the sporadic 65-80 ms "stall" of rounds
+# 1-3 (profiles/r03_stall_root_cause.json).  Must happen before numpy is imported.
+for _v in ("OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -128,32 +135,7 @@ def main():
     achieved = b_pose * kcand / (k_ms * 1e-3) / 1e9   # GB/s
     peak = 8000.0
     best_i = int(np.argmax(lcp))
-    # Counters of THIS run: the same command is re-run under rocprofv3 (child processes, one --pmc pass per counter group,
-    # a few steps each) and the LCP kernel's per-launch means come back; HBM traffic as the guide prescribes (FETCH_SIZE x2 +
-    # WRITE_SIZE on gfx950), and the utilisation of the units that can actually bound a cache-resident kernel.
     traffic, binding, pmc_info = None, None, None
-    if rank == 0 and world == 1 and not args.no_pmc:
-        try:
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            import pmc as pmc_tool
-            import shutil
-            import tempfile
-            if shutil.which("rocprofv3"):
-                pdir = tempfile.mkdtemp(prefix="stocs_pmc_")
-                child = ["python3", os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pipeline", "--no-pmc",
-                         "--workload", args.workload] + (["--candidates", str(args.candidates)] if args.candidates else [])
-                raw = pmc_tool.collect("lcp_coop", child, pdir)
-                der = pmc_tool.derive(raw, k_ms)
-                traffic = der.get("hbm_bytes_per_launch")
-                binding = der.get("binding")
-                pmc_info = {"kernel": raw["kernel"], "passes": raw["passes"], "derived": {k: v for k, v in der.items() if k != "binding"},
-                            "counters_per_launch": {k: v["per_launch_mean"] for k, v in raw["counters"].items()},
-                            "source": "rocprofv3 --pmc child runs of this command (tools/pmc.py), launched by this bench process"}
-                shutil.rmtree(pdir, ignore_errors=True)
-            else:
-                pmc_info = {"error": "rocprofv3 not found"}
-        except Exception as e:   # the bench line must not depend on the profiler
-            pmc_info = {"error": repr(e)}
 
     out = {
         "metric": "candidate poses verified/sec",
@@ -253,6 +235,38 @@ def main():
                                x[k] > 10.0 * float(np.median([y[k] for y in runs if not y["warmup"]])) for k in ("sample_ms", "congruent_ms", "transforms_ms", "verify_ms"))]}
         pe.close()
 
+    # Counters of THIS run: the same command is re-run under rocprofv3 (child processes, one --pmc pass per counter group,
+    # a few steps each) and the LCP kernel's per-launch means come back; HBM traffic as the guide prescribes (FETCH_SIZE x2 +
+    # WRITE_SIZE on gfx950), and the utilisation of the units that can actually bound a cache-resident kernel.
+    if rank == 0 and world == 1 and not args.no_pmc:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import pmc as pmc_tool
+            import shutil
+            import tempfile
+            if shutil.which("rocprofv3"):
+                pdir = tempfile.mkdtemp(prefix="stocs_pmc_")
+                child = ["python3", os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pipeline", "--no-pmc",
+                         "--workload", args.workload] + (["--candidates", str(args.candidates)] if args.candidates else [])
+                raw = pmc_tool.collect("lcp_coop", child, pdir)
+                der = pmc_tool.derive(raw, k_ms)
+                traffic = der.get("hbm_bytes_per_launch")
+                binding = der.get("binding")
+                pmc_info = {"kernel": raw["kernel"], "passes": raw["passes"], "derived": {k: v for k, v in der.items() if k != "binding"},
+                            "counters_per_launch": {k: v["per_launch_mean"] for k, v in raw["counters"].items()},
+                            "source": "rocprofv3 --pmc child runs of this command (tools/pmc.py), launched by this bench process"}
+                shutil.rmtree(pdir, ignore_errors=True)
+            else:
+                pmc_info = {"error": "rocprofv3 not found"}
+        except Exception as e:   # the bench line must not depend on the profiler
+            pmc_info = {"error": repr(e)}
+
+    if pmc_info is not None:
+        out["roofline"]["traffic"] = traffic
+        out["roofline"]["binding"] = binding
+        out["roofline"]["traffic_over_algorithmic"] = (traffic / float(b_pose * kcand)) if traffic is not None else None
+        out["roofline"]["pmc"] = pmc_info
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the oracle (single-threaded restatement of the reference's kd-tree LCP) on a
         # bounded sample of the SAME candidate batch.  Reported, never the target.
@@ -279,17 +293,33 @@ def main():
             ncore = len(os.sched_getaffinity(0))
         except AttributeError:
             ncore = os.cpu_count() or 1
-        # one thread per physical core: the kd-tree walk is latency bound and SMT siblings slow it down (256 threads on the
-        # 256-CPU host of the GPU box gave 14.9 k poses/s, 64 threads 22 k in round 1)
+        # The cores this process may actually use: its cgroup's CPU quota, when there is one (the GPU boxes show 256 CPUs and
+        # grant 16 -- cpu.max "1600000 100000"; more runnable threads than that get the whole process frozen for the rest of each
+        # 100 ms period, profiles/r03_stall_root_cause.json; rounds 1-2 quoted "64 / 128 threads" that ran on 16 CPUs' worth of time)
         host_cpus = ncore
+        quota_cpus = None
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                quota_cpus = float(q) / float(per)
+        except Exception:
+            try:
+                q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    quota_cpus = q / per
+            except Exception:
+                pass
+        # without a quota: one thread per physical core (the kd-tree walk is latency bound and SMT siblings slow it down)
         ncore = max(1, min(ncore // 2 if ncore >= 64 else ncore, 128))
+        if quota_cpus is not None:
+            ncore = max(1, min(ncore, int(quota_cpus)))
         t = time.perf_counter()
         ref_all, exact_all = orc.lcp_batch_exact(T, nthreads=ncore)   # the reference's running float sum, and the same matches summed in double
         all_dt = time.perf_counter() - t
         diff = np.abs(ref_all - lcp)
         diff_exact = np.abs(lcp.astype(np.float64) - exact_all)
         out["cpu_baseline_all_cores"] = {"value": kcand / all_dt, "unit": "poses/s", "cores": ncore, "kind": "port",
-                                         "host_cpus_available": host_cpus,
+                                         "host_cpus_available": host_cpus, "cgroup_cpu_quota": quota_cpus,
                                          "sample": "all %d candidates of rank 0's batch, OpenMP over candidates, %.1f s" % (kcand, all_dt),
                                          "max_abs_lcp_diff_vs_gpu": float(diff.max()), "candidates_compared": int(kcand),
                                          "argmax_oracle": int(np.argmax(ref_all)), "argmax_gpu": int(np.argmax(lcp)),

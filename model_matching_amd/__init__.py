@@ -7,3 +7,24 @@ workloads).  There is no CPU fallback: importing :mod:`model_matching_amd.capi` 
 library raises.
 """
 __all__ = ["capi", "estimator", "synth"]
+
+
+def _pin_host_thread_pools():
+    """The Python side of this package (test harness, bench, tools) does a few tiny numpy calls between GPU calls.  On the GPU
+    boxes a process sees 256 CPUs while its cgroup has a CPU quota of 16: OpenBLAS sizes its worker pool by the former, the
+    spinning workers exhaust the latter, and the kernel freezes the WHOLE process for the rest of a 100 ms scheduler period --
+    the sporadic 65-80 ms pause of rounds 1-3 (profiles/r03_stall_root_cause.json).  One BLAS thread is plenty here.
+    STOCS_KEEP_BLAS_THREADS=1 leaves the pools alone (tools/stall_watch.py reproduces the pause that way)."""
+    import os
+    if os.environ.get("STOCS_KEEP_BLAS_THREADS") == "1":
+        return
+    for v in ("OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        os.environ.setdefault(v, "1")            # for libraries loaded after this point
+    try:
+        import threadpoolctl                      # for a BLAS that numpy has already loaded
+        threadpoolctl.threadpool_limits(limits=1, user_api="blas")
+    except Exception:
+        pass
+
+
+_pin_host_thread_pools()

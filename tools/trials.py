@@ -14,6 +14,13 @@ import os
 import sys
 import time
 
+# The host-side bookkeeping around the trials is a few tiny numpy calls: keep the BLAS / OpenMP pools to one thread.  On the GPU boxes
+# the process sees 256 CPUs but its cgroup has a quota of 16; OpenBLAS sizes its pool by the former, its spinning workers exhaust the
+# latter, and the kernel then freezes the whole process for the rest of a 100 ms period -- the sporadic 65-80 ms "stall" of rounds
+# 1-3 (profiles/r03_stall_root_cause.json).  Must happen before numpy is imported.
+for _v in ("OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
