@@ -479,6 +479,7 @@ protected:
         if (K.size() < 4) throw std::runtime_error("camera_intrinsics must hold {fx, cx, fy, cy}");
         stocs_camera cam;
         cam.fx = K[0]; cam.cx = K[1]; cam.fy = K[2]; cam.cy = K[3]; cam.depth_scale = read_depth_scale; cam.width = image_width; cam.height = image_height;
+        cam.normal_method = STOCS_NORMALS_DEPTH_GRADIENT;   // rgbd.cpp:203: RGBD_NORMALS_METHOD_LINEMOD
         const int cap = image_width * image_height;
         scene_.pos.resize((size_t)cap * 3); scene_.nrm.resize((size_t)cap * 3); scene_.class_probability.resize((size_t)cap); scene_.pixel.resize((size_t)cap * 2);
         int n = 0;

@@ -208,10 +208,22 @@ int stocs_cluster_poses(const float* poses16, const float* lcp, int n, float acc
 /* ---- upstream rows, GPU implementations.  PARITY WITH THE REFERENCE IS UNPINNED:
  * their arithmetic lives in PCL / OpenCV-contrib, absent here; these are pinned against this repo's
  * numpy restatement (oracle/ingest_oracle.py).  Stand-alone calls (no context). ---- */
+enum {
+    /* surface normals of the depth image, rgbd.cpp:199-205 (cv::rgbd::RgbdNormals, RGBD_NORMALS_METHOD_LINEMOD on the raw
+     * 16-bit depth image).  0: the published method restated -- Hinterstoisser et al., "Gradient Response Maps for Real-Time
+     * Detection of Texture-Less Objects", PAMI 2012, section 2.4: least-squares depth gradient over the 8 neighbours at
+     * +-5 pixels whose depth differs from the centre by at most 50 raw units, normal of the tangent plane through the three
+     * back-projected points X, X(x+1), X(y+1), oriented toward the camera; integer sums, float normal.  Parity with OpenCV's
+     * implementation is UNPINNED (library absent): patch, threshold and arithmetic follow the paper and the library's
+     * documented defaults.  1: the least-squares plane over the 5x5 window of rounds 1-2 (tests/golden/example_*.npz hold its clouds) */
+    STOCS_NORMALS_DEPTH_GRADIENT = 0,
+    STOCS_NORMALS_PLANE_FIT = 1
+};
 typedef struct stocs_camera {
     float fx, cx, fy, cy;      /* stocs_match_one_object.cpp:20 */
     float depth_scale;         /* :21 */
     int width, height;         /* :23-24 */
+    int normal_method;         /* STOCS_NORMALS_* */
 } stocs_camera;
 /* rgbd::load_rgbd_data_sampled (rgbd.cpp:179-281): depth + class-probability images (uint16) -> voxelised,
  * outlier-filtered, oriented scene cloud with class probability and (row, col) pixel per point */

@@ -30,7 +30,7 @@ class Params(C.Structure):
 
 class Camera(C.Structure):
     _fields_ = [("fx", C.c_float), ("cx", C.c_float), ("fy", C.c_float), ("cy", C.c_float), ("depth_scale", C.c_float),
-                ("width", C.c_int), ("height", C.c_int)]
+                ("width", C.c_int), ("height", C.c_int), ("normal_method", C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/stocs_hip.h

@@ -70,8 +70,8 @@ __global__ __launch_bounds__(256) void backproject_kernel(const uint16_t* __rest
     P[idx] = make_float4((float)(((double)j - (double)cx) * (double)d / (double)fx), (float)(((double)i - (double)cy) * (double)d / (double)fy), d, 0.f);
 }
 
-// stand-in for cv::rgbd::RgbdNormals(..., window 5, LINEMOD) (rgbd.cpp:203): least-squares plane over the
-// valid pixels of the 5x5 window, oriented toward the camera; NaN where unreliable
+// STOCS_NORMALS_PLANE_FIT (the stand-in of rounds 1-2 for rgbd.cpp:203, kept for the fixtures it produced and as an A/B):
+// least-squares plane over the valid pixels of the 5x5 window, oriented toward the camera; NaN where unreliable
 __global__ __launch_bounds__(256) void depth_normals_kernel(const float4* __restrict__ P, int W, int H, float4* __restrict__ N) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= W * H) return;
@@ -99,6 +99,50 @@ __global__ __launch_bounds__(256) void depth_normals_kernel(const float4* __rest
                 double s = (v[0] * pc.x + v[1] * pc.y + v[2] * pc.z) > 0 ? -1.0 : 1.0;  // toward the camera: n . p < 0
                 out = make_float4((float)(s * v[0]), (float)(s * v[1]), (float)(s * v[2]), 0.f);
             }
+        }
+    }
+    N[idx] = out;
+}
+
+// cv::rgbd::RgbdNormals(rows, cols, CV_32F, K, 5, RGBD_NORMALS_METHOD_LINEMOD) applied to the raw 16-bit depth image
+// (rgbd.cpp:199-205), restated from the published method -- Hinterstoisser et al., PAMI 2012, section 2.4: the depth gradient
+// that best explains, in the least-squares sense, the depth differences to the 8 neighbours at +-5 pixels (neighbours whose depth
+// differs from the centre by more than 50 raw units are left out: they lie across a depth edge); the normal is that of the plane
+// through the back-projected points X, X1 = v(x+1, y)(D + dD/dx), X2 = v(x, y+1)(D + dD/dy).  Sums and the 2x2 solve in 64-bit
+// integers (the division by the determinant is dropped: it scales both tangent vectors), the cross product in float, the result
+// normalised and pointed at the camera (z <= 0).  Pixels within 5 (6 at the far sides) of the border, and pixels whose patch
+// gives a zero vector (no admissible neighbour, zero depth), stay NaN: rgbd.cpp:263-267 drops them.  OpenCV is absent: UNPINNED.
+__global__ __launch_bounds__(256) void gradient_normals_kernel(const uint16_t* __restrict__ depth, int W, int H, float fx, float cx, float fy, float cy,
+                                                               float4* __restrict__ N) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= W * H) return;
+    const int y = idx / W, x = idx % W;
+    const float nanf_ = __int_as_float(0x7fc00000);
+    float4 out = make_float4(nanf_, nanf_, nanf_, 0.f);
+    const int r = 5;
+    if (y >= r && y < H - r - 1 && x >= r && x < W - r - 1) {
+        const long long d = depth[idx];
+        long long A0 = 0, A1 = 0, A3 = 0, b0 = 0, b1 = 0;
+        for (int j = -r; j <= r; j += r)
+            for (int i = -r; i <= r; i += r) {
+                const long long delta = (long long)depth[(y + j) * W + (x + i)] - d;
+                if (delta > 50 || delta < -50) continue;
+                A0 += i * i; A1 += i * j; A3 += j * j;
+                b0 += i * delta; b1 += j * delta;
+            }
+        const long long det = A0 * A3 - A1 * A1;
+        const long long gx = A3 * b0 - A1 * b1, gy = -A1 * b0 + A0 * b1;   // det * (dD/dx, dD/dy)
+        // K^-1 by hand: (1/fx, 0, -cx/fx; 0, 1/fy, -cy/fy; 0, 0, 1), in float
+        const float k00 = 1.0f / fx, k02 = (0.0f * cy - cx * fy) / (fx * fy), k11 = 1.0f / fy, k12 = -cy / fy;
+        const float a1 = (float)(d * det + (long long)(x + 1) * gx), b1f = (float)((long long)y * gx), c1 = (float)gx;
+        const float a2 = (float)((long long)x * gy), b2f = (float)(d * det + (long long)(y + 1) * gy), c2 = (float)gy;
+        const float X1x = k00 * a1 + (0.0f * b1f + k02 * c1), X1y = k11 * b1f + k12 * c1, X1z = c1;
+        const float X2x = k00 * a2 + (0.0f * b2f + k02 * c2), X2y = k11 * b2f + k12 * c2, X2z = c2;
+        const float nx = X1y * X2z - X1z * X2y, ny = X1z * X2x - X1x * X2z, nz = X1x * X2y - X1y * X2x;
+        const double len = sqrt((double)nx * nx + (double)ny * ny + (double)nz * nz);
+        if (len > 0) {
+            const double s = (nz > 0 ? -1.0 : 1.0) / len;
+            out = make_float4((float)(nx * s), (float)(ny * s), (float)(nz * s), 0.f);
         }
     }
     N[idx] = out;
@@ -461,6 +505,7 @@ int stocs_trim(void) {
 int stocs_ingest_scene(const stocs_camera* cam, const uint16_t* depth, const uint16_t* class_prob, float voxel_size,
                        float class_threshold, int device, float* pos3, float* nrm3, float* prob, int32_t* pixel2, int cap, int* n_out) {
     if (!cam || !depth || !class_prob || !n_out || cam->width <= 0 || cam->height <= 0 || !(voxel_size > 0)) return STOCS_ERR_INVALID;
+    if (cam->normal_method != STOCS_NORMALS_DEPTH_GRADIENT && cam->normal_method != STOCS_NORMALS_PLANE_FIT) { set_error("stocs_ingest_scene: unknown normal_method %d", cam->normal_method); return STOCS_ERR_INVALID; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available: this library has no CPU fallback"); return STOCS_ERR_NO_DEVICE; }
     if (device >= 0) STOCS_HIP_CHECK(hipSetDevice(device));
@@ -484,7 +529,8 @@ int stocs_ingest_scene(const stocs_camera* cam, const uint16_t* depth, const uin
     STOCS_HIP_CHECK(hipMemcpyAsync(dC.p, class_prob, 2 * (size_t)npx, hipMemcpyHostToDevice, st));
     const dim3 g((unsigned)((npx + 255) / 256));
     hipLaunchKernelGGL(backproject_kernel, g, dim3(256), 0, st, dD.p, W, H, cam->fx, cam->cx, cam->fy, cam->cy, cam->depth_scale, dP.p);
-    hipLaunchKernelGGL(depth_normals_kernel, g, dim3(256), 0, st, dP.p, W, H, dN.p);
+    if (cam->normal_method == STOCS_NORMALS_PLANE_FIT) hipLaunchKernelGGL(depth_normals_kernel, g, dim3(256), 0, st, dP.p, W, H, dN.p);
+    else hipLaunchKernelGGL(gradient_normals_kernel, g, dim3(256), 0, st, dD.p, W, H, cam->fx, cam->cx, cam->fy, cam->cy, dN.p);
     tick("upload+backproject+normals");
     Buf<float4> cen, ext;
     int nv = 0;

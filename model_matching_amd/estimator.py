@@ -328,12 +328,13 @@ def cluster_poses(poses16, lcp, acceptable_fraction, best_score, maximum_pose_co
     return out[:n.value]
 
 
-def ingest_scene(depth_u16, prob_u16, K, depth_scale, voxel_size=0.005, class_threshold=0.10, device=-1):
-    """GPU scene ingest (stocs_ingest_scene): returns pos, nrm, prob, pixel arrays."""
+def ingest_scene(depth_u16, prob_u16, K, depth_scale, voxel_size=0.005, class_threshold=0.10, device=-1, normal_method=0):
+    """GPU scene ingest (stocs_ingest_scene): returns pos, nrm, prob, pixel arrays.  normal_method 0: depth-gradient normals (the
+    published LINEMOD method, what the reference asks OpenCV for), 1: the 5x5 plane fit of rounds 1-2 (the golden fixtures)."""
     L = capi.load()
     d = np.ascontiguousarray(depth_u16, np.uint16); p = np.ascontiguousarray(prob_u16, np.uint16)
     H, W = d.shape
-    cam = capi.Camera(K[0], K[1], K[2], K[3], depth_scale, W, H)
+    cam = capi.Camera(K[0], K[1], K[2], K[3], depth_scale, W, H, normal_method)
     cap = W * H
     pos = np.zeros((cap, 3), np.float32); nrm = np.zeros((cap, 3), np.float32); pr = np.zeros(cap, np.float32); px = np.zeros((cap, 2), np.int32)
     n = C.c_int(0)

@@ -33,8 +33,8 @@ def voxel_grid(points, leaf, extra=None):
 
 
 def depth_normals(P, valid, win=5):
-    """Least-squares plane over the valid pixels of a win x win window (stand-in for RgbdNormals LINEMOD
-    with window 5, rgbd.cpp:203), oriented toward the camera; NaN where unreliable."""
+    """Least-squares plane over the valid pixels of a win x win window (normal_method 1: the stand-in of rounds 1-2 for
+    RgbdNormals LINEMOD, rgbd.cpp:203; the golden fixtures hold its clouds), oriented toward the camera; NaN where unreliable."""
     H, W, _ = P.shape
     r = win // 2
     acc = {k: np.zeros((H, W)) for k in ("n", "x", "y", "z", "xx", "xy", "xz", "yy", "yz", "zz")}
@@ -67,13 +67,53 @@ def depth_normals(P, valid, win=5):
     return nrm.astype(np.float32), w[..., 0]
 
 
-def ingest_scene(depth_u16, prob_u16, K, depth_scale, voxel=0.005, class_threshold=0.10):
+def depth_normals_gradient(depth_u16, K):
+    """cv::rgbd::RgbdNormals(..., RGBD_NORMALS_METHOD_LINEMOD) on the raw 16-bit depth image (rgbd.cpp:199-205), restated from the
+    published method (Hinterstoisser et al., PAMI 2012, section 2.4): least-squares depth gradient over the 8 neighbours at +-5
+    pixels whose depth differs from the centre by at most 50 raw units; normal of the tangent plane through the back-projected
+    X, X(x+1), X(y+1); integer sums, float cross product, normalised, pointed at the camera.  OpenCV absent: UNPINNED."""
+    fx, cx, fy, cy = (np.float32(v) for v in K)
+    D = np.asarray(depth_u16).astype(np.int64)
+    H, W = D.shape
+    r = 5
+    A0 = np.zeros((H, W), np.int64); A1 = np.zeros_like(A0); A3 = np.zeros_like(A0); b0 = np.zeros_like(A0); b1 = np.zeros_like(A0)
+    ys, xs = slice(r, H - r - 1), slice(r, W - r - 1)
+    d = D[ys, xs]
+    for j in (-r, 0, r):
+        for i in (-r, 0, r):
+            delta = D[r + j:H - r - 1 + j, r + i:W - r - 1 + i] - d
+            ok = np.abs(delta) <= 50
+            A0[ys, xs] += ok * (i * i); A1[ys, xs] += ok * (i * j); A3[ys, xs] += ok * (j * j)
+            b0[ys, xs] += np.where(ok, i * delta, 0); b1[ys, xs] += np.where(ok, j * delta, 0)
+    det = A0 * A3 - A1 * A1
+    gx = A3 * b0 - A1 * b1
+    gy = -A1 * b0 + A0 * b1
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.int64), np.arange(W, dtype=np.int64), indexing="ij")
+    f = np.float32
+    k00 = f(1.0) / fx; k02 = (f(0.0) * cy - cx * fy) / (fx * fy); k11 = f(1.0) / fy; k12 = -cy / fy
+    a1 = (D * det + (xx + 1) * gx).astype(np.float32); b1f = (yy * gx).astype(np.float32); c1 = gx.astype(np.float32)
+    a2 = (xx * gy).astype(np.float32); b2f = (D * det + (yy + 1) * gy).astype(np.float32); c2 = gy.astype(np.float32)
+    X1x = k00 * a1 + (f(0.0) * b1f + k02 * c1); X1y = k11 * b1f + k12 * c1; X1z = c1
+    X2x = k00 * a2 + (f(0.0) * b2f + k02 * c2); X2y = k11 * b2f + k12 * c2; X2z = c2
+    nx = X1y * X2z - X1z * X2y; ny = X1z * X2x - X1x * X2z; nz = X1x * X2y - X1y * X2x
+    ln = np.sqrt(nx.astype(np.float64) ** 2 + ny.astype(np.float64) ** 2 + nz.astype(np.float64) ** 2)
+    out = np.full((H, W, 3), np.nan, np.float32)
+    inner = np.zeros((H, W), bool); inner[ys, xs] = True
+    good = inner & (ln > 0)
+    s = np.where(nz > 0, -1.0, 1.0) / np.where(good, ln, 1.0)
+    for k, c in enumerate((nx, ny, nz)):
+        out[..., k] = np.where(good, (c.astype(np.float64) * s).astype(np.float32), np.float32(np.nan))
+    return out
+
+
+def ingest_scene(depth_u16, prob_u16, K, depth_scale, voxel=0.005, class_threshold=0.10, normal_method=0):
+    """normal_method 0: depth-gradient normals (depth_normals_gradient), 1: the 5x5 plane fit (depth_normals; the golden fixtures)."""
     fx, cx, fy, cy = (np.float32(v) for v in K)
     d = depth_u16.astype(np.float32) * np.float32(depth_scale)
     H, W = d.shape
     jj, ii = np.meshgrid(np.arange(W), np.arange(H))
     P = np.stack([((jj - np.float64(cx)) * d / np.float64(fx)), ((ii - np.float64(cy)) * d / np.float64(fy)), d], axis=-1).astype(np.float32)  # rgbd.cpp:214-216
-    normals, _ = depth_normals(P, d > 0)
+    normals = depth_normals_gradient(depth_u16, K) if normal_method == 0 else depth_normals(P, d > 0)[0]
     cloud = voxel_grid(P.reshape(-1, 3), voxel)                                                  # :228-231
     radius = 2.0 * float(np.float32(voxel)) + 0.005                                              # :235
     tree = cKDTree(cloud.astype(np.float64))

@@ -323,3 +323,30 @@ def test_greedy_clustering(oracle_lib):
     # stop once size > maximum_pose_count (sic: one more than the count is kept)
     keep = oracle_lib.greedy_clustering(poses, lcp, 0.0, 0.9, 1, 0.01, 5.0, sym)
     assert len(keep) == 2
+
+
+def test_depth_gradient_normals_recover_a_tilted_plane():
+    """Known answer for the restated LINEMOD normals (oracle/ingest_oracle.py::depth_normals_gradient, reference rgbd.cpp:203): the
+    depth image of a tilted plane n . X = c, rendered through a pin-hole camera in raw units of 0.1 mm, must give the plane's own
+    normal (pointed at the camera) at every interior pixel, up to the quantisation of the 16-bit depth; border pixels, zero
+    depth and pixels whose 8 neighbours all lie across a depth step give no normal."""
+    from oracle.ingest_oracle import depth_normals_gradient
+    fx, cx, fy, cy = 600.0, 160.0, 600.0, 120.0
+    W, H = 320, 240
+    n = np.array([0.2, -0.3, -1.0]); n /= np.linalg.norm(n)        # toward the camera: z < 0
+    c = n @ np.array([0.0, 0.0, 0.9])                               # the plane passes through (0, 0, 0.9 m)
+    jj, ii = np.meshgrid(np.arange(W), np.arange(H))
+    ray = np.stack([(jj - cx) / fx, (ii - cy) / fy, np.ones_like(jj, float)], -1)
+    z = c / (ray @ n)                                               # depth along the optical axis
+    depth = np.round(z * 10000.0).astype(np.uint16)
+    N = depth_normals_gradient(depth, (fx, cx, fy, cy))
+    inner = N[5:H - 6, 5:W - 6]
+    assert np.isfinite(inner).all() and np.isnan(N[:5]).all() and np.isnan(N[:, :5]).all() and np.isnan(N[H - 6:]).all() and np.isnan(N[:, W - 6:]).all()
+    ang = np.degrees(np.arccos(np.clip(inner.reshape(-1, 3).astype(np.float64) @ n, -1, 1)))
+    assert ang.max() < 1.0 and np.median(ang) < 0.2
+    assert np.abs(np.linalg.norm(inner, axis=-1) - 1).max() < 1e-6 and (inner[..., 2] <= 0).all()
+    # a hole (zero depth) and an isolated spike 1 cm in front of the plane: no admissible neighbour -> no normal at the spike
+    d2 = depth.copy(); d2[100, 100] = 0; d2[60, 200] -= 100
+    N2 = depth_normals_gradient(d2, (fx, cx, fy, cy))
+    assert np.isnan(N2[60, 200]).all()
+    assert np.isfinite(N2[100, 105]).all()                          # the hole's neighbours drop it (|delta| > 50) and keep their normal
