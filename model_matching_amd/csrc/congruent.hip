@@ -172,7 +172,8 @@ __device__ __forceinline__ int64_t index_pos(V3 p, float cell, int eg) {
 template <class KeyT>
 __global__ __launch_bounds__(256) void gather_key_kernel(const uint32_t* __restrict__ pairs, const Segment* __restrict__ segs, int nseg, uint32_t total,
                                                          const BaseJob* __restrict__ jobs, const float4* __restrict__ munit, int is_q, int cell_bits,
-                                                         long long cell_limit, KeyT* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                         long long cell_limit, KeyT* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                         uint8_t* __restrict__ occ) {
     // segment of the workgroup's first entry: one uniform binary search (scalar loads); a segment holds thousands of
     // entries, so the lanes then step forward zero or one segment
     const uint32_t e0 = blockIdx.x * blockDim.x;
@@ -192,8 +193,137 @@ __global__ __launch_bounds__(256) void gather_key_kernel(const uint32_t* __restr
     const float inv = is_q ? J.inv2 : J.inv1;
     const int64_t pc = index_pos(p1 + inv * (p2 - p1), J.cell, J.egSize);
     const KeyT cmask = ((KeyT)1 << cell_bits) - (KeyT)1;
-    keys[e] = ((KeyT)sg.base << cell_bits) | ((pc < 0 || pc >= cell_limit) ? cmask : (KeyT)pc);
+    const bool no_cell = pc < 0 || pc >= cell_limit;
+    const KeyT key = ((KeyT)sg.base << cell_bits) | (no_cell ? cmask : (KeyT)pc);
+    keys[e] = key;
     vals[e] = pr;
+    if (occ && !no_cell) occ[(size_t)key] = 1;   // which (base, cell) this list occupies: a byte each, plain stores (every writer writes 1;
+                                                 // neighbours in the index share a first point, not a cell, and 18 M atomics took 1.7 ms)
+}
+
+// ---- survivors ----
+// A P entry can only ever be matched by a Q entry of the same (base, position cell) and the other way round (Q9: only the
+// query's own cell is inspected), and on the metric workload three entries out of four have no partner cell at all (CPU census
+// of a Cm trial: 23 % of 7.9 M Q entries and 27 % of 10 M P entries do).  So each gather also marks the cells its list occupies,
+// and both lists are reduced to the entries whose cell the OTHER list occupies -- in gather order, so the stable sorts that
+// follow see the same relative order -- before anything is sorted: the sorts, the records and the join work on a quarter of
+// the entries.  Entries dropped here have an empty partner run: they contribute no quad and no rank of the walk order.
+#define SURV_TILE 1024
+template <class KeyT>
+__device__ __forceinline__ bool occ_test(const uint8_t* __restrict__ occ, KeyT key) { return occ[(size_t)key] != 0; }
+
+// per tile of SURV_TILE entries: how many survive
+template <class KeyT>
+__global__ __launch_bounds__(256) void survivors_count_kernel(const KeyT* __restrict__ keys, uint32_t n, const uint8_t* __restrict__ other,
+                                                              uint32_t* __restrict__ tile_cnt) {
+    __shared__ uint32_t s_w[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < SURV_TILE / 256; ++k) {
+        const uint32_t e = blockIdx.x * SURV_TILE + k * 256 + threadIdx.x;
+        const bool alive = e < n && occ_test(other, keys[e]);   // the all-ones cell is never marked
+        cnt += (uint32_t)__popcll(__ballot(alive));
+    }
+    if (lane == 0) s_w[w] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// exclusive scan of a[0 .. n) by one workgroup of 1024, in place; emit(i, offset, value) sees every element
+template <class F>
+__device__ __forceinline__ void block_scan_1024(uint32_t* __restrict__ a, uint32_t n, uint32_t* s_part, F emit) {
+    const uint32_t tid = threadIdx.x, chunk = (n + 1023u) / 1024u;
+    const uint32_t lo = min(tid * chunk, n), hi = min(lo + chunk, n);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += a[i];
+    __syncthreads();
+    s_part[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+        const uint32_t v = tid >= d ? s_part[tid - d] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[tid] - sum;
+    for (uint32_t i = lo; i < hi; ++i) { const uint32_t v = a[i]; a[i] = run; emit(i, run, v); run += v; }
+}
+
+// workgroup 0: P list, workgroup 1: Q list.  Tile counts -> tile offsets (element n_tiles receives the total)
+__global__ __launch_bounds__(1024) void survivors_scan_kernel(uint32_t* __restrict__ tiles_p, uint32_t ntp, uint32_t* __restrict__ tiles_q, uint32_t ntq) {
+    __shared__ uint32_t s_part[1024];
+    const bool q = blockIdx.x == 1;
+    block_scan_1024(q ? tiles_q : tiles_p, (q ? ntq : ntp) + 1u, s_part, [](uint32_t, uint32_t, uint32_t) {});
+}
+
+// Where every base's stretch begins and ends in the reduced lists (the lists are base-major, so that is the number of
+// survivors in front of the stretch's old bounds: the offset of the tile a bound falls into plus the survivors of that
+// tile in front of it), patched into the base jobs and the offset arrays the join reads.  Workgroup (b, list).
+template <class KeyT>
+__global__ __launch_bounds__(256) void survivors_base_offsets_kernel(const KeyT* __restrict__ pkeys, uint32_t nP, const uint8_t* __restrict__ occ_q,
+                                                                     const uint32_t* __restrict__ tiles_p, const KeyT* __restrict__ qkeys, uint32_t nQ,
+                                                                     const uint8_t* __restrict__ occ_p, const uint32_t* __restrict__ tiles_q, int nB,
+                                                                     BaseJob* __restrict__ jobs, uint32_t* __restrict__ p_off, uint32_t* __restrict__ q_off) {
+    __shared__ uint32_t s_w[2][4];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool q = blockIdx.y == 1;
+    const KeyT* keys = q ? qkeys : pkeys;
+    const uint8_t* other = q ? occ_p : occ_q;
+    const uint32_t* tiles = q ? tiles_q : tiles_p;
+    const uint32_t r0 = q ? jobs[b].q_off : jobs[b].p_off, r1 = r0 + (q ? jobs[b].q_len : jobs[b].p_len);
+    uint32_t got[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t r = h ? r1 : r0, t0 = (r / SURV_TILE) * SURV_TILE;
+        uint32_t cnt = 0;
+        for (uint32_t e = t0 + threadIdx.x; e < r; e += 256) cnt += occ_test(other, keys[e]) ? 1u : 0u;
+        for (int d = 32; d; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+        if (lane == 0) s_w[h][w] = cnt;
+        got[h] = tiles[r / SURV_TILE];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t n0 = got[0] + s_w[0][0] + s_w[0][1] + s_w[0][2] + s_w[0][3], n1 = got[1] + s_w[1][0] + s_w[1][1] + s_w[1][2] + s_w[1][3];
+        if (q) { jobs[b].q_off = n0; jobs[b].q_len = n1 - n0; q_off[b] = n0; if (b == nB - 1) q_off[nB] = n1; }
+        else   { jobs[b].p_off = n0; jobs[b].p_len = n1 - n0; p_off[b] = n0; if (b == nB - 1) p_off[nB] = n1; }
+    }
+}
+
+// the survivors of a tile, in order, behind the tile's offset
+template <class KeyT>
+__global__ __launch_bounds__(256) void survivors_compact_kernel(const KeyT* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n,
+                                                                const uint8_t* __restrict__ other, const uint32_t* __restrict__ tile_off,
+                                                                KeyT* __restrict__ okeys, uint32_t* __restrict__ ovals) {
+    constexpr int R = SURV_TILE / 256;
+    __shared__ uint32_t s_c[R][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    KeyT key[R];
+    uint32_t rank[R];
+    bool alive[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const uint32_t e = blockIdx.x * SURV_TILE + k * 256 + threadIdx.x;
+        const bool in = e < n;
+        key[k] = in ? keys[e] : (KeyT)0;
+        alive[k] = in && occ_test(other, key[k]);
+        const unsigned long long am = __ballot(alive[k]);
+        rank[k] = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+        if (lane == 0) s_c[k][w] = (uint32_t)__popcll(am);
+    }
+    __syncthreads();
+    uint32_t base = tile_off[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        uint32_t o = base;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) { if (ww < w) o += s_c[k][ww]; base += s_c[k][ww]; }
+        if (alive[k]) {
+            const uint32_t e = blockIdx.x * SURV_TILE + k * 256 + threadIdx.x;
+            okeys[o + rank[k]] = key[k];
+            ovals[o + rank[k]] = vals[e];
+        }
+    }
 }
 
 // Zero fill as an ordinary kernel on the context's stream
@@ -660,6 +790,7 @@ struct CongruentState {
     // (those calls return without synchronising; the caller's own synchronisation point comes before the next reuse)
     std::vector<unsigned long long> h_out_base, h_off;
     std::vector<uint32_t> h_qoff;          // Q range of every base (host copy of d_qoff)
+    bool no_quads = false;                 // the last count found no (base, cell) that both lists occupy
     std::vector<uint2> h_blocks;           // workgroup -> Q range of the last materialise
     void* h_stage = NULL;         // pinned staging of the per-trial tables (one upload per trial)
     size_t stage_bytes = 0;
@@ -771,16 +902,15 @@ struct PlanDev {
 template <class KeyT>
 static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool dbg, double& tprev) {
     const int nB = S->nB;
-    const size_t totP = S->totP, totQ = S->totQ;
+    const size_t totP0 = S->totP, totQ0 = S->totQ;   // the gathered lists as planned
+    size_t totP = totP0, totQ = totQ0;               // the lists that are sorted and joined (the survivors, when the lists are reduced)
     hipStream_t st = c->stream;
+    hipStream_t sq = c->aux_stream ? c->aux_stream : st;
     DevBuf<KeyT> d_pk_raw, d_qk_raw;
     DevBuf<uint32_t> d_pv_raw, d_qv_raw;
     DevBuf<char> d_tmp;
     int rc;
-    if ((rc = d_pk_raw.alloc(totP)) || (rc = d_pv_raw.alloc(totP)) || (rc = d_qk_raw.alloc(totQ)) || (rc = d_qv_raw.alloc(totQ)) ||
-        (rc = S->d_pkeys.alloc(totP * sizeof(KeyT))) || (rc = S->d_pvals.alloc(totP)) || (rc = S->d_qkeys.alloc(totQ * sizeof(KeyT))) || (rc = S->d_qvals.alloc(totQ)) ||
-        (rc = S->d_prec.alloc(totP)) || (rc = S->d_pdc.alloc(((size_t)totP + 15) & ~(size_t)7)))
-        return rc;
+    if ((rc = d_pk_raw.alloc(totP0)) || (rc = d_pv_raw.alloc(totP0)) || (rc = d_qk_raw.alloc(totQ0)) || (rc = d_qv_raw.alloc(totQ0))) return rc;
     S->d_jobs.p = plan.jobs;
     const Segment* d_psegs = plan.psegs;
     const Segment* d_qsegs = plan.qsegs;
@@ -790,19 +920,78 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     const int n_pseg = plan.n_pseg, n_qseg = plan.n_qseg;
     const PpfIndex& ix = c->index;
     const long long cell_limit = S->use_table ? S->NC : ((long long)1 << 31);
-    // The P side (gather, sort, records) and the Q side (gather, sort) are independent until the join: the Q side runs on
-    // the context's auxiliary stream next to the P side (a radix pass of 7 M pairs moves ~1.8 TB/s: two of them share the chip)
     const unsigned end_bit = (unsigned)(S->cell_bits + S->base_bits);
+    // The lists are reduced to the entries with a partner cell (survivors, above) when one byte per (base, cell) is a small table
+    const unsigned long long occ_bits = (unsigned long long)nB << S->cell_bits;
+    const bool reduce = S->use_table && occ_bits <= (1ull << 25) && !getenv("STOCS_CONGRUENT_KEEP_ALL");
+    const KeyT* pk_in = d_pk_raw.p; const uint32_t* pv_in = d_pv_raw.p;   // what the sorts read
+    const KeyT* qk_in = d_qk_raw.p; const uint32_t* qv_in = d_qv_raw.p;
+    DevBuf<KeyT> d_pk_c, d_qk_c;
+    DevBuf<uint32_t> d_pv_c, d_qv_c, d_surv;
+    bool have_surv_clock = false;
+    if (reduce) {
+        // one zeroed block: occupancy of P | occupancy of Q | P tile counts (+ total) | Q tile counts (+ total)
+        const size_t W = (size_t)((occ_bits + 3) >> 2);   // words of one occupancy table
+        const uint32_t ntp = (uint32_t)((totP0 + SURV_TILE - 1) / SURV_TILE), ntq = (uint32_t)((totQ0 + SURV_TILE - 1) / SURV_TILE);
+        const size_t o_tp = 2 * W, o_tq = o_tp + ntp + 1, n_words = o_tq + ntq + 1;
+        if ((rc = d_surv.alloc(n_words))) return rc;
+        uint8_t* occ_p = (uint8_t*)d_surv.p;
+        uint8_t* occ_q = (uint8_t*)(d_surv.p + W);
+        hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, d_surv.p, n_words, (uint32_t*)NULL);
+        STOCS_HIP_CHECK(hipEventRecord(c->ev_t[6], st));
+        if (sq != st) {
+            STOCS_HIP_CHECK(hipEventRecord(c->ev_fork, st));          // the plan upload and the zero fill are on st
+            STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_fork, 0));
+        }
+        hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totQ0 + 255) / 256)), dim3(256), 0, sq, ix.d_pairs, d_qsegs, n_qseg, (uint32_t)totQ0,
+                           S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p, occ_q);
+        STOCS_HIP_CHECK(hipEventRecord(c->ev_t[8], sq));             // Q's cells are marked
+        hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totP0 + 255) / 256)), dim3(256), 0, st, ix.d_pairs, d_psegs, n_pseg, (uint32_t)totP0,
+                           S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p, occ_p);
+        STOCS_HIP_CHECK(hipEventRecord(c->ev_t[9], st));             // P's cells are marked
+        if (sq != st) { STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_t[9], 0)); STOCS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_t[8], 0)); }
+        hipLaunchKernelGGL(survivors_count_kernel<KeyT>, dim3(ntq), dim3(256), 0, sq, (const KeyT*)d_qk_raw.p, (uint32_t)totQ0, (const uint8_t*)occ_p, d_surv.p + o_tq);
+        if (sq != st) STOCS_HIP_CHECK(hipEventRecord(c->ev_join, sq));
+        hipLaunchKernelGGL(survivors_count_kernel<KeyT>, dim3(ntp), dim3(256), 0, st, (const KeyT*)d_pk_raw.p, (uint32_t)totP0, (const uint8_t*)occ_q, d_surv.p + o_tp);
+        if (sq != st) STOCS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_join, 0));
+        hipLaunchKernelGGL(survivors_scan_kernel, dim3(2), dim3(1024), 0, st, d_surv.p + o_tp, ntp, d_surv.p + o_tq, ntq);
+        hipLaunchKernelGGL(survivors_base_offsets_kernel<KeyT>, dim3((unsigned)nB, 2), dim3(256), 0, st, (const KeyT*)d_pk_raw.p, (uint32_t)totP0, (const uint8_t*)occ_q,
+                           (const uint32_t*)(d_surv.p + o_tp), (const KeyT*)d_qk_raw.p, (uint32_t)totQ0, (const uint8_t*)occ_p, (const uint32_t*)(d_surv.p + o_tq), nB,
+                           S->d_jobs.p, plan.p_off, plan.q_off);
+        STOCS_HIP_CHECK(hipGetLastError());
+        // the host sizes the sorts and the join with the survivors' totals and lays the materialise blocks out with their Q offsets
+        uint32_t* tot_pin = (uint32_t*)((char*)c->h_pin + PIN_CONGRUENT + 128);
+        uint32_t* qoff_pin = (uint32_t*)((char*)c->h_pin + PIN_VAR + 8 * ((size_t)nB + 1));
+        STOCS_HIP_CHECK(hipMemcpyAsync(tot_pin, d_surv.p + o_tp + ntp, 4, hipMemcpyDeviceToHost, st));
+        STOCS_HIP_CHECK(hipMemcpyAsync(tot_pin + 1, d_surv.p + o_tq + ntq, 4, hipMemcpyDeviceToHost, st));
+        STOCS_HIP_CHECK(hipMemcpyAsync(qoff_pin, plan.q_off, 4 * ((size_t)nB + 1), hipMemcpyDeviceToHost, st));
+        STOCS_HIP_CHECK(hipEventRecord(c->ev_t[7], st));
+        c->timing[0].lap("enqueue gather + occupancy + survivor counts");
+        STOCS_HIP_CHECK(hipStreamSynchronize(st));
+        c->timing[0].lap("wait for the device (survivors)");
+        have_surv_clock = true;
+        totP = tot_pin[0]; totQ = tot_pin[1];
+        memcpy(S->h_qoff.data(), qoff_pin, 4 * ((size_t)nB + 1));
+        if (dbg) fprintf(stderr, "[stocs congruent] survivors: P %zu of %zu, Q %zu of %zu\n", totP, totP0, totQ, totQ0);
+        S->totP = (uint32_t)totP; S->totQ = (uint32_t)totQ;
+        if (totP == 0 || totQ == 0) { S->no_quads = true; return STOCS_OK; }   // no cell is shared: no quads (quad_off is all zero already)
+        if ((rc = d_pk_c.alloc(totP)) || (rc = d_pv_c.alloc(totP)) || (rc = d_qk_c.alloc(totQ)) || (rc = d_qv_c.alloc(totQ))) return rc;
+        pk_in = d_pk_c.p; pv_in = d_pv_c.p; qk_in = d_qk_c.p; qv_in = d_qv_c.p;
+    }
+    if ((rc = S->d_pkeys.alloc(totP * sizeof(KeyT))) || (rc = S->d_pvals.alloc(totP)) || (rc = S->d_qkeys.alloc(totQ * sizeof(KeyT))) || (rc = S->d_qvals.alloc(totQ)) ||
+        (rc = S->d_prec.alloc(totP)) || (rc = S->d_pdc.alloc(((size_t)totP + 15) & ~(size_t)7)))
+        return rc;
+    // The P side (sort, records) and the Q side (sort) are independent until the join: the Q side runs on
+    // the context's auxiliary stream next to the P side (a radix pass of 7 M pairs moves ~1.8 TB/s: two of them share the chip)
     size_t tb1 = 0, tb2 = 0;
     // P side with the run table: sorted by position cell ALONE.  The gather emits base after base and the sort is stable, so
     // inside a cell the entries stay grouped by base, in index order inside a base: the runs of (base, cell) are contiguous
     // all the same, the table finds them wherever they are, and 15 bits are two radix passes where 22 are three.
     const unsigned end_bit_p = (S->use_table && !getenv("STOCS_CONGRUENT_P_FULLSORT")) ? (unsigned)S->cell_bits : end_bit;
-    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb1, d_pk_raw.p, (KeyT*)S->d_pkeys.p, d_pv_raw.p, S->d_pvals.p, totP, 0, end_bit_p, st));
-    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb2, d_qk_raw.p, (KeyT*)S->d_qkeys.p, d_qv_raw.p, S->d_qvals.p, totQ, 0, end_bit, st));
+    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb1, (KeyT*)pk_in, (KeyT*)S->d_pkeys.p, (uint32_t*)pv_in, S->d_pvals.p, totP, 0, end_bit_p, st));
+    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb2, (KeyT*)qk_in, (KeyT*)S->d_qkeys.p, (uint32_t*)qv_in, S->d_qvals.p, totQ, 0, end_bit, st));
     DevBuf<char> d_tmp2;
     if ((rc = d_tmp.alloc(tb1)) || (rc = d_tmp2.alloc(tb2))) return rc;
-    hipStream_t sq = c->aux_stream ? c->aux_stream : st;
     // device-side clock of the groups below (HIP events on the streams they run on; read after the call's closing
     // synchronisation): a call that takes 70 ms instead of 1 then says which group of kernels it spent them in
     STOCS_HIP_CHECK(hipEventRecord(c->ev_t[0], st));
@@ -810,16 +999,30 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         STOCS_HIP_CHECK(hipEventRecord(c->ev_fork, st));          // the upload above is on st
         STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_fork, 0));
     }
-    hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totQ + 255) / 256)), dim3(256), 0, sq, ix.d_pairs, d_qsegs, n_qseg, (uint32_t)totQ,
-                       S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p);
-    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_tmp2.p, tb2, d_qk_raw.p, (KeyT*)S->d_qkeys.p, d_qv_raw.p, S->d_qvals.p, totQ, 0, end_bit, sq));
+    if (reduce) {
+        const uint32_t ntp = (uint32_t)((totP0 + SURV_TILE - 1) / SURV_TILE), ntq = (uint32_t)((totQ0 + SURV_TILE - 1) / SURV_TILE);
+        const size_t W = (size_t)((occ_bits + 3) >> 2), o_tp = 2 * W, o_tq = o_tp + ntp + 1;
+        hipLaunchKernelGGL(survivors_compact_kernel<KeyT>, dim3(ntq), dim3(256), 0, sq, (const KeyT*)d_qk_raw.p, (const uint32_t*)d_qv_raw.p, (uint32_t)totQ0,
+                           (const uint8_t*)d_surv.p, (const uint32_t*)(d_surv.p + o_tq), d_qk_c.p, d_qv_c.p);
+    } else {
+        hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totQ + 255) / 256)), dim3(256), 0, sq, ix.d_pairs, d_qsegs, n_qseg, (uint32_t)totQ,
+                           S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p, (uint8_t*)NULL);
+    }
+    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_tmp2.p, tb2, (KeyT*)qk_in, (KeyT*)S->d_qkeys.p, (uint32_t*)qv_in, S->d_qvals.p, totQ, 0, end_bit, sq));
     STOCS_HIP_CHECK(hipEventRecord(c->ev_t[1], sq));
     if (sq != st) STOCS_HIP_CHECK(hipEventRecord(c->ev_join, sq));
-    hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, ix.d_pairs, d_psegs, n_pseg, (uint32_t)totP,
-                       S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p);
+    if (reduce) {
+        const uint32_t ntp = (uint32_t)((totP0 + SURV_TILE - 1) / SURV_TILE);
+        const size_t W = (size_t)((occ_bits + 3) >> 2), o_tp = 2 * W;
+        hipLaunchKernelGGL(survivors_compact_kernel<KeyT>, dim3(ntp), dim3(256), 0, st, (const KeyT*)d_pk_raw.p, (const uint32_t*)d_pv_raw.p, (uint32_t)totP0,
+                           (const uint8_t*)(d_surv.p + W), (const uint32_t*)(d_surv.p + o_tp), d_pk_c.p, d_pv_c.p);
+    } else {
+        hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, ix.d_pairs, d_psegs, n_pseg, (uint32_t)totP,
+                           S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p, (uint8_t*)NULL);
+    }
     STOCS_HIP_CHECK(hipGetLastError());
     // one stable sort per list: (base, position cell); inside a cell the entries keep the index order of the gather
-    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_tmp.p, tb1, d_pk_raw.p, (KeyT*)S->d_pkeys.p, d_pv_raw.p, S->d_pvals.p, totP, 0, end_bit_p, st));
+    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_tmp.p, tb1, (KeyT*)pk_in, (KeyT*)S->d_pkeys.p, (uint32_t*)pv_in, S->d_pvals.p, totP, 0, end_bit_p, st));
     STOCS_HIP_CHECK(hipEventRecord(c->ev_t[2], st));
     if (S->use_table) {
         const size_t ncell = (size_t)(S->NC * nB);
@@ -853,18 +1056,20 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     STOCS_HIP_CHECK(hipGetLastError());
     STOCS_HIP_CHECK(hipMemcpyAsync(qoff_at, d_boff.p, 8 * (size_t)(nB + 1), hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipEventRecord(c->ev_t[5], st));
-    c->timing[0].lap("enqueue gather/sort/records/join/scan");
+    c->timing[0].lap(reduce ? "enqueue compact/sort/records/join/scan" : "enqueue gather/sort/records/join/scan");
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
     c->timing[0].lap("wait for the device (counts)");
     {   // the device's own account of that wait (every event has completed: the stream is idle, the Q side was joined into it)
-        static const char* const what[5] = {"device: Q gather + sort (aux stream, from the fork)", "device: P gather + sort", "device: P records + wait for Q", "device: join count",
-                                            "device: scan + offsets + read-back"};
-        const int from[5] = {0, 0, 2, 3, 4}, to[5] = {1, 2, 3, 4, 5};
-        for (int k = 0; k < 5; ++k) {
+        static const char* const what_all[5] = {"device: Q gather + sort (aux stream, from the fork)", "device: P gather + sort", "device: P records + wait for Q",
+                                                "device: join count", "device: scan + offsets + read-back"};
+        static const char* const what_red[6] = {"device: gathers + occupancy + survivor counts (both lists)", "device: Q compact + sort (aux stream, from the fork)",
+                                                "device: P compact + sort", "device: P records + wait for Q", "device: join count", "device: scan + offsets + read-back"};
+        const int from[6] = {6, 0, 0, 2, 3, 4}, to[6] = {7, 1, 2, 3, 4, 5};
+        for (int k = have_surv_clock ? 0 : 1; k < 6; ++k) {
             float ms = -1.0f;
             if (hipEventElapsedTime(&ms, c->ev_t[from[k]], c->ev_t[to[k]]) != hipSuccess) ms = -1.0f;
             CallTiming& T = c->timing[0];
-            if (T.n < CallTiming::MAX_STEPS) { T.label[T.n] = what[k]; T.ms[T.n] = (double)ms; ++T.n; }
+            if (T.n < CallTiming::MAX_STEPS) { T.label[T.n] = have_surv_clock ? what_red[k] : what_all[k - 1]; T.ms[T.n] = (double)ms; ++T.n; }
         }
         c->timing[0].t_last = CallTiming::now_s();
     }
@@ -1105,8 +1310,10 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
         S->close_cells = diag2 < 0.999 * (double)c->prm.distance_threshold && !getenv("STOCS_CONGRUENT_DISTANCE_GATE");
     }
     S->id_bits = id_bits; S->base_bits = base_bits; S->cell_bits = cell_bits;
+    S->no_quads = false;
     int rc = wide ? count_pass<uint64_t>(c, S, plan, dbg, tprev) : count_pass<uint32_t>(c, S, plan, dbg, tprev);
     if (rc) return rc;
+    if (S->no_quads) return STOCS_OK;   // as with empty lists: nothing to materialise, every base has zero quads
     S->valid = true;
     c->quad_id_bits = id_bits;
     if (total_quads) *total_quads = (int64_t)c->quad_off[nB];

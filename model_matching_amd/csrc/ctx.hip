@@ -340,7 +340,7 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
         delete c;
         return STOCS_ERR_NO_DEVICE;
     }
-    for (int k = 0; k < 6; ++k)
+    for (int k = 0; k < 10; ++k)
         if (hipEventCreate(&c->ev_t[k]) != hipSuccess) { set_error("event creation failed"); delete c; return STOCS_ERR_NO_DEVICE; }
     c->stream = c->own_stream;
     compute_thresholds(c->prm, &c->thr);
@@ -432,7 +432,7 @@ int stocs_ctx_destroy(stocs_ctx* c) {
     (void)hipEventDestroy(c->ev1);
     (void)hipEventDestroy(c->ev_fork);
     (void)hipEventDestroy(c->ev_join);
-    for (int k = 0; k < 6; ++k) (void)hipEventDestroy(c->ev_t[k]);
+    for (int k = 0; k < 10; ++k) (void)hipEventDestroy(c->ev_t[k]);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;

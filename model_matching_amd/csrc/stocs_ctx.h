@@ -186,7 +186,7 @@ struct stocs_ctx {
     hipStream_t own_stream;   // created with the context; `stream` may point to a caller's stream instead
     hipStream_t aux_stream;   // second stream of the context for work that is independent of `stream` until an event joins it
     hipEvent_t ev0, ev1, ev_fork, ev_join;
-    hipEvent_t ev_t[6];   // timing events around the device groups of stocs_find_congruent_all (always recorded; read after the call's own sync)
+    hipEvent_t ev_t[10];   // timing events around the device groups of stocs_find_congruent_all (always recorded; read after the call's own sync)
     int nS, nM;
     stocs::Thresholds thr;
 

@@ -194,6 +194,35 @@ def test_host_planned_lookups_equal_device_planned(setup, monkeypatch):
         slot += 1
 
 
+def test_unreduced_pair_lists_give_the_same_sets(setup, monkeypatch):
+    """Before anything is sorted both pair lists are reduced to the entries whose (base, position cell) the other list
+    occupies too (an entry without a partner cell can form no set).  The unreduced form -- what a position grid too fine
+    for the one-bit-per-cell table takes -- is forced here: same counts, same quads, same walk order; and with the 64-bit
+    keys on top."""
+    m, s, est, orc = setup
+    est.L.stocs_clear_bases(est.h)
+    valid, ids, inv = est.sample_bases(4242, 24)
+    n_red = est.find_congruent_all()
+    nv = int(valid.sum())
+    quads = [est.get_quads(k) for k in range(nv)]
+    walk = [est.get_quads_at(k, np.arange(min(len(quads[k]), 300))) for k in range(nv)]
+    assert len(est.last_call_timing(0)) >= 16     # the reduced form has its own synchronisation point and device group
+    for wide in ("", "1"):
+        monkeypatch.setenv("STOCS_CONGRUENT_KEEP_ALL", "1")
+        if wide:
+            monkeypatch.setenv("STOCS_CONGRUENT_WIDE_KEYS", "1")
+        assert est.find_congruent_all() == n_red and n_red > 0
+        for k in range(nv):
+            assert np.array_equal(est.get_quads(k), quads[k])
+            assert np.array_equal(est.get_quads_at(k, np.arange(min(len(quads[k]), 300))), walk[k])
+    slot = 0
+    for a in range(24):
+        if not valid[a]:
+            continue
+        assert np.array_equal(quads[slot], orc.find_congruent(ids[a], float(inv[a][0]), float(inv[a][1])))
+        slot += 1
+
+
 def test_distance_gate_path_of_the_count(setup, monkeypatch):
     """The count pass normally tests direction cells alone: inside one position cell the gate of stocs.cpp:854 (squared
     metres against epsilon, Q1) cannot fail while 12 epsilon^2 < epsilon.  The general path -- the gate evaluated per
@@ -462,10 +491,10 @@ def test_repeated_trials_on_one_context_equal_fresh_contexts():
     steps = est.last_call_timing(0)
     host = [(k, v) for k, v in steps if not k.startswith("device:")]
     dev = [(k, v) for k, v in steps if k.startswith("device:")]
-    assert len(host) >= 6 and len(dev) == 5 and all(v >= 0 for _, v in steps)
+    assert len(host) >= 8 and len(dev) == 6 and all(v >= 0 for _, v in steps)
     assert any("wait for the device" in k for k, _ in host)
     assert 0.5 * wall_ms <= sum(v for _, v in host) <= wall_ms * 1.05 + 0.05       # the host steps account for the call
-    assert sum(v for k, v in dev if "Q gather" not in k) <= wall_ms                 # the device groups ran inside it
+    assert sum(v for k, v in dev if "aux stream" not in k) <= wall_ms               # the device groups ran inside it
     est.make_transforms(200, 1234); est.compute_best_transform()
     assert len(est.last_call_timing(1)) >= 2 and len(est.last_call_timing(2)) == 2
     est.close()

@@ -56,7 +56,11 @@ def main():
             dR = P[:3, :3].T @ T_gt[:3, :3]
             run["rot_err_deg"] = float(np.degrees(np.arccos(min(1.0, (np.trace(dR) - 1) / 2))))
             run["tr_err_mm"] = float(np.linalg.norm(P[:3, 3] - T_gt[:3, 3]) * 1e3)
+        run["steps_ms"] = {c: est.last_call_timing(w) for w, c in enumerate(("find_congruent_all", "make_transforms", "verify_all"))}
         rep["runs"].append(run)
+    if len(rep["runs"]) > 2:   # the library's own step record, median over the runs after the first two
+        rep["steps_ms_median"] = {c: [[lab, float(np.median([dict(r["steps_ms"][c]).get(lab, 0.0) for r in rep["runs"][2:]]))] for lab, _ in rep["runs"][-1]["steps_ms"][c]]
+                                  for c in rep["runs"][-1]["steps_ms"]}
     print(json.dumps(rep))
 
 
