@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void survivors_base_offsets_kernel(const KeyT*
     if (threadIdx.x == 0) {
         const uint32_t n0 = got[0] + s_w[0][0] + s_w[0][1] + s_w[0][2] + s_w[0][3], n1 = got[1] + s_w[1][0] + s_w[1][1] + s_w[1][2] + s_w[1][3];
         if (q) { jobs[b].q_off = n0; jobs[b].q_len = n1 - n0; q_off[b] = n0; if (b == nB - 1) q_off[nB] = n1; }
-        else   { jobs[b].p_off = n0; jobs[b].p_len = n1 - n0; p_off[b] = n0; if (b == nB - 1) p_off[nB] = n1; }
+        else   { jobs[b].p_off = n0; jobs[b].p_len = n1 - n0; p_off[b] = n0; if (b == nB - 1) { p_off[nB] = n1; q_off[nB + 1] = n1; } }   // q_off[nB + 1]: P's total rides along with the Q offsets
     }
 }
 
@@ -790,6 +790,7 @@ struct CongruentState {
     // (those calls return without synchronising; the caller's own synchronisation point comes before the next reuse)
     std::vector<unsigned long long> h_out_base, h_off;
     std::vector<uint32_t> h_qoff;          // Q range of every base (host copy of d_qoff)
+    bool reduce = false;                   // this trial's lists are reduced to the entries with a partner cell
     bool no_quads = false;                 // the last count found no (base, cell) that both lists occupy
     std::vector<uint2> h_blocks;           // workgroup -> Q range of the last materialise
     void* h_stage = NULL;         // pinned staging of the per-trial tables (one upload per trial)
@@ -921,9 +922,8 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     const PpfIndex& ix = c->index;
     const long long cell_limit = S->use_table ? S->NC : ((long long)1 << 31);
     const unsigned end_bit = (unsigned)(S->cell_bits + S->base_bits);
-    // The lists are reduced to the entries with a partner cell (survivors, above) when one byte per (base, cell) is a small table
-    const unsigned long long occ_bits = (unsigned long long)nB << S->cell_bits;
-    const bool reduce = S->use_table && occ_bits <= (1ull << 25) && !getenv("STOCS_CONGRUENT_KEEP_ALL");
+    const unsigned long long occ_bits = (unsigned long long)nB << S->cell_bits;   // (base, cell) values = bytes of an occupancy table
+    const bool reduce = S->reduce;
     const KeyT* pk_in = d_pk_raw.p; const uint32_t* pv_in = d_pv_raw.p;   // what the sorts read
     const KeyT* qk_in = d_qk_raw.p; const uint32_t* qv_in = d_qv_raw.p;
     DevBuf<KeyT> d_pk_c, d_qk_c;
@@ -960,22 +960,30 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
                            S->d_jobs.p, plan.p_off, plan.q_off);
         STOCS_HIP_CHECK(hipGetLastError());
         // the host sizes the sorts and the join with the survivors' totals and lays the materialise blocks out with their Q offsets
-        uint32_t* tot_pin = (uint32_t*)((char*)c->h_pin + PIN_CONGRUENT + 128);
         uint32_t* qoff_pin = (uint32_t*)((char*)c->h_pin + PIN_VAR + 8 * ((size_t)nB + 1));
-        STOCS_HIP_CHECK(hipMemcpyAsync(tot_pin, d_surv.p + o_tp + ntp, 4, hipMemcpyDeviceToHost, st));
-        STOCS_HIP_CHECK(hipMemcpyAsync(tot_pin + 1, d_surv.p + o_tq + ntq, 4, hipMemcpyDeviceToHost, st));
-        STOCS_HIP_CHECK(hipMemcpyAsync(qoff_pin, plan.q_off, 4 * ((size_t)nB + 1), hipMemcpyDeviceToHost, st));
+        STOCS_HIP_CHECK(hipMemcpyAsync(qoff_pin, plan.q_off, 4 * ((size_t)nB + 2), hipMemcpyDeviceToHost, st));   // Q offsets, Q total, P total
         STOCS_HIP_CHECK(hipEventRecord(c->ev_t[7], st));
+        // the survivors move behind their tiles' offsets while the host waits for the totals: the compacted lists are sized by
+        // the gathered ones here (the totals are what the wait is for)
+        if ((rc = d_pk_c.alloc(totP0)) || (rc = d_pv_c.alloc(totP0)) || (rc = d_qk_c.alloc(totQ0)) || (rc = d_qv_c.alloc(totQ0))) return rc;
+        if (sq != st) {
+            STOCS_HIP_CHECK(hipEventRecord(c->ev_fork, st));          // tile offsets are scanned on st
+            STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_fork, 0));
+        }
+        hipLaunchKernelGGL(survivors_compact_kernel<KeyT>, dim3(ntq), dim3(256), 0, sq, (const KeyT*)d_qk_raw.p, (const uint32_t*)d_qv_raw.p, (uint32_t)totQ0,
+                           (const uint8_t*)occ_p, (const uint32_t*)(d_surv.p + o_tq), d_qk_c.p, d_qv_c.p);
+        hipLaunchKernelGGL(survivors_compact_kernel<KeyT>, dim3(ntp), dim3(256), 0, st, (const KeyT*)d_pk_raw.p, (const uint32_t*)d_pv_raw.p, (uint32_t)totP0,
+                           (const uint8_t*)occ_q, (const uint32_t*)(d_surv.p + o_tp), d_pk_c.p, d_pv_c.p);
+        STOCS_HIP_CHECK(hipGetLastError());
         c->timing[0].lap("enqueue gather + occupancy + survivor counts");
-        STOCS_HIP_CHECK(hipStreamSynchronize(st));
+        STOCS_HIP_CHECK(hipEventSynchronize(c->ev_t[7]));   // the read-back, not the compaction behind it
         c->timing[0].lap("wait for the device (survivors)");
         have_surv_clock = true;
-        totP = tot_pin[0]; totQ = tot_pin[1];
+        totP = qoff_pin[nB + 1]; totQ = qoff_pin[nB];
         memcpy(S->h_qoff.data(), qoff_pin, 4 * ((size_t)nB + 1));
         if (dbg) fprintf(stderr, "[stocs congruent] survivors: P %zu of %zu, Q %zu of %zu\n", totP, totP0, totQ, totQ0);
         S->totP = (uint32_t)totP; S->totQ = (uint32_t)totQ;
         if (totP == 0 || totQ == 0) { S->no_quads = true; return STOCS_OK; }   // no cell is shared: no quads (quad_off is all zero already)
-        if ((rc = d_pk_c.alloc(totP)) || (rc = d_pv_c.alloc(totP)) || (rc = d_qk_c.alloc(totQ)) || (rc = d_qv_c.alloc(totQ))) return rc;
         pk_in = d_pk_c.p; pv_in = d_pv_c.p; qk_in = d_qk_c.p; qv_in = d_qv_c.p;
     }
     if ((rc = S->d_pkeys.alloc(totP * sizeof(KeyT))) || (rc = S->d_pvals.alloc(totP)) || (rc = S->d_qkeys.alloc(totQ * sizeof(KeyT))) || (rc = S->d_qvals.alloc(totQ)) ||
@@ -999,27 +1007,15 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         STOCS_HIP_CHECK(hipEventRecord(c->ev_fork, st));          // the upload above is on st
         STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_fork, 0));
     }
-    if (reduce) {
-        const uint32_t ntp = (uint32_t)((totP0 + SURV_TILE - 1) / SURV_TILE), ntq = (uint32_t)((totQ0 + SURV_TILE - 1) / SURV_TILE);
-        const size_t W = (size_t)((occ_bits + 3) >> 2), o_tp = 2 * W, o_tq = o_tp + ntp + 1;
-        hipLaunchKernelGGL(survivors_compact_kernel<KeyT>, dim3(ntq), dim3(256), 0, sq, (const KeyT*)d_qk_raw.p, (const uint32_t*)d_qv_raw.p, (uint32_t)totQ0,
-                           (const uint8_t*)d_surv.p, (const uint32_t*)(d_surv.p + o_tq), d_qk_c.p, d_qv_c.p);
-    } else {
+    if (!reduce)
         hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totQ + 255) / 256)), dim3(256), 0, sq, ix.d_pairs, d_qsegs, n_qseg, (uint32_t)totQ,
                            S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p, (uint8_t*)NULL);
-    }
     STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_tmp2.p, tb2, (KeyT*)qk_in, (KeyT*)S->d_qkeys.p, (uint32_t*)qv_in, S->d_qvals.p, totQ, 0, end_bit, sq));
     STOCS_HIP_CHECK(hipEventRecord(c->ev_t[1], sq));
     if (sq != st) STOCS_HIP_CHECK(hipEventRecord(c->ev_join, sq));
-    if (reduce) {
-        const uint32_t ntp = (uint32_t)((totP0 + SURV_TILE - 1) / SURV_TILE);
-        const size_t W = (size_t)((occ_bits + 3) >> 2), o_tp = 2 * W;
-        hipLaunchKernelGGL(survivors_compact_kernel<KeyT>, dim3(ntp), dim3(256), 0, st, (const KeyT*)d_pk_raw.p, (const uint32_t*)d_pv_raw.p, (uint32_t)totP0,
-                           (const uint8_t*)(d_surv.p + W), (const uint32_t*)(d_surv.p + o_tp), d_pk_c.p, d_pv_c.p);
-    } else {
+    if (!reduce)
         hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, ix.d_pairs, d_psegs, n_pseg, (uint32_t)totP,
                            S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p, (uint8_t*)NULL);
-    }
     STOCS_HIP_CHECK(hipGetLastError());
     // one stable sort per list: (base, position cell); inside a cell the entries keep the index order of the gather
     STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_tmp.p, tb1, (KeyT*)pk_in, (KeyT*)S->d_pkeys.p, (uint32_t*)pv_in, S->d_pvals.p, totP, 0, end_bit_p, st));
@@ -1027,7 +1023,9 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     if (S->use_table) {
         const size_t ncell = (size_t)(S->NC * nB);
         if ((rc = S->d_cfirst.alloc(ncell)) || (rc = S->d_cend.alloc(ncell))) return rc;
-        hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, S->d_cfirst.p, ncell, S->d_cend.p);
+        // the table is read at the cells of the Q entries only: in the reduced lists every such cell holds P entries, so the
+        // records kernel writes every slot that is read and the 8 bytes per (base, cell) need no zero fill
+        if (!reduce) hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, S->d_cfirst.p, ncell, S->d_cend.p);
     }
     hipLaunchKernelGGL(p_records_kernel<KeyT>, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, (const KeyT*)S->d_pkeys.p, S->d_pvals.p, (uint32_t)totP,
                        S->cell_bits, S->NC, S->d_jobs.p, c->d_munit, c->d_mpos, S->nepsilon, S->d_prec.p, S->close_cells ? S->d_pdc.p : (uint16_t*)NULL,
@@ -1062,8 +1060,8 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     {   // the device's own account of that wait (every event has completed: the stream is idle, the Q side was joined into it)
         static const char* const what_all[5] = {"device: Q gather + sort (aux stream, from the fork)", "device: P gather + sort", "device: P records + wait for Q",
                                                 "device: join count", "device: scan + offsets + read-back"};
-        static const char* const what_red[6] = {"device: gathers + occupancy + survivor counts (both lists)", "device: Q compact + sort (aux stream, from the fork)",
-                                                "device: P compact + sort", "device: P records + wait for Q", "device: join count", "device: scan + offsets + read-back"};
+        static const char* const what_red[6] = {"device: gathers + occupancy + survivor counts (both lists)", "device: Q sort (aux stream, from the fork; its compaction ran during the wait)",
+                                                "device: P sort", "device: P records + wait for Q", "device: join count", "device: scan + offsets + read-back"};
         const int from[6] = {6, 0, 0, 2, 3, 4}, to[6] = {7, 1, 2, 3, 4, 5};
         for (int k = have_surv_clock ? 0 : 1; k < 6; ++k) {
             float ms = -1.0f;
@@ -1162,6 +1160,19 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     const int egSize = (int)pow(2.0, (double)gridDepth);          // :118
     const float cell = 1.f / egSize;                               // :119
     const float nepsilon = (float)((double)(1.0f / 7.0f) + 0.00001);  // normalset.h:86
+    // ---- key layout ----
+    const long long NC = (long long)egSize * egSize * egSize;
+    const bool use_table = NC > 0 && NC * (long long)nB <= (long long)32 * 1024 * 1024;
+    int base_bits = 1, id_bits = 1, cell_bits = 1;
+    while ((1 << base_bits) < nB) base_bits++;
+    while ((1 << id_bits) < c->nM) id_bits++;
+    {   // cells 0 .. limit-1 plus the all-ones "no cell" value
+        const unsigned long long lim = use_table ? (unsigned long long)NC : ((unsigned long long)1 << 31);
+        while (cell_bits < 40 && (((unsigned long long)1 << cell_bits) - 1ull) < lim) cell_bits++;
+    }
+    const bool wide = base_bits + cell_bits > 32 || getenv("STOCS_CONGRUENT_WIDE_KEYS") != NULL;   // env: keeps the 64-bit path testable
+    // both pair lists are reduced to the entries with a partner cell when one byte per (base, cell) is a small table (count_pass)
+    const bool reduce = use_table && ((unsigned long long)nB << cell_bits) <= (1ull << 25) && !getenv("STOCS_CONGRUENT_KEEP_ALL");
     for (int b = 0; b < nB; ++b) {
         const BaseRec& B = c->bases[b];
         BaseJob& J = jobs[b];
@@ -1177,7 +1188,7 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     const size_t nb = (size_t)nB;
     const size_t o_jobs = 0, o_bids = o_jobs + al(sizeof(BaseJob) * nb), o_err = o_bids + al(16 * nb), o_rng = o_err + 256, o_nr = o_rng + al(2 * nb * 128 * 8),
                  o_tot = o_nr + al(2 * nb * 4), o_pseg = o_tot + al(2 * nb * 4), o_qseg = o_pseg + al(nb * 128 * sizeof(Segment)),
-                 o_poff = o_qseg + al(nb * 128 * sizeof(Segment)), o_qoff = o_poff + al((nb + 1) * 4), o_spo = o_qoff + al((nb + 1) * 4), o_sqo = o_spo + al(nb * 4),
+                 o_poff = o_qseg + al(nb * 128 * sizeof(Segment)), o_qoff = o_poff + al((nb + 1) * 4), o_spo = o_qoff + al((nb + 2) * 4), o_sqo = o_spo + al(nb * 4),
                  o_out = o_sqo + al(nb * 4), plan_bytes = o_out + 256, up_bytes = o_err + 256;
     if (S->plan_bytes < plan_bytes) {
         if (S->d_plan) (void)hipFree(S->d_plan);
@@ -1223,12 +1234,12 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
         PlanOut* po_pin = (PlanOut*)((char*)c->h_pin + PIN_CONGRUENT);
         uint32_t* qoff_pin = (uint32_t*)((char*)c->h_pin + PIN_VAR + 8 * (nb + 1));
         STOCS_HIP_CHECK(hipMemcpyAsync(po_pin, dpl + o_out, sizeof(PlanOut), hipMemcpyDeviceToHost, c->stream));
-        STOCS_HIP_CHECK(hipMemcpyAsync(qoff_pin, plan.q_off, 4 * (nb + 1), hipMemcpyDeviceToHost, c->stream));
+        if (!reduce) STOCS_HIP_CHECK(hipMemcpyAsync(qoff_pin, plan.q_off, 4 * (nb + 1), hipMemcpyDeviceToHost, c->stream));   // (reduced lists: their own offsets come later)
         c->timing[0].lap("enqueue plan upload + kernels + read-back");
         STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
         c->timing[0].lap("wait for the device (plan)");
         const PlanOut po = *po_pin;
-        memcpy(q_off.data(), qoff_pin, 4 * (nb + 1));
+        if (!reduce) memcpy(q_off.data(), qoff_pin, 4 * (nb + 1));
         if (po.overflow) { set_error("pair lists exceed 2^32 entries"); return STOCS_ERR_CAPACITY; }
         totP = po.totP; totQ = po.totQ; plan.n_pseg = (int)po.n_pseg; plan.n_qseg = (int)po.n_qseg;
         STOCS_TICK("plan (device)")
@@ -1281,29 +1292,20 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     }
     if (dbg) fprintf(stderr, "[stocs congruent] totP %llu totQ %llu segs %d %d\n", (unsigned long long)totP, (unsigned long long)totQ, plan.n_pseg, plan.n_qseg);
     if (totP == 0 || totQ == 0) return STOCS_OK;
-
-    // ---- key layout ----
-    const long long NC = (long long)egSize * egSize * egSize;
-    const bool use_table = NC > 0 && NC * (long long)nB <= (long long)32 * 1024 * 1024;
-    int base_bits = 1, id_bits = 1, cell_bits = 1;
-    while ((1 << base_bits) < nB) base_bits++;
-    while ((1 << id_bits) < c->nM) id_bits++;
-    {   // cells 0 .. limit-1 plus the all-ones "no cell" value
-        const unsigned long long lim = use_table ? (unsigned long long)NC : ((unsigned long long)1 << 31);
-        while (cell_bits < 40 && (((unsigned long long)1 << cell_bits) - 1ull) < lim) cell_bits++;
-    }
     if (4 * id_bits + base_bits > 64) { set_error("|M| = %d with %d bases does not fit the 64-bit quad key", c->nM, nB); return STOCS_ERR_CAPACITY; }
-    const bool wide = base_bits + cell_bits > 32 || getenv("STOCS_CONGRUENT_WIDE_KEYS") != NULL;   // env: keeps the 64-bit path testable
+
     {   // everything this call allocates, estimated up front: one slab, one hipMalloc in a context's lifetime (if sizes stay put)
         const size_t kb = wide ? 8 : 4;
         const size_t tables = use_table ? (size_t)(NC * nB) * 8 : 0;
-        int rc0 = S->arena_state.reserve((size_t)totP * (3 * kb + 8 + 16 + 8) + (size_t)totQ * (3 * kb + 8 + 16 + 8) + tables + ((size_t)48 << 20));
+        const size_t per_entry = 3 * kb + 8 + 16 + 8 + (reduce ? kb + 4 : 0);   // (the compacted copies of the reduced form)
+        const size_t occ = reduce ? 2 * ((size_t)nB << cell_bits) : 0;
+        int rc0 = S->arena_state.reserve((size_t)totP * per_entry + (size_t)totQ * per_entry + tables + occ + ((size_t)48 << 20));
         if (rc0) return rc0;
     }
     c->timing[0].lap("arena reserve");
     S->nB = nB; S->totP = (uint32_t)totP; S->totQ = (uint32_t)totQ; S->nepsilon = nepsilon;
     S->half_inv_neps = (float)(0.5 / (double)nepsilon);
-    S->NC = NC; S->use_table = use_table; S->wide = wide;
+    S->NC = NC; S->use_table = use_table; S->wide = wide; S->reduce = reduce;
     {   // two points of one position cell are at most a cell diagonal apart (cell edge = ratio / egSize < 2 epsilon); the
         // float roundings of the two world-space points and of the unit-cube coordinates are far below the 1e-5 m allowed for
         const double cell_world = (double)c->ratio / (double)egSize, diag2 = 3.0 * (cell_world * 1.001 + 1e-5) * (cell_world * 1.001 + 1e-5);
