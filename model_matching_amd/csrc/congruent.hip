@@ -375,6 +375,7 @@ struct JoinArgs {
     const uint32_t* cfirst; const uint32_t* cend; long long NC;
     float nepsilon, half_inv_neps, dist_thr;
     int id_bits, cell_bits;
+    int base_in_key;   // the packed quad key carries the base above the four ids (it does whenever 4 id_bits + base_bits <= 64)
 #ifdef STOCS_TOOLS_BUILD
     int gmin, rmin;   // STOCS_JOIN_GMIN / STOCS_JOIN_RMIN: the thresholds of join_count_kernel's group-wise counting, for sweeps
     int ablate;   // measurement build (STOCS_JOIN_ABLATE): 1 = no cone sampling (every direction cell set), 2 = no walk over the P run
@@ -483,7 +484,7 @@ __device__ __forceinline__ uint32_t join_one(const JoinArgs<KeyT>& A, uint32_t i
             if (MODE == 1) {   // sort key: base, then (P.first, P.second, Q.first, Q.second) == the std::set order
                 const uint32_t pr = A.pvals[k];
                 const int pa = pr >> 16, pb = pr & 0xFFFF;
-                out[local] = ((uint64_t)b << (4 * id_bits)) | ((uint64_t)pa << (3 * id_bits)) | ((uint64_t)pb << (2 * id_bits)) |
+                out[local] = (A.base_in_key ? (uint64_t)b << (4 * id_bits) : 0ull) | ((uint64_t)pa << (3 * id_bits)) | ((uint64_t)pb << (2 * id_bits)) |
                              ((uint64_t)qa << id_bits) | (uint64_t)qb;
             }
             local++;
@@ -727,7 +728,7 @@ __global__ __launch_bounds__(256) void resolve_picks_kernel(JoinArgs<KeyT> A, co
             if (want < cnt) {
                 const unsigned long long below = m & ((1ull << lane) - 1ull);
                 if (hit && (unsigned long long)__popcll(below) == want)
-                    key = ((uint64_t)b << (4 * id_bits)) | ((uint64_t)pa << (3 * id_bits)) | ((uint64_t)pb << (2 * id_bits)) |
+                    key = (A.base_in_key ? (uint64_t)b << (4 * id_bits) : 0ull) | ((uint64_t)pa << (3 * id_bits)) | ((uint64_t)pb << (2 * id_bits)) |
                           ((uint64_t)qa << id_bits) | (uint64_t)qb;
                 // hand the winner's key to every lane
                 const int src = __ffsll((long long)__ballot(key != ~0ull)) - 1;
@@ -777,6 +778,7 @@ struct CongruentState {
     bool use_table = false;
     float nepsilon = 0, half_inv_neps = 0;
     int id_bits = 16, base_bits = 1, cell_bits = 1;
+    bool base_in_key = true;   // packed quad keys carry the base (4 id_bits + base_bits <= 64); else bases are told apart by their runs
     DevBuf<BaseJob> d_jobs;
     DevBuf<uint32_t> d_qoff, d_pvals, d_qvals, d_cfirst, d_cend;
     DevBuf<char> d_pkeys, d_qkeys;   // KeyT arrays (uint32_t, or uint64_t when wide)
@@ -805,6 +807,7 @@ struct CongruentState {
         A.pkeys = (const KeyT*)d_pkeys.p; A.pvals = d_pvals.p; A.prec = d_prec.p; A.pdc = close_cells ? d_pdc.p : NULL;
         A.cfirst = use_table ? d_cfirst.p : NULL; A.cend = use_table ? d_cend.p : NULL; A.NC = NC;
         A.nepsilon = nepsilon; A.half_inv_neps = half_inv_neps; A.dist_thr = c->prm.distance_threshold; A.id_bits = id_bits; A.cell_bits = cell_bits;
+        A.base_in_key = base_in_key ? 1 : 0;
 #ifdef STOCS_TOOLS_BUILD
         A.gmin = JOIN_GROUP_MIN; A.rmin = JOIN_RUN_MIN;
         A.ablate = getenv("STOCS_JOIN_ABLATE") ? atoi(getenv("STOCS_JOIN_ABLATE")) : 0;
@@ -846,10 +849,24 @@ static int materialise_t(stocs_ctx* c, CongruentState* S, const std::vector<char
         hipLaunchKernelGGL(join_fill_kernel<KeyT>, dim3((unsigned)blocks.size()), dim3(256), 0, st, S->args<KeyT>(c), S->d_qoffe.p, d_ob.p, d_raw.p, d_blocks.p);
     STOCS_HIP_CHECK(hipGetLastError());
     size_t tmp = 0;
-    const unsigned end_bit = (unsigned)(4 * S->id_bits + S->base_bits);
-    STOCS_HIP_CHECK(rocprim::radix_sort_keys(NULL, tmp, d_raw.p, out->p, (size_t)tot, 0, end_bit, st));
-    if ((rc = d_tmp.alloc(tmp))) return rc;
-    STOCS_HIP_CHECK(rocprim::radix_sort_keys(d_tmp.p, tmp, d_raw.p, out->p, (size_t)tot, 0, end_bit, st));
+    int n_sel = 0;
+    for (int b = 0; b < nB; ++b) n_sel += sel[b] ? 1 : 0;
+    if (S->base_in_key || n_sel <= 1) {   // one sort over everything: the base is part of the key (or there is only one)
+        const unsigned end_bit = (unsigned)(4 * S->id_bits + (S->base_in_key ? S->base_bits : 0));
+        STOCS_HIP_CHECK(rocprim::radix_sort_keys(NULL, tmp, d_raw.p, out->p, (size_t)tot, 0, end_bit, st));
+        if ((rc = d_tmp.alloc(tmp))) return rc;
+        STOCS_HIP_CHECK(rocprim::radix_sort_keys(d_tmp.p, tmp, d_raw.p, out->p, (size_t)tot, 0, end_bit, st));
+    } else {
+        // models beyond 16 384 points at 100 bases: four 15- or 16-bit ids fill the 64 bits, so the key holds the ids alone and
+        // every base's run (off[b] .. off[b+1], filled base by base) is sorted as a segment of its own
+        DevBuf<unsigned long long> d_off;
+        if ((rc = d_off.alloc((size_t)nB + 1))) return rc;
+        STOCS_HIP_CHECK(hipMemcpyAsync(d_off.p, off->data(), 8 * ((size_t)nB + 1), hipMemcpyHostToDevice, st));   // *off outlives the copy (S->h_off or the caller's)
+        const unsigned end_bit = (unsigned)(4 * S->id_bits);
+        STOCS_HIP_CHECK(rocprim::segmented_radix_sort_keys(NULL, tmp, d_raw.p, out->p, (unsigned)tot, (unsigned)nB, d_off.p, d_off.p + 1, 0, end_bit, st));
+        if ((rc = d_tmp.alloc(tmp))) return rc;
+        STOCS_HIP_CHECK(rocprim::segmented_radix_sort_keys(d_tmp.p, tmp, d_raw.p, out->p, (unsigned)tot, (unsigned)nB, d_off.p, d_off.p + 1, 0, end_bit, st));
+    }
     // no synchronisation: the temporaries are arena memory, recycled only by a later call's reset, and every later use is
     // ordered behind this work on the context's stream (out_base was copied from pageable memory: staged by the runtime
     // before hipMemcpyAsync returned)
@@ -1166,6 +1183,7 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     int base_bits = 1, id_bits = 1, cell_bits = 1;
     while ((1 << base_bits) < nB) base_bits++;
     while ((1 << id_bits) < c->nM) id_bits++;
+    if (const char* e = getenv("STOCS_CONGRUENT_ID_BITS")) id_bits = std::max(id_bits, std::min(16, atoi(e)));   // keeps the wide-id form of the quad keys testable on small models
     {   // cells 0 .. limit-1 plus the all-ones "no cell" value
         const unsigned long long lim = use_table ? (unsigned long long)NC : ((unsigned long long)1 << 31);
         while (cell_bits < 40 && (((unsigned long long)1 << cell_bits) - 1ull) < lim) cell_bits++;
@@ -1292,7 +1310,7 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     }
     if (dbg) fprintf(stderr, "[stocs congruent] totP %llu totQ %llu segs %d %d\n", (unsigned long long)totP, (unsigned long long)totQ, plan.n_pseg, plan.n_qseg);
     if (totP == 0 || totQ == 0) return STOCS_OK;
-    if (4 * id_bits + base_bits > 64) { set_error("|M| = %d with %d bases does not fit the 64-bit quad key", c->nM, nB); return STOCS_ERR_CAPACITY; }
+    if (id_bits > 16) { set_error("|M| = %d: model ids beyond 16 bits do not fit the packed pairs and quads", c->nM); return STOCS_ERR_CAPACITY; }
 
     {   // everything this call allocates, estimated up front: one slab, one hipMalloc in a context's lifetime (if sizes stay put)
         const size_t kb = wide ? 8 : 4;
@@ -1312,6 +1330,7 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
         S->close_cells = diag2 < 0.999 * (double)c->prm.distance_threshold && !getenv("STOCS_CONGRUENT_DISTANCE_GATE");
     }
     S->id_bits = id_bits; S->base_bits = base_bits; S->cell_bits = cell_bits;
+    S->base_in_key = 4 * id_bits + base_bits <= 64;
     S->no_quads = false;
     int rc = wide ? count_pass<uint64_t>(c, S, plan, dbg, tprev) : count_pass<uint32_t>(c, S, plan, dbg, tprev);
     if (rc) return rc;

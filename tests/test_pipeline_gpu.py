@@ -171,6 +171,35 @@ def test_wide_key_path_of_the_pair_lists(setup, monkeypatch):
         slot += 1
 
 
+def test_quad_keys_of_models_beyond_16384_points(setup, monkeypatch):
+    """Four model ids of up to 13 bits and the base fit one 64-bit quad key; beyond 16 384 model points (15- and 16-bit
+    ids) the key holds the ids alone and the bases' runs are sorted as segments.  That form is forced here on the small
+    model: same quads in the std::set order, same walk order, same candidates."""
+    m, s, est, orc = setup
+    est.L.stocs_clear_bases(est.h)
+    valid, ids, inv = est.sample_bases(99, 24)
+    est.find_congruent_all()
+    nv = int(valid.sum())
+    quads = [est.get_quads(k) for k in range(nv)]
+    est.make_transforms(200, 99)
+    T0, P0, l0, b0 = est.get_pose_candidates()
+    monkeypatch.setenv("STOCS_CONGRUENT_ID_BITS", "16")
+    est.find_congruent_all()
+    slot = 0
+    for a in range(24):
+        if not valid[a]:
+            continue
+        qo = orc.find_congruent(ids[a], float(inv[a][0]), float(inv[a][1]))
+        assert np.array_equal(est.get_quads(slot), qo) and np.array_equal(quads[slot], qo)
+        if len(qo):
+            so = orc.find_congruent_seq(ids[a], float(inv[a][0]), float(inv[a][1]))
+            assert np.array_equal(est.get_quads_at(slot, np.arange(len(so))), so)
+        slot += 1
+    est.make_transforms(200, 99)      # several small bases at once: the segmented sort
+    T1, P1, l1, b1 = est.get_pose_candidates()
+    assert len(T0) > 0 and np.array_equal(T0, T1) and np.array_equal(P0, P1) and np.array_equal(b0, b1)
+
+
 def test_host_planned_lookups_equal_device_planned(setup, monkeypatch):
     """The lookups of a trial (128 buckets per key merged into ranges, list offsets per base) are planned by two small
     kernels; the host form (plan_lookup over the host copy of the bucket table, kept for very many bases) must lay out the
