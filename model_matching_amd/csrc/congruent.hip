@@ -1450,7 +1450,8 @@ int stocs_internal_prepare_small(stocs_ctx* c, int max_per_base) {
     return STOCS_OK;
 }
 
-int stocs_internal_make_jobs(stocs_ctx* c, const int32_t* picks4_host, int n, void* d_jobs_out, const unsigned int** d_unresolved_out) {
+// picks4_dev != NULL: the picks are on the device already (drawn there; stocs_internal_prepare_small has run)
+int stocs_internal_make_jobs(stocs_ctx* c, const int32_t* picks4_host, const int32_t* picks4_dev, int n, void* d_jobs_out, const unsigned int** d_unresolved_out) {
     if (d_unresolved_out) *d_unresolved_out = NULL;
     CongruentState* S = (CongruentState*)c->cong;
     const bool prepared = S && S->small_ready;
@@ -1461,6 +1462,7 @@ int stocs_internal_make_jobs(stocs_ctx* c, const int32_t* picks4_host, int n, vo
     const uint64_t* d_sorted = NULL; const unsigned long long* d_soff = NULL;
     DevBuf<uint64_t> d_sorted_here; DevBuf<unsigned long long> d_soff_here; DevBuf<Pick> d_picks;
     int rc;
+    if (picks4_dev && !prepared) { set_error("internal: device picks without the small bases prepared"); return STOCS_ERR_STATE; }
     if (prepared) {   // the temporaries of stocs_internal_prepare_small are still in the arena
         tl_arena = &S->arena_tmp;
         if (S->small_any) { d_sorted = S->d_small_sorted.p; d_soff = S->d_small_soff.p; }
@@ -1477,8 +1479,12 @@ int stocs_internal_make_jobs(stocs_ctx* c, const int32_t* picks4_host, int n, vo
             d_sorted = d_sorted_here.p; d_soff = d_soff_here.p;
         }
     }
-    if ((rc = d_picks.alloc(n))) return rc;
-    STOCS_HIP_CHECK(hipMemcpyAsync(d_picks.p, picks, sizeof(Pick) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    if (picks4_dev) {
+        d_picks.p = (Pick*)picks4_dev;
+    } else {
+        if ((rc = d_picks.alloc(n))) return rc;
+        STOCS_HIP_CHECK(hipMemcpyAsync(d_picks.p, picks, sizeof(Pick) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    }
     if (S->wide)
         hipLaunchKernelGGL(resolve_picks_kernel<uint64_t>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, S->args<uint64_t>(c), S->d_qoffe.p, d_picks.p, n, d_sorted,
                            d_soff, S->d_bids.p, (XformJobC*)d_jobs_out, (uint64_t*)NULL, S->d_err.p);

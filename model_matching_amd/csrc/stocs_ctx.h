@@ -276,7 +276,7 @@ enum { PIN_CONGRUENT = 0, PIN_TRANSFORMS = 256, PIN_VERIFY = 512, PIN_BEST = 768
 int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d_hit, uint8_t* d_counted, unsigned long long* d_best8, uint32_t id_offset);
 int build_ppf_index(stocs_ctx* c);
 int build_grid_gpu(stocs_ctx* c, int div, int dense);
-extern "C" int stocs_internal_make_jobs(stocs_ctx* c, const int32_t* picks4_host, int n, void* d_jobs_out, const unsigned int** d_unresolved_out);
+extern "C" int stocs_internal_make_jobs(stocs_ctx* c, const int32_t* picks4_host, const int32_t* picks4_dev, int n, void* d_jobs_out, const unsigned int** d_unresolved_out);
 extern "C" int stocs_internal_prepare_small(stocs_ctx* c, int max_per_base);   // small bases materialised while the host draws the picks
 extern "C" void stocs_internal_free_congruent(stocs_ctx* c);
 extern "C" void stocs_internal_invalidate_congruent(stocs_ctx* c);

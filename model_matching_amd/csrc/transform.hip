@@ -132,6 +132,54 @@ __global__ __launch_bounds__(64) void winner_pose_kernel(const unsigned long lon
     }
 }
 
+// The picks of stocs_make_transforms on the device, one workgroup per base: a base with fewer quads than the per-base maximum is
+// used whole (ranks 0 .. nq-1 of its sorted run); a larger one gets the seeded sample without replacement -- the same sparse
+// partial Fisher-Yates the host form runs (open-addressing table of the touched entries of the identity permutation, here in
+// LDS): the draws r_j are independent and computed by all threads, the swaps are sequential and done by one.  Runs on the
+// auxiliary stream next to the materialisation of the small bases.  table[b] = (first job, quad count lo, hi, unused).
+__global__ __launch_bounds__(256) void draw_picks_kernel(const uint4* __restrict__ table, uint64_t seed, int max_per_base, uint32_t hmask,
+                                                         int4* __restrict__ picks, int32_t* __restrict__ job_base) {
+    extern __shared__ uint32_t lds_dyn[];
+    int* hkeys = (int*)lds_dyn;                          // hmask + 1
+    int* hvals = hkeys + (hmask + 1);                    // hmask + 1
+    int* out = hvals + (hmask + 1);                      // max_per_base
+    uint64_t* r = (uint64_t*)(out + ((max_per_base + 1) & ~1));   // max_per_base (8-byte aligned: everything before is an even number of words)
+    const int b = blockIdx.x;
+    const uint4 t = table[b];
+    const int first = (int)t.x;
+    const long long nq = (long long)(((unsigned long long)t.z << 32) | (unsigned long long)t.y);
+    if (nq <= 0) return;
+    if (nq < max_per_base) {   // stocs_match_one_object.cpp:126: strictly fewer -> all, in the std::set order of stocs.cpp:860-866
+        for (int i = threadIdx.x; i < (int)nq; i += blockDim.x) { picks[first + i] = make_int4(b, i, first + i, 1); job_base[first + i] = b; }
+        return;
+    }
+    for (uint32_t h = threadIdx.x; h <= hmask; h += blockDim.x) hkeys[h] = -1;
+    for (int j = threadIdx.x; j < max_per_base; j += blockDim.x) r[j] = rng64(seed, 0x5E1EC7ull + (uint64_t)b, (uint64_t)j);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        auto slot_of = [&](int i) {
+            uint32_t h = ((uint32_t)i * 2654435761u) & hmask;
+            while (hkeys[h] != -1 && hkeys[h] != i) h = (h + 1) & hmask;
+            return h;
+        };
+        for (int j = 0; j < max_per_base; ++j) {
+            const int k = j + (int)mulhi64(r[j], (uint64_t)(nq - j));
+            const uint32_t hj = slot_of(j);
+            const int vj = hkeys[hj] == j ? hvals[hj] : j;
+            int vk = vj;
+            if (k != j) {
+                const uint32_t hk = slot_of(k);
+                vk = hkeys[hk] == k ? hvals[hk] : k;
+                hkeys[hk] = k; hvals[hk] = vj;
+            }
+            // (position j is never read again: steps go upward and k >= j -- the host form stores it all the same, with the same result)
+            out[j] = vk;
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < max_per_base; j += blockDim.x) { picks[first + j] = make_int4(b, out[j], first + j, 0); job_base[first + j] = b; }
+}
+
 // accepted candidates (ok != 0) keep their pick order: destination = exclusive scan of the flags
 __global__ __launch_bounds__(256) void compact_candidates_kernel(const float4* __restrict__ T, const float4* __restrict__ P, const int32_t* __restrict__ ok,
                                                                  const int32_t* __restrict__ pos, const int32_t* __restrict__ job_base, int n,
@@ -190,12 +238,28 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
     uint32_t hsize = 64;
     while (hsize < 4u * (uint32_t)max_per_base) hsize <<= 1;
     const uint32_t hmask = hsize - 1;
+    // the picks are drawn on the device (draw_picks_kernel, on the auxiliary stream next to the small bases' materialisation)
+    // while the table of touched entries fits LDS; the host form below is the same draw and serves larger per-base maxima
+    const bool device_picks = max_per_base <= 1024 && c->aux_stream && !getenv("STOCS_TRANSFORMS_HOST_PICKS");
+    size_t n_dev = 0;
+    if (device_picks) {
+        const size_t nb = c->bases.size();
+        int rc0 = ensure_pinned(c, (size_t)PIN_VAR + 16 * nb + 256);
+        if (rc0) return rc0;
+        uint4* table = (uint4*)((char*)c->h_pin + PIN_VAR);
+        for (size_t b = 0; b < nb; ++b) {
+            const unsigned long long nq64 = c->quad_off[b + 1] - c->quad_off[b];
+            if (nq64 > 0x7FFFFFFFull) { set_error("base %zu has %llu congruent quads (more than 2^31 - 1)", b, nq64); return STOCS_ERR_CAPACITY; }
+            table[b] = make_uint4((uint32_t)n_dev, (uint32_t)nq64, (uint32_t)(nq64 >> 32), 0u);
+            n_dev += (size_t)std::min<unsigned long long>(nq64, (unsigned long long)max_per_base);
+        }
+    }
     std::vector<int> hkeys(hsize), hvals(hsize);
     auto add_pick = [&](size_t b, int rank, int sorted) {
         picks.push_back((int32_t)b); picks.push_back((int32_t)rank); picks.push_back((int32_t)job_base.size()); picks.push_back(sorted);
         job_base.push_back((int)b);
     };
-    for (size_t b = 0; b < c->bases.size(); ++b) {
+    for (size_t b = 0; b < c->bases.size() && !device_picks; ++b) {
         const unsigned long long nq64 = c->quad_off[b + 1] - c->quad_off[b];
         if (nq64 > 0x7FFFFFFFull) { set_error("base %zu has %llu congruent quads (more than 2^31 - 1)", b, nq64); return STOCS_ERR_CAPACITY; }
         const long long nq = (long long)nq64;
@@ -225,8 +289,8 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
             }
         }
     }
-    const size_t n = job_base.size();
-    c->timing[1].lap("small bases enqueued + host picks");
+    const size_t n = device_picks ? n_dev : job_base.size();
+    c->timing[1].lap(device_picks ? "small bases enqueued + pick table" : "small bases enqueued + host picks");
     tick("host picks");
     clear_candidates(c);
     c->best_lcp = 0; c->best_index = -1;
@@ -236,9 +300,10 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
         size_t scan_tmp = 0;
         STOCS_HIP_CHECK(rocprim::exclusive_scan(NULL, scan_tmp, (int32_t*)NULL, (int32_t*)NULL, 0, n + 1, rocprim::plus<int32_t>(), c->stream));
         scan_tmp = ((scan_tmp + 255) / 256) * 256;
-        int rc = ensure_scratch(c, jb + 2 * tb + 3 * ob + scan_tmp);
+        const size_t pb = device_picks ? ((n * 16 + 255) / 256) * 256 + ((c->bases.size() * 16 + 255) / 256) * 256 : 0;   // picks + table
+        int rc = ensure_scratch(c, jb + 2 * tb + 3 * ob + scan_tmp + pb);
         if (rc) return rc;
-        if ((rc = ensure_pinned(c, PIN_VAR))) return rc;
+        if (!device_picks && (rc = ensure_pinned(c, PIN_VAR))) return rc;
         if ((size_t)c->cand_cap < n) {
             if (c->d_cand) { STOCS_HIP_CHECK(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_cand); c->d_cand = NULL; }
             c->cand_cap = (int)(n + n / 4 + 1024);
@@ -254,10 +319,24 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
         int32_t* dB = (int32_t*)(base + jb + 2 * tb + 2 * ob);
         void* dTmp = base + jb + 2 * tb + 3 * ob;
         const unsigned int* d_unresolved = NULL;
-        rc = stocs_internal_make_jobs(c, picks.data(), (int)n, dJ, &d_unresolved);
+        const int32_t* d_picks = NULL;
+        if (device_picks) {
+            char* pk = base + jb + 2 * tb + 3 * ob + scan_tmp;
+            uint4* d_table = (uint4*)(pk + ((n * 16 + 255) / 256) * 256);
+            d_picks = (const int32_t*)pk;
+            const size_t lds = (size_t)(2 * (hmask + 1) + ((max_per_base + 1) & ~1)) * 4 + (size_t)max_per_base * 8;
+            // on the auxiliary stream: nothing it touches is in use on the main one (the scratch block is idle between calls)
+            STOCS_HIP_CHECK(hipMemcpyAsync(d_table, (char*)c->h_pin + PIN_VAR, 16 * c->bases.size(), hipMemcpyHostToDevice, c->aux_stream));
+            hipLaunchKernelGGL(draw_picks_kernel, dim3((unsigned)c->bases.size()), dim3(256), lds, c->aux_stream, (const uint4*)d_table, seed, max_per_base, hmask,
+                               (int4*)pk, dB);
+            STOCS_HIP_CHECK(hipGetLastError());
+            STOCS_HIP_CHECK(hipEventRecord(c->ev_join, c->aux_stream));
+            STOCS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        }
+        rc = stocs_internal_make_jobs(c, device_picks ? NULL : picks.data(), d_picks, (int)n, dJ, &d_unresolved);
         if (rc) return rc;
         tick("resolve picks");
-        STOCS_HIP_CHECK(hipMemcpyAsync(dB, job_base.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+        if (!device_picks) STOCS_HIP_CHECK(hipMemcpyAsync(dB, job_base.data(), n * 4, hipMemcpyHostToDevice, c->stream));
         STOCS_HIP_CHECK(hipMemsetAsync(dO + n, 0, 4, c->stream));
         hipLaunchKernelGGL(rigid_transform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_spos, c->d_mpos, dJ, (int)n,
                            c->centroid_scene, c->centroid_model, dT, dP, dO);

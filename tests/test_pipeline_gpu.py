@@ -273,6 +273,36 @@ def test_distance_gate_path_of_the_count(setup, monkeypatch):
         slot += 1
 
 
+def test_picks_drawn_on_the_device_equal_the_host_draw(setup, monkeypatch):
+    """stocs_make_transforms draws the <= max_per_base quads of a large base with a seeded partial Fisher-Yates: on the device
+    (one workgroup per base, next to the materialisation of the small bases) while its table fits LDS, on the host beyond.
+    Both forms -- and a per-base maximum above the device form's limit -- against each other and against the oracle's draw."""
+    m, s, est, orc = setup
+    r = orc.run(4321, 60, 50)
+    est.L.stocs_clear_bases(est.h)
+    est.sample_bases(4321, 60)
+    est.find_congruent_all()
+    n_dev = est.make_transforms(50, 4321)
+    dev = est.get_pose_candidates()
+    To, Po, bo = orc.candidates()
+    assert n_dev == r.n_candidates and np.array_equal(dev[0], To) and np.array_equal(dev[1], Po) and np.array_equal(dev[3], bo)
+    monkeypatch.setenv("STOCS_TRANSFORMS_HOST_PICKS", "1")
+    assert est.make_transforms(50, 4321) == n_dev
+    host = est.get_pose_candidates()
+    assert all(np.array_equal(a, b) for a, b in zip(dev, host))
+    monkeypatch.delenv("STOCS_TRANSFORMS_HOST_PICKS")
+    n_big = est.make_transforms(1500, 4321)          # beyond 1024 per base: the host form by itself
+    big = est.get_pose_candidates()
+    r2 = orc.run(4321, 60, 1500)
+    To2, Po2, bo2 = orc.candidates()
+    assert n_big == r2.n_candidates and np.array_equal(big[0], To2) and np.array_equal(big[3], bo2)
+    n_mid = est.make_transforms(1000, 4321)          # the device form near its limit
+    mid = est.get_pose_candidates()
+    monkeypatch.setenv("STOCS_TRANSFORMS_HOST_PICKS", "1")
+    assert est.make_transforms(1000, 4321) == n_mid
+    assert all(np.array_equal(a, b) for a, b in zip(mid, est.get_pose_candidates()))
+
+
 def test_full_run_equals_oracle_and_recovers_pose(setup, oracle_lib):
     """run_stocs_estimation (stocs_match_one_object.cpp:51-185), class mode, seeded."""
     m, s, est, orc = setup
