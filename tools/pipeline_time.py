@@ -21,6 +21,12 @@ from model_matching_amd.estimator import StocsEstimator  # noqa: E402
 
 
 def main():
+    if os.environ.get("PT_TORCH"):      # A/B: the same trials in a process that has torch's HIP runtime state (bench.py has)
+        import torch
+        torch.cuda.init()
+        _keep = torch.zeros(1 << 20, device="cuda")
+        if os.environ["PT_TORCH"] == "2":
+            torch.cuda.set_stream(torch.cuda.Stream())
     name = sys.argv[1] if len(sys.argv) > 1 else "Cm"
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1234
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
