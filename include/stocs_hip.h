@@ -263,8 +263,20 @@ int stocs_icp_point_to_plane(const float* src_pos3, int nsrc, const float* tgt_p
  * "lcp_split": 1 (default) = four wavefronts share a candidate's model points, 0 = one wavefront per candidate.  Scores are
  *   accumulated as integers, so neither option changes a single bit of them.
  * "lcp_order": 0 = candidates in batch order, 1 (default) = big batches are processed in a spatial order of their
- *   translations (scores are bitwise independent of it), >= 2 = XCD-blocked variants of that order. ---- */
+ *   translations (scores are bitwise independent of it), >= 2 = XCD-blocked variants of that order.
+ * "lcp_cull": the patch test of the queue-fed scoring kernels.  The reference walks every model point of every candidate
+ *   (stocs.cpp:1016-1035); a 64-point step of the model whose bounding sphere, under the candidate transform, is farther
+ *   than epsilon from every scene point cannot add to the score and is skipped after one look-up in a distance field of
+ *   the scene.  0 = off, 1 (default) = on once the field pays (third scoring call against a scene, or a batch of
+ *   candidates x model points >= 1e8), 2 = from the first call.  Scores are bitwise the same in every case. ---- */
 int stocs_set_option(stocs_ctx* ctx, const char* key, int value);
+/* Diagnostics of that patch test (tests only; no reference counterpart).  patches4: n_patches x (centre x, y, z, radius) in the
+ * centred model frame, one per 64 consecutive slots of the sorted model; perm: sorted slot -> model index (|M| entries);
+ * geom8: origin x, y, z, cell edge, cap, nx, ny, nz of the scene's distance field; dist: its nx*ny*nz values (x fastest;
+ * the field is filled by this call if it was not yet): distance from a cell's centre to the nearest scene point, rounded
+ * down, capped.  NULL outputs are skipped; *n_patches and *n_dist are always set (0 when the context has no field). */
+int stocs_get_cull_state(stocs_ctx* ctx, float* patches4, int32_t* perm, int* n_patches, float* geom8, float* dist,
+                         int64_t dist_cap, int64_t* n_dist);
 
 /* ---- stream / timing plumbing ---- */
 /* run the context's work on a caller-owned HIP stream (e.g. PyTorch's current stream, so that RCCL

@@ -124,6 +124,7 @@ static int upload(T** dptr, const T* h, size_t n) {
 
 static void free_grid(stocs_ctx* c) {   // the grid lives in c->grid_mem, which the next build resets
     c->grid.d_top = NULL; c->grid.d_cells = NULL; c->grid.d_list = NULL; c->grid.d_chunk_r = NULL; c->grid.d_flat = NULL;
+    c->grid.d_dist = NULL; c->grid.dist_ready = false;
 }
 
 // one build at cell edge eps / div; lists longer than 16 on average get the centre-sorted layout + chunk bounds
@@ -134,7 +135,7 @@ static int build_grid_once(stocs_ctx* c, int div) {
     return build_grid_gpu(c, div, 1);
 }
 
-static int build_grid(stocs_ctx* c) {
+static int build_grid_levels(stocs_ctx* c) {
     int div = c->grid_div;
     const char* e = getenv("STOCS_GRID_DIV");
     if (e) div = atoi(e);
@@ -158,6 +159,12 @@ static int build_grid(stocs_ctx* c) {
     if (getenv("STOCS_DEBUG_TIMING"))
         fprintf(stderr, "[stocs grid] cell edge eps/%d, %d bricks, %lld list entries (%.1f per non-empty cell)\n", (int)lround((double)c->prm.distance_threshold / c->grid.h),
                 c->grid.n_bricks, (long long)c->grid.n_entries, c->grid.avg_list_len);
+    return rc;
+}
+
+static int build_grid(stocs_ctx* c) {
+    int rc = build_grid_levels(c);
+    if (!rc) rc = prepare_cull_field(c);   // geometry + memory only; filled when scoring calls make it pay (lcp.hip)
     return rc;
 }
 
@@ -222,6 +229,7 @@ static int load_scene_impl(stocs_ctx* c, const float* sp, const float* sn, const
     // per-trial state belongs to the old scene
     c->bases.clear(); c->quad_off.clear(); clear_candidates(c);
     c->best_lcp = 0; c->best_index = -1;
+    c->scene_scored = 0;
     stocs_internal_invalidate_congruent(c);
     const size_t npx = (size_t)c->prm.image_width * c->prm.image_height;
     c->has_edge = false;
@@ -331,7 +339,9 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     c->d_order = NULL; c->order_bytes = 0;
     memset(&c->grid, 0, sizeof(c->grid));
     c->d_spos = c->d_snrmw = c->d_mpos = c->d_mnrm = c->d_munit = c->d_mpos_raw = c->d_mpos_s = c->d_mnrm_s = NULL;
-    c->d_spix = NULL; c->d_mperm = NULL; c->d_scene_mem = NULL; c->scene_cap = 0;
+    c->d_spix = NULL; c->d_mperm = NULL; c->d_mpatch = NULL; c->d_scene_mem = NULL; c->scene_cap = 0;
+    c->patch_r_ref = 0.0f; c->scene_scored = 0;
+    c->lcp_cull = getenv("STOCS_LCP_CULL") ? atoi(getenv("STOCS_LCP_CULL")) : 1;
     c->stream = NULL; c->own_stream = NULL; c->aux_stream = NULL;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
@@ -375,19 +385,80 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
         for (int i = 0; i < nM; ++i) c->h_munit[i] = (c->h_mpos[i] - c->gcenter) / c->ratio + half;
     }
 
-    // Morton order of the centred model for the LCP kernel (spatially coherent wavefronts)
+    // Order of the centred model for the LCP kernel: 64 consecutive points = one step of a wavefront = one compact surface patch
+    // (spatially coherent look-ups, and a small bounding sphere for the patch test).  Median splits along the longest axis with
+    // the left part a multiple of 64 points: every leaf is one step, neighbouring leaves are neighbouring patches.
+    // (Rounds 1-2 used the Morton order of the unit-cube coordinates: patches of 25 mm radius in the median on the 5 000-point
+    // model against 19 mm here; STOCS_MODEL_ORDER=morton keeps it selectable for the A/B.)
     c->h_mperm.resize(nM);
-    {
+    std::iota(c->h_mperm.begin(), c->h_mperm.end(), 0);
+    if (getenv("STOCS_MODEL_ORDER") && !strcmp(getenv("STOCS_MODEL_ORDER"), "morton")) {
         std::vector<uint32_t> code(nM);
-        const V3 ext = mk3(c->ratio, c->ratio, c->ratio);
         for (int i = 0; i < nM; ++i) {
             const V3 u = c->h_munit[i];
             auto q10 = [](float v) { int k = (int)(v * 1024.0f); return (uint32_t)(k < 0 ? 0 : (k > 1023 ? 1023 : k)); };
             code[i] = (part1by2(q10(u.z)) << 2) | (part1by2(q10(u.y)) << 1) | part1by2(q10(u.x));
         }
-        (void)ext;
-        std::iota(c->h_mperm.begin(), c->h_mperm.end(), 0);
         std::stable_sort(c->h_mperm.begin(), c->h_mperm.end(), [&](int a, int b) { return code[a] < code[b]; });
+    } else {
+        struct Range { int lo, hi; };
+        std::vector<Range> todo(1, Range{0, nM});
+        while (!todo.empty()) {
+            const Range r = todo.back(); todo.pop_back();
+            const int n = r.hi - r.lo;
+            if (n <= 64) continue;
+            float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
+            for (int k = r.lo; k < r.hi; ++k) {
+                const V3 q = c->h_mpos[c->h_mperm[k]];
+                const float v[3] = {q.x, q.y, q.z};
+                for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], v[a]); mx[a] = std::max(mx[a], v[a]); }
+            }
+            int ax = 0;
+            for (int a = 1; a < 3; ++a) if (mx[a] - mn[a] > mx[ax] - mn[ax]) ax = a;
+            const int leaves = (n + 63) / 64, nl = (leaves / 2) * 64;   // >= 64, < n
+            auto coord = [&](int id) { const V3 q = c->h_mpos[id]; return ax == 0 ? q.x : (ax == 1 ? q.y : q.z); };
+            std::stable_sort(c->h_mperm.begin() + r.lo, c->h_mperm.begin() + r.hi, [&](int a, int b) { return coord(a) < coord(b); });
+            todo.push_back(Range{r.lo + nl, r.hi});
+            todo.push_back(Range{r.lo, r.lo + nl});
+        }
+    }
+    // bounding sphere per 64-point step (double arithmetic; centre = a few steps of Ritter's iteration towards the farthest point,
+    // radius = the exact maximum distance from that centre, rounded up)
+    const int n_patch = (nM + 63) / 64;
+    std::vector<float4> patch((size_t)std::max(n_patch, 1));
+    {
+        std::vector<float> radii;
+        for (int s = 0; s < n_patch; ++s) {
+            const int lo = 64 * s, hi = std::min(nM, lo + 64);
+            double ctr[3] = {0, 0, 0};
+            for (int k = lo; k < hi; ++k) { const V3 q = c->h_mpos[c->h_mperm[k]]; ctr[0] += q.x; ctr[1] += q.y; ctr[2] += q.z; }
+            for (int a = 0; a < 3; ++a) ctr[a] /= (double)(hi - lo);
+            auto farthest = [&](double* d_out) {
+                int best = lo; double bd = -1;
+                for (int k = lo; k < hi; ++k) {
+                    const V3 q = c->h_mpos[c->h_mperm[k]];
+                    const double dx = q.x - ctr[0], dy = q.y - ctr[1], dz = q.z - ctr[2], d = dx * dx + dy * dy + dz * dz;
+                    if (d > bd) { bd = d; best = k; }
+                }
+                *d_out = sqrt(bd);
+                return best;
+            };
+            double rad = 0;
+            for (int it = 0; it < 64; ++it) {
+                const int f = farthest(&rad);
+                const V3 q = c->h_mpos[c->h_mperm[f]];
+                const double step = 0.5 / (double)(it + 2);
+                ctr[0] += (q.x - ctr[0]) * step; ctr[1] += (q.y - ctr[1]) * step; ctr[2] += (q.z - ctr[2]) * step;
+            }
+            const float cf[3] = {(float)ctr[0], (float)ctr[1], (float)ctr[2]};
+            ctr[0] = cf[0]; ctr[1] = cf[1]; ctr[2] = cf[2];   // the radius belongs to the centre as stored
+            (void)farthest(&rad);
+            const float rf = (float)(rad * (1.0 + 1e-6) + 1e-7);
+            patch[s] = make_float4(cf[0], cf[1], cf[2], rf);
+            radii.push_back(rf);
+        }
+        std::sort(radii.begin(), radii.end());
+        c->patch_r_ref = radii.empty() ? 0.0f : radii[(size_t)((radii.size() - 1) * 0.8)];
     }
 
     int rc = STOCS_OK;
@@ -401,6 +472,9 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
             raw[i] = make_float4(c->h_mpos_raw[i].x, c->h_mpos_raw[i].y, c->h_mpos_raw[i].z, 0.f);
         }
         for (int i = 0; i < nM; ++i) { as[i] = a[c->h_mperm[i]]; bs[i] = b[c->h_mperm[i]]; }
+        // the sorted positions are padded to whole 64-point steps with NaN: the scan kernels load and transform a step without
+        // bounds checks, and a NaN query matches nothing (every comparison of its distances fails)
+        as.resize((size_t)n_patch * 64 + 64, make_float4(NAN, NAN, NAN, 0.f));
         if (!rc) rc = upload(&c->d_mpos, a.data(), a.size());
         if (!rc) rc = upload(&c->d_mnrm, b.data(), b.size());
         if (!rc) rc = upload(&c->d_munit, u.data(), u.size());
@@ -408,6 +482,7 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
         if (!rc) rc = upload(&c->d_mpos_s, as.data(), as.size());
         if (!rc) rc = upload(&c->d_mnrm_s, bs.data(), bs.size());
         if (!rc) rc = upload(&c->d_mperm, c->h_mperm.data(), c->h_mperm.size());
+        if (!rc) rc = upload(&c->d_mpatch, patch.data(), patch.size());
     }
     if (!rc) rc = load_scene(c, sp, sn, sprob, spix, nS);
     if (!rc && build_index) rc = build_ppf_index(c);
@@ -421,7 +496,7 @@ int stocs_ctx_destroy(stocs_ctx* c) {
     DeviceGuard dev_guard(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_scene_mem, c->d_mpos, c->d_mnrm, c->d_munit, c->d_mpos_raw, c->d_mpos_s,
-                    c->d_mnrm_s, c->d_mperm, c->index.d_bucket_start,
+                    c->d_mnrm_s, c->d_mperm, c->d_mpatch, c->index.d_bucket_start,
                     c->index.d_pairs, c->index.d_exists, c->d_scratch, c->d_best, c->d_cand, c->d_order};
     stocs_internal_free_congruent(c);
     stocs_internal_free_instance(c);

@@ -266,6 +266,8 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense) {
         for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], v[k]); mx[k] = std::max(mx[k], v[k]); }
     }
     if (nS == 0) { for (int k = 0; k < 3; ++k) { mn[k] = 0; mx[k] = 0; } }
+    for (int k = 0; k < 3; ++k) { g.bb_mn[k] = mn[k]; g.bb_mx[k] = mx[k]; }
+    g.d_dist = NULL; g.dist_ready = false;
     const double pad = r + 2 * h;  // a query outside the grid is farther than epsilon from every point
     const double o[3] = {mn[0] - pad, mn[1] - pad, mn[2] - pad};
     int n[3];
@@ -401,6 +403,93 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense) {
     g.n_bricks = (int)n_bricks;
     g.n_entries = (int64_t)n_list;
     g.avg_list_len = n_cells ? (double)n_inc / (double)n_cells : 0.0;
+    return STOCS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Distance field for the patch test of the scan kernels (SceneGrid::d_dist).  A 64-point step of the model whose bounding
+// sphere, under a candidate transform, is farther than epsilon from every scene point cannot contribute to the score
+// (stocs.cpp:1019-1024: a model point only counts with a scene point within epsilon), so the kernel skips it after ONE
+// look-up here instead of 64 in the cell table.  Per coarse cell: the distance from the cell's centre to the nearest scene
+// point (exact, in double, rounded down), capped; a position x in the cell is at least value - |x - centre| from the scene.
+// ---------------------------------------------------------------------------------------------
+struct CullGeom {
+    double o[3], g, cap;
+    int n[3], w;
+};
+
+__global__ __launch_bounds__(256) void dist_fill_kernel(float* __restrict__ t, size_t n, float v) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) t[i] = v;
+}
+
+// one thread per (scene point, (y, z) offset of its window); the thread walks the window's x row.  Distances are non-negative
+// floats, whose bit patterns order like unsigned integers: an integer atomic minimum, tried only when the plain read is larger.
+__global__ __launch_bounds__(256) void dist_splat_kernel(CullGeom G, const float4* __restrict__ spos, int nS, uint32_t* __restrict__ t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nS) return;
+    const int side = 2 * G.w + 1;
+    const int oy = (int)(blockIdx.y % (unsigned)side) - G.w, oz = (int)(blockIdx.y / (unsigned)side) - G.w;
+    const float4 pf = spos[i];
+    const double p[3] = {pf.x, pf.y, pf.z};
+    const int ix = (int)floor((p[0] - G.o[0]) / G.g), iy = (int)floor((p[1] - G.o[1]) / G.g) + oy, iz = (int)floor((p[2] - G.o[2]) / G.g) + oz;
+    if (iy < 0 || iy >= G.n[1] || iz < 0 || iz >= G.n[2]) return;
+    const double dy = p[1] - (G.o[1] + (iy + 0.5) * G.g), dz = p[2] - (G.o[2] + (iz + 0.5) * G.g);
+    const double dyz = dy * dy + dz * dz, cap2 = G.cap * G.cap;
+    if (dyz >= cap2) return;
+    const size_t row = ((size_t)iz * G.n[1] + iy) * G.n[0];
+    for (int cx = std::max(ix - G.w, 0); cx <= std::min(ix + G.w, G.n[0] - 1); ++cx) {
+        const double dx = p[0] - (G.o[0] + (cx + 0.5) * G.g);
+        const double d2 = dx * dx + dyz;
+        if (d2 >= cap2) continue;
+        const uint32_t u = __float_as_uint(__double2float_rd(sqrt(d2) * (1.0 - 1e-7)));
+        if (u < t[row + cx]) atomicMin(&t[row + cx], u);
+    }
+}
+
+// Geometry and memory of the field for the current grid, scene box and model (the cap follows the model's patch radii: a
+// patch can only be ruled out when field value - half a cell diagonal exceeds its radius + epsilon).  Called at the end of a
+// grid build so that filling it later allocates nothing.
+int prepare_cull_field(stocs_ctx* c) {
+    SceneGrid& g = c->grid;
+    g.d_dist = NULL; g.dist_ready = false;
+    if (c->nS <= 0 || c->nM < 64 || !c->d_mpatch) return STOCS_OK;
+    const double eps = (double)c->prm.distance_threshold;
+    if (!(eps > 0)) return STOCS_OK;
+    double cg = eps;
+    const double cap = std::min((double)c->patch_r_ref, 8.0 * eps) + eps + cg;
+    double ext[3];
+    int64_t cells = 0;
+    for (;;) {   // coarser cells for boxes that would need more than 16 M of them
+        cells = 1;
+        for (int k = 0; k < 3; ++k) { ext[k] = (g.bb_mx[k] - g.bb_mn[k]) + 2.0 * (cap + cg); cells *= (int64_t)floor(ext[k] / cg) + 1; }
+        if (cells <= ((int64_t)16 << 20)) break;
+        cg *= 1.25;
+    }
+    g.cg_g = (float)cg; g.cg_inv_g = (float)(1.0 / (double)g.cg_g);
+    g.cg_cap = (float)cap;
+    g.cg_ox = (float)(g.bb_mn[0] - cap - cg); g.cg_oy = (float)(g.bb_mn[1] - cap - cg); g.cg_oz = (float)(g.bb_mn[2] - cap - cg);
+    const double of[3] = {g.cg_ox, g.cg_oy, g.cg_oz};
+    int n[3];
+    for (int k = 0; k < 3; ++k) n[k] = (int)floor((g.bb_mx[k] + cap + cg - of[k]) / (double)g.cg_g) + 1;
+    g.cg_nx = n[0]; g.cg_ny = n[1]; g.cg_nz = n[2];
+    g.cg_w = (int)ceil(cap / (double)g.cg_g);
+    return c->grid_mem.take((size_t)n[0] * n[1] * n[2] * sizeof(float), (void**)&g.d_dist);
+}
+
+int fill_cull_field(stocs_ctx* c) {
+    SceneGrid& g = c->grid;
+    if (!g.d_dist || g.dist_ready) return STOCS_OK;
+    CullGeom G;
+    G.o[0] = g.cg_ox; G.o[1] = g.cg_oy; G.o[2] = g.cg_oz;   // the float origin and edge the scan kernels use, widened
+    G.g = g.cg_g; G.cap = g.cg_cap;
+    G.n[0] = g.cg_nx; G.n[1] = g.cg_ny; G.n[2] = g.cg_nz; G.w = g.cg_w;
+    const size_t n = (size_t)g.cg_nx * g.cg_ny * g.cg_nz;
+    hipLaunchKernelGGL(dist_fill_kernel, dim3(grid_of(n)), dim3(256), 0, c->stream, g.d_dist, n, g.cg_cap);
+    const int side = 2 * g.cg_w + 1;
+    hipLaunchKernelGGL(dist_splat_kernel, dim3(grid_of((size_t)c->nS), (unsigned)(side * side)), dim3(256), 0, c->stream, G, c->d_spos, c->nS, (uint32_t*)g.d_dist);
+    STOCS_HIP_CHECK(hipGetLastError());
+    g.dist_ready = true;
     return STOCS_OK;
 }
 

@@ -48,6 +48,11 @@ struct LcpArgs {
     int xcd_blocks;         // != 0: workgroups of one XCD take a contiguous run of slots (each XCD has its own L2)
     unsigned long long* best;   // != NULL: compute_best_transform in the kernel's epilogue -- every candidate's packed (score, ~id) key joins an
     uint32_t id_offset;         // atomic max on this word (integer max: order independent), id = id_offset + candidate
+    // patch test (lcp_coopq_kernel): bounding sphere per 64-point step + the scene's distance field (SceneGrid::d_dist); patch == NULL: off
+    const float4* patch;
+    const float* dist;
+    float gox, goy, goz, g, inv_g, cap;
+    int gnx, gny, gnz;
 #ifdef STOCS_TOOLS_BUILD
     int ablate;             // measurement build only (STOCS_LCP_ABLATE): parts of the kernel switched off to price them; scores are then wrong
 #endif
@@ -365,6 +370,41 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coop_kernel(LcpArgs a, const flo
 }
 
 // ---------------------------------------------------------------------------------------------
+// Patch test.  The 64 model points of a step lie in a sphere (centre c, radius r; ctx.hip).  Under the candidate transform
+// x -> A x + t every one of them lands within s * r of A c + t, s >= the largest singular value of A (1 for a rigid
+// transform; bounded here by the square root of the largest absolute row sum of A^T A, so that a caller's non-rigid matrix
+// is handled too).  The scene's distance field gives a lower bound of the distance from A c + t to the nearest scene point;
+// when that exceeds s * r + epsilon no point of the step has a scene point within epsilon, the step adds nothing to the
+// score (stocs.cpp:1019-1024) and is skipped: one look-up per step instead of 64.  Margins cover the float rounding of the
+// transform, of the field and of the cell centre; positions that are not finite are never ruled out here.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lcp_linear_norm_bound(float t0, float t1, float t2, float t4, float t5, float t6, float t8, float t9, float t10) {
+    const float g00 = t0 * t0 + (t1 * t1 + t2 * t2), g11 = t4 * t4 + (t5 * t5 + t6 * t6), g22 = t8 * t8 + (t9 * t9 + t10 * t10);
+    const float g01 = fabsf(t0 * t4 + (t1 * t5 + t2 * t6)), g02 = fabsf(t0 * t8 + (t1 * t9 + t2 * t10)), g12 = fabsf(t4 * t8 + (t5 * t9 + t6 * t10));
+    const float rho = fmaxf(g00 + (g01 + g02), fmaxf(g11 + (g01 + g12), g22 + (g02 + g12)));
+    return sqrtf(rho) * 1.00001f;   // NaN / inf entries give NaN / inf: nothing is ruled out then (every comparison below fails)
+}
+__device__ __forceinline__ bool lcp_patch_dead(const LcpArgs& a, const float4 sp, float sn, float t0, float t1, float t2, float t4, float t5, float t6,
+                                               float t8, float t9, float t10, float t12, float t13, float t14) {
+    const float cx = ((t0 * sp.x + t4 * sp.y) + t8 * sp.z) + t12;
+    const float cy = ((t1 * sp.x + t5 * sp.y) + t9 * sp.z) + t13;
+    const float cz = ((t2 * sp.x + t6 * sp.y) + t10 * sp.z) + t14;
+    const float mag = fabsf(cx) + (fabsf(cy) + fabsf(cz));
+    if (!(mag < 1.0e18f)) return false;
+    const float need = (sn * sp.w + a.eps * 1.002f) + (4.0e-6f + 4.0e-6f * mag);
+    const float ux = (cx - a.gox) * a.inv_g, uy = (cy - a.goy) * a.inv_g, uz = (cz - a.goz) * a.inv_g;
+    const float fx = floorf(ux), fy = floorf(uy), fz = floorf(uz);
+    // one cell inside the border: the float cell of a position next to the box never names a cell outside the table
+    if (fx >= 1.0f && fy >= 1.0f && fz >= 1.0f && fx < (float)(a.gnx - 1) && fy < (float)(a.gny - 1) && fz < (float)(a.gnz - 1)) {
+        const float v = a.dist[((size_t)(int)fz * a.gny + (int)fy) * a.gnx + (int)fx];
+        const float ex = cx - (a.gox + (fx + 0.5f) * a.g), ey = cy - (a.goy + (fy + 0.5f) * a.g), ez = cz - (a.goz + (fz + 0.5f) * a.g);
+        return v - sqrtf(ex * ex + (ey * ey + ez * ez)) > need;
+    }
+    // outside (or in the border cells of) the table: at least cap from every scene point
+    return a.cap > need;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Variant 20 ("coop8 + queue"): the cooperative scan of variant 1 fed from a per-wave LDS ring that
 // collects the hit queries of successive steps (ballot + mbcnt compaction), so that every 8-lane group
 // always owns a query (with ~11 hits per 64-point step the groups of variant 1 are ~69 % busy) and the
@@ -380,7 +420,7 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coop_kernel(LcpArgs a, const flo
 // stops at the first line the triangle inequality rules out, as in variant 31 -- but fed from the queue, so that the first
 // lines of 32 queries are in flight together where variant 31 has the two lines of 8.
 template <bool DETAIL, int UNR, bool SORTQ = false, int PIPE = 4, bool IDX = true, int WPB = 4, int FLAT = 0, bool SPLIT = false, bool TILE = false, bool EARLY = false>
-__global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
+__global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
                                                         int n, int32_t* __restrict__ hit_out, uint8_t* __restrict__ cnt_out) {
     __shared__ float4 qt[WPB][128];     // qx, qy, qz, bits(list offset)
     __shared__ float qcd[EARLY ? WPB : 1][EARLY ? 128 : 1];   // |query - cell centre| (EARLY)
@@ -394,7 +434,6 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
     const int w = threadIdx.x >> 6;
     const int cand = SPLIT ? lcp_candidate(a, n, 0, 1) : lcp_candidate(a, n, w, WPB);
     if (cand < 0 && !TILE) return;   // SPLIT: the whole workgroup leaves together; TILE: the wavefront stays for the barriers
-    const int first = SPLIT ? 64 * w : 0, stride = SPLIT ? 64 * WPB : 64;
     const float* T = T16 + (size_t)(cand < 0 ? 0 : cand) * 16;
     const float t0 = T[0], t1 = T[1], t2 = T[2], t4 = T[4], t5 = T[5], t6 = T[6], t8 = T[8], t9 = T[9], t10 = T[10],
                 t12 = T[12], t13 = T[13], t14 = T[14];
@@ -520,7 +559,9 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
     auto step = [&](const int i, const float4 p) {
         float qx = 0.f, qy = 0.f, qz = 0.f, qcentre = 0.f, nearest = 0.f;
         uint32_t off = 0, cnt = 0;
-        if (i < a.M) {
+        // slots beyond the model hold NaN positions (ctx.hip): they run through the look-up like any other query and match nothing;
+        // only the per-point outputs of the detail form need the bound
+        if (!DETAIL || i < a.M) {
             qx = ((t0 * p.x + t4 * p.y) + t8 * p.z) + t12;
             qy = ((t1 * p.x + t5 * p.y) + t9 * p.z) + t13;
             qz = ((t2 * p.x + t6 * p.y) + t10 * p.z) + t14;
@@ -583,12 +624,13 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
     if (TILE) {
         __shared__ float4 tile[2][64 * WPB];
         const int tid = threadIdx.x;
-        tile[0][tid] = tid < a.M ? a.mpos[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 pad = make_float4(__int_as_float(0x7fc00000), __int_as_float(0x7fc00000), __int_as_float(0x7fc00000), 0.f);   // matches nothing
+        tile[0][tid] = tid < a.M ? a.mpos[tid] : pad;
         __syncthreads();
         int buf = 0;
         for (int tbase = 0; tbase < a.M; tbase += 64 * WPB) {
             const int nxt = tbase + 64 * WPB + tid;                  // the next tile is requested before this one is worked on
-            const float4 gn = nxt < a.M ? a.mpos[nxt] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 gn = nxt < a.M ? a.mpos[nxt] : pad;
             if (cand >= 0)
                 for (int s = 0; s < WPB && tbase + 64 * s < a.M; ++s) step(tbase + 64 * s + lane, tile[buf][64 * s + lane]);
             tile[buf ^ 1][tid] = gn;
@@ -597,16 +639,45 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coopq_kernel(LcpArgs a, const fl
         }
         if (cand < 0) return;
     } else {
-    // the model point of the NEXT step is requested one step ahead (takes one of the three dependent
-    // loads of the look-up chain off the critical path)
-    float4 p_next = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (first + lane < a.M) p_next = a.mpos[first + lane];
-    for (int base = first; base < a.M; base += stride) {
-        const int i = base + lane;
-        const float4 p = p_next;
-        if (STOCS_ABLATE(a, 64)) p_next = make_float4(0.001f * (float)(i & 63), 0.0007f * (float)(i >> 6), 0.02f, 0.f);   // 64: no model-point loads
-        else if (i + stride < a.M) p_next = a.mpos[i + stride];
-        step(i, p);
+    // The wavefront's steps, 64 at a time: every lane tests the patch of one step (a.patch), the ballot is the list of the
+    // steps that have to be walked; the model point of the NEXT such step is requested one step ahead (takes one of the
+    // three dependent loads of the look-up chain off the critical path).
+    const int nsteps = (a.M + 63) >> 6;
+    const int wfirst = SPLIT ? w : 0, nw = SPLIT ? WPB : 1;
+    const int nk = (nsteps - wfirst + nw - 1) / nw;
+    const float snorm = a.patch ? lcp_linear_norm_bound(t0, t1, t2, t4, t5, t6, t8, t9, t10) : 0.0f;
+    for (int k0 = 0; k0 < nk; k0 += 64) {
+        const int kk = k0 + lane;
+        bool live = kk < nk;
+        if (a.patch && live && !STOCS_ABLATE(a, 64))
+            live = !lcp_patch_dead(a, a.patch[wfirst + kk * nw], snorm, t0, t1, t2, t4, t5, t6, t8, t9, t10, t12, t13, t14);
+        unsigned long long todo = __ballot(live);
+        if (DETAIL && a.patch) {   // the skipped steps' points: no neighbour, not counted
+            unsigned long long dead = __ballot(kk < nk && !live);
+            while (dead) {
+                const int j = __builtin_ctzll(dead);
+                dead &= dead - 1ull;
+                const int i = ((wfirst + (k0 + j) * nw) << 6) + lane;
+                if (i < a.M) {
+                    const int orig = a.mperm[i];
+                    hit_out[(size_t)cand * a.M + orig] = -1;
+                    cnt_out[(size_t)cand * a.M + orig] = 0;
+                }
+            }
+        }
+        if (!todo) continue;
+        // (the sorted positions are padded to whole steps and one step beyond: no bounds checks on these loads)
+        int j = __builtin_ctzll(todo);
+        float4 p_next = a.mpos[((wfirst + (k0 + j) * nw) << 6) + lane];
+        for (;;) {
+            const int i = ((wfirst + (k0 + j) * nw) << 6) + lane;
+            const float4 p = p_next;
+            todo &= todo - 1ull;
+            j = todo ? __builtin_ctzll(todo) : j;   // behind the last step its own point is requested once more: no branch around the load
+            p_next = a.mpos[((wfirst + (k0 + j) * nw) << 6) + lane];
+            step(i, p);
+            if (!todo) break;
+        }
     }
     }
     if (tail - head > 0) process(tail - head);
@@ -723,6 +794,18 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
     a.dot_lo = c->thr.lcp_dot_lo;
     a.eps = c->prm.distance_threshold;
     a.has_nearest = c->grid.has_nearest ? 1 : 0;
+    // patch test: worth its distance field (one pass over the scene points, ~0.1 ms) once a scene is scored against repeatedly
+    // or by a big batch; the scores do not depend on it
+    a.patch = NULL; a.dist = NULL;
+    a.gox = a.goy = a.goz = 0.f; a.g = a.inv_g = a.cap = 0.f; a.gnx = a.gny = a.gnz = 0;
+    c->scene_scored++;
+    if (c->lcp_cull && c->grid.d_dist && c->d_mpatch && (c->grid.dist_ready || c->lcp_cull >= 2 || c->scene_scored >= 3 || (double)n * (double)c->nM >= 1.0e8)) {
+        int rc = fill_cull_field(c);
+        if (rc) return rc;
+        a.patch = c->d_mpatch; a.dist = c->grid.d_dist;
+        a.gox = c->grid.cg_ox; a.goy = c->grid.cg_oy; a.goz = c->grid.cg_oz; a.g = c->grid.cg_g; a.inv_g = c->grid.cg_inv_g; a.cap = c->grid.cg_cap;
+        a.gnx = c->grid.cg_nx; a.gny = c->grid.cg_ny; a.gnz = c->grid.cg_nz;
+    }
     const int blocks = (n + 3) / 4;
     a.order = NULL; a.xcd_blocks = 0;
 #ifdef STOCS_TOOLS_BUILD
@@ -953,8 +1036,35 @@ int stocs_set_option(stocs_ctx* c, const char* key, int value) {
     if (!strcmp(key, "lcp_flat") && (value == 0 || value == 1)) { c->lcp_flat = value; return STOCS_OK; }
     // 0: one wavefront per candidate, 1 (default): four wavefronts share a candidate's model points (same scores)
     if (!strcmp(key, "lcp_split") && (value == 0 || value == 1)) { c->lcp_split = value; return STOCS_OK; }
+    // 0: every 64-point step is walked; 1 (default): steps whose bounding sphere is out of reach of the scene are skipped once the scene's
+    // distance field pays (third scoring call against a scene, or a big batch); 2: from the first call (same scores in every case)
+    if (!strcmp(key, "lcp_cull") && value >= 0 && value <= 2) { c->lcp_cull = value; return STOCS_OK; }
     set_error("stocs_set_option: unknown option or value");
     return STOCS_ERR_INVALID;
+}
+
+int stocs_get_cull_state(stocs_ctx* c, float* patches4, int32_t* perm, int* n_patches, float* geom8, float* dist, int64_t dist_cap, int64_t* n_dist) {
+    if (!c || !n_patches || !n_dist) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
+    const int np = c->d_mpatch ? (c->nM + 63) / 64 : 0;
+    *n_patches = np;
+    const SceneGrid& g = c->grid;
+    const int64_t nd = g.d_dist ? (int64_t)g.cg_nx * g.cg_ny * g.cg_nz : 0;
+    *n_dist = nd;
+    if (patches4 && np) STOCS_HIP_CHECK(hipMemcpyAsync(patches4, c->d_mpatch, (size_t)np * 16, hipMemcpyDeviceToHost, c->stream));
+    if (perm) for (int i = 0; i < c->nM; ++i) perm[i] = c->h_mperm[i];
+    if (geom8) {
+        geom8[0] = g.cg_ox; geom8[1] = g.cg_oy; geom8[2] = g.cg_oz; geom8[3] = g.cg_g; geom8[4] = g.cg_cap;
+        geom8[5] = (float)g.cg_nx; geom8[6] = (float)g.cg_ny; geom8[7] = (float)g.cg_nz;
+    }
+    if (dist && nd) {
+        if (dist_cap < nd) return STOCS_ERR_CAPACITY;
+        int rc = fill_cull_field(c);
+        if (rc) return rc;
+        STOCS_HIP_CHECK(hipMemcpyAsync(dist, g.d_dist, (size_t)nd * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return STOCS_OK;
 }
 
 int stocs_time_score_kernel(stocs_ctx* c, const void* d_T16, int n, void* d_lcp, int reps, float* avg_ms) {

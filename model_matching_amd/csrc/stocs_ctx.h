@@ -141,6 +141,15 @@ struct SceneGrid {
     float h;             // cell edge
     bool has_nearest;    // dense grids with cell edges below epsilon: the z word of a cell is a lower bound of the distance from the
                          // cell centre to the nearest listed point (the sub-cell mask it replaces is all ones there)
+    // Distance field of the scene on a coarse grid (cell edge cg_g >= epsilon), for the patch test of the scan kernels (lcp.hip):
+    // d_dist[cell] = distance from the cell's centre to the nearest scene point, rounded down, capped at cg_cap.  The box covers the
+    // scene's bounding box widened by cg_cap + cg_g on every side, so a position outside it is at least cg_cap from every scene point.
+    // The memory is taken with the grid (no allocation later); the values are filled on first use (fill_cull_field).
+    float* d_dist;
+    bool dist_ready;
+    float cg_ox, cg_oy, cg_oz, cg_g, cg_inv_g, cg_cap;
+    int cg_nx, cg_ny, cg_nz, cg_w;   // cg_w: cells a point reaches on either side (ceil(cap / g))
+    double bb_mn[3], bb_mx[3];       // bounding box of the centred scene
 };
 
 // Model PPF index on the device: every ordered pair stored once under its own quantised key F
@@ -211,6 +220,10 @@ struct stocs_ctx {
     float4* d_mpos_s;  // Morton-sorted copies for the LCP kernel
     float4* d_mnrm_s;
     int32_t* d_mperm;
+    float4* d_mpatch;  // per 64-point step of the sorted model: bounding sphere (centre xyz, radius) of its points (patch test, lcp.hip)
+    float patch_r_ref; // the radius most patches stay below (sizes the cap of the scene's distance field)
+    int lcp_cull;      // 1: the scan kernels skip the 64-point steps whose bounding sphere is farther than epsilon from every scene point
+    int scene_scored;  // scoring launches against the current scene (the distance field is filled when it starts to pay)
 
     stocs::SceneGrid grid;
     stocs::Arena grid_mem;   // top / cells / list / chunk_r of the current grid (reset by every build)
@@ -276,6 +289,8 @@ enum { PIN_CONGRUENT = 0, PIN_TRANSFORMS = 256, PIN_VERIFY = 512, PIN_BEST = 768
 int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d_hit, uint8_t* d_counted, unsigned long long* d_best8, uint32_t id_offset);
 int build_ppf_index(stocs_ctx* c);
 int build_grid_gpu(stocs_ctx* c, int div, int dense);
+int prepare_cull_field(stocs_ctx* c);   // geometry + memory of SceneGrid::d_dist for the current grid and model (end of a grid build)
+int fill_cull_field(stocs_ctx* c);      // the values, on c->stream (no synchronisation)
 extern "C" int stocs_internal_make_jobs(stocs_ctx* c, const int32_t* picks4_host, const int32_t* picks4_dev, int n, void* d_jobs_out, const unsigned int** d_unresolved_out);
 extern "C" int stocs_internal_prepare_small(stocs_ctx* c, int max_per_base);   // small bases materialised while the host draws the picks
 extern "C" void stocs_internal_free_congruent(stocs_ctx* c);

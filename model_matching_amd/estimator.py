@@ -268,6 +268,21 @@ class StocsEstimator:
             capi.check(self.L.stocs_get_segment(self.h, out.ctypes.data_as(capi._ip), n.value, C.byref(n)))
         return out
 
+    def cull_state(self, with_field=True):
+        """(patches (n,4), perm (|M|,), geom dict, dist (nz,ny,nx) or None) of the scoring kernels' patch test (diagnostics)."""
+        npat = C.c_int(0); nd = C.c_int64(0)
+        capi.check(self.L.stocs_get_cull_state(self.h, None, None, C.byref(npat), None, None, 0, C.byref(nd)))
+        patches = np.zeros((max(npat.value, 1), 4), np.float32); perm = np.zeros(self.nM, np.int32); geom = np.zeros(8, np.float32)
+        dist = np.zeros(max(nd.value, 1), np.float32) if with_field else None
+        capi.check(self.L.stocs_get_cull_state(self.h, patches.ctypes.data_as(capi._fp), perm.ctypes.data_as(capi._ip), C.byref(npat), geom.ctypes.data_as(capi._fp),
+                                               dist.ctypes.data_as(capi._fp) if with_field else None, nd.value, C.byref(nd)))
+        g = dict(origin=geom[:3].copy(), g=float(geom[3]), cap=float(geom[4]), dims=(int(geom[5]), int(geom[6]), int(geom[7])))
+        if with_field and nd.value:
+            dist = dist[:nd.value].reshape(g["dims"][2], g["dims"][1], g["dims"][0])
+        else:
+            dist = None
+        return patches[:npat.value], perm, g, dist
+
     def set_option(self, key, value):
         capi.check(self.L.stocs_set_option(self.h, key.encode(), int(value)))
 

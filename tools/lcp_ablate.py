@@ -30,7 +30,7 @@ dense_cases = [(0, "full kernel"), (8, "no normal test"), (256, "no chunk bounds
                (2, "cell words read, nobody survives"), (128, "top table only (no cell words), nobody survives"), (1, "no look-ups at all")]
 cases = [(0, "full kernel"), (32, "no scene-normal gather"), (16, "no model-normal gather"), (48, "no normal gathers"), (8, "no normal test at all"),
          (4, "no list loads"), (4 | 8, "no list loads, no normal test"), (2, "cell look-up done, nobody survives"), (1, "no cell look-up, nobody survives"),
-         (1 | 64, "no cell look-up, no model-point loads (transform + bookkeeping only)"), (64, "no model-point loads")]
+         (64, "no patch test (every 64-point step walked)"), (1 | 64, "no patch test, no cell look-up")]
 if name in ("C5", "dense"):   # the dense default is the queue kernel with early exit: its switches are those of the Cm list
     cases = [(0, "full kernel"), (48, "no normal gathers"), (8, "no normal test at all"), (4, "no list loads"), (4 | 8, "no list loads, no normal test"),
              (2, "cell look-up done, nobody survives"), (1, "no cell look-up, nobody survives")]
