@@ -268,7 +268,9 @@ int stocs_icp_point_to_plane(const float* src_pos3, int nsrc, const float* tgt_p
  *   (stocs.cpp:1016-1035); a 64-point step of the model whose bounding sphere, under the candidate transform, is farther
  *   than epsilon from every scene point cannot add to the score and is skipped after one look-up in a distance field of
  *   the scene.  0 = off, 1 (default) = on once the field pays (third scoring call against a scene, or a batch of
- *   candidates x model points >= 1e8), 2 = from the first call.  Scores are bitwise the same in every case. ---- */
+ *   candidates x model points >= 1e8), 2 = from the first call.  Scores are bitwise the same in every case.
+ * "lcp_group": lanes that verify one queued query together in the queue-fed kernels: 4 (default; two entries of a 128-byte
+ *   list line per lane, sixteen queries per trip) or 8 (one entry per lane, the form of rounds 1-3).  Same scores. ---- */
 int stocs_set_option(stocs_ctx* ctx, const char* key, int value);
 /* Diagnostics of that patch test (tests only; no reference counterpart).  patches4: n_patches x (centre x, y, z, radius) in the
  * centred model frame, one per 64 consecutive slots of the sorted model; perm: sorted slot -> model index (|M| entries);

@@ -341,6 +341,7 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     c->d_spos = c->d_snrmw = c->d_mpos = c->d_mnrm = c->d_munit = c->d_mpos_raw = c->d_mpos_s = c->d_mnrm_s = NULL;
     c->d_spix = NULL; c->d_mperm = NULL; c->d_mpatch = NULL; c->d_scene_mem = NULL; c->scene_cap = 0;
     c->patch_r_ref = 0.0f; c->scene_scored = 0;
+    c->lcp_group = getenv("STOCS_LCP_GROUP") ? atoi(getenv("STOCS_LCP_GROUP")) : 4;
     c->lcp_cull = getenv("STOCS_LCP_CULL") ? atoi(getenv("STOCS_LCP_CULL")) : 1;
     c->stream = NULL; c->own_stream = NULL; c->aux_stream = NULL;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||

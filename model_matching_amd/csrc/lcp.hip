@@ -201,13 +201,15 @@ __device__ __forceinline__ int dpp_i32(int v) {
 // minimum of a squared distance over the 8 lanes of a query group.  Squared distances are non-negative and never NaN here
 // (a NaN distance fails `d <= best` and is never kept), so their bit patterns order like unsigned integers: an integer
 // minimum needs no NaN canonicalisation and takes its DPP operand directly -- 3 instructions instead of 10.
-__device__ __forceinline__ float group8_min_nonneg(float v) {
+template <int GL = 8>
+__device__ __forceinline__ float group_min_nonneg(float v) {
     uint32_t u = __float_as_uint(v);
-    u = min(u, (uint32_t)__builtin_amdgcn_update_dpp((int)u, (int)u, DPP_QUAD_XOR1, 0xF, 0xF, false));
-    u = min(u, (uint32_t)__builtin_amdgcn_update_dpp((int)u, (int)u, DPP_QUAD_XOR2, 0xF, 0xF, false));
-    u = min(u, (uint32_t)__builtin_amdgcn_update_dpp((int)u, (int)u, DPP_HALF_MIRROR, 0xF, 0xF, false));
+    if (GL >= 2) u = min(u, (uint32_t)__builtin_amdgcn_update_dpp((int)u, (int)u, DPP_QUAD_XOR1, 0xF, 0xF, false));
+    if (GL >= 4) u = min(u, (uint32_t)__builtin_amdgcn_update_dpp((int)u, (int)u, DPP_QUAD_XOR2, 0xF, 0xF, false));
+    if (GL == 8) u = min(u, (uint32_t)__builtin_amdgcn_update_dpp((int)u, (int)u, DPP_HALF_MIRROR, 0xF, 0xF, false));
     return __uint_as_float(u);
 }
+__device__ __forceinline__ float group8_min_nonneg(float v) { return group_min_nonneg<8>(v); }
 
 template <bool DETAIL, int UNR, bool MASK = true, bool EARLY = false, bool IDX = true, int WPB = 4, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WPB) void lcp_coop_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
@@ -419,7 +421,7 @@ __device__ __forceinline__ bool lcp_patch_dead(const LcpArgs& a, const float4 sp
 // EARLY (dense scenes: lists sorted by distance from the cell centre, a lower bound of that distance per 8-entry line): a query
 // stops at the first line the triangle inequality rules out, as in variant 31 -- but fed from the queue, so that the first
 // lines of 32 queries are in flight together where variant 31 has the two lines of 8.
-template <bool DETAIL, int UNR, bool SORTQ = false, int PIPE = 4, bool IDX = true, int WPB = 4, int FLAT = 0, bool SPLIT = false, bool TILE = false, bool EARLY = false>
+template <bool DETAIL, int UNR, bool SORTQ = false, int PIPE = 4, bool IDX = true, int WPB = 4, int FLAT = 0, bool SPLIT = false, bool TILE = false, bool EARLY = false, int GL = 8, int FIRST = 1>
 __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
                                                         int n, int32_t* __restrict__ hit_out, uint8_t* __restrict__ cnt_out) {
     __shared__ float4 qt[WPB][128];     // qx, qy, qz, bits(list offset)
@@ -430,7 +432,13 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
     __shared__ uint8_t ord[WPB][64];    // batch order sorted by list length (SORTQ)
     __shared__ unsigned long long part[WPB];
     const int lane = threadIdx.x & 63;
-    const int sub = lane & 7, grp = lane >> 3;
+    // GL lanes verify one query together: each reads EPL = 8 / GL entries of a 128-byte list line (GL = 8: one entry per lane, eight
+    // queries per trip; GL = 4: two entries per lane, sixteen queries per trip and one reduction level less)
+    // FIRST: list lines requested in a query's first trip (the second line of a list that has one arrives with the first: half of
+    // the survivors' lists at Cm are longer than a line); not with EARLY, whose later lines wait for the bound test
+    constexpr int EPL = 8 / GL, NG = 64 / GL, E0 = EPL * FIRST;
+    static_assert(!EARLY || FIRST == 1, "early exit decides line by line");
+    const int sub = lane & (GL - 1), grp = lane / GL;
     const int w = threadIdx.x >> 6;
     const int cand = SPLIT ? lcp_candidate(a, n, 0, 1) : lcp_candidate(a, n, w, WPB);
     if (cand < 0 && !TILE) return;   // SPLIT: the whole workgroup leaves together; TILE: the wavefront stays for the barriers
@@ -447,7 +455,7 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
             // (most lists are one or two lines: three classes -- one line, two, more -- keep the eight groups of a step on
             //  lists of similar length at a third of the instructions of a sort over all lengths)
             uint32_t cls = 3;
-            if (lane < nq) { const uint32_t nch = (qn[w][(head + lane) & 127] + 7u) >> 3; cls = nch <= 1u ? 0u : (nch == 2u ? 1u : 2u); }
+            if (lane < nq) { const uint32_t nch = (qn[w][(head + lane) & 127] + 7u) >> 3; cls = nch <= (uint32_t)FIRST ? 0u : (nch <= (uint32_t)(FIRST + UNR) ? 1u : 2u); }   // one trip, two, more
             const unsigned long long below = (1ull << lane) - 1ull;
             const unsigned long long m0 = __ballot(cls == 0u), m1 = __ballot(cls == 1u), m2 = __ballot(cls == 2u);
             const int n0 = __popcll(m0), n1 = __popcll(m1);
@@ -457,22 +465,28 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
         }
         // PIPE query-steps are in flight together: their first 128-byte list lines (most lists are a single
         // line) are requested back to back, so one memory round trip serves PIPE*8 queries
-        for (int s0 = 0; s0 < nq; s0 += 8 * PIPE) {
-            float4 e0[PIPE];
+        for (int s0 = 0; s0 < nq; s0 += NG * PIPE) {
+            float4 e0[PIPE][E0];
             int idxs[PIPE];
             uint32_t cs[PIPE];
 #pragma unroll
             for (int u = 0; u < PIPE; ++u) {
-                const int slot = s0 + 8 * u + grp;
+                const int slot = s0 + NG * u + grp;
                 const bool gact = slot < nq;
                 idxs[u] = (head + (SORTQ ? (int)ord[w][gact ? slot : 0] : slot)) & 127;
                 cs[u] = gact ? qn[w][idxs[u]] : 0u;
-                e0[u] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(-1));
+#pragma unroll
+                for (int e = 0; e < E0; ++e) e0[u][e] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(-1));
                 if (STOCS_ABLATE(a, 4)) {   // 4: no list loads (every survivor "hits" scene point 0 at distance 0)
-                    if (cs[u]) { const float4 qq0 = qt[w][idxs[u]]; e0[u] = make_float4(qq0.x, qq0.y, qq0.z, __int_as_float(0)); }
+                    if (cs[u]) { const float4 qq0 = qt[w][idxs[u]]; e0[u][0] = make_float4(qq0.x, qq0.y, qq0.z, __int_as_float(0)); }
                     cs[u] = cs[u] ? 1u : 0u;
                 }
-                else if (cs[u]) e0[u] = a.list[(uint32_t)__float_as_int(qt[w][idxs[u]].w) + sub];
+                else if (cs[u]) {
+                    const float4* l0 = a.list + (uint32_t)__float_as_int(qt[w][idxs[u]].w) + sub;
+#pragma unroll
+                    for (int e = 0; e < E0; ++e)
+                        if (e < EPL || (uint32_t)(8 * (e / EPL)) < cs[u]) e0[u][e] = l0[8 * (e / EPL) + GL * (e % EPL)];
+                }
             }
 #pragma unroll
             for (int u = 0; u < PIPE; ++u) {
@@ -481,10 +495,11 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
                 const float4* lp = a.list + (uint32_t)__float_as_int(qq.w) + sub;
                 float gd = a.sq_eps;
                 int gi = -1;
-                {
-                    const float dx = qq.x - e0[u].x, dy = qq.y - e0[u].y, dz = qq.z - e0[u].z;
+#pragma unroll
+                for (int e = 0; e < E0; ++e) {   // ascending entries: `<=` keeps the larger index on ties (IDX lists)
+                    const float dx = qq.x - e0[u][e].x, dy = qq.y - e0[u][e].y, dz = qq.z - e0[u][e].z;
                     const float d = dx * dx + (dy * dy + dz * dz);
-                    take_if_better<IDX>(d, __float_as_int(e0[u].w), gd, gi);
+                    take_if_better<IDX>(d, __float_as_int(e0[u][e].w), gd, gi);
                 }
                 if (EARLY) {
                     const float qcg = qcd[w][idxs[u]];
@@ -492,40 +507,48 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
                     uint32_t cc = c;   // entries still to be looked at (0 once the rest of the list is ruled out)
                     for (uint32_t k = 8; __any(k < cc); k += 8 * UNR) {
                         // |q - p| >= |p - centre| - |q - centre| > sqrt(best of the group) for every later p: stop
-                        if (k < cc && a.chunk_r[chunk0 + (k >> 3)] - qcg > sqrtf(group8_min_nonneg(gd)) + 2e-6f) cc = 0;
-                        float4 e[UNR];
+                        if (k < cc && a.chunk_r[chunk0 + (k >> 3)] - qcg > sqrtf(group_min_nonneg<GL>(gd)) + 2e-6f) cc = 0;
+                        float4 e[UNR][EPL];
 #pragma unroll
-                        for (int v = 0; v < UNR; ++v) {
-                            e[v] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(-1));
-                            if (k + 8 * v < cc) e[v] = lp[k + 8 * v];
-                        }
+                        for (int v = 0; v < UNR; ++v)
 #pragma unroll
-                        for (int v = 0; v < UNR; ++v) {
-                            const float dx = qq.x - e[v].x, dy = qq.y - e[v].y, dz = qq.z - e[v].z;
-                            const float d = dx * dx + (dy * dy + dz * dz);
-                            take_if_better<IDX>(d, __float_as_int(e[v].w), gd, gi);
-                        }
+                            for (int x = 0; x < EPL; ++x) {
+                                e[v][x] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(-1));
+                                if (k + 8 * v < cc) e[v][x] = lp[k + 8 * v + GL * x];
+                            }
+#pragma unroll
+                        for (int v = 0; v < UNR; ++v)
+#pragma unroll
+                            for (int x = 0; x < EPL; ++x) {
+                                const float dx = qq.x - e[v][x].x, dy = qq.y - e[v][x].y, dz = qq.z - e[v][x].z;
+                                const float d = dx * dx + (dy * dy + dz * dz);
+                                take_if_better<IDX>(d, __float_as_int(e[v][x].w), gd, gi);
+                            }
                     }
                 } else
-                for (uint32_t k = 8; __any(k < c); k += 8 * UNR) {
-                    float4 e[UNR];
+                for (uint32_t k = 8 * FIRST; __any(k < c); k += 8 * UNR) {
+                    float4 e[UNR][EPL];
 #pragma unroll
-                    for (int v = 0; v < UNR; ++v) {
-                        e[v] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(-1));
-                        if (k + 8 * v < c) e[v] = lp[k + 8 * v];
-                    }
+                    for (int v = 0; v < UNR; ++v)
 #pragma unroll
-                    for (int v = 0; v < UNR; ++v) {
-                        const float dx = qq.x - e[v].x, dy = qq.y - e[v].y, dz = qq.z - e[v].z;
-                        const float d = dx * dx + (dy * dy + dz * dz);
-                        take_if_better<IDX>(d, __float_as_int(e[v].w), gd, gi);
-                    }
+                        for (int x = 0; x < EPL; ++x) {
+                            e[v][x] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(-1));
+                            if (k + 8 * v < c) e[v][x] = lp[k + 8 * v + GL * x];
+                        }
+#pragma unroll
+                    for (int v = 0; v < UNR; ++v)
+#pragma unroll
+                        for (int x = 0; x < EPL; ++x) {
+                            const float dx = qq.x - e[v][x].x, dy = qq.y - e[v][x].y, dz = qq.z - e[v][x].z;
+                            const float d = dx * dx + (dy * dy + dz * dz);
+                            take_if_better<IDX>(d, __float_as_int(e[v][x].w), gd, gi);
+                        }
                 }
-                const float dm = group8_min_nonneg(gd);
+                const float dm = group_min_nonneg<GL>(gd);
                 int im = (gd == dm) ? gi : -1;
-                im = max(im, dpp_i32<DPP_QUAD_XOR1>(im));
-                im = max(im, dpp_i32<DPP_QUAD_XOR2>(im));
-                im = max(im, dpp_i32<DPP_HALF_MIRROR>(im));
+                if (GL >= 2) im = max(im, dpp_i32<DPP_QUAD_XOR1>(im));
+                if (GL >= 4) im = max(im, dpp_i32<DPP_QUAD_XOR2>(im));
+                if (GL == 8) im = max(im, dpp_i32<DPP_HALF_MIRROR>(im));
                 if (c && sub == 0) ri[w][idxs[u]] = im;
             }
         }
@@ -863,8 +886,13 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
             case 34: hipLaunchKernelGGL((lcp_coop_kernel<false, 1, true, true, false, 4, true>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); break;   // 31 with one line per trip
             case 35: hipLaunchKernelGGL((lcp_coop_kernel<false, 4, true, true, false, 4, true>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); break;   // 31 with four lines per trip
 #endif
-            case 39:   // queue-fed scan with early exit (16-byte lists)
-                hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 4, false, 4, 0, true, false, true>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
+            case 39:   // queue-fed scan with early exit (16-byte lists); lanes per query as on sparse scenes (C5: 6.33 -> 5.81 ms)
+                if (c->lcp_group == 8) hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 4, false, 4, 0, true, false, true, 8>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
+#ifdef STOCS_TOOLS_BUILD
+                else if (c->lcp_group == 42) hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 2, false, 4, 0, true, false, true, 4>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
+                else if (c->lcp_group == 2) hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 1, false, 4, 0, true, false, true, 2>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
+#endif
+                else hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 1, false, 4, 0, true, false, true, 4>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
                 break;
 #ifdef STOCS_TOOLS_BUILD
             case 41: hipLaunchKernelGGL((lcp_coopq_kernel<false, 2, true, 4, false, 4, 0, true, false, true>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); break;   // 39, two lines per trip after the first
@@ -903,9 +931,32 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
                 // four wavefronts per candidate: a trial's ~8 000 candidates finish 40 % sooner (one round of long wavefronts
                 // becomes four rounds of short ones), 32 768 candidates 9 % sooner, 65 536 the same (tools/lcp_flat_ab.py)
                 const bool split = c->lcp_split && a.M >= 512;
-#define STOCS_LCP_Q(FLATV, WPBV, SPLITV, GRID, BLOCK) hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 4, true, WPBV, FLATV, SPLITV>), dim3(GRID), dim3(BLOCK), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted)
-                if (split) { if (flat) STOCS_LCP_Q(1, 4, true, n, 256); else STOCS_LCP_Q(0, 4, true, n, 256); }
-                else { if (flat) STOCS_LCP_Q(1, 1, false, n, 64); else STOCS_LCP_Q(0, 1, false, n, 64); }
+#define STOCS_LCP_Q(SORTV, PIPEV, GLV, UNRV, ...) do { \
+                    if (split) { if (flat) hipLaunchKernelGGL((lcp_coopq_kernel<false, UNRV, SORTV, PIPEV, true, 4, 1, true, false, false, GLV, ##__VA_ARGS__>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); \
+                                 else hipLaunchKernelGGL((lcp_coopq_kernel<false, UNRV, SORTV, PIPEV, true, 4, 0, true, false, false, GLV, ##__VA_ARGS__>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); } \
+                    else { if (flat) hipLaunchKernelGGL((lcp_coopq_kernel<false, UNRV, SORTV, PIPEV, true, 1, 1, false, false, false, GLV, ##__VA_ARGS__>), dim3(n), dim3(64), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); \
+                           else hipLaunchKernelGGL((lcp_coopq_kernel<false, UNRV, SORTV, PIPEV, true, 1, 0, false, false, false, GLV, ##__VA_ARGS__>), dim3(n), dim3(64), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); } } while (0)
+                // lanes per queued query in the verify trips (stocs_set_option "lcp_group"; profiles/r03_lcp_group_ab.json): 4 lanes with
+                // two list entries each and one trip (16 queries) in flight -- Cm 1.34 -> 1.18 ms; 8 lanes with one entry each and four
+                // trips in flight is the form of rounds 1-3
+                switch (c->lcp_group) {
+                    case 8: STOCS_LCP_Q(true, 4, 8, 1); break;
+#ifdef STOCS_TOOLS_BUILD
+                    case 42: STOCS_LCP_Q(true, 2, 4, 1); break;    // 4 lanes, two trips in flight (1.185 ms)
+                    case 41: STOCS_LCP_Q(true, 1, 4, 1, 1); break; // 4 with one line in the first trip (+2 % at 65 536 candidates, +7 % at 8 192)
+                    case 46: STOCS_LCP_Q(true, 1, 4, 1, 3); break; // ... three lines (+3 %)
+                    case 47: STOCS_LCP_Q(true, 1, 4, 2, 2); break; // 4 with two lines per later trip as well (+3 %)
+                    case 48: STOCS_LCP_Q(true, 1, 4, 2, 1); break; // one line first, then two per trip (+5 %)
+                    case 85: STOCS_LCP_Q(true, 2, 8, 1, 2); break; // 8 lanes, two trips, two lines
+                    case 43: STOCS_LCP_Q(true, 3, 4, 1); break;    // ... three (1.35 ms: spills)
+                    case 44: STOCS_LCP_Q(true, 4, 4, 1); break;    // ... four (2.56 ms: spills)
+                    case 40: STOCS_LCP_Q(false, 2, 4, 1); break;   // 42 without the ordering by list length (1.24 ms)
+                    case 2: STOCS_LCP_Q(true, 1, 2, 1); break;     // 2 lanes, four entries each (1.45 ms)
+                    case 22: STOCS_LCP_Q(true, 2, 2, 1); break;    // ... two trips in flight (2.11 ms)
+                    case 1: STOCS_LCP_Q(true, 1, 1, 1); break;     // a lane per query, a whole line per lane (3.16 ms)
+#endif
+                    default: STOCS_LCP_Q(true, 1, 4, 1, 2); break;    // 4: four lanes, one trip in flight, a list's first two lines together
+                }
 #undef STOCS_LCP_Q
                 break;
             }
@@ -1039,6 +1090,14 @@ int stocs_set_option(stocs_ctx* c, const char* key, int value) {
     // 0: every 64-point step is walked; 1 (default): steps whose bounding sphere is out of reach of the scene are skipped once the scene's
     // distance field pays (third scoring call against a scene, or a big batch); 2: from the first call (same scores in every case)
     if (!strcmp(key, "lcp_cull") && value >= 0 && value <= 2) { c->lcp_cull = value; return STOCS_OK; }
+    // lanes that verify one queued query together: 4 (default: two list entries per lane) or 8 (one entry per lane; rounds 1-3); same scores
+    if (!strcmp(key, "lcp_group")) {
+        bool ok = value == 4 || value == 8;
+#ifdef STOCS_TOOLS_BUILD
+        ok = ok || value == 41 || value == 46 || value == 47 || value == 48 || value == 85 || value == 42 || value == 43 || value == 44 || value == 40 || value == 2 || value == 22 || value == 1;
+#endif
+        if (ok) { c->lcp_group = value; return STOCS_OK; }
+    }
     set_error("stocs_set_option: unknown option or value");
     return STOCS_ERR_INVALID;
 }

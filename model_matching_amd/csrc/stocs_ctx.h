@@ -223,6 +223,7 @@ struct stocs_ctx {
     float4* d_mpatch;  // per 64-point step of the sorted model: bounding sphere (centre xyz, radius) of its points (patch test, lcp.hip)
     float patch_r_ref; // the radius most patches stay below (sizes the cap of the scene's distance field)
     int lcp_cull;      // 1: the scan kernels skip the 64-point steps whose bounding sphere is farther than epsilon from every scene point
+    int lcp_group;     // lanes per queued query in the verify trips: 4 (default, two list entries per lane) or 8 (one entry per lane)
     int scene_scored;  // scoring launches against the current scene (the distance field is filled when it starts to pay)
 
     stocs::SceneGrid grid;
