@@ -421,7 +421,7 @@ __device__ __forceinline__ bool lcp_patch_dead(const LcpArgs& a, const float4 sp
 // EARLY (dense scenes: lists sorted by distance from the cell centre, a lower bound of that distance per 8-entry line): a query
 // stops at the first line the triangle inequality rules out, as in variant 31 -- but fed from the queue, so that the first
 // lines of 32 queries are in flight together where variant 31 has the two lines of 8.
-template <bool DETAIL, int UNR, bool SORTQ = false, int PIPE = 4, bool IDX = true, int WPB = 4, int FLAT = 0, bool SPLIT = false, bool TILE = false, bool EARLY = false, int GL = 8, int FIRST = 1>
+template <bool DETAIL, int UNR, bool SORTQ = false, int PIPE = 4, bool IDX = true, int WPB = 4, int FLAT = 0, bool SPLIT = false, bool TILE = false, bool EARLY = false, int GL = 8, int FIRST = 1, bool NOSENT = false>
 __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
                                                         int n, int32_t* __restrict__ hit_out, uint8_t* __restrict__ cnt_out) {
     __shared__ float4 qt[WPB][128];     // qx, qy, qz, bits(list offset)
@@ -467,6 +467,7 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
         // line) are requested back to back, so one memory round trip serves PIPE*8 queries
         for (int s0 = 0; s0 < nq; s0 += NG * PIPE) {
             float4 e0[PIPE][E0];
+            bool wide[PIPE];
             int idxs[PIPE];
             uint32_t cs[PIPE];
 #pragma unroll
@@ -475,11 +476,29 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
                 const bool gact = slot < nq;
                 idxs[u] = (head + (SORTQ ? (int)ord[w][gact ? slot : 0] : slot)) & 127;
                 cs[u] = gact ? qn[w][idxs[u]] : 0u;
+                wide[u] = true;
+                if (!NOSENT) {
 #pragma unroll
-                for (int e = 0; e < E0; ++e) e0[u][e] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(-1));
+                    for (int e = 0; e < E0; ++e) e0[u][e] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(-1));
+                }
                 if (STOCS_ABLATE(a, 4)) {   // 4: no list loads (every survivor "hits" scene point 0 at distance 0)
                     if (cs[u]) { const float4 qq0 = qt[w][idxs[u]]; e0[u][0] = make_float4(qq0.x, qq0.y, qq0.z, __int_as_float(0)); }
                     cs[u] = cs[u] ? 1u : 0u;
+                }
+                else if (NOSENT) {
+                    // no sentinels, no predication: a group without a query reads list line 0 (its result is never stored), a list
+                    // shorter than the trip reads its last line again -- the same entries, the same winner
+                    const float4* l0 = a.list + (cs[u] ? (uint32_t)__float_as_int(qt[w][idxs[u]].w) : 0u) + sub;
+                    const uint32_t last = cs[u] ? ((cs[u] - 1u) & ~7u) : 0u;
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) e0[u][e] = l0[GL * e];
+                    // the later lines of the first trip only when some list of this trip has them (the queries are ordered by list
+                    // length, so a third of the trips are single-line lists throughout: no addresses spent on re-reading those)
+                    wide[u] = FIRST > 1 && __any(cs[u] > 8u);
+                    if (wide[u]) {
+#pragma unroll
+                        for (int e = EPL; e < E0; ++e) e0[u][e] = l0[min((uint32_t)(8 * (e / EPL)), last) + GL * (e % EPL)];
+                    }
                 }
                 else if (cs[u]) {
                     const float4* l0 = a.list + (uint32_t)__float_as_int(qt[w][idxs[u]].w) + sub;
@@ -493,13 +512,22 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
                 const float4 qq = qt[w][idxs[u]];
                 const uint32_t c = cs[u];
                 const float4* lp = a.list + (uint32_t)__float_as_int(qq.w) + sub;
+                const uint32_t last_line = c ? ((c - 1u) & ~7u) : 0u;
                 float gd = a.sq_eps;
                 int gi = -1;
 #pragma unroll
-                for (int e = 0; e < E0; ++e) {   // ascending entries: `<=` keeps the larger index on ties (IDX lists)
+                for (int e = 0; e < EPL; ++e) {   // ascending entries: `<=` keeps the larger index on ties (IDX lists)
                     const float dx = qq.x - e0[u][e].x, dy = qq.y - e0[u][e].y, dz = qq.z - e0[u][e].z;
                     const float d = dx * dx + (dy * dy + dz * dz);
                     take_if_better<IDX>(d, __float_as_int(e0[u][e].w), gd, gi);
+                }
+                if (FIRST > 1 && (!NOSENT || wide[u])) {
+#pragma unroll
+                    for (int e = EPL; e < E0; ++e) {
+                        const float dx = qq.x - e0[u][e].x, dy = qq.y - e0[u][e].y, dz = qq.z - e0[u][e].z;
+                        const float d = dx * dx + (dy * dy + dz * dz);
+                        take_if_better<IDX>(d, __float_as_int(e0[u][e].w), gd, gi);
+                    }
                 }
                 if (EARLY) {
                     const float qcg = qcd[w][idxs[u]];
@@ -510,12 +538,15 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
                         if (k < cc && a.chunk_r[chunk0 + (k >> 3)] - qcg > sqrtf(group_min_nonneg<GL>(gd)) + 2e-6f) cc = 0;
                         float4 e[UNR][EPL];
 #pragma unroll
-                        for (int v = 0; v < UNR; ++v)
+                        for (int v = 0; v < UNR; ++v) {   // a line's entries under ONE condition: its loads leave together
+                            if (k + 8 * v < cc) {
 #pragma unroll
-                            for (int x = 0; x < EPL; ++x) {
-                                e[v][x] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(-1));
-                                if (k + 8 * v < cc) e[v][x] = lp[k + 8 * v + GL * x];
+                                for (int x = 0; x < EPL; ++x) e[v][x] = lp[k + 8 * v + GL * x];
+                            } else {
+#pragma unroll
+                                for (int x = 0; x < EPL; ++x) e[v][x] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(-1));
                             }
+                        }
 #pragma unroll
                         for (int v = 0; v < UNR; ++v)
 #pragma unroll
@@ -529,12 +560,19 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
                 for (uint32_t k = 8 * FIRST; __any(k < c); k += 8 * UNR) {
                     float4 e[UNR][EPL];
 #pragma unroll
-                    for (int v = 0; v < UNR; ++v)
+                    for (int v = 0; v < UNR; ++v) {
+                        if (NOSENT) {   // a list shorter than this trip reads its last line again (the same entries: harmless)
+                            const uint32_t kk = min(k + 8u * v, last_line);
 #pragma unroll
-                        for (int x = 0; x < EPL; ++x) {
-                            e[v][x] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(-1));
-                            if (k + 8 * v < c) e[v][x] = lp[k + 8 * v + GL * x];
+                            for (int x = 0; x < EPL; ++x) e[v][x] = lp[kk + GL * x];
+                        } else if (k + 8 * v < c) {
+#pragma unroll
+                            for (int x = 0; x < EPL; ++x) e[v][x] = lp[k + 8 * v + GL * x];
+                        } else {
+#pragma unroll
+                            for (int x = 0; x < EPL; ++x) e[v][x] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(-1));
                         }
+                    }
 #pragma unroll
                     for (int v = 0; v < UNR; ++v)
 #pragma unroll
@@ -944,6 +982,7 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
 #ifdef STOCS_TOOLS_BUILD
                     case 42: STOCS_LCP_Q(true, 2, 4, 1); break;    // 4 lanes, two trips in flight (1.185 ms)
                     case 41: STOCS_LCP_Q(true, 1, 4, 1, 1); break; // 4 with one line in the first trip (+2 % at 65 536 candidates, +7 % at 8 192)
+                    case 49: STOCS_LCP_Q(true, 1, 4, 1, 2, false); break; // 4 with predicated list loads and sentinel entries (+1.2 %; +2.4 % at 8 192)
                     case 46: STOCS_LCP_Q(true, 1, 4, 1, 3); break; // ... three lines (+3 %)
                     case 47: STOCS_LCP_Q(true, 1, 4, 2, 2); break; // 4 with two lines per later trip as well (+3 %)
                     case 48: STOCS_LCP_Q(true, 1, 4, 2, 1); break; // one line first, then two per trip (+5 %)
@@ -955,7 +994,7 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
                     case 22: STOCS_LCP_Q(true, 2, 2, 1); break;    // ... two trips in flight (2.11 ms)
                     case 1: STOCS_LCP_Q(true, 1, 1, 1); break;     // a lane per query, a whole line per lane (3.16 ms)
 #endif
-                    default: STOCS_LCP_Q(true, 1, 4, 1, 2); break;    // 4: four lanes, one trip in flight, a list's first two lines together
+                    default: STOCS_LCP_Q(true, 1, 4, 1, 2, true); break;    // 4: four lanes, one trip in flight, a list's first two lines together, no sentinels
                 }
 #undef STOCS_LCP_Q
                 break;
@@ -1094,7 +1133,7 @@ int stocs_set_option(stocs_ctx* c, const char* key, int value) {
     if (!strcmp(key, "lcp_group")) {
         bool ok = value == 4 || value == 8;
 #ifdef STOCS_TOOLS_BUILD
-        ok = ok || value == 41 || value == 46 || value == 47 || value == 48 || value == 85 || value == 42 || value == 43 || value == 44 || value == 40 || value == 2 || value == 22 || value == 1;
+        ok = ok || value == 41 || value == 49 || value == 46 || value == 47 || value == 48 || value == 85 || value == 42 || value == 43 || value == 44 || value == 40 || value == 2 || value == 22 || value == 1;
 #endif
         if (ok) { c->lcp_group = value; return STOCS_OK; }
     }
