@@ -63,6 +63,17 @@ struct LcpArgs {
 #define STOCS_ABLATE(a, bit) false
 #endif
 
+// Linear cell / brick index of the queue-fed kernels.  A 32-bit integer multiply is a quarter-rate instruction on CDNA (16 cycles per
+// wavefront; the compiler even reaches for the 64-bit multiply-add here), the 24-bit multiply-add runs at full rate.  The grid build
+// refuses tables whose dimensions do not fit it (ny * nz and nx below 2^24: build_grid_gpu) -- a scene would have to be kilometres wide.
+__device__ __forceinline__ uint32_t lin3(int x, int y, int z, int nx, int ny) {
+    // (written as instructions: from `__umul24(z, ny) + y` the compiler's combiner makes a v_mad_u64_u32 again; nx, ny are wave-uniform)
+    uint32_t t, r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t) : "v"(z), "s"(ny), "v"(y));
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(t), "s"(nx), "v"(x));
+    return r;
+}
+
 // workgroup -> first processing slot.  The hardware hands consecutive workgroups to the 8 XCDs round-robin; with
 // xcd_blocks the workgroups that land on one XCD take consecutive slot blocks, so an XCD's L2 sees one
 // contiguous part of the (spatially ordered) candidate list.  Then slot -> candidate through the order array.
@@ -398,7 +409,7 @@ __device__ __forceinline__ bool lcp_patch_dead(const LcpArgs& a, const float4 sp
     const float fx = floorf(ux), fy = floorf(uy), fz = floorf(uz);
     // one cell inside the border: the float cell of a position next to the box never names a cell outside the table
     if (fx >= 1.0f && fy >= 1.0f && fz >= 1.0f && fx < (float)(a.gnx - 1) && fy < (float)(a.gny - 1) && fz < (float)(a.gnz - 1)) {
-        const float v = a.dist[((size_t)(int)fz * a.gny + (int)fy) * a.gnx + (int)fx];
+        const float v = a.dist[((uint32_t)(int)fz * (uint32_t)a.gny + (uint32_t)(int)fy) * (uint32_t)a.gnx + (uint32_t)(int)fx];   // <= 16 M cells
         const float ex = cx - (a.gox + (fx + 0.5f) * a.g), ey = cy - (a.goy + (fy + 0.5f) * a.g), ez = cz - (a.goz + (fz + 0.5f) * a.g);
         return v - sqrtf(ex * ex + (ey * ey + ez * ez)) > need;
     }
@@ -637,12 +648,12 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
                 if (FLAT) {   // one look-up: an empty cell is an all-zero word (count 0, mask 0)
                     uint4 cw = make_uint4(0u, 0u, 0u, 0u);
                     if (!STOCS_ABLATE(a, 1))   // 1: no cell-word look-up at all
-                        cw = a.flat[(uint32_t)((cz * a.ny + cy) * a.nx + cx)];
+                        cw = a.flat[lin3(cx, cy, cz, a.nx, a.ny)];
                     const uint32_t mw = sb < 32 ? cw.z : cw.w;
                     off = cw.x; cnt = ((mw >> (sb & 31)) & 1u) ? cw.y : 0u;
                     if (STOCS_ABLATE(a, 2)) cnt = cw.x == 0xFFFFFFF1u ? 1u : 0u;   // 2: look-up done, nobody survives
                 } else {
-                    const int brick = a.top[((cz >> 3) * a.nby + (cy >> 3)) * a.nbx + (cx >> 3)];
+                    const int brick = a.top[lin3(cx >> 3, cy >> 3, cz >> 3, a.nbx, a.nby)];
                     if (brick >= 0) {
                         const uint4 cw = a.cells[(uint32_t)brick * 512u + (uint32_t)(((cz & 7) << 6) | ((cy & 7) << 3) | (cx & 7))];
                         if (EARLY && a.has_nearest) { off = cw.x; cnt = cw.y; nearest = __uint_as_float(cw.z); }   // no mask on these grids: z = distance bound

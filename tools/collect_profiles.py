@@ -22,14 +22,14 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
     shutil.copy(newest(os.path.join(src, "stats", "**", "*_kernel_stats.csv")), os.path.join(dst, "%s_final_bench_kernel_stats.csv" % tag))
-    shutil.copy(newest(os.path.join(src, "pipe", "**", "*_kernel_stats.csv")), os.path.join(dst, "%s_pipeline_Cm_kernel_stats.csv" % tag))
+    shutil.copy(newest(os.path.join(src, "pmc_pipe", "**", "*_kernel_stats.csv")), os.path.join(dst, "%s_pipeline_Cm_kernel_stats.csv" % tag))
     for f, name in (("bench.json", "final_bench"), ("bench_C5.json", "C5_bench"), ("frame_latency.json", "frame_latency"), ("sweep.json", "sweep"), ("trials64_s1.json", "trials64_streams1"),
                     ("trials64_s8.json", "trials64_streams8"), ("pipeline_Cm.json", "pipeline_Cm")):
         if os.path.exists(os.path.join(src, f)):
             shutil.copy(os.path.join(src, f), os.path.join(dst, "%s_%s.json" % (tag, name)))
     # counter passes: raw per-launch means + the derived bounds (kernel time: rocprofv3's own average of the stats pass)
     import csv
-    for f, name, kern, stats in (("lcp_pmc.json", "final_lcp_pmc", "lcp_coop", "stats"), ("join_pmc.json", "join_count_pmc", "join_count_kernel", "pipe")):
+    for f, name, kern, stats in (("lcp_pmc.json", "final_lcp_pmc", "lcp_coop", "stats"), ("join_pmc.json", "join_count_pmc", "join_count_kernel", "pmc_pipe")):
         p = os.path.join(src, f)
         if not os.path.exists(p):
             continue
