@@ -229,7 +229,7 @@ static int load_scene_impl(stocs_ctx* c, const float* sp, const float* sn, const
     // per-trial state belongs to the old scene
     c->bases.clear(); c->quad_off.clear(); clear_candidates(c);
     c->best_lcp = 0; c->best_index = -1;
-    c->scene_scored = 0;
+    c->scene_scored = 0; c->scene_work = 0.0;
     stocs_internal_invalidate_congruent(c);
     const size_t npx = (size_t)c->prm.image_width * c->prm.image_height;
     c->has_edge = false;
@@ -340,7 +340,7 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     memset(&c->grid, 0, sizeof(c->grid));
     c->d_spos = c->d_snrmw = c->d_mpos = c->d_mnrm = c->d_munit = c->d_mpos_raw = c->d_mpos_s = c->d_mnrm_s = NULL;
     c->d_spix = NULL; c->d_mperm = NULL; c->d_mpatch = NULL; c->d_scene_mem = NULL; c->scene_cap = 0;
-    c->patch_r_ref = 0.0f; c->scene_scored = 0;
+    c->patch_r_ref = 0.0f; c->scene_scored = 0; c->scene_work = 0.0;
     c->lcp_group = getenv("STOCS_LCP_GROUP") ? atoi(getenv("STOCS_LCP_GROUP")) : 4;
     c->lcp_cull = getenv("STOCS_LCP_CULL") ? atoi(getenv("STOCS_LCP_CULL")) : 1;
     c->stream = NULL; c->own_stream = NULL; c->aux_stream = NULL;

@@ -281,8 +281,6 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense) {
     g.d_top = NULL; g.d_cells = NULL; g.d_list = NULL; g.d_chunk_r = NULL; g.d_flat = NULL;
     const int64_t n_top = (int64_t)g.nbx * g.nby * g.nbz;
     if (n_top > (int64_t)400 * 1000 * 1000) { set_error("scene extent too large for the brick grid"); return STOCS_ERR_INVALID; }
-    // the scan kernels index the tables with 24-bit multiplies (lcp.hip, lin3)
-    if ((int64_t)n[1] * n[2] >= (1 << 24) || n[0] >= (1 << 24)) { set_error("scene extent too large for the brick grid (%d x %d x %d cells)", n[0], n[1], n[2]); return STOCS_ERR_INVALID; }
     int cell_bits = 1;
     while (((int64_t)1 << cell_bits) < n_top * 512) cell_bits++;
 

@@ -63,17 +63,6 @@ struct LcpArgs {
 #define STOCS_ABLATE(a, bit) false
 #endif
 
-// Linear cell / brick index of the queue-fed kernels.  A 32-bit integer multiply is a quarter-rate instruction on CDNA (16 cycles per
-// wavefront; the compiler even reaches for the 64-bit multiply-add here), the 24-bit multiply-add runs at full rate.  The grid build
-// refuses tables whose dimensions do not fit it (ny * nz and nx below 2^24: build_grid_gpu) -- a scene would have to be kilometres wide.
-__device__ __forceinline__ uint32_t lin3(int x, int y, int z, int nx, int ny) {
-    // (written as instructions: from `__umul24(z, ny) + y` the compiler's combiner makes a v_mad_u64_u32 again; nx, ny are wave-uniform)
-    uint32_t t, r;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t) : "v"(z), "s"(ny), "v"(y));
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(t), "s"(nx), "v"(x));
-    return r;
-}
-
 // workgroup -> first processing slot.  The hardware hands consecutive workgroups to the 8 XCDs round-robin; with
 // xcd_blocks the workgroups that land on one XCD take consecutive slot blocks, so an XCD's L2 sees one
 // contiguous part of the (spatially ordered) candidate list.  Then slot -> candidate through the order array.
@@ -648,12 +637,12 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
                 if (FLAT) {   // one look-up: an empty cell is an all-zero word (count 0, mask 0)
                     uint4 cw = make_uint4(0u, 0u, 0u, 0u);
                     if (!STOCS_ABLATE(a, 1))   // 1: no cell-word look-up at all
-                        cw = a.flat[lin3(cx, cy, cz, a.nx, a.ny)];
+                        cw = a.flat[(uint32_t)((cz * a.ny + cy) * a.nx + cx)];
                     const uint32_t mw = sb < 32 ? cw.z : cw.w;
                     off = cw.x; cnt = ((mw >> (sb & 31)) & 1u) ? cw.y : 0u;
                     if (STOCS_ABLATE(a, 2)) cnt = cw.x == 0xFFFFFFF1u ? 1u : 0u;   // 2: look-up done, nobody survives
                 } else {
-                    const int brick = a.top[lin3(cx >> 3, cy >> 3, cz >> 3, a.nbx, a.nby)];
+                    const int brick = a.top[((cz >> 3) * a.nby + (cy >> 3)) * a.nbx + (cx >> 3)];
                     if (brick >= 0) {
                         const uint4 cw = a.cells[(uint32_t)brick * 512u + (uint32_t)(((cz & 7) << 6) | ((cy & 7) << 3) | (cx & 7))];
                         if (EARLY && a.has_nearest) { off = cw.x; cnt = cw.y; nearest = __uint_as_float(cw.z); }   // no mask on these grids: z = distance bound
@@ -866,12 +855,14 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
     a.dot_lo = c->thr.lcp_dot_lo;
     a.eps = c->prm.distance_threshold;
     a.has_nearest = c->grid.has_nearest ? 1 : 0;
-    // patch test: worth its distance field (one pass over the scene points, ~0.1 ms) once a scene is scored against repeatedly
-    // or by a big batch; the scores do not depend on it
+    // patch test: its distance field costs one pass over the scene points (0.24 ms at Cm) and takes ~6 % off a launch, so it is filled
+    // once the scene has seen 1e9 point queries (three steps of the metric batch; ~25 trials of one frame) -- a caller that scores one
+    // trial per frame never pays for it.  The scores do not depend on it
     a.patch = NULL; a.dist = NULL;
     a.gox = a.goy = a.goz = 0.f; a.g = a.inv_g = a.cap = 0.f; a.gnx = a.gny = a.gnz = 0;
     c->scene_scored++;
-    if (c->lcp_cull && c->grid.d_dist && c->d_mpatch && (c->grid.dist_ready || c->lcp_cull >= 2 || c->scene_scored >= 3 || (double)n * (double)c->nM >= 1.0e8)) {
+    c->scene_work += (double)n * (double)c->nM;
+    if (c->lcp_cull && c->grid.d_dist && c->d_mpatch && (c->grid.dist_ready || c->lcp_cull >= 2 || c->scene_work >= 1.0e9)) {
         int rc = fill_cull_field(c);
         if (rc) return rc;
         a.patch = c->d_mpatch; a.dist = c->grid.d_dist;
@@ -1138,7 +1129,7 @@ int stocs_set_option(stocs_ctx* c, const char* key, int value) {
     // 0: one wavefront per candidate, 1 (default): four wavefronts share a candidate's model points (same scores)
     if (!strcmp(key, "lcp_split") && (value == 0 || value == 1)) { c->lcp_split = value; return STOCS_OK; }
     // 0: every 64-point step is walked; 1 (default): steps whose bounding sphere is out of reach of the scene are skipped once the scene's
-    // distance field pays (third scoring call against a scene, or a big batch); 2: from the first call (same scores in every case)
+    // distance field pays (1e9 point queries against the scene so far); 2: from the first call (same scores in every case)
     if (!strcmp(key, "lcp_cull") && value >= 0 && value <= 2) { c->lcp_cull = value; return STOCS_OK; }
     // lanes that verify one queued query together: 4 (default: two list entries per lane) or 8 (one entry per lane; rounds 1-3); same scores
     if (!strcmp(key, "lcp_group")) {

@@ -224,7 +224,8 @@ struct stocs_ctx {
     float patch_r_ref; // the radius most patches stay below (sizes the cap of the scene's distance field)
     int lcp_cull;      // 1: the scan kernels skip the 64-point steps whose bounding sphere is farther than epsilon from every scene point
     int lcp_group;     // lanes per queued query in the verify trips: 4 (default, two list entries per lane) or 8 (one entry per lane)
-    int scene_scored;  // scoring launches against the current scene (the distance field is filled when it starts to pay)
+    int scene_scored;  // scoring launches against the current scene
+    double scene_work; // candidates x model points scored against the current scene so far (the distance field is filled when it pays)
 
     stocs::SceneGrid grid;
     stocs::Arena grid_mem;   // top / cells / list / chunk_r of the current grid (reset by every build)

@@ -110,30 +110,30 @@ def test_scores_are_bitwise_the_same_with_and_without_the_patch_test(name, oracl
 
 
 def test_metric_size_bitwise_and_default_policy(oracle_lib):
-    """Cm (20 000 / 5 000): 4 096 candidates of the bench batch + 1 024 poses anywhere in the scene, test on / off bitwise
-    equal; the default policy (field filled on the third scoring call against a scene, or for a big batch) allocates
-    nothing when it engages and changes no score; a new scene starts over."""
+    """Cm (20 000 / 5 000): 36 864 candidates of the bench batch + 4 096 poses anywhere in the scene (2e8 point queries per call), test
+    on / off bitwise equal; the default policy (field filled once the scene has seen 1e9 point queries) allocates nothing when it
+    engages and changes no score; a new scene starts over."""
     from model_matching_amd import synth, capi
     m, s, k, est, orc, Tgt = _setup("Cm", oracle_lib)
     rng = np.random.default_rng(5)
-    T = np.concatenate([synth.make_candidates(Tgt, 4096), _random_poses(rng, 1024, Tgt[:3, 3], 0.3)])
-    first = est.score_transforms(T)          # default policy, first call on this scene: 5120 x 5000 < 1e8 -> not yet
+    T = np.concatenate([synth.make_candidates(Tgt, 36864), _random_poses(rng, 4096, Tgt[:3, 3], 0.3)])
+    runs = [est.score_transforms(T)]          # default policy, first call on this scene: not yet
     a0 = capi.load().stocs_device_alloc_count()
-    second = est.score_transforms(T)
-    third = est.score_transforms(T)          # third call: the field is filled and used
+    for _ in range(6):                        # the fifth call crosses 1e9: the field is filled and used from there on
+        runs.append(est.score_transforms(T))
     assert capi.load().stocs_device_alloc_count() == a0
     est.set_option("lcp_cull", 0)
     off = est.score_transforms(T)
-    for got in (first, second, third):
+    for got in runs:
         assert np.array_equal(got.view(np.uint32), off.view(np.uint32))
     ref = orc.lcp_batch(T[:512], nthreads=8)
-    assert np.abs(third[:512] - ref).max() <= LCP_TOL
+    assert np.abs(runs[-1][:512] - ref).max() <= LCP_TOL
     # a new frame (the same cloud shifted): scores follow the scene, the field is rebuilt for it
     est.set_option("lcp_cull", 2)
     shift = np.array([0.013, -0.007, 0.021], np.float32)
     est.set_scene(s.pos + shift, s.nrm, s.prob, s.pixel)
-    moved = est.score_transforms(T)
+    moved = est.score_transforms(T[:8192])
     est.set_option("lcp_cull", 0)
-    assert np.array_equal(moved.view(np.uint32), est.score_transforms(T).view(np.uint32))
+    assert np.array_equal(moved.view(np.uint32), est.score_transforms(T[:8192]).view(np.uint32))
     # (the centred scene is the same cloud up to the float rounding of the shift: the scores stay close to the old ones)
-    assert np.abs(moved - off).max() < 0.05
+    assert np.abs(moved - off[:8192]).max() < 0.05
