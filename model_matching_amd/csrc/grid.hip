@@ -423,34 +423,40 @@ __global__ __launch_bounds__(256) void dist_fill_kernel(float* __restrict__ t, s
     if (i < n) t[i] = v;
 }
 
-// A workgroup takes 16 scene points and one (y, z) offset of their windows; 16 lanes walk a point's x row, so that a wavefront
-// touches 4 table lines per access instead of 64 (the first form, a thread per (point, row) walking x alone, took 0.46 ms at Cm for
-// what is 44 M cell visits: every access a 64-line gather).  Float arithmetic with the cell centre computed exactly as the scan
-// kernel computes it; the stored value is shortened by more than every rounding on the way.  Distances are non-negative floats,
-// whose bit patterns order like unsigned integers: an integer atomic minimum, tried only when the plain read is larger.
+// One wavefront per scene point: 16 lanes walk an x row of the point's window, the four quarter-waves take four (y, z) rows at a
+// time, so that an access touches 4 table lines instead of 64 and a point's set-up is done once.  Float arithmetic with the cell
+// centre computed exactly as the scan kernel computes it; the stored value is shortened by more than every rounding on the way.
+// Distances are non-negative floats, whose bit patterns order like unsigned integers: an integer atomic minimum, tried only when a
+// device-scope read is larger (a plain load may be served by this XCD's L2 with a value other XCDs have lowered long ago).
+// 0.23 ms at Cm (20 000 points x 2 197 cells: 44 M visits, 23 M inside the cap) -- and that is the memory-side atomic minima on
+// lines that ~20 points fight over at the same time, not the shape of the loop: a thread per (point, row) walking x alone took
+// 0.46 ms (64 lines per access), a workgroup per 16 points and row 0.24, this form 0.23, four reads in flight per lane 0.31.
 __global__ __launch_bounds__(256) void dist_splat_kernel(CullGeom G, float ox, float oy, float oz, float g, float cap, const float4* __restrict__ spos, int nS,
                                                          uint32_t* __restrict__ t) {
-    const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= nS) return;
+    const int lane = threadIdx.x & 63, xo0 = lane & 15, rsub = lane >> 4;
     const int side = 2 * G.w + 1;
-    const int oyc = (int)(blockIdx.y % (unsigned)side) - G.w, ozc = (int)(blockIdx.y / (unsigned)side) - G.w;
     const float4 p = spos[i];
-    const float inv_g = 1.0f / g;
-    const int ix = (int)floorf((p.x - ox) * inv_g), iy = (int)floorf((p.y - oy) * inv_g) + oyc, iz = (int)floorf((p.z - oz) * inv_g) + ozc;
-    if (iy < 0 || iy >= G.n[1] || iz < 0 || iz >= G.n[2]) return;
-    const float dy = p.y - (oy + ((float)iy + 0.5f) * g), dz = p.z - (oz + ((float)iz + 0.5f) * g);
-    const float dyz = dy * dy + dz * dz, cap2 = cap * cap;
-    if (dyz >= cap2) return;
-    const size_t row = ((size_t)iz * G.n[1] + iy) * G.n[0];
-    for (int xo = (int)(threadIdx.x & 15); xo < side; xo += 16) {
-        const int cx = ix - G.w + xo;
-        if (cx < 0 || cx >= G.n[0]) continue;
-        const float dx = p.x - (ox + ((float)cx + 0.5f) * g);
-        const float d2 = dx * dx + dyz;
-        if (d2 >= cap2) continue;
-        const float v = fmaxf(sqrtf(d2) * (1.0f - 2.0e-6f) - 1.0e-6f, 0.0f);
-        const uint32_t u = __float_as_uint(v);
-        if (u < t[row + cx]) atomicMin(&t[row + cx], u);
+    const float inv_g = 1.0f / g, cap2 = cap * cap;
+    const int ix = (int)floorf((p.x - ox) * inv_g), iy0 = (int)floorf((p.y - oy) * inv_g) - G.w, iz0 = (int)floorf((p.z - oz) * inv_g) - G.w;
+    for (int r = rsub; r < side * side; r += 4) {
+        const int iz = iz0 + r / side, iy = iy0 + r % side;
+        if (iy < 0 || iy >= G.n[1] || iz < 0 || iz >= G.n[2]) continue;
+        const float dy = p.y - (oy + ((float)iy + 0.5f) * g), dz = p.z - (oz + ((float)iz + 0.5f) * g);
+        const float dyz = dy * dy + dz * dz;
+        if (dyz >= cap2) continue;
+        const size_t row = ((size_t)iz * G.n[1] + iy) * G.n[0];
+        for (int xo = xo0; xo < side; xo += 16) {
+            const int cx = ix - G.w + xo;
+            if (cx < 0 || cx >= G.n[0]) continue;
+            const float dx = p.x - (ox + ((float)cx + 0.5f) * g);
+            const float d2 = dx * dx + dyz;
+            if (d2 >= cap2) continue;
+            const float v = fmaxf(sqrtf(d2) * (1.0f - 2.0e-6f) - 1.0e-6f, 0.0f);
+            const uint32_t u = __float_as_uint(v);
+            if (u < __hip_atomic_load(&t[row + cx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&t[row + cx], u);
+        }
     }
 }
 
@@ -493,8 +499,7 @@ int fill_cull_field(stocs_ctx* c) {
     G.n[0] = g.cg_nx; G.n[1] = g.cg_ny; G.n[2] = g.cg_nz; G.w = g.cg_w;
     const size_t n = (size_t)g.cg_nx * g.cg_ny * g.cg_nz;
     hipLaunchKernelGGL(dist_fill_kernel, dim3(grid_of(n)), dim3(256), 0, c->stream, g.d_dist, n, g.cg_cap);
-    const int side = 2 * g.cg_w + 1;
-    hipLaunchKernelGGL(dist_splat_kernel, dim3((unsigned)((c->nS + 15) / 16), (unsigned)(side * side)), dim3(256), 0, c->stream, G, g.cg_ox, g.cg_oy, g.cg_oz, g.cg_g, g.cg_cap,
+    hipLaunchKernelGGL(dist_splat_kernel, dim3((unsigned)((c->nS + 3) / 4)), dim3(256), 0, c->stream, G, g.cg_ox, g.cg_oy, g.cg_oz, g.cg_g, g.cg_cap,
                        c->d_spos, c->nS, (uint32_t*)g.d_dist);
     STOCS_HIP_CHECK(hipGetLastError());
     g.dist_ready = true;
