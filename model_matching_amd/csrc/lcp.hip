@@ -904,7 +904,9 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
     // instantiated with the order-independent tie rule may scan them
     const bool dense = c->grid.d_chunk_r != NULL;
     if (variant == 99)   // automatic; must not depend on the batch size (a candidate's score is batch-invariant)
-        variant = dense ? 39 : (c->grid.avg_list_len <= 10.0 ? 24 : 15);   // measured: tools/lcp_ab.py (Cm, C5; profiles/r03_C5_lcp_ab.json)
+        // (until the first half of round 3 sparse grids with more than 10 entries per list went to the per-step scan, variant 15; since the
+        //  queue kernel verifies with four lanes per query it wins there too: 50 000 / 12 500 points 3.54 -> 2.35 ms, tools/sweep_variants.py)
+        variant = dense ? 39 : 24;
     const bool dense_only = (variant >= 30 && variant <= 35) || variant == 39 || (variant >= 41 && variant <= 43);   // kernels with the order-independent tie rule / early exit
     if (dense && !(variant == 0 || variant == 16 || dense_only)) variant = 39;
     if (!dense && dense_only) variant = 24;
