@@ -874,9 +874,13 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
 #ifdef STOCS_TOOLS_BUILD
     a.ablate = getenv("STOCS_LCP_ABLATE") ? atoi(getenv("STOCS_LCP_ABLATE")) : 0;
 #endif
-    // big batches (the ordering costs ~50 us, the gain is ~10 % of a kernel time that grows with n * |M|): spatially ordered
-    // processing; scores do not depend on it
-    if (!d_hit && n >= 1024 && (double)n * (double)c->nM >= 1.5e8 && c->lcp_order) {
+    // big batches against scenes whose lists do not stay in the caches: spatially ordered processing (the ordering costs ~50 us; scores
+    // do not depend on it).  Until the first half of round 3 it paid at Cm too (1.67 -> 1.44 ms in round 1); with the four-lane verify
+    // trips it is a wash there (9 MB of lists: 1.115 ms either way at 65 536 candidates, +3 % at 32 768, +8 % for a 1 000-point model)
+    // and still worth 7-12 % from 20 MB of lists on (50 000-point scene 2.55 -> 2.38 ms, C5 6.53 -> 5.73): the threshold is 12 MB;
+    // lcp_order >= 2 orders whatever the size
+    const bool lists_spill = (double)c->grid.n_entries * 16.0 >= 12.0e6;
+    if (!d_hit && n >= 1024 && (double)n * (double)c->nM >= 1.5e8 && c->lcp_order && (lists_spill || c->lcp_order >= 2)) {
         const size_t kb = (((size_t)n * 4 + 255) / 256) * 256;
         size_t tb = 0;
         STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb, (uint32_t*)NULL, (uint32_t*)NULL, (int32_t*)NULL, (int32_t*)NULL, (size_t)n, 0, 24, c->stream));
