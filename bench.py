@@ -164,7 +164,7 @@ def main():
                              "`traffic` is what HBM really moved and `binding` is the unit that does bound the kernel, both from counters of this run",
                      "traffic": traffic, "binding": binding,
                      "traffic_over_algorithmic": (traffic / float(b_pose * kcand)) if traffic is not None else None,
-                     "kernel": "lcp_coopq_kernel behind stocs_score_transforms_device (kernel_ms includes the ~50 us candidate ordering in front of it)",
+                     "kernel": "lcp_coopq_kernel behind stocs_score_transforms_device (kernel_ms includes the ~50 us candidate ordering in front of it where the library orders: scenes with >= 12 MB of lists, i.e. C5, not Cm)",
                      "kernel_ms": k_ms, "kernel_timed_launches": reps,
                      "algorithmic_bytes_per_launch": b_pose * kcand,
                      "kernel_poses_per_s": kcand / (k_ms * 1e-3), "pmc": pmc_info},
