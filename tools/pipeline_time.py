@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Wall-clock timing of the whole hot path through the C ABI (index build, phases 1-4) on one workload.
-usage: python tools/pipeline_time.py [Cm|small|tiny|example:<name>] [seed] [reps]"""
+usage: python tools/pipeline_time.py [Cm|small|tiny|example:<name>] [seed] [reps] [base attempts per trial, default 100]"""
 import json
 import os
 import sys
@@ -30,6 +30,7 @@ def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "Cm"
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1234
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    attempts = int(sys.argv[4]) if len(sys.argv) > 4 else 100
     if name.startswith("example:"):
         d = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "example_%s.npz" % name.split(":")[1]))
         args = (d["scene_pos"], d["scene_nrm"], d["scene_prob"], d["scene_pixel"], d["model_pos"], d["model_nrm"])
@@ -46,7 +47,7 @@ def main():
     for r in range(reps):
         est.L.stocs_clear_bases(est.h)
         t0 = time.perf_counter()
-        valid, ids, inv = est.sample_bases(seed + r, 100)
+        valid, ids, inv = est.sample_bases(seed + r, attempts)
         t1 = time.perf_counter()
         nq = est.find_congruent_all()
         t2 = time.perf_counter()
