@@ -900,7 +900,13 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
         best_zeroed = true;
         STOCS_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tb, keys, keys_s, vals, order, (size_t)n, 0, 24, c->stream));
         a.order = order;
-        a.xcd_blocks = c->lcp_order >= 2 ? (c->lcp_order == 2 ? 1 : c->lcp_order) : 0;
+        // XCD placement of the ordered list (lcp_candidate): 0 = workgroup i takes slot i, and the hardware deals consecutive workgroups to
+        // the eight XCDs in turn; k > 2 = an XCD takes runs of k consecutive slots, so that what is resident on it at one time (~250
+        // workgroups) comes from one or two stretches of the ordered list and shares list lines in ITS L2.  Pays only when the lists are
+        // far beyond the Infinity Cache: C5 (1.6 GB) 5.73 -> 5.38 ms with runs of 128 (96: 5.60, 160: 5.95, 256: 5.49, 512 and more: 6.3
+        // -- whole XCDs finish late), 65 536 candidates 20.6 -> 19.4; a 100 000-point scene (158 MB) 2.74 -> 2.98, 50 000 points 2.38 -> 2.50
+        const bool lists_huge = (double)c->grid.n_entries * 16.0 >= 512.0e6;
+        a.xcd_blocks = c->lcp_order >= 2 ? (c->lcp_order == 2 ? 1 : c->lcp_order) : (lists_huge ? 128 : 0);
     }
     if (d_best8 && !best_zeroed) STOCS_HIP_CHECK(hipMemsetAsync(d_best8, 0, 8, c->stream));
     int variant = c->lcp_variant >= 0 ? c->lcp_variant : lcp_variant();
