@@ -6,7 +6,7 @@
 // Mapping: one candidate transform per workgroup of four wavefronts, which take the candidate's 64-point steps in turn and
 // add their integer partial sums through LDS at the end (the only barrier); small models run one wavefront per candidate.
 // Several candidates per workgroup, and a model tile shared through LDS, were measured and lost.
-// The 3x4 transform is wave-uniform (scalar loads -> SGPRs).  A lane takes one Morton-sorted model
+// The 3x4 transform is wave-uniform (scalar loads -> SGPRs).  A lane takes one patch-ordered model
 // point per step: coalesced 16-byte loads, and the 64 queries of one step fall into a handful
 // of neighbouring grid cells, so the cell/list gathers of a wave share cache lines.
 // Per query: transform the point, locate its cell (one word of the flat cell table, or top -> brick -> cell word), scan that cell's
@@ -14,6 +14,10 @@
 // d^2 <= epsilon^2, then the 30-degree normal test as an exact threshold on the dot product, and an
 // integer (2^32 fixed-point) sum of the class-probability weights.  No atomics: results are run-to-run
 // deterministic and do not depend on the batch or on how the points are split over wavefronts.
+// The queue-fed kernel (lcp_coopq_kernel, the automatic choice) first rules out whole 64-point steps whose bounding
+// sphere is out of reach of the scene (patch test, one look-up in a distance field of the scene), collects the
+// queries that survive the sub-cell mask in a per-wave LDS ring and verifies them 16 at a time, four lanes per query
+// with two entries of a 128-byte list line each.
 //
 // Roofline: HBM-read model, algorithmic bytes 68 + 52*|M| per pose.
 #include <stdlib.h>
@@ -30,7 +34,7 @@
 namespace stocs {
 
 struct LcpArgs {
-    const float4* mpos;   // Morton-sorted centred model positions
+    const float4* mpos;   // centred model positions in patch order (ctx.hip), NaN-padded to whole 64-point steps + one
     const float4* mnrm;
     const int32_t* mperm; // sorted slot -> original model index (detail output only)
     int M;
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
     __shared__ float4 qt[WPB][128];     // qx, qy, qz, bits(list offset)
     __shared__ float qcd[EARLY ? WPB : 1][EARLY ? 128 : 1];   // |query - cell centre| (EARLY)
     __shared__ uint32_t qn[WPB][128];   // list length
-    __shared__ uint32_t qs[WPB][128];   // model slot (Morton order)
+    __shared__ uint32_t qs[WPB][128];   // model slot (patch order)
     __shared__ int ri[WPB][128];        // best scene index
     __shared__ uint8_t ord[WPB][64];    // batch order sorted by list length (SORTQ)
     __shared__ unsigned long long part[WPB];

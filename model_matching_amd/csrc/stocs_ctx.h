@@ -206,7 +206,7 @@ struct stocs_ctx {
     std::vector<int32_t> h_spix;      // row, col
     stocs::V3 centroid_scene, centroid_model, gcenter;
     float ratio;
-    std::vector<int32_t> h_mperm;     // Morton order of the model used by the LCP kernel
+    std::vector<int32_t> h_mperm;     // patch order of the model used by the LCP kernel (sorted slot -> model index)
 
     // device clouds
     char* d_scene_mem; size_t scene_cap;   // one grow-only slab for the three scene arrays below (a new frame reuses it)
@@ -217,7 +217,7 @@ struct stocs_ctx {
     float4* d_mnrm;
     float4* d_munit;   // unit-cube model (pairCreationFunctor.h:96-132)
     float4* d_mpos_raw;  // un-shifted model positions (index build)
-    float4* d_mpos_s;  // Morton-sorted copies for the LCP kernel
+    float4* d_mpos_s;  // copies in patch order for the LCP kernel (positions NaN-padded to whole 64-point steps + one)
     float4* d_mnrm_s;
     int32_t* d_mperm;
     float4* d_mpatch;  // per 64-point step of the sorted model: bounding sphere (centre xyz, radius) of its points (patch test, lcp.hip)
