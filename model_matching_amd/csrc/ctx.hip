@@ -127,10 +127,17 @@ static void free_grid(stocs_ctx* c) {   // the grid lives in c->grid_mem, which 
     c->grid.d_dist = NULL; c->grid.dist_ready = false;
 }
 
-// one build at cell edge eps / div; lists longer than 16 on average get the centre-sorted layout + chunk bounds
-static int build_grid_once(stocs_ctx* c, int div) {
+// One build at cell edge eps / div.  At eps the index-ordered lists with the flat cell table and the sub-cell masks (the sparse
+// layout); finer grids have neither, and the centre-sorted lists with early exit (the dense layout) win there whatever the list
+// length (65 000-point scene at eps/2: 1.53 ms against 1.99 for index-ordered lists of 13 entries; tools/layout_sweep.py).
+// last_resort: eps is final although its lists are long (the finer grid does not fit): centre-sorted there too.
+static int build_grid_once(stocs_ctx* c, int div, bool last_resort = false) {
+    // STOCS_GRID_DENSE (measurement switch, tools/layout_sweep.py): 0 = index-ordered lists whatever their length, 1 = centre-sorted always
+    const char* force = getenv("STOCS_GRID_DENSE");
+    if (force) return build_grid_gpu(c, div, atoi(force) == 1 ? 1 : 0);
+    if (div > 1) return build_grid_gpu(c, div, 1);
     int rc = build_grid_gpu(c, div, 0);
-    if (rc || c->grid.avg_list_len <= 16.0) return rc;
+    if (rc || !last_resort || c->grid.avg_list_len <= 16.0) return rc;
     free_grid(c);
     return build_grid_gpu(c, div, 1);
 }
@@ -139,19 +146,22 @@ static int build_grid_levels(stocs_ctx* c) {
     int div = c->grid_div;
     const char* e = getenv("STOCS_GRID_DIV");
     if (e) div = atoi(e);
-    int rc = build_grid_once(c, div);
-    if (rc || e || c->grid_div != 1) return rc;
+    const bool fixed = e || c->grid_div != 1;
+    int rc = build_grid_once(c, div, fixed);
+    if (rc || fixed) return rc;
     for (int next = 2; next <= 4; next *= 2) {
-        // stop when the lists are short, or when the finer grid would not fit comfortably (entries x ~8, 16 B each)
-        // (measured, profiles/r01_sweep.json: 100k points, 20 per list at eps/2 -> eps/4 is 10 % slower; 200k points, 39 per
-        // list -> eps/4 is 20 % faster: the second halving needs lists well beyond the first threshold)
-        if (c->grid.avg_list_len <= (next == 2 ? 16.0 : 28.0) || c->grid.n_entries * 8 >= ((int64_t)1 << 29)) break;
+        // Stop when the lists are short, or when the finer grid would not fit comfortably (entries x ~8, 16 B each).  Thresholds
+        // (second half of round 3, tools/layout_sweep.py, 16 384-32 768 candidates; entries per non-empty list at the coarser edge):
+        //   eps -> eps/2 from 12.5 on: 10.2: 1.22 (eps) vs 1.24 ms (eps/2); 12.5: 1.68 vs 1.64; 15.8: 2.40 vs 2.14;
+        //   eps/2 -> eps/4 from 18 on: 13.1: 1.51 (eps/2) vs 1.68 (eps/4); 16.2: 2.08 vs 2.09; 20.9: 2.73 vs 2.60; 140 000 points: 4.39 vs 3.76
+        // (rounds 1-3a: 16 and 28, with the sparse layout kept at eps/2 for lists up to 16 entries)
+        if (c->grid.avg_list_len <= (next == 2 ? 12.5 : 18.0) || c->grid.n_entries * 8 >= ((int64_t)1 << 29)) break;
         const int prev = next / 2;
         free_grid(c);
         rc = build_grid_once(c, next);
         if (rc == STOCS_ERR_INVALID) {   // the finer grid does not fit the 32-bit list offsets: stay with the coarser one
             free_grid(c);
-            rc = build_grid_once(c, prev);
+            rc = build_grid_once(c, prev, true);
             break;
         }
         if (rc) return rc;
