@@ -38,11 +38,18 @@ STOCS_HD void quat_from_z(V3 n, float q[4]) {
     const V3 v1 = normalized3(n);
     float c = dot3(v1, v0);
     if (c < -1.0f + 1e-5f) {
-        // Eigen picks the axis from an SVD here; bit-exact restatement is impossible, axis (1,0,0) is used
+        // Eigen takes the axis from an SVD here (Quaternion.h: the right-singular vector of the 2x3 matrix [v0; v1] that belongs to
+        // the vanishing singular value, i.e. the unit vector orthogonal to both).  Restated as what that vector IS -- normalize(v0 x v1),
+        // signed so that the rotation by acos(c) about it takes v0 to v1; (1,0,0) when the two are exactly opposite and every vector
+        // orthogonal to v0 qualifies.  The sign the library's Jacobi sweeps would leave on it, and its choice in the exactly opposite
+        // case, cannot be pinned without the library (parity unpinned; the case has probability ~1e-5 per query normal).
         c = c > -1.0f ? c : -1.0f;
         const float w2 = (1.0f + c) * 0.5f;
         const float s = stocs_sqrtf(1.0f - w2);
-        q[0] = 1.0f * s; q[1] = 0.0f * s; q[2] = 0.0f * s; q[3] = stocs_sqrtf(w2);
+        const V3 x = cross3(v0, v1);
+        const float x2 = dot3(x, x);
+        const V3 ax = x2 > 0.0f ? x / stocs_sqrtf(x2) : mk3(1.0f, 0.0f, 0.0f);
+        q[0] = ax.x * s; q[1] = ax.y * s; q[2] = ax.z * s; q[3] = stocs_sqrtf(w2);
         return;
     }
     const V3 axis = cross3(v0, v1);

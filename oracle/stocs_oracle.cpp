@@ -661,12 +661,17 @@ struct NormalSet {
         V3 v1 = normalized(n);
         float c = dot(v1, v0);
         if (c < -1.0f + 1e-5f) {
-            // Eigen falls back to an SVD to pick a perpendicular axis; unrestatable bit-for-bit.
-            // Use axis (1,0,0): rotation by ~pi about x.  (probability ~1e-5 per query; documented)
+            // Eigen falls back to an SVD here: the axis is the right-singular vector of [v0; v1] for the vanishing singular value,
+            // i.e. the unit vector orthogonal to both = normalize(v0 x v1) (signed so that the rotation takes v0 to v1); (1,0,0) when
+            // they are exactly opposite.  The sign and the degenerate choice of the library's own SVD are unpinned (Eigen absent);
+            // probability ~1e-5 per query normal
             c = std::max(c, -1.0f);
             float w2 = (1.0f + c) * 0.5f;
             float s = sqrtf(1.0f - w2);
-            q[0] = 1.0f * s; q[1] = 0.0f * s; q[2] = 0.0f * s; q[3] = sqrtf(w2);
+            V3 x = cross(v0, v1);
+            float x2 = dot(x, x);
+            V3 ax = x2 > 0.0f ? x / sqrtf(x2) : mk(1.0f, 0.0f, 0.0f);
+            q[0] = ax.x * s; q[1] = ax.y * s; q[2] = ax.z * s; q[3] = sqrtf(w2);
             return;
         }
         V3 axis = cross(v0, v1);
