@@ -255,15 +255,17 @@ int stocs_icp_point_to_plane(const float* src_pos3, int nsrc, const float* tgt_p
                              int* n_correspondences);
 
 /* ---- tuning knobs (never change results beyond float summation order).
- * "lcp_variant": 99 = automatic (default): cooperative 8-lane scan fed from an LDS queue for scenes with short
- *   candidate lists (24), cooperative scan with 4 list lines in flight for medium lists (15), centre-sorted lists with
- *   triangle-inequality early exit for dense scenes (31); 0 = plain lane-per-query scan (independent cross-check).
- *   Every selectable kernel returns the reference's scores; any other value is STOCS_ERR_INVALID.
+ * "lcp_variant": 99 = automatic (default): the scan fed from a per-wavefront LDS queue of the queries that have a list -- over
+ *   index-ordered lists at cell edge epsilon (24, sparse scenes), over centre-sorted lists with triangle-inequality early exit
+ *   at epsilon/2 or epsilon/4 (39, dense scenes); selectable cross-checks: 15 and 31 (the per-step cooperative scans of rounds
+ *   1-2 over the same two layouts) and 0 (plain lane-per-query scan).  Every selectable kernel returns the reference's scores;
+ *   any other value is STOCS_ERR_INVALID.
  * "lcp_flat": 1 (default) = sparse scenes address a flat copy of the cell table (one look-up per query), 0 = brick look-ups.
  * "lcp_split": 1 (default) = four wavefronts share a candidate's model points, 0 = one wavefront per candidate.  Scores are
  *   accumulated as integers, so neither option changes a single bit of them.
- * "lcp_order": 0 = candidates in batch order, 1 (default) = big batches are processed in a spatial order of their
- *   translations (scores are bitwise independent of it), >= 2 = XCD-blocked variants of that order.
+ * "lcp_order": 0 = candidates in batch order, 1 (default) = big batches against scenes whose lists do not stay in the caches
+ *   are processed in a spatial order of their translations (scores are bitwise independent of it), >= 2 = always ordered, in
+ *   XCD-blocked variants of that order (k > 2: runs of k consecutive slots per XCD).
  * "lcp_cull": the patch test of the queue-fed scoring kernels.  The reference walks every model point of every candidate
  *   (stocs.cpp:1016-1035); a 64-point step of the model whose bounding sphere, under the candidate transform, is farther
  *   than epsilon from every scene point cannot add to the score and is skipped after one look-up in a distance field of

@@ -820,10 +820,10 @@ __global__ __launch_bounds__(256) void order_keys_kernel(const float* __restrict
     vals[i] = i;
 }
 
-// Kernel selection.  The product library ships the kernels the automatic choice uses (24: cooperative scan fed from an
-// LDS queue, sparse scenes; 15: cooperative scan, 4 lines in flight, medium lists; 31: centre-sorted lists with early
-// exit, dense scenes) plus the plain lane-per-query kernel (0) as an independent cross-check; every one of them returns
-// the reference's scores.  The other measured variants (profiles/r01_lcp_analysis.md) exist only in a tools build
+// Kernel selection.  The product library ships the kernels the automatic choice uses (24: scan fed from an LDS queue over
+// index-ordered lists, sparse scenes; 39: the same over centre-sorted lists with early exit, dense scenes) plus the per-step
+// cooperative scans of rounds 1-2 (15, 31) and the plain lane-per-query kernel (0) as independent cross-checks; every one of
+// them returns the reference's scores.  The other measured variants (profiles/r01_lcp_analysis.md) exist only in a tools build
 // (make tools -> libstocs_hip_tools.so, -DSTOCS_TOOLS_BUILD), which also honours the STOCS_LCP_VARIANT environment variable.
 static bool lcp_variant_selectable(int v) {
     if (v == 99 || v == 0 || v == 15 || v == 24 || v == 31 || v == 39) return true;
