@@ -281,6 +281,10 @@ int stocs_set_option(stocs_ctx* ctx, const char* key, int value);
  * down, capped.  NULL outputs are skipped; *n_patches and *n_dist are always set (0 when the context has no field). */
 int stocs_get_cull_state(stocs_ctx* ctx, float* patches4, int32_t* perm, int* n_patches, float* geom8, float* dist,
                          int64_t dist_cap, int64_t* n_dist);
+/* The model-side half of that test without a context or a device (host code: what stocs_ctx_create computes): the order in
+ * which the scoring kernels walk the model -- perm[slot] = model index, 64 consecutive slots = one compact surface patch --
+ * and the bounding sphere of every patch (centre x, y, z in the CENTRED model frame, radius), ceil(nM / 64) of them. */
+int stocs_model_patch_order(const float* model_pos3, int nM, int32_t* perm, float* patches4);
 
 /* ---- stream / timing plumbing ---- */
 /* run the context's work on a caller-owned HIP stream (e.g. PyTorch's current stream, so that RCCL

@@ -96,6 +96,7 @@ SIGNATURES = {
     "stocs_last_call_timing": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.c_int, _intp]),
     "stocs_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "stocs_get_cull_state": (C.c_int, [_vp, _fp, _ip, _intp, _fp, _fp, C.c_int64, _i64p]),
+    "stocs_model_patch_order": (C.c_int, [_fp, C.c_int, _ip, _fp]),
     "stocs_set_stream": (C.c_int, [_vp, _vp]),
     "stocs_best_device_async": (C.c_int, [_vp, _vp, C.c_int, C.c_uint32, _vp]),
     "stocs_score_best_device_async": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_uint32, _vp]),

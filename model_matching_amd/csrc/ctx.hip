@@ -276,6 +276,88 @@ static int load_scene(stocs_ctx* c, const float* sp, const float* sn, const floa
     return rc;
 }
 
+// Order of the centred model for the scan kernels and the bounding sphere of every 64-point step (host only: no device involved;
+// stocs_model_patch_order exposes it to the CPU tests).  mpos: centred positions, munit: unit-cube positions (Morton order only).
+static void model_patch_order(const std::vector<V3>& mpos, const std::vector<V3>& munit, std::vector<int32_t>& perm, std::vector<float4>& patch, float* r_ref) {
+    const int nM = (int)mpos.size();
+    // Order of the centred model for the LCP kernel: 64 consecutive points = one step of a wavefront = one compact surface patch
+    // (spatially coherent look-ups, and a small bounding sphere for the patch test).  Median splits along the longest axis with
+    // the left part a multiple of 64 points: every leaf is one step, neighbouring leaves are neighbouring patches.
+    // (Rounds 1-2 used the Morton order of the unit-cube coordinates: patches of 25 mm radius in the median on the 5 000-point
+    // model against 19 mm here; STOCS_MODEL_ORDER=morton keeps it selectable for the A/B.)
+    perm.resize(nM);
+    std::iota(perm.begin(), perm.end(), 0);
+    if (getenv("STOCS_MODEL_ORDER") && !strcmp(getenv("STOCS_MODEL_ORDER"), "morton")) {
+        std::vector<uint32_t> code(nM);
+        for (int i = 0; i < nM; ++i) {
+            const V3 u = munit[i];
+            auto q10 = [](float v) { int k = (int)(v * 1024.0f); return (uint32_t)(k < 0 ? 0 : (k > 1023 ? 1023 : k)); };
+            code[i] = (part1by2(q10(u.z)) << 2) | (part1by2(q10(u.y)) << 1) | part1by2(q10(u.x));
+        }
+        std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return code[a] < code[b]; });
+    } else {
+        struct Range { int lo, hi; };
+        std::vector<Range> todo(1, Range{0, nM});
+        while (!todo.empty()) {
+            const Range r = todo.back(); todo.pop_back();
+            const int n = r.hi - r.lo;
+            if (n <= 64) continue;
+            float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
+            for (int k = r.lo; k < r.hi; ++k) {
+                const V3 q = mpos[perm[k]];
+                const float v[3] = {q.x, q.y, q.z};
+                for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], v[a]); mx[a] = std::max(mx[a], v[a]); }
+            }
+            int ax = 0;
+            for (int a = 1; a < 3; ++a) if (mx[a] - mn[a] > mx[ax] - mn[ax]) ax = a;
+            const int leaves = (n + 63) / 64, nl = (leaves / 2) * 64;   // >= 64, < n
+            auto coord = [&](int id) { const V3 q = mpos[id]; return ax == 0 ? q.x : (ax == 1 ? q.y : q.z); };
+            std::stable_sort(perm.begin() + r.lo, perm.begin() + r.hi, [&](int a, int b) { return coord(a) < coord(b); });
+            todo.push_back(Range{r.lo + nl, r.hi});
+            todo.push_back(Range{r.lo, r.lo + nl});
+        }
+    }
+    // bounding sphere per 64-point step (double arithmetic; centre = a few steps of Ritter's iteration towards the farthest point,
+    // radius = the exact maximum distance from that centre, rounded up)
+    const int n_patch = (nM + 63) / 64;
+    patch.assign((size_t)std::max(n_patch, 1), make_float4(0.f, 0.f, 0.f, 0.f));
+    {
+        std::vector<float> radii;
+        for (int s = 0; s < n_patch; ++s) {
+            const int lo = 64 * s, hi = std::min(nM, lo + 64);
+            double ctr[3] = {0, 0, 0};
+            for (int k = lo; k < hi; ++k) { const V3 q = mpos[perm[k]]; ctr[0] += q.x; ctr[1] += q.y; ctr[2] += q.z; }
+            for (int a = 0; a < 3; ++a) ctr[a] /= (double)(hi - lo);
+            auto farthest = [&](double* d_out) {
+                int best = lo; double bd = -1;
+                for (int k = lo; k < hi; ++k) {
+                    const V3 q = mpos[perm[k]];
+                    const double dx = q.x - ctr[0], dy = q.y - ctr[1], dz = q.z - ctr[2], d = dx * dx + dy * dy + dz * dz;
+                    if (d > bd) { bd = d; best = k; }
+                }
+                *d_out = sqrt(bd);
+                return best;
+            };
+            double rad = 0;
+            for (int it = 0; it < 64; ++it) {
+                const int f = farthest(&rad);
+                const V3 q = mpos[perm[f]];
+                const double step = 0.5 / (double)(it + 2);
+                ctr[0] += (q.x - ctr[0]) * step; ctr[1] += (q.y - ctr[1]) * step; ctr[2] += (q.z - ctr[2]) * step;
+            }
+            const float cf[3] = {(float)ctr[0], (float)ctr[1], (float)ctr[2]};
+            ctr[0] = cf[0]; ctr[1] = cf[1]; ctr[2] = cf[2];   // the radius belongs to the centre as stored
+            (void)farthest(&rad);
+            const float rf = (float)(rad * (1.0 + 1e-6) + 1e-7);
+            patch[s] = make_float4(cf[0], cf[1], cf[2], rf);
+            radii.push_back(rf);
+        }
+        std::sort(radii.begin(), radii.end());
+        *r_ref = radii.empty() ? 0.0f : radii[(size_t)((radii.size() - 1) * 0.8)];
+    }
+
+}
+
 }  // namespace stocs
 
 using namespace stocs;
@@ -396,81 +478,9 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
         for (int i = 0; i < nM; ++i) c->h_munit[i] = (c->h_mpos[i] - c->gcenter) / c->ratio + half;
     }
 
-    // Order of the centred model for the LCP kernel: 64 consecutive points = one step of a wavefront = one compact surface patch
-    // (spatially coherent look-ups, and a small bounding sphere for the patch test).  Median splits along the longest axis with
-    // the left part a multiple of 64 points: every leaf is one step, neighbouring leaves are neighbouring patches.
-    // (Rounds 1-2 used the Morton order of the unit-cube coordinates: patches of 25 mm radius in the median on the 5 000-point
-    // model against 19 mm here; STOCS_MODEL_ORDER=morton keeps it selectable for the A/B.)
-    c->h_mperm.resize(nM);
-    std::iota(c->h_mperm.begin(), c->h_mperm.end(), 0);
-    if (getenv("STOCS_MODEL_ORDER") && !strcmp(getenv("STOCS_MODEL_ORDER"), "morton")) {
-        std::vector<uint32_t> code(nM);
-        for (int i = 0; i < nM; ++i) {
-            const V3 u = c->h_munit[i];
-            auto q10 = [](float v) { int k = (int)(v * 1024.0f); return (uint32_t)(k < 0 ? 0 : (k > 1023 ? 1023 : k)); };
-            code[i] = (part1by2(q10(u.z)) << 2) | (part1by2(q10(u.y)) << 1) | part1by2(q10(u.x));
-        }
-        std::stable_sort(c->h_mperm.begin(), c->h_mperm.end(), [&](int a, int b) { return code[a] < code[b]; });
-    } else {
-        struct Range { int lo, hi; };
-        std::vector<Range> todo(1, Range{0, nM});
-        while (!todo.empty()) {
-            const Range r = todo.back(); todo.pop_back();
-            const int n = r.hi - r.lo;
-            if (n <= 64) continue;
-            float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
-            for (int k = r.lo; k < r.hi; ++k) {
-                const V3 q = c->h_mpos[c->h_mperm[k]];
-                const float v[3] = {q.x, q.y, q.z};
-                for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], v[a]); mx[a] = std::max(mx[a], v[a]); }
-            }
-            int ax = 0;
-            for (int a = 1; a < 3; ++a) if (mx[a] - mn[a] > mx[ax] - mn[ax]) ax = a;
-            const int leaves = (n + 63) / 64, nl = (leaves / 2) * 64;   // >= 64, < n
-            auto coord = [&](int id) { const V3 q = c->h_mpos[id]; return ax == 0 ? q.x : (ax == 1 ? q.y : q.z); };
-            std::stable_sort(c->h_mperm.begin() + r.lo, c->h_mperm.begin() + r.hi, [&](int a, int b) { return coord(a) < coord(b); });
-            todo.push_back(Range{r.lo + nl, r.hi});
-            todo.push_back(Range{r.lo, r.lo + nl});
-        }
-    }
-    // bounding sphere per 64-point step (double arithmetic; centre = a few steps of Ritter's iteration towards the farthest point,
-    // radius = the exact maximum distance from that centre, rounded up)
+    std::vector<float4> patch;
+    model_patch_order(c->h_mpos, c->h_munit, c->h_mperm, patch, &c->patch_r_ref);
     const int n_patch = (nM + 63) / 64;
-    std::vector<float4> patch((size_t)std::max(n_patch, 1));
-    {
-        std::vector<float> radii;
-        for (int s = 0; s < n_patch; ++s) {
-            const int lo = 64 * s, hi = std::min(nM, lo + 64);
-            double ctr[3] = {0, 0, 0};
-            for (int k = lo; k < hi; ++k) { const V3 q = c->h_mpos[c->h_mperm[k]]; ctr[0] += q.x; ctr[1] += q.y; ctr[2] += q.z; }
-            for (int a = 0; a < 3; ++a) ctr[a] /= (double)(hi - lo);
-            auto farthest = [&](double* d_out) {
-                int best = lo; double bd = -1;
-                for (int k = lo; k < hi; ++k) {
-                    const V3 q = c->h_mpos[c->h_mperm[k]];
-                    const double dx = q.x - ctr[0], dy = q.y - ctr[1], dz = q.z - ctr[2], d = dx * dx + dy * dy + dz * dz;
-                    if (d > bd) { bd = d; best = k; }
-                }
-                *d_out = sqrt(bd);
-                return best;
-            };
-            double rad = 0;
-            for (int it = 0; it < 64; ++it) {
-                const int f = farthest(&rad);
-                const V3 q = c->h_mpos[c->h_mperm[f]];
-                const double step = 0.5 / (double)(it + 2);
-                ctr[0] += (q.x - ctr[0]) * step; ctr[1] += (q.y - ctr[1]) * step; ctr[2] += (q.z - ctr[2]) * step;
-            }
-            const float cf[3] = {(float)ctr[0], (float)ctr[1], (float)ctr[2]};
-            ctr[0] = cf[0]; ctr[1] = cf[1]; ctr[2] = cf[2];   // the radius belongs to the centre as stored
-            (void)farthest(&rad);
-            const float rf = (float)(rad * (1.0 + 1e-6) + 1e-7);
-            patch[s] = make_float4(cf[0], cf[1], cf[2], rf);
-            radii.push_back(rf);
-        }
-        std::sort(radii.begin(), radii.end());
-        c->patch_r_ref = radii.empty() ? 0.0f : radii[(size_t)((radii.size() - 1) * 0.8)];
-    }
 
     int rc = STOCS_OK;
     {
@@ -499,6 +509,31 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     if (!rc && build_index) rc = build_ppf_index(c);
     if (rc) { stocs_ctx_destroy(c); return rc; }
     *out = c;
+    return STOCS_OK;
+}
+
+int stocs_model_patch_order(const float* model_pos3, int nM, int32_t* perm, float* patches4) {
+    if (!model_pos3 || nM <= 0 || !perm || !patches4) return STOCS_ERR_INVALID;
+    // centroid_shift and the unit cube exactly as stocs_ctx_create does them (stocs.cpp:943-964, pairCreationFunctor.h:96-132)
+    std::vector<V3> mpos(nM), munit(nM);
+    V3 cm = mk3(0, 0, 0);
+    for (int i = 0; i < nM; ++i) { mpos[i] = mk3(model_pos3[3 * i], model_pos3[3 * i + 1], model_pos3[3 * i + 2]); cm = cm + mpos[i]; }
+    cm = cm / (float)nM;
+    const float big = std::numeric_limits<float>::max() / 2;
+    V3 bmn = mk3(big, big, big), bmx = mk3(-big, -big, -big);
+    for (int i = 0; i < nM; ++i) {
+        mpos[i] = mpos[i] - cm;
+        const V3 q = mpos[i];
+        if (q.x < bmn.x) bmn.x = q.x; if (q.y < bmn.y) bmn.y = q.y; if (q.z < bmn.z) bmn.z = q.z;
+        if (q.x > bmx.x) bmx.x = q.x; if (q.y > bmx.y) bmx.y = q.y; if (q.z > bmx.z) bmx.z = q.z;
+    }
+    const V3 gcenter = bmn + ((bmx - bmn) / 2.0f), ext = bmx - bmn;
+    const float ratio = (float)std::max((double)ext.z + 0.001, std::max((double)ext.y + 0.001, (double)ext.x + 0.001));
+    for (int i = 0; i < nM; ++i) munit[i] = (mpos[i] - gcenter) / ratio + mk3(0.5f, 0.5f, 0.5f);
+    std::vector<int32_t> pm; std::vector<float4> patch; float r_ref = 0.0f;
+    model_patch_order(mpos, munit, pm, patch, &r_ref);
+    for (int i = 0; i < nM; ++i) perm[i] = pm[i];
+    for (int s = 0; s < (nM + 63) / 64; ++s) { patches4[4 * s] = patch[s].x; patches4[4 * s + 1] = patch[s].y; patches4[4 * s + 2] = patch[s].z; patches4[4 * s + 3] = patch[s].w; }
     return STOCS_OK;
 }
 

@@ -340,3 +340,38 @@ int main() {
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert int(out.stdout.split()[1]) > 70_000_000
+
+
+def test_model_patch_order_on_the_host(capi):
+    """The order in which the scoring kernels walk the model and the bounding spheres of its 64-point steps (ctx.hip, host code;
+    the patch test of lcp.hip relies on them): a permutation; every sphere contains its points (in the float-centred frame the
+    library scores in); the patches are compact (median radius well below the Morton order's); sizes that are not a multiple of 64."""
+    import ctypes as C
+    import os
+    from model_matching_amd import synth
+    L = capi.load()
+    for n in (5000, 1000, 130, 64, 63, 1):
+        m = synth.make_model(max(n, 400), seed=21 + n)
+        pos = np.ascontiguousarray(m.pos[:n], np.float32)
+        npat = (n + 63) // 64
+        def order():
+            perm = np.zeros(n, np.int32); pat = np.zeros((npat, 4), np.float32)
+            assert L.stocs_model_patch_order(pos.ctypes.data_as(capi._fp), n, perm.ctypes.data_as(capi._ip), pat.ctypes.data_as(capi._fp)) == 0
+            return perm, pat
+        perm, pat = order()
+        assert sorted(perm.tolist()) == list(range(n))
+        c = np.zeros(3, np.float32)
+        for p in pos:                                   # centroid_shift: sequential float sums (stocs.cpp:943-964)
+            c = (c + p).astype(np.float32)
+        cen = (pos - (c / np.float32(n)).astype(np.float32)).astype(np.float32).astype(np.float64)
+        for j in range(npat):
+            pts = cen[perm[64 * j: 64 * j + 64]]
+            assert np.linalg.norm(pts - pat[j, :3].astype(np.float64), axis=1).max() <= float(pat[j, 3]) + 1e-7
+        if n == 5000:
+            os.environ["STOCS_MODEL_ORDER"] = "morton"
+            try:
+                _, pat_m = order()
+            finally:
+                del os.environ["STOCS_MODEL_ORDER"]
+            assert np.median(pat[:, 3]) < 0.85 * np.median(pat_m[:, 3])
+            assert pat[:, 3].max() < 0.6 * pat_m[:, 3].max()
