@@ -137,3 +137,22 @@ def test_metric_size_bitwise_and_default_policy(oracle_lib):
     assert np.array_equal(moved.view(np.uint32), est.score_transforms(T[:8192]).view(np.uint32))
     # (the centred scene is the same cloud up to the float rounding of the shift: the scores stay close to the old ones)
     assert np.abs(moved - off[:8192]).max() < 0.05
+
+
+@pytest.mark.parametrize("name,n", [("Cm", 2048), ("C5", 256)])
+def test_step_lists_longer_than_one_ballot(name, n):
+    """A wavefront tests 64 steps per ballot: with one wavefront per candidate (lcp_split 0) the 79 steps of the Cm model take two
+    rounds, the 782 of the C5 model thirteen (four with the default four wavefronts per candidate).  Scores bitwise equal in
+    all four combinations of the split and the patch test."""
+    from model_matching_amd import synth
+    m, s, k, est, _, Tgt = _setup(name)
+    T = synth.make_candidates(Tgt, n)
+    outs = {}
+    for split in (1, 0):
+        for cull in (0, 2):
+            est.set_option("lcp_split", split); est.set_option("lcp_cull", cull)
+            outs[(split, cull)] = est.score_transforms(T)
+    base = outs[(1, 0)]
+    assert base.max() > 0.3
+    for key, v in outs.items():
+        assert np.array_equal(v.view(np.uint32), base.view(np.uint32)), key
