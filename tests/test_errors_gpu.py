@@ -212,3 +212,35 @@ def test_set_scene_and_workspace_calls_reject_bad_arguments():
     b = ingest_scene(depth, prob, (60.0, 32.0, 60.0, 24.0), 1e-4)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
     est.close()
+
+
+def test_patch_test_entry_points_reject_bad_arguments():
+    """stocs_get_cull_state / stocs_model_patch_order / the options behind the patch test and the verify trips: status codes, and a
+    model too small for the test (fewer than 64 points) simply has no distance field."""
+    from model_matching_amd import capi
+    L = capi.load()
+    m, s, est = _mk(build_index=False, n_scene=600, n_model=150)
+    npat, nd = C.c_int(-1), C.c_int64(-1)
+    assert L.stocs_get_cull_state(None, None, None, C.byref(npat), None, None, 0, C.byref(nd)) == -1
+    assert L.stocs_get_cull_state(est.h, None, None, None, None, None, 0, C.byref(nd)) == -1
+    assert L.stocs_get_cull_state(est.h, None, None, C.byref(npat), None, None, 0, C.byref(nd)) == 0
+    assert npat.value == 3 and nd.value > 0
+    small = np.zeros(8, np.float32)
+    assert L.stocs_get_cull_state(est.h, None, None, C.byref(npat), None, small.ctypes.data_as(capi._fp), 8, C.byref(nd)) == -4   # capacity
+    for key, bad in (("lcp_cull", 3), ("lcp_cull", -1), ("lcp_group", 3), ("lcp_group", 16), ("lcp_order", -1)):
+        assert L.stocs_set_option(est.h, key.encode(), bad) == -1, (key, bad)
+    for key, ok in (("lcp_cull", 0), ("lcp_cull", 2), ("lcp_group", 8), ("lcp_group", 4)):
+        assert L.stocs_set_option(est.h, key.encode(), ok) == 0, (key, ok)
+    est.close()
+    # fewer than 64 model points: no field, scoring works as ever
+    m2, s2, est2 = _mk(build_index=False, n_scene=600, n_model=40)
+    assert L.stocs_get_cull_state(est2.h, None, None, C.byref(npat), None, None, 0, C.byref(nd)) == 0 and nd.value == 0
+    est2.set_option("lcp_cull", 2)
+    T = np.eye(4, dtype=np.float32).reshape(1, 16)
+    assert est2.score_transforms(T).shape == (1,)
+    est2.close()
+    perm = np.zeros(10, np.int32); pat = np.zeros(4, np.float32); pos = np.zeros(30, np.float32)
+    assert L.stocs_model_patch_order(None, 10, perm.ctypes.data_as(capi._ip), pat.ctypes.data_as(capi._fp)) == -1
+    assert L.stocs_model_patch_order(pos.ctypes.data_as(capi._fp), 0, perm.ctypes.data_as(capi._ip), pat.ctypes.data_as(capi._fp)) == -1
+    assert L.stocs_model_patch_order(pos.ctypes.data_as(capi._fp), 10, perm.ctypes.data_as(capi._ip), pat.ctypes.data_as(capi._fp)) == 0
+    assert sorted(perm.tolist()) == list(range(10)) and pat[3] >= 0.0    # ten coincident points: a sphere of radius ~0
