@@ -22,11 +22,132 @@ import time
 # 1-3 (profiles/r03_stall_root_cause.json).  Must happen before numpy is imported.
 for _v in ("OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
     os.environ.setdefault(_v, "1")
+os.environ.setdefault("STOCS_PIN_BLAS", "1")   # harness side (importing the library itself has no side effects)
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+PEAK_HBM_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
+NEEDED_BYTES_PER_HIT = 28      # one nearest scene record: position 12 + normal 12 + class probability 4
+
+
+def kernel_record(est, dT, kcand, dL, reps, workload, candidates_arg, run_pmc, groups=None, prefix=""):
+    """Flat, scalar-only description of the dominant kernel for one workload -- everything a reader needs to recompute it:
+    * contract figure: ALGORITHMIC bytes (68 + 52 |M| per pose) / kernel time / HBM peak.  Not a ceiling on
+      cache-resident workloads: it charges a scene record to every model point and the model to every pose.
+    * needed bytes: what a pose cannot do without -- 64-byte transform in, 4-byte score out, and ONE 28-byte scene record per
+      model point that really has a neighbour within epsilon (hits counted by the kernel's own per-point detail form over the
+      whole batch, stocs_lcp_hit_count).  needed_frac = needed bytes / kernel time / HBM peak is <= 1 by construction and can be
+      recomputed from the kernel's average duration in profiles/r04_*_kernel_stats.csv.
+    * counters of THIS command (child rocprofv3 --pmc passes, tools/pmc.py): L2 memory-side bytes (FETCH_SIZE x2 + WRITE_SIZE; the
+      guide: Infinity-Cache hits are counted, so this is NOT pure HBM), L2 -> L1 bytes, unit utilisations, and the binding unit."""
+    b_pose = 68 + 52 * est.nM
+    k_ms = est.time_score_kernel(dT, kcand, dL, reps)
+    hits, counted = est.lcp_hit_count(dT, kcand)
+    needed = float(hits) * NEEDED_BYTES_PER_HIT + 68.0 * kcand
+    sec = k_ms * 1e-3
+    rec = {
+        "kernel_ms": k_ms, "kernel_timed_launches": reps, "kernel_poses_per_s": kcand / sec,
+        "nn_queries_per_s": kcand * float(est.nM) / sec,
+        "algorithmic_bytes_per_launch": float(b_pose) * kcand,
+        "contract_frac": float(b_pose) * kcand / sec / 1e9 / PEAK_HBM_GBS,
+        "hits_per_pose": hits / float(kcand), "hit_fraction_of_queries": hits / (float(kcand) * est.nM),
+        "counted_per_pose": counted / float(kcand),
+        "needed_bytes_per_launch": needed, "needed_frac": needed / sec / 1e9 / PEAK_HBM_GBS,
+        "memory_side_bytes_per_launch": None, "memory_side_frac": None, "traffic_over_needed": None, "traffic_over_algorithmic": None,
+        "l2_to_l1_bytes_per_launch_64B": None, "l2_to_l1_bytes_per_launch_128B": None, "l2_to_l1_frac_64B": None, "l2_to_l1_frac_128B": None,
+        "l2_hit_rate": None, "ta_busy_frac": None, "valu_issue_frac": None, "wave_wait_frac": None, "waves_per_simd_avg": None,
+        "binding_unit": None, "binding_frac": None,
+    }
+    nested = {"pmc": None, "binding": None}
+    if run_pmc:
+        add_counters(rec, nested, workload, candidates_arg, groups)
+    if prefix:
+        rec = {prefix + k: v for k, v in rec.items()}
+    return rec, nested
+
+
+def add_counters(rec, nested, workload, candidates_arg, groups=None):
+    """Counters of the command that produced `rec` (un-prefixed keys): child rocprofv3 --pmc passes of this script (tools/pmc.py)."""
+    import os, shutil, sys, tempfile
+    k_ms, needed, algorithmic = rec["kernel_ms"], rec["needed_bytes_per_launch"], rec["algorithmic_bytes_per_launch"]
+    sec = k_ms * 1e-3
+    try:
+        root = os.path.dirname(os.path.abspath(__file__))
+        sys.path.insert(0, os.path.join(root, "tools"))
+        import pmc as pmc_tool
+        if shutil.which("rocprofv3"):
+            pdir = tempfile.mkdtemp(prefix="stocs_pmc_")
+            child = ["python3", os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pipeline", "--no-pmc", "--no-c5",
+                     "--workload", workload] + (["--candidates", str(candidates_arg)] if candidates_arg else [])
+            grp = pmc_tool.GROUPS if not groups else type(pmc_tool.GROUPS)((g, pmc_tool.GROUPS[g]) for g in groups if g in pmc_tool.GROUPS)
+            raw = pmc_tool.collect("lcp_coop", child, pdir, groups=grp)
+            der = pmc_tool.derive(raw, k_ms)
+            shutil.rmtree(pdir, ignore_errors=True)
+            mem = der.get("hbm_bytes_per_launch")
+            if mem is not None:
+                rec["memory_side_bytes_per_launch"] = mem
+                rec["memory_side_frac"] = mem / sec / 1e9 / PEAK_HBM_GBS
+                rec["traffic_over_needed"] = mem / needed
+                rec["traffic_over_algorithmic"] = mem / algorithmic
+            l2b = der.get("l2_bytes_per_launch_64B_128B")
+            if l2b:
+                rec["l2_to_l1_bytes_per_launch_64B"], rec["l2_to_l1_bytes_per_launch_128B"] = l2b
+                rec["l2_to_l1_frac_64B"], rec["l2_to_l1_frac_128B"] = der["l2_bw_frac_64B_128B"]
+            for k in ("l2_hit_rate", "ta_busy_frac", "valu_issue_frac", "wave_wait_frac", "waves_per_simd_avg"):
+                rec[k] = der.get(k)
+            b = der.get("binding")
+            if b:
+                # the memory-side figure is named for what it is (the guide: FETCH_SIZE counts the L2's fabric requests, Infinity-Cache hits included)
+                name = {"hbm_fabric": "l2_memory_side"}.get(b["bound"], b["bound"])
+                rec["binding_unit"], rec["binding_frac"] = name, b["frac"]
+                nested["binding"] = dict(b, bound=name, all={{"hbm_fabric": "l2_memory_side"}.get(k, k): v for k, v in b["all"].items()})
+            nested["pmc"] = {"kernel": raw["kernel"], "passes": raw["passes"], "counters_per_launch": {k: v["per_launch_mean"] for k, v in raw["counters"].items()},
+                             "source": "rocprofv3 --pmc child runs of this command (tools/pmc.py), launched by this bench process"}
+        else:
+            nested["pmc"] = {"error": "rocprofv3 not found"}
+    except Exception as e:   # the bench line must not depend on the profiler
+        nested["pmc"] = {"error": repr(e)}
+
+
+def c5_leg(device, run_pmc, groups, launches=8, oracle_candidates=256):
+    """The one configuration whose lists do not stay in any cache (SURVEY 8d "C5": 200 000-point scene, 50 000-point model, 16 384
+    candidates): a few timed launches with the same record as Cm, and an oracle check of the first candidates."""
+    import numpy as np
+    from model_matching_amd import synth
+    from model_matching_amd.estimator import StocsEstimator
+    model, scene, kcand = synth.workload("C5")
+    est = StocsEstimator(scene.pos, scene.nrm, scene.prob, scene.pixel, model.pos, model.nrm, build_index=False, device=device)
+    cs = est.get_scene_centroid().astype(np.float64); cm = est.get_model_centroid().astype(np.float64)
+    T = synth.make_candidates(synth.centred_gt(scene.T_gt, cs, cm), kcand, seed=synth.SEED_CAND)
+    dT = est.dev_alloc(T.nbytes); dL = est.dev_alloc(kcand * 4)
+    est.dev_upload(dT, T)
+    lcp = np.zeros(kcand, np.float32)
+    for _ in range(3):      # warm: the patch test's distance field is filled once the scene has seen 1e9 point queries
+        est.score_device(dT, kcand, dL)
+    est.sync()
+    rec, nested = kernel_record(est, dT, kcand, dL, launches, "C5", 0, run_pmc, groups, prefix="c5_")
+    est.score_device(dT, kcand, dL)
+    est.dev_download(dL, lcp)
+    rec["c5_workload"] = "C5: synthetic %d-pt scene vs %d-pt model, %d candidate transforms per launch, eps=5mm" % (est.nS, est.nM, kcand)
+    try:
+        from oracle import pyoracle
+        pyoracle.build()
+        orc = pyoracle.Oracle(scene.pos, scene.nrm, scene.prob, scene.pixel, model.pos, model.nrm, build_index=False)
+        nth = max(1, min(16, len(os.sched_getaffinity(0))))
+        ref = orc.lcp_batch(T[:oracle_candidates], nthreads=nth)
+        d = np.abs(ref - lcp[:oracle_candidates])
+        rec["c5_oracle_candidates_compared"] = int(oracle_candidates)
+        rec["c5_oracle_max_abs_lcp_diff"] = float(d.max())
+        rec["c5_oracle_candidates_over_1e-5"] = int((d > 1e-5).sum())   # only exact-distance ties of the lattice-sampled scene (Q11) get here
+    except Exception as e:
+        rec["c5_oracle_error"] = repr(e)
+    est.dev_free(dT); est.dev_free(dL)
+    est.close()
+    return rec, nested
 
 
 def main():
@@ -40,6 +161,8 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="skip the untimed phases 1-4 report")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (roofline.traffic / binding become null)")
+    ap.add_argument("--no-c5", action="store_true", help="skip the C5 leg of the roofline record (200 000-point scene, 50 000-point model: the HBM-bound configuration)")
+    ap.add_argument("--pmc-groups", default="", help="comma-separated counter groups of tools/pmc.py for the live passes (default: all)")
     args = ap.parse_args()
 
     # --gpus N > 1 without a launcher around it: this process becomes the launcher of N rank children (before torch or the
@@ -131,11 +254,13 @@ def main():
         assert final_gid == i_chk and final_lcp == float(lcp[i_chk]), (final_gid, i_chk)
     b_pose = 68 + 52 * est.nM                      # algorithmic bytes per pose
     reps = max(5, min(args.steps, 400))
-    k_ms = est.time_score_kernel(dT, kcand, dL, reps)
-    achieved = b_pose * kcand / (k_ms * 1e-3) / 1e9   # GB/s
-    peak = 8000.0
     best_i = int(np.argmax(lcp))
-    traffic, binding, pmc_info = None, None, None
+    run_pmc = rank == 0 and world == 1 and not args.no_pmc
+    groups = [g for g in args.pmc_groups.split(",") if g] or None
+    krec, knest = kernel_record(est, dT, kcand, dL, reps, args.workload, args.candidates, False)   # (counters: after the pipeline section, below)
+    k_ms = krec["kernel_ms"]
+    achieved = b_pose * kcand / (k_ms * 1e-3) / 1e9   # GB/s
+    peak = PEAK_HBM_GBS
 
     out = {
         "metric": "candidate poses verified/sec",
@@ -157,17 +282,17 @@ def main():
         "rehearsal": rehearsal,
         "final_lcp_percent": float(final_lcp) * 100.0,
         "best_global_candidate_id": int(final_gid),
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-                     "frac_is_a_ceiling": False,
-                     "note": "SURVEY 8(d) contract figure: ALGORITHMIC bytes (68 + 52 |M| per pose) over the kernel time against the HBM peak. "
-                             "The working set (scene grid + model, a few MB) is cache resident, so this fraction is not bounded by 1; "
-                             "`traffic` is what HBM really moved and `binding` is the unit that does bound the kernel, both from counters of this run",
-                     "traffic": traffic, "binding": binding,
-                     "traffic_over_algorithmic": (traffic / float(b_pose * kcand)) if traffic is not None else None,
-                     "kernel": "lcp_coopq_kernel behind stocs_score_transforms_device (kernel_ms includes the ~50 us candidate ordering in front of it where the library orders: scenes with >= 12 MB of lists, i.e. C5, not Cm)",
-                     "kernel_ms": k_ms, "kernel_timed_launches": reps,
-                     "algorithmic_bytes_per_launch": b_pose * kcand,
-                     "kernel_poses_per_s": kcand / (k_ms * 1e-3), "pmc": pmc_info},
+        "roofline": dict({"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+                          "frac_is_a_ceiling": False, "traffic": None,
+                          "note": "achieved / frac: the SURVEY 8(d) contract figure -- ALGORITHMIC bytes (68 + 52 |M| per pose) over the kernel time against the "
+                                  "HBM peak; it charges a 28-byte scene record to every model point and the model to every pose, so on a cache-resident "
+                                  "workload it is not bounded by 1.  The physical numbers are the flat keys next to it: needed_* (transform + score + one "
+                                  "28-byte record per model point that has a neighbour; needed_frac <= 1, recomputable from the kernel's average duration), "
+                                  "memory_side_* (FETCH_SIZE x2 + WRITE_SIZE of this run: the L2's memory-side requests, Infinity-Cache hits included), "
+                                  "l2_to_l1_*, the unit utilisations and binding_unit / binding_frac = the busiest unit.  `bound` names that unit once the "
+                                  "counters are in (else the contract's \"hbm\"); c5_* is the same record for the one workload whose lists leave the caches",
+                          "kernel": "lcp_coopq_kernel behind stocs_score_transforms_device (kernel_ms includes the ~50 us candidate ordering in front of it where the library orders: scenes with >= 12 MB of lists, i.e. C5, not Cm)"},
+                         **krec),
     }
 
     # what the collective saw: every rank reports itself through the same backend (evidence that RCCL ran with N ranks)
@@ -241,36 +366,25 @@ def main():
         pe.close()
 
     # Counters of THIS run: the same command is re-run under rocprofv3 (child processes, one --pmc pass per counter group,
-    # a few steps each) and the LCP kernel's per-launch means come back; HBM traffic as the guide prescribes (FETCH_SIZE x2 +
-    # WRITE_SIZE on gfx950), and the utilisation of the units that can actually bound a cache-resident kernel.
-    if rank == 0 and world == 1 and not args.no_pmc:
+    # a few steps each) and the LCP kernel's per-launch means come back: memory-side traffic as the guide prescribes (FETCH_SIZE x2 +
+    # WRITE_SIZE on gfx950) and the utilisation of the units that can actually bound a cache-resident kernel.
+    if run_pmc:
+        add_counters(krec, knest, args.workload, args.candidates, groups)
+        out["roofline"].update(krec)
+        out["roofline"]["traffic"] = krec["memory_side_bytes_per_launch"]
+        if krec["binding_unit"]:
+            out["roofline"]["bound"] = krec["binding_unit"]
+        out["roofline"]["binding"] = knest["binding"]
+        out["roofline"]["pmc"] = knest["pmc"]
+    # the same record on C5 (the configuration where the memory side IS the bound): flat c5_* keys in the same object
+    if rank == 0 and world == 1 and not args.no_c5 and args.workload == "Cm":
         try:
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            import pmc as pmc_tool
-            import shutil
-            import tempfile
-            if shutil.which("rocprofv3"):
-                pdir = tempfile.mkdtemp(prefix="stocs_pmc_")
-                child = ["python3", os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pipeline", "--no-pmc",
-                         "--workload", args.workload] + (["--candidates", str(args.candidates)] if args.candidates else [])
-                raw = pmc_tool.collect("lcp_coop", child, pdir)
-                der = pmc_tool.derive(raw, k_ms)
-                traffic = der.get("hbm_bytes_per_launch")
-                binding = der.get("binding")
-                pmc_info = {"kernel": raw["kernel"], "passes": raw["passes"], "derived": {k: v for k, v in der.items() if k != "binding"},
-                            "counters_per_launch": {k: v["per_launch_mean"] for k, v in raw["counters"].items()},
-                            "source": "rocprofv3 --pmc child runs of this command (tools/pmc.py), launched by this bench process"}
-                shutil.rmtree(pdir, ignore_errors=True)
-            else:
-                pmc_info = {"error": "rocprofv3 not found"}
-        except Exception as e:   # the bench line must not depend on the profiler
-            pmc_info = {"error": repr(e)}
-
-    if pmc_info is not None:
-        out["roofline"]["traffic"] = traffic
-        out["roofline"]["binding"] = binding
-        out["roofline"]["traffic_over_algorithmic"] = (traffic / float(b_pose * kcand)) if traffic is not None else None
-        out["roofline"]["pmc"] = pmc_info
+            c5rec, c5nest = c5_leg(local_rank, run_pmc, groups or ["fetch", "write", "mem"])
+            out["roofline"].update(c5rec)
+            out["roofline"]["c5_binding"] = c5nest["binding"]
+            out["roofline"]["c5_pmc"] = c5nest["pmc"]
+        except Exception as e:   # the Cm line must not depend on the second workload
+            out["roofline"]["c5_error"] = repr(e)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the oracle (single-threaded restatement of the reference's kd-tree LCP) on a

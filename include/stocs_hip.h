@@ -177,6 +177,11 @@ int stocs_score_best_device(stocs_ctx* ctx, const void* d_T16, int n, void* d_lc
 int stocs_score_best_device_async(stocs_ctx* ctx, const void* d_T16, int n, void* d_lcp, uint32_t id_offset, void* d_key8);
 /* per model point: index of the matched scene point (-1 none) and whether it was counted */
 int stocs_lcp_detail(stocs_ctx* ctx, const float* T16_centred_host, int32_t* hit, uint8_t* counted);
+/* measurement aid (bench.py's `needed_bytes_per_launch`; no reference counterpart): over n device-resident transforms, the number of
+ * (candidate, model point) queries of stocs.cpp:1016-1024 that found a scene point within epsilon (*hits: the nearest-neighbour
+ * records a pose really needs, 28 bytes each) and how many of those passed the normal test of :1028-1032 (*counted, may be NULL).
+ * Runs the per-point detail form of the scoring kernel in chunks; synchronises. */
+int stocs_lcp_hit_count(stocs_ctx* ctx, const void* d_T16, int n, int64_t* hits, int64_t* counted);
 /* compute_best_transform (stocs.cpp:982-1004): score every stored candidate, arg-max with first
  * maximum winning; best_idx = -1 and best_lcp = 0 when every score is 0 */
 int stocs_verify_all(stocs_ctx* ctx, float* best_lcp, int* best_idx, float* best_pose16_camera);
@@ -212,7 +217,7 @@ enum {
     /* surface normals of the depth image, rgbd.cpp:199-205 (cv::rgbd::RgbdNormals, RGBD_NORMALS_METHOD_LINEMOD on the raw
      * 16-bit depth image).  0: the published method restated -- Hinterstoisser et al., "Gradient Response Maps for Real-Time
      * Detection of Texture-Less Objects", PAMI 2012, section 2.4: least-squares depth gradient over the 8 neighbours at
-     * +-5 pixels whose depth differs from the centre by at most 50 raw units, normal of the tangent plane through the three
+     * +-5 pixels whose depth differs from the centre by less than 50 raw units, normal of the tangent plane through the three
      * back-projected points X, X(x+1), X(y+1), oriented toward the camera; integer sums, float normal.  Parity with OpenCV's
      * implementation is UNPINNED (library absent): patch, threshold and arithmetic follow the paper and the library's
      * documented defaults.  1: the least-squares plane over the 5x5 window of rounds 1-2 (tests/golden/example_*.npz hold its clouds) */
@@ -257,9 +262,9 @@ int stocs_icp_point_to_plane(const float* src_pos3, int nsrc, const float* tgt_p
 /* ---- tuning knobs (never change results beyond float summation order).
  * "lcp_variant": 99 = automatic (default): the scan fed from a per-wavefront LDS queue of the queries that have a list -- over
  *   index-ordered lists at cell edge epsilon (24, sparse scenes), over centre-sorted lists with triangle-inequality early exit
- *   at epsilon/2 or epsilon/4 (39, dense scenes); selectable cross-checks: 15 and 31 (the per-step cooperative scans of rounds
- *   1-2 over the same two layouts) and 0 (plain lane-per-query scan).  Every selectable kernel returns the reference's scores;
- *   any other value is STOCS_ERR_INVALID.
+ *   at epsilon/2 or epsilon/4 (39, dense scenes); selectable cross-checks: 31 (the per-step cooperative scan of round 2 over the
+ *   centre-sorted lists) and 0 (plain lane-per-query scan).  Every selectable kernel returns the reference's scores; any other
+ *   value is STOCS_ERR_INVALID (the variants that lost their A/B runs exist in the measurement build only: make tools).
  * "lcp_flat": 1 (default) = sparse scenes address a flat copy of the cell table (one look-up per query), 0 = brick look-ups.
  * "lcp_split": 1 (default) = four wavefronts share a candidate's model points, 0 = one wavefront per candidate.  Scores are
  *   accumulated as integers, so neither option changes a single bit of them.
@@ -271,8 +276,9 @@ int stocs_icp_point_to_plane(const float* src_pos3, int nsrc, const float* tgt_p
  *   than epsilon from every scene point cannot add to the score and is skipped after one look-up in a distance field of
  *   the scene.  0 = off, 1 (default) = on once the field pays (1e9 candidates x model points scored against the scene so
  *   far: the field costs ~0.25 ms per scene and takes ~6 % off a launch), 2 = from the first call.  Same scores, bitwise.
- * "lcp_group": lanes that verify one queued query together in the queue-fed kernels: 4 (default; two entries of a 128-byte
- *   list line per lane, sixteen queries per trip) or 8 (one entry per lane, the form of rounds 1-3).  Same scores. ---- */
+ * "lcp_group": lanes that verify one queued query together in the queue-fed kernels: 4 (two entries of a 128-byte list line per
+ *   lane, sixteen queries per trip).  The only value of the product library (8, one entry per lane, is the form of rounds 1-3a
+ *   and lives in the measurement build). ---- */
 int stocs_set_option(stocs_ctx* ctx, const char* key, int value);
 /* Diagnostics of that patch test (tests only; no reference counterpart).  patches4: n_patches x (centre x, y, z, radius) in the
  * centred model frame, one per 64 consecutive slots of the sorted model; perm: sorted slot -> model index (|M| entries);

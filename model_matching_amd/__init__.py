@@ -9,12 +9,14 @@ library raises.
 __all__ = ["capi", "estimator", "synth"]
 
 
-def _pin_host_thread_pools():
-    """The Python side of this package (test harness, bench, tools) does a few tiny numpy calls between GPU calls.  On the GPU
-    boxes a process sees 256 CPUs while its cgroup has a CPU quota of 16: OpenBLAS sizes its worker pool by the former, the
+def pin_host_thread_pools():
+    """For harnesses (tests, bench.py, tools/): the Python side around the library does a few tiny numpy calls between GPU calls.  On
+    the GPU boxes a process sees 256 CPUs while its cgroup has a CPU quota of 16: OpenBLAS sizes its worker pool by the former, the
     spinning workers exhaust the latter, and the kernel freezes the WHOLE process for the rest of a 100 ms scheduler period --
-    the sporadic 65-80 ms pause of rounds 1-3 (profiles/r03_stall_root_cause.json).  One BLAS thread is plenty here.
-    STOCS_KEEP_BLAS_THREADS=1 leaves the pools alone (tools/stall_watch.py reproduces the pause that way)."""
+    the sporadic 65-80 ms pause of rounds 1-3 (profiles/r03_stall_root_cause.json).  One BLAS thread is plenty there.
+    Importing the package does NOT do this by itself (a host application keeps its BLAS pools): a harness opts in by calling this
+    function or by setting STOCS_PIN_BLAS=1 before the import; STOCS_KEEP_BLAS_THREADS=1 overrides both (tools/stall_watch.py
+    reproduces the pause that way)."""
     import os
     if os.environ.get("STOCS_KEEP_BLAS_THREADS") == "1":
         return
@@ -27,4 +29,10 @@ def _pin_host_thread_pools():
         pass
 
 
-_pin_host_thread_pools()
+def _opt_in():
+    import os
+    if os.environ.get("STOCS_PIN_BLAS") == "1":
+        pin_host_thread_pools()
+
+
+_opt_in()

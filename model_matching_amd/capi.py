@@ -79,6 +79,7 @@ SIGNATURES = {
     "stocs_score_transforms_device": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "stocs_score_best_device": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_uint32, C.POINTER(C.c_uint64)]),
     "stocs_lcp_detail": (C.c_int, [_vp, _fp, _ip, _u8p]),
+    "stocs_lcp_hit_count": (C.c_int, [_vp, _vp, C.c_int, _i64p, _i64p]),
     "stocs_verify_all": (C.c_int, [_vp, _fp, _intp, _fp]),
     "stocs_best_device": (C.c_int, [_vp, _vp, C.c_int, C.c_uint32, C.POINTER(C.c_uint64)]),
     "stocs_pack_best": (C.c_uint64, [C.c_float, C.c_uint32]),

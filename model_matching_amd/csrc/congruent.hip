@@ -38,11 +38,11 @@
 #include <time.h>
 #include <cstring>
 
-#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 
 #include "cone_cells.h"
+#include "prims.h"
 #include "stocs_ctx.h"
 
 namespace stocs {
@@ -853,9 +853,9 @@ static int materialise_t(stocs_ctx* c, CongruentState* S, const std::vector<char
     for (int b = 0; b < nB; ++b) n_sel += sel[b] ? 1 : 0;
     if (S->base_in_key || n_sel <= 1) {   // one sort over everything: the base is part of the key (or there is only one)
         const unsigned end_bit = (unsigned)(4 * S->id_bits + (S->base_in_key ? S->base_bits : 0));
-        STOCS_HIP_CHECK(rocprim::radix_sort_keys(NULL, tmp, d_raw.p, out->p, (size_t)tot, 0, end_bit, st));
+        STOCS_HIP_CHECK(sort_keys(NULL, tmp, d_raw.p, out->p, (size_t)tot, 0, end_bit, st));
         if ((rc = d_tmp.alloc(tmp))) return rc;
-        STOCS_HIP_CHECK(rocprim::radix_sort_keys(d_tmp.p, tmp, d_raw.p, out->p, (size_t)tot, 0, end_bit, st));
+        STOCS_HIP_CHECK(sort_keys(d_tmp.p, tmp, d_raw.p, out->p, (size_t)tot, 0, end_bit, st));
     } else {
         // models beyond 16 384 points at 100 bases: four 15- or 16-bit ids fill the 64 bits, so the key holds the ids alone and
         // every base's run (off[b] .. off[b+1], filled base by base) is sorted as a segment of its own
@@ -863,9 +863,9 @@ static int materialise_t(stocs_ctx* c, CongruentState* S, const std::vector<char
         if ((rc = d_off.alloc((size_t)nB + 1))) return rc;
         STOCS_HIP_CHECK(hipMemcpyAsync(d_off.p, off->data(), 8 * ((size_t)nB + 1), hipMemcpyHostToDevice, st));   // *off outlives the copy (S->h_off or the caller's)
         const unsigned end_bit = (unsigned)(4 * S->id_bits);
-        STOCS_HIP_CHECK(rocprim::segmented_radix_sort_keys(NULL, tmp, d_raw.p, out->p, (unsigned)tot, (unsigned)nB, d_off.p, d_off.p + 1, 0, end_bit, st));
+        STOCS_HIP_CHECK(segmented_sort_keys(NULL, tmp, d_raw.p, out->p, (unsigned)tot, (unsigned)nB, d_off.p, d_off.p + 1, 0, end_bit, st));
         if ((rc = d_tmp.alloc(tmp))) return rc;
-        STOCS_HIP_CHECK(rocprim::segmented_radix_sort_keys(d_tmp.p, tmp, d_raw.p, out->p, (unsigned)tot, (unsigned)nB, d_off.p, d_off.p + 1, 0, end_bit, st));
+        STOCS_HIP_CHECK(segmented_sort_keys(d_tmp.p, tmp, d_raw.p, out->p, (unsigned)tot, (unsigned)nB, d_off.p, d_off.p + 1, 0, end_bit, st));
     }
     // no synchronisation: the temporaries are arena memory, recycled only by a later call's reset, and every later use is
     // ordered behind this work on the context's stream (out_base was copied from pageable memory: staged by the runtime
@@ -1013,8 +1013,8 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     // inside a cell the entries stay grouped by base, in index order inside a base: the runs of (base, cell) are contiguous
     // all the same, the table finds them wherever they are, and 15 bits are two radix passes where 22 are three.
     const unsigned end_bit_p = (S->use_table && !getenv("STOCS_CONGRUENT_P_FULLSORT")) ? (unsigned)S->cell_bits : end_bit;
-    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb1, (KeyT*)pk_in, (KeyT*)S->d_pkeys.p, (uint32_t*)pv_in, S->d_pvals.p, totP, 0, end_bit_p, st));
-    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb2, (KeyT*)qk_in, (KeyT*)S->d_qkeys.p, (uint32_t*)qv_in, S->d_qvals.p, totQ, 0, end_bit, st));
+    STOCS_HIP_CHECK(sort_pairs(NULL, tb1, pk_in, (KeyT*)S->d_pkeys.p, pv_in, S->d_pvals.p, totP, 0, end_bit_p, st));
+    STOCS_HIP_CHECK(sort_pairs(NULL, tb2, qk_in, (KeyT*)S->d_qkeys.p, qv_in, S->d_qvals.p, totQ, 0, end_bit, st));
     DevBuf<char> d_tmp2;
     if ((rc = d_tmp.alloc(tb1)) || (rc = d_tmp2.alloc(tb2))) return rc;
     // device-side clock of the groups below (HIP events on the streams they run on; read after the call's closing
@@ -1027,7 +1027,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     if (!reduce)
         hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totQ + 255) / 256)), dim3(256), 0, sq, ix.d_pairs, d_qsegs, n_qseg, (uint32_t)totQ,
                            S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p, (uint8_t*)NULL);
-    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_tmp2.p, tb2, (KeyT*)qk_in, (KeyT*)S->d_qkeys.p, (uint32_t*)qv_in, S->d_qvals.p, totQ, 0, end_bit, sq));
+    STOCS_HIP_CHECK(sort_pairs(d_tmp2.p, tb2, qk_in, (KeyT*)S->d_qkeys.p, qv_in, S->d_qvals.p, totQ, 0, end_bit, sq));
     STOCS_HIP_CHECK(hipEventRecord(c->ev_t[1], sq));
     if (sq != st) STOCS_HIP_CHECK(hipEventRecord(c->ev_join, sq));
     if (!reduce)
@@ -1035,7 +1035,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
                            S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p, (uint8_t*)NULL);
     STOCS_HIP_CHECK(hipGetLastError());
     // one stable sort per list: (base, position cell); inside a cell the entries keep the index order of the gather
-    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_tmp.p, tb1, (KeyT*)pk_in, (KeyT*)S->d_pkeys.p, (uint32_t*)pv_in, S->d_pvals.p, totP, 0, end_bit_p, st));
+    STOCS_HIP_CHECK(sort_pairs(d_tmp.p, tb1, pk_in, (KeyT*)S->d_pkeys.p, pv_in, S->d_pvals.p, totP, 0, end_bit_p, st));
     STOCS_HIP_CHECK(hipEventRecord(c->ev_t[2], st));
     if (S->use_table) {
         const size_t ncell = (size_t)(S->NC * nB);
@@ -1059,10 +1059,10 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     STOCS_HIP_CHECK(hipGetLastError());
     STOCS_HIP_CHECK(hipEventRecord(c->ev_t[4], st));
     size_t tmp_scan = 0;
-    STOCS_HIP_CHECK(rocprim::exclusive_scan(NULL, tmp_scan, d_qcnt.p, S->d_qoffe.p, 0ull, totQ + 1, rocprim::plus<unsigned long long>(), st));
+    STOCS_HIP_CHECK(exclusive_scan(NULL, tmp_scan, d_qcnt.p, S->d_qoffe.p, totQ + 1, st));
     DevBuf<char> d_tmp_scan;
     if ((rc = d_tmp_scan.alloc(tmp_scan))) return rc;
-    STOCS_HIP_CHECK(rocprim::exclusive_scan(d_tmp_scan.p, tmp_scan, d_qcnt.p, S->d_qoffe.p, 0ull, totQ + 1, rocprim::plus<unsigned long long>(), st));
+    STOCS_HIP_CHECK(exclusive_scan(d_tmp_scan.p, tmp_scan, d_qcnt.p, S->d_qoffe.p, totQ + 1, st));
     // per-base offsets = scan value at the first Q entry of each base
     unsigned long long* qoff_at = (unsigned long long*)((char*)c->h_pin + PIN_VAR);   // pinned (sized by the caller)
     DevBuf<unsigned long long> d_boff;

@@ -20,11 +20,11 @@
 #include <string.h>
 #include <cstring>
 
-#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <vector>
 
+#include "prims.h"
 #include "stocs_ctx.h"
 
 namespace stocs {
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void list_fill_kernel(const uint32_t* __restri
     list[(size_t)list_off[c] + (e - cell_first[c])] = make_float4(p.x, p.y, p.z, __int_as_float((int)pt));
 }
 
-// dense scenes: chunk_r[j] = (minimum exact distance to the cell centre over chunks >= j) - 2e-6
+// dense scenes: chunk_r[j] = (minimum exact distance to the cell centre over chunks >= j), rounded down
 __global__ __launch_bounds__(256) void chunk_bounds_kernel(GridGeom G, const uint32_t* __restrict__ cell_first, const uint64_t* __restrict__ cell_key,
                                                            const uint32_t* __restrict__ list_off, uint32_t n_cells, uint32_t n_inc,
                                                            const float4* __restrict__ list, float* __restrict__ chunk_r) {
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void chunk_bounds_kernel(GridGeom G, const uin
         const float4 e = list[(size_t)o + k];
         const double dx = e.x - ccx, dy = e.y - ccy, dz = e.z - ccz;
         run = fmin(run, sqrt(dx * dx + dy * dy + dz * dz));
-        if ((k & 7) == 0) chunk_r[(o + (uint32_t)k) >> 3] = (float)(run - 2e-6);
+        if ((k & 7) == 0) chunk_r[(o + (uint32_t)k) >> 3] = (float)(run - (2e-6 + 2.5e-7 * run));   // below the exact value also after the conversion to float, at any coordinate scale
     }
 }
 
@@ -314,11 +314,10 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense) {
                        (uint64_t*)NULL, (uint32_t*)NULL);
     hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(256), 0, st, (int32_t*)(d_cnt + nS), (size_t)1, 0);
     size_t tb = 0;
-    auto plus64 = rocprim::plus<unsigned long long>();
-    STOCS_HIP_CHECK(rocprim::exclusive_scan(NULL, tb, d_cnt, d_off, 0ull, (size_t)nS + 1, plus64, st));
+    STOCS_HIP_CHECK(exclusive_scan(NULL, tb, d_cnt, d_off, (size_t)nS + 1, st));
     char* d_tmp;
     if ((rc = T.get(&d_tmp, tb))) return rc;
-    STOCS_HIP_CHECK(rocprim::exclusive_scan(d_tmp, tb, d_cnt, d_off, 0ull, (size_t)nS + 1, plus64, st));
+    STOCS_HIP_CHECK(exclusive_scan(d_tmp, tb, d_cnt, d_off, (size_t)nS + 1, st));
     unsigned long long n_inc64 = 0;
     STOCS_HIP_CHECK(hipMemcpyAsync(&n_inc64, d_off + nS, 8, hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
@@ -332,10 +331,10 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense) {
     // ---- 2. stable sort by cell (and quantised centre distance) ----
     size_t ts = 0;
     const unsigned end_bit = (unsigned)std::min(64, cell_bits + qbits);
-    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, ts, d_keys, d_keys_s, d_vals, d_vals_s, n_inc, 0, end_bit, st));
+    STOCS_HIP_CHECK(sort_pairs(NULL, ts, d_keys, d_keys_s, d_vals, d_vals_s, n_inc, 0, end_bit, st));
     char* d_ts;
     if ((rc = T.get(&d_ts, ts))) return rc;
-    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(d_ts, ts, d_keys, d_keys_s, d_vals, d_vals_s, n_inc, 0, end_bit, st));
+    STOCS_HIP_CHECK(sort_pairs(d_ts, ts, d_keys, d_keys_s, d_vals, d_vals_s, n_inc, 0, end_bit, st));
     // ---- 3. cells and bricks ----
     uint32_t *d_cflag, *d_bflag, *d_cidx, *d_bidx;
     if ((rc = T.get(&d_cflag, n_inc + 1)) || (rc = T.get(&d_bflag, n_inc + 1)) || (rc = T.get(&d_cidx, n_inc + 1)) || (rc = T.get(&d_bidx, n_inc + 1))) return rc;
@@ -343,12 +342,11 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense) {
     hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(256), 0, st, (int32_t*)(d_cflag + n_inc), (size_t)1, 0);
     hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(256), 0, st, (int32_t*)(d_bflag + n_inc), (size_t)1, 0);
     size_t t32 = 0;
-    auto plus32 = rocprim::plus<uint32_t>();
-    STOCS_HIP_CHECK(rocprim::exclusive_scan(NULL, t32, d_cflag, d_cidx, 0u, n_inc + 1, plus32, st));
+    STOCS_HIP_CHECK(exclusive_scan(NULL, t32, d_cflag, d_cidx, (size_t)n_inc + 1, st));
     char* d_t32;
     if ((rc = T.get(&d_t32, t32))) return rc;
-    STOCS_HIP_CHECK(rocprim::exclusive_scan(d_t32, t32, d_cflag, d_cidx, 0u, n_inc + 1, plus32, st));
-    STOCS_HIP_CHECK(rocprim::exclusive_scan(d_t32, t32, d_bflag, d_bidx, 0u, n_inc + 1, plus32, st));
+    STOCS_HIP_CHECK(exclusive_scan(d_t32, t32, d_cflag, d_cidx, (size_t)n_inc + 1, st));
+    STOCS_HIP_CHECK(exclusive_scan(d_t32, t32, d_bflag, d_bidx, (size_t)n_inc + 1, st));
     uint32_t counts[2] = {0, 0};
     STOCS_HIP_CHECK(hipMemcpyAsync(&counts[0], d_cidx + n_inc, 4, hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipMemcpyAsync(&counts[1], d_bidx + n_inc, 4, hipMemcpyDeviceToHost, st));
@@ -364,7 +362,7 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense) {
     hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(256), 0, st, (int32_t*)d_max, (size_t)1, 0);
     hipLaunchKernelGGL(cell_padded_kernel, dim3(grid_of(n_cells)), dim3(256), 0, st, d_cell_first, n_cells, (uint32_t)n_inc, 8u, d_padded, d_max);
     hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(256), 0, st, (int32_t*)(d_padded + n_cells), (size_t)1, 0);
-    STOCS_HIP_CHECK(rocprim::exclusive_scan(d_t32, t32, d_padded, d_list_off, 0u, (size_t)n_cells + 1, plus32, st));
+    STOCS_HIP_CHECK(exclusive_scan(d_t32, t32, d_padded, d_list_off, (size_t)n_cells + 1, st));
     uint32_t tail[2] = {0, 0};
     STOCS_HIP_CHECK(hipMemcpyAsync(&tail[0], d_list_off + n_cells, 4, hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipMemcpyAsync(&tail[1], d_max, 4, hipMemcpyDeviceToHost, st));

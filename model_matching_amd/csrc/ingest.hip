@@ -17,7 +17,6 @@
 #include <time.h>
 #include <cstring>
 
-#include <rocprim/rocprim.hpp>
 
 #include <limits.h>
 
@@ -25,6 +24,7 @@
 #include <map>
 #include <vector>
 
+#include "prims.h"
 #include "stocs_ctx.h"
 
 namespace stocs {
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void depth_normals_kernel(const float4* __rest
 // cv::rgbd::RgbdNormals(rows, cols, CV_32F, K, 5, RGBD_NORMALS_METHOD_LINEMOD) applied to the raw 16-bit depth image
 // (rgbd.cpp:199-205), restated from the published method -- Hinterstoisser et al., PAMI 2012, section 2.4: the depth gradient
 // that best explains, in the least-squares sense, the depth differences to the 8 neighbours at +-5 pixels (neighbours whose depth
-// differs from the centre by more than 50 raw units are left out: they lie across a depth edge); the normal is that of the plane
+// differs from the centre by 50 raw units or more are left out: they lie across a depth edge); the normal is that of the plane
 // through the back-projected points X, X1 = v(x+1, y)(D + dD/dx), X2 = v(x, y+1)(D + dD/dy).  Sums and the 2x2 solve in 64-bit
 // integers (the division by the determinant is dropped: it scales both tangent vectors), the cross product in float, the result
 // normalised and pointed at the camera (z <= 0).  Pixels within 5 (6 at the far sides) of the border, and pixels whose patch
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void gradient_normals_kernel(const uint16_t* _
         for (int j = -r; j <= r; j += r)
             for (int i = -r; i <= r; i += r) {
                 const long long delta = (long long)depth[(y + j) * W + (x + i)] - d;
-                if (delta > 50 || delta < -50) continue;
+                if (delta >= 50 || delta <= -50) continue;   // strict: |delta| < 50 is kept (the library's accumBilateral test as recalled; UNPINNED, OpenCV is absent)
                 A0 += i * i; A1 += i * j; A3 += j * j;
                 b0 += i * delta; b1 += j * delta;
             }
@@ -447,22 +447,22 @@ static int voxel_grid_device(const float4* dP, const float4* dExtra, int n, doub
     int key_bits = 1;   // sort only the bits the keys can have
     while (key_bits < 64 && (double)(1ull << key_bits) < (double)dims.x * dims.y * dims.z) key_bits++;
     size_t tb = 0, tb2 = 0;
-    STOCS_HIP_CHECK(rocprim::exclusive_scan(NULL, tb2, head.p, seg.p, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
+    STOCS_HIP_CHECK(exclusive_scan(NULL, tb2, head.p, seg.p, (size_t)n, st));
     if (key_bits <= 32) {
         uint32_t* k32 = (uint32_t*)keys.p; uint32_t* k32s = (uint32_t*)keys_s.p;
         hipLaunchKernelGGL(leaf_keys_kernel<uint32_t>, g, dim3(256), 0, st, ijk.p, n, mn, dims, k32, ids.p);
-        STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb, k32, k32s, ids.p, ids_s.p, (size_t)n, 0, (unsigned)key_bits, st));   // stable
+        STOCS_HIP_CHECK(sort_pairs(NULL, tb, k32, k32s, ids.p, ids_s.p, (size_t)n, 0, (unsigned)key_bits, st));   // stable
         if ((rc = tmp.alloc(std::max(tb, tb2)))) return rc;
-        STOCS_HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, tb, k32, k32s, ids.p, ids_s.p, (size_t)n, 0, (unsigned)key_bits, st));
+        STOCS_HIP_CHECK(sort_pairs(tmp.p, tb, k32, k32s, ids.p, ids_s.p, (size_t)n, 0, (unsigned)key_bits, st));
         hipLaunchKernelGGL(seg_heads_kernel<uint32_t>, g, dim3(256), 0, st, k32s, n, head.p);
     } else {
         hipLaunchKernelGGL(leaf_keys_kernel<uint64_t>, g, dim3(256), 0, st, ijk.p, n, mn, dims, keys.p, ids.p);
-        STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb, keys.p, keys_s.p, ids.p, ids_s.p, (size_t)n, 0, (unsigned)key_bits, st));   // stable
+        STOCS_HIP_CHECK(sort_pairs(NULL, tb, keys.p, keys_s.p, ids.p, ids_s.p, (size_t)n, 0, (unsigned)key_bits, st));   // stable
         if ((rc = tmp.alloc(std::max(tb, tb2)))) return rc;
-        STOCS_HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, tb, keys.p, keys_s.p, ids.p, ids_s.p, (size_t)n, 0, (unsigned)key_bits, st));
+        STOCS_HIP_CHECK(sort_pairs(tmp.p, tb, keys.p, keys_s.p, ids.p, ids_s.p, (size_t)n, 0, (unsigned)key_bits, st));
         hipLaunchKernelGGL(seg_heads_kernel<uint64_t>, g, dim3(256), 0, st, keys_s.p, n, head.p);
     }
-    STOCS_HIP_CHECK(rocprim::exclusive_scan(tmp.p, tb2, head.p, seg.p, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
+    STOCS_HIP_CHECK(exclusive_scan(tmp.p, tb2, head.p, seg.p, (size_t)n, st));
     uint32_t last_seg = 0, last_head = 0;
     STOCS_HIP_CHECK(hipMemcpyAsync(&last_seg, seg.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipMemcpyAsync(&last_head, head.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
@@ -556,10 +556,10 @@ int stocs_ingest_scene(const stocs_camera* cam, const uint16_t* depth, const uin
     size_t tb = 0, tb2 = 0;
     int cell_bits = 1;
     while (cell_bits < 32 && ((size_t)1 << cell_bits) < ncell) cell_bits++;
-    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb, cell.p, cell_s.p, ids.p, ids_s.p, (size_t)nv, 0, (unsigned)cell_bits, st));
-    STOCS_HIP_CHECK(rocprim::exclusive_scan(NULL, tb2, keep.p, kpos.p, 0u, (size_t)nv + 1, rocprim::plus<uint32_t>(), st));
+    STOCS_HIP_CHECK(sort_pairs(NULL, tb, cell.p, cell_s.p, ids.p, ids_s.p, (size_t)nv, 0, (unsigned)cell_bits, st));
+    STOCS_HIP_CHECK(exclusive_scan(NULL, tb2, keep.p, kpos.p, (size_t)nv + 1, st));
     if ((rc = tmp.alloc(std::max(tb, tb2)))) return rc;
-    STOCS_HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, tb, cell.p, cell_s.p, ids.p, ids_s.p, (size_t)nv, 0, (unsigned)cell_bits, st));
+    STOCS_HIP_CHECK(sort_pairs(tmp.p, tb, cell.p, cell_s.p, ids.p, ids_s.p, (size_t)nv, 0, (unsigned)cell_bits, st));
     hipLaunchKernelGGL(zero_u32x2_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, cstart.p, cend.p, ncell);
     hipLaunchKernelGGL(cell_start_kernel, gv, dim3(256), 0, st, cell_s.p, nv, cstart.p, cend.p);
     hipLaunchKernelGGL(ror_count_kernel, gv, dim3(256), 0, st, cen.p, nv, mn, 1.0 / radius, dims, radius, cstart.p, cend.p, ids_s.p, count.p);
@@ -569,7 +569,7 @@ int stocs_ingest_scene(const stocs_camera* cam, const uint16_t* depth, const uin
                        keep.p, on.p, op.p, opx.p);
     // stable compaction on the device: destination = exclusive scan of the keep flags
     hipLaunchKernelGGL(zero_u32x2_kernel, dim3(1), dim3(256), 0, st, keep.p + nv, kpos.p + nv, (size_t)1);
-    STOCS_HIP_CHECK(rocprim::exclusive_scan(tmp.p, tb2, keep.p, kpos.p, 0u, (size_t)nv + 1, rocprim::plus<uint32_t>(), st));
+    STOCS_HIP_CHECK(exclusive_scan(tmp.p, tb2, keep.p, kpos.p, (size_t)nv + 1, st));
     Buf<float> o_pos, o_nrm, o_prob; Buf<int32_t> o_px;
     if ((rc = o_pos.alloc((size_t)nv * 3)) || (rc = o_nrm.alloc((size_t)nv * 3)) || (rc = o_prob.alloc(nv)) || (rc = o_px.alloc((size_t)nv * 2))) return rc;
     hipLaunchKernelGGL(scene_pack_kernel, gv, dim3(256), 0, st, cen.p, on.p, op.p, opx.p, keep.p, kpos.p, nv, o_pos.p, o_nrm.p, o_prob.p, o_px.p);

@@ -25,10 +25,10 @@
 
 #include <cstring>
 
-#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 
+#include "prims.h"
 #include "stocs_ctx.h"
 
 namespace stocs {
@@ -47,6 +47,8 @@ struct LcpArgs {
     float ox, oy, oz, inv_h, inv_h4, h;
     int nx, ny, nz, nbx, nby;
     float sq_eps, dot_lo, eps;
+    float bound_margin;     // slack of the early-exit / nearest-point bound tests of the centre-sorted lists: relative to epsilon and to the
+                            // scene's coordinate magnitude (the float rounding of |query - cell centre| scales with the coordinates)
     int has_nearest;        // the z word of a dense grid's cell is a lower bound of |cell centre - nearest listed point| (SceneGrid::has_nearest)
     const int32_t* order;   // processing slot -> candidate (NULL: identity): candidates that land in the same part of the scene run together
     int xcd_blocks;         // != 0: workgroups of one XCD take a contiguous run of slots (each XCD has its own L2)
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coop_kernel(LcpArgs a, const flo
                     float gb = a.sq_eps;   // best d^2 of the whole group so far
                     if (STOCS_ABLATE(a, 4)) nchunks = min(nchunks, (uint32_t)UNR);   // 4: the first trip of every list only
                     for (uint32_t j = 0; __any(j < nchunks); j += UNR) {
-                        if (j < nchunks && j > 0 && (STOCS_ABLATE(a, 256) ? 0.0f : a.chunk_r[chunk0 + j]) - qcg > sqrtf(gb) + 2e-6f) nchunks = 0;   // 256: no chunk bounds (scan everything)
+                        if (j < nchunks && j > 0 && (STOCS_ABLATE(a, 256) ? 0.0f : a.chunk_r[chunk0 + j]) - qcg > sqrtf(gb) + a.bound_margin) nchunks = 0;   // 256: no chunk bounds (scan everything)
                         float4 e[UNR];
 #pragma unroll
                         for (int u = 0; u < UNR; ++u) {
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
                     uint32_t cc = c;   // entries still to be looked at (0 once the rest of the list is ruled out)
                     for (uint32_t k = 8; __any(k < cc); k += 8 * UNR) {
                         // |q - p| >= |p - centre| - |q - centre| > sqrt(best of the group) for every later p: stop
-                        if (k < cc && a.chunk_r[chunk0 + (k >> 3)] - qcg > sqrtf(group_min_nonneg<GL>(gd)) + 2e-6f) cc = 0;
+                        if (k < cc && a.chunk_r[chunk0 + (k >> 3)] - qcg > sqrtf(group_min_nonneg<GL>(gd)) + a.bound_margin) cc = 0;
                         float4 e[UNR][EPL];
 #pragma unroll
                         for (int v = 0; v < UNR; ++v) {   // a line's entries under ONE condition: its loads leave together
@@ -659,7 +661,7 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
                 qcentre = sqrtf(ex * ex + (ey * ey + ez * ez));
                 // every listed point is at least `nearest` from the cell centre, hence at least nearest - |q - centre| from the query:
                 // beyond epsilon the list is not worth a look
-                if (a.has_nearest && nearest - qcentre > a.eps + 2e-6f) cnt = 0;
+                if (a.has_nearest && nearest - qcentre > a.eps + a.bound_margin) cnt = 0;
             }
             if (DETAIL && cnt == 0) {
                 const int orig = a.mperm[i];
@@ -821,14 +823,15 @@ __global__ __launch_bounds__(256) void order_keys_kernel(const float* __restrict
 }
 
 // Kernel selection.  The product library ships the kernels the automatic choice uses (24: scan fed from an LDS queue over
-// index-ordered lists, sparse scenes; 39: the same over centre-sorted lists with early exit, dense scenes) plus the per-step
-// cooperative scans of rounds 1-2 (15, 31) and the plain lane-per-query kernel (0) as independent cross-checks; every one of
-// them returns the reference's scores.  The other measured variants (profiles/r01_lcp_analysis.md) exist only in a tools build
-// (make tools -> libstocs_hip_tools.so, -DSTOCS_TOOLS_BUILD), which also honours the STOCS_LCP_VARIANT environment variable.
+// index-ordered lists, sparse scenes; 39: the same over centre-sorted lists with early exit, dense scenes) plus two independent
+// cross-checks: the per-step cooperative scan of round 2 over the centre-sorted lists (31) and the plain lane-per-query kernel
+// (0); every one of them returns the reference's scores.  Everything that lost an A/B run (profiles/r01_lcp_analysis.md,
+// profiles/r03_lcp_patch_and_group_ab.json: the per-step scan over index-ordered lists 15, eight lanes per query, ...) exists
+// only in a tools build (make tools -> libstocs_hip_tools.so, -DSTOCS_TOOLS_BUILD), which also honours STOCS_LCP_VARIANT.
 static bool lcp_variant_selectable(int v) {
-    if (v == 99 || v == 0 || v == 15 || v == 24 || v == 31 || v == 39) return true;
+    if (v == 99 || v == 0 || v == 24 || v == 31 || v == 39) return true;
 #ifdef STOCS_TOOLS_BUILD
-    static const int extra[] = {1, 9, 16, 17, 20, 25, 26, 27, 28, 30, 32, 33, 34, 35, 40, 41, 42, 43, 44, 45, 46};
+    static const int extra[] = {15, 1, 9, 16, 17, 20, 25, 26, 27, 28, 30, 32, 33, 34, 35, 40, 41, 42, 43, 44, 45, 46};
     for (size_t i = 0; i < sizeof(extra) / sizeof(extra[0]); ++i) if (extra[i] == v) return true;
 #endif
     return false;
@@ -859,6 +862,11 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
     a.dot_lo = c->thr.lcp_dot_lo;
     a.eps = c->prm.distance_threshold;
     a.has_nearest = c->grid.has_nearest ? 1 : 0;
+    {   // 4e-6 at metre scale (epsilon 5 mm, coordinates below half a metre); clouds in millimetres get a thousand times that
+        double mag = 0.0;
+        for (int k = 0; k < 3; ++k) mag = std::max(mag, std::max(fabs(c->grid.bb_mn[k]), fabs(c->grid.bb_mx[k])));
+        a.bound_margin = (float)(4.0e-4 * (double)c->prm.distance_threshold + 4.0e-6 * mag);
+    }
     // patch test: its distance field costs one pass over the scene points (0.24 ms at Cm) and takes ~6 % off a launch, so it is filled
     // once the scene has seen 1e9 point queries (three steps of the metric batch; ~25 trials of one frame) -- a caller that scores one
     // trial per frame never pays for it.  The scores do not depend on it
@@ -887,7 +895,7 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
     if (!d_hit && n >= 1024 && (double)n * (double)c->nM >= 1.5e8 && c->lcp_order && (lists_spill || c->lcp_order >= 2)) {
         const size_t kb = (((size_t)n * 4 + 255) / 256) * 256;
         size_t tb = 0;
-        STOCS_HIP_CHECK(rocprim::radix_sort_pairs(NULL, tb, (uint32_t*)NULL, (uint32_t*)NULL, (int32_t*)NULL, (int32_t*)NULL, (size_t)n, 0, 24, c->stream));
+        STOCS_HIP_CHECK(sort_pairs(NULL, tb, (const uint32_t*)NULL, (uint32_t*)NULL, (const uint32_t*)NULL, (uint32_t*)NULL, (size_t)n, 0, 24, c->stream));
         const size_t need = 4 * kb + tb;
         if (c->order_bytes < need) {
             if (c->d_order) { STOCS_HIP_CHECK(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_order); c->d_order = NULL; c->order_bytes = 0; }
@@ -902,7 +910,7 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
         hipLaunchKernelGGL(order_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_T16, n, c->grid.ox, c->grid.oy, c->grid.oz, sx, sy, sz,
                            keys, vals, d_best8);
         best_zeroed = true;
-        STOCS_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tb, keys, keys_s, vals, order, (size_t)n, 0, 24, c->stream));
+        STOCS_HIP_CHECK(sort_pairs(tmp, tb, keys, keys_s, (const uint32_t*)vals, (uint32_t*)order, (size_t)n, 0, 24, c->stream));
         a.order = order;
         // XCD placement of the ordered list (lcp_candidate): 0 = workgroup i takes slot i, and the hardware deals consecutive workgroups to
         // the eight XCDs in turn; k > 2 = an XCD takes runs of k consecutive slots, so that what is resident on it at one time (~250
@@ -929,8 +937,10 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
         if (dense && variant == 39) STOCS_LCP_LAUNCH(lcp_coopq_kernel<true, 1, true, 4, false, 4, 0, false, false, true>);
         else if (dense) STOCS_LCP_LAUNCH(lcp_coop_kernel<true, 2, true, true, false>);
         else if (variant == 0) STOCS_LCP_LAUNCH(lcp_kernel<true, true>);
-        else if (variant >= 20 && variant <= 28) STOCS_LCP_LAUNCH(lcp_coopq_kernel<true, 1, true, 4, true>);
-        else STOCS_LCP_LAUNCH(lcp_coop_kernel<true, 1, true, false, true>);
+#ifdef STOCS_TOOLS_BUILD
+        else if (!(variant >= 20 && variant <= 28)) STOCS_LCP_LAUNCH(lcp_coop_kernel<true, 1, true, false, true>);
+#endif
+        else STOCS_LCP_LAUNCH(lcp_coopq_kernel<true, 1, true, 4, true>);
     } else if (dense) {
         switch (variant) {
             case 0: STOCS_LCP_LAUNCH(lcp_kernel<false, false>); break;
@@ -943,12 +953,13 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
             case 35: hipLaunchKernelGGL((lcp_coop_kernel<false, 4, true, true, false, 4, true>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); break;   // 31 with four lines per trip
 #endif
             case 39:   // queue-fed scan with early exit (16-byte lists); lanes per query as on sparse scenes (C5: 6.33 -> 5.81 ms)
-                if (c->lcp_group == 8) hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 4, false, 4, 0, true, false, true, 8>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
 #ifdef STOCS_TOOLS_BUILD
+                if (c->lcp_group == 8) hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 4, false, 4, 0, true, false, true, 8>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
                 else if (c->lcp_group == 42) hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 2, false, 4, 0, true, false, true, 4>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
                 else if (c->lcp_group == 2) hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 1, false, 4, 0, true, false, true, 2>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
+                else
 #endif
-                else hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 1, false, 4, 0, true, false, true, 4>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
+                hipLaunchKernelGGL((lcp_coopq_kernel<false, 1, true, 1, false, 4, 0, true, false, true, 4>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted);
                 break;
 #ifdef STOCS_TOOLS_BUILD
             case 41: hipLaunchKernelGGL((lcp_coopq_kernel<false, 2, true, 4, false, 4, 0, true, false, true>), dim3(n), dim3(256), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); break;   // 39, two lines per trip after the first
@@ -964,8 +975,8 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
     } else {
         switch (variant) {
             case 0: STOCS_LCP_LAUNCH(lcp_kernel<false, true>); break;
-            case 15: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 4, true, false, true>); break;
 #ifdef STOCS_TOOLS_BUILD
+            case 15: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 4, true, false, true>); break;
             case 1: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 1, true, false, true>); break;
             case 9: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 2, true, false, true>); break;
             case 16: STOCS_LCP_LAUNCH(lcp_coop_kernel<false, 8, true, false, true>); break;
@@ -994,10 +1005,10 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
                            else hipLaunchKernelGGL((lcp_coopq_kernel<false, UNRV, SORTV, PIPEV, true, 1, 0, false, false, false, GLV, ##__VA_ARGS__>), dim3(n), dim3(64), 0, c->stream, a, d_T16, d_lcp, n, d_hit, d_counted); } } while (0)
                 // lanes per queued query in the verify trips (stocs_set_option "lcp_group"; profiles/r03_lcp_group_ab.json): 4 lanes with
                 // two list entries each and one trip (16 queries) in flight -- Cm 1.34 -> 1.18 ms; 8 lanes with one entry each and four
-                // trips in flight is the form of rounds 1-3
+                // trips in flight is the form of rounds 1-3 (tools build)
                 switch (c->lcp_group) {
-                    case 8: STOCS_LCP_Q(true, 4, 8, 1); break;
 #ifdef STOCS_TOOLS_BUILD
+                    case 8: STOCS_LCP_Q(true, 4, 8, 1); break;       // eight lanes with one entry each, four trips in flight: the form of rounds 1-3a
                     case 42: STOCS_LCP_Q(true, 2, 4, 1); break;    // 4 lanes, two trips in flight (1.185 ms)
                     case 41: STOCS_LCP_Q(true, 1, 4, 1, 1); break; // 4 with one line in the first trip (+2 % at 65 536 candidates, +7 % at 8 192)
                     case 49: STOCS_LCP_Q(true, 1, 4, 1, 2, false); break; // 4 with predicated list loads and sentinel entries (+1.2 %; +2.4 % at 8 192)
@@ -1073,6 +1084,47 @@ int stocs_lcp_detail(stocs_ctx* c, const float* T_host, int32_t* hit, uint8_t* c
     return STOCS_OK;
 }
 
+// hits / counted flags of a chunk of candidates -> two totals
+__global__ __launch_bounds__(256) void hit_count_kernel(const int32_t* __restrict__ hit, const uint8_t* __restrict__ counted, size_t n, unsigned long long* __restrict__ out2) {
+    unsigned long long h = 0, k = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { h += hit[i] >= 0 ? 1u : 0u; k += counted[i] ? 1u : 0u; }
+    for (int off = 32; off > 0; off >>= 1) { h += __shfl_xor(h, off, 64); k += __shfl_xor(k, off, 64); }
+    if ((threadIdx.x & 63) == 0) { if (h) atomicAdd(&out2[0], h); if (k) atomicAdd(&out2[1], k); }
+}
+
+int stocs_lcp_hit_count(stocs_ctx* c, const void* d_T16, int n, int64_t* hits, int64_t* counted) {
+    if (!c || n < 0 || (n && !d_T16) || !hits) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
+    *hits = 0;
+    if (counted) *counted = 0;
+    if (n == 0 || c->nM == 0) return STOCS_OK;
+    const size_t M = (size_t)c->nM;
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)256 << 20) / (5 * M)));
+    const size_t hb = (((size_t)chunk * M * 4 + 255) / 256) * 256, cb = (((size_t)chunk * M + 255) / 256) * 256, lb = (((size_t)chunk * 4 + 255) / 256) * 256;
+    int rc = ensure_scratch(c, 256 + lb + hb + cb);
+    if (rc) return rc;
+    char* base = (char*)c->d_scratch;
+    unsigned long long* d_out = (unsigned long long*)base;
+    float* dL = (float*)(base + 256);
+    int32_t* dH = (int32_t*)(base + 256 + lb);
+    uint8_t* dC = (uint8_t*)(base + 256 + lb + hb);
+    STOCS_HIP_CHECK(hipMemsetAsync(d_out, 0, 16, c->stream));
+    for (int i0 = 0; i0 < n; i0 += chunk) {
+        const int m = std::min(chunk, n - i0);
+        rc = launch_lcp(c, (const float*)d_T16 + (size_t)i0 * 16, m, dL, dH, dC, NULL, 0);
+        if (rc) return rc;
+        hipLaunchKernelGGL(hit_count_kernel, dim3(1024), dim3(256), 0, c->stream, (const int32_t*)dH, (const uint8_t*)dC, (size_t)m * M, d_out);
+        STOCS_HIP_CHECK(hipGetLastError());
+    }
+    if ((rc = ensure_pinned(c, PIN_VAR))) return rc;
+    unsigned long long* pin = (unsigned long long*)((char*)c->h_pin + PIN_BEST);
+    STOCS_HIP_CHECK(hipMemcpyAsync(pin, d_out, 16, hipMemcpyDeviceToHost, c->stream));
+    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *hits = (int64_t)pin[0];
+    if (counted) *counted = (int64_t)pin[1];
+    return STOCS_OK;
+}
+
 int stocs_best_device(stocs_ctx* c, const void* d_lcp, int n, uint32_t id_offset, uint64_t* key) {
     if (!c || !key || n < 0 || (n && !d_lcp)) return STOCS_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
@@ -1133,7 +1185,7 @@ int stocs_score_best_device(stocs_ctx* c, const void* d_T16, int n, void* d_lcp,
 int stocs_set_option(stocs_ctx* c, const char* key, int value) {
     if (!c || !key) return STOCS_ERR_INVALID;
     if (!strcmp(key, "lcp_variant")) {
-        if (!lcp_variant_selectable(value)) { set_error("stocs_set_option: lcp_variant %d is not part of this build (99 automatic, 0, 15, 24, 31, 39)", value); return STOCS_ERR_INVALID; }
+        if (!lcp_variant_selectable(value)) { set_error("stocs_set_option: lcp_variant %d is not part of this build (99 automatic, 0, 24, 31, 39)", value); return STOCS_ERR_INVALID; }
         c->lcp_variant = value;
         return STOCS_OK;
     }
@@ -1147,11 +1199,11 @@ int stocs_set_option(stocs_ctx* c, const char* key, int value) {
     // 0: every 64-point step is walked; 1 (default): steps whose bounding sphere is out of reach of the scene are skipped once the scene's
     // distance field pays (1e9 point queries against the scene so far); 2: from the first call (same scores in every case)
     if (!strcmp(key, "lcp_cull") && value >= 0 && value <= 2) { c->lcp_cull = value; return STOCS_OK; }
-    // lanes that verify one queued query together: 4 (default: two list entries per lane) or 8 (one entry per lane; rounds 1-3); same scores
+    // lanes that verify one queued query together: 4 (two list entries per lane); the eight-lane form of rounds 1-3a lost its A/B and lives in the tools build
     if (!strcmp(key, "lcp_group")) {
-        bool ok = value == 4 || value == 8;
+        bool ok = value == 4;
 #ifdef STOCS_TOOLS_BUILD
-        ok = ok || value == 41 || value == 49 || value == 46 || value == 47 || value == 48 || value == 85 || value == 42 || value == 43 || value == 44 || value == 40 || value == 2 || value == 22 || value == 1;
+        ok = ok || value == 8 || value == 41 || value == 49 || value == 46 || value == 47 || value == 48 || value == 85 || value == 42 || value == 43 || value == 44 || value == 40 || value == 2 || value == 22 || value == 1;
 #endif
         if (ok) { c->lcp_group = value; return STOCS_OK; }
     }
@@ -1167,19 +1219,22 @@ int stocs_get_cull_state(stocs_ctx* c, float* patches4, int32_t* perm, int* n_pa
     const SceneGrid& g = c->grid;
     const int64_t nd = g.d_dist ? (int64_t)g.cg_nx * g.cg_ny * g.cg_nz : 0;
     *n_dist = nd;
+    // (everything that can fail comes before the first copy into the caller's pageable buffers: no copy is left in flight on an error return)
+    if (dist && nd) {
+        if (dist_cap < nd) return STOCS_ERR_CAPACITY;
+        int rc = fill_cull_field(c);
+        if (rc) return rc;
+    }
     if (patches4 && np) STOCS_HIP_CHECK(hipMemcpyAsync(patches4, c->d_mpatch, (size_t)np * 16, hipMemcpyDeviceToHost, c->stream));
     if (perm) for (int i = 0; i < c->nM; ++i) perm[i] = c->h_mperm[i];
     if (geom8) {
         geom8[0] = g.cg_ox; geom8[1] = g.cg_oy; geom8[2] = g.cg_oz; geom8[3] = g.cg_g; geom8[4] = g.cg_cap;
         geom8[5] = (float)g.cg_nx; geom8[6] = (float)g.cg_ny; geom8[7] = (float)g.cg_nz;
     }
-    if (dist && nd) {
-        if (dist_cap < nd) return STOCS_ERR_CAPACITY;
-        int rc = fill_cull_field(c);
-        if (rc) return rc;
-        STOCS_HIP_CHECK(hipMemcpyAsync(dist, g.d_dist, (size_t)nd * 4, hipMemcpyDeviceToHost, c->stream));
-    }
-    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    hipError_t e = hipSuccess;
+    if (dist && nd) e = hipMemcpyAsync(dist, g.d_dist, (size_t)nd * 4, hipMemcpyDeviceToHost, c->stream);
+    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));   // also behind a failed enqueue: the earlier copies have landed before the caller's buffers go away
+    STOCS_HIP_CHECK(e);
     return STOCS_OK;
 }
 

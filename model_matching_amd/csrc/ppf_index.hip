@@ -13,10 +13,10 @@
 #include <string.h>
 #include <cstring>
 
-#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 
+#include "prims.h"
 #include "stocs_ctx.h"
 
 namespace stocs {
@@ -121,9 +121,9 @@ int build_ppf_index(stocs_ctx* c) {
         while (((int64_t)1 << key_bits) < ix.n_keys) key_bits++;
         const unsigned end_bit = 64;  // invalid entries (all ones) must sort last
         (void)key_bits;
-        STOCS_HIP_CHECK(rocprim::radix_sort_keys(NULL, tmp_bytes, d_keys, d_sorted, (size_t)total, 0, end_bit, c->stream));
+        STOCS_HIP_CHECK(sort_keys(NULL, tmp_bytes, d_keys, d_sorted, (size_t)total, 0, end_bit, c->stream));
         STOCS_HIP_CHECK(dev_malloc(&d_tmp, tmp_bytes));
-        STOCS_HIP_CHECK(rocprim::radix_sort_keys(d_tmp, tmp_bytes, d_keys, d_sorted, (size_t)total, 0, end_bit, c->stream));
+        STOCS_HIP_CHECK(sort_keys(d_tmp, tmp_bytes, d_keys, d_sorted, (size_t)total, 0, end_bit, c->stream));
         hipLaunchKernelGGL(ppf_exists_kernel, dim3((unsigned)ix.n_keys), dim3(128), 0, c->stream, d_hist, ix.n_keys, ix.tr, ix.rot,
                            ix.NA, ix.nD, ix.d_exists);
         STOCS_HIP_CHECK(hipGetLastError());

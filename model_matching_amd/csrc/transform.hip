@@ -13,11 +13,11 @@
 
 #include <cstring>
 
-#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <unordered_map>
 
+#include "prims.h"
 #include "stocs_ctx.h"
 
 namespace stocs {
@@ -229,6 +229,15 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
         fprintf(stderr, "[stocs transforms] %-18s %8.3f ms\n", label, (t1.tv_sec - ts0.tv_sec) * 1e3 + (t1.tv_nsec - ts0.tv_nsec) * 1e-6);
         ts0 = t1;
     };
+    // A trial without a single congruent set -- no bases, empty pair lists, or no (base, cell) that both lists occupy -- is a valid,
+    // empty result (the reference's loop simply appends nothing, stocs_match_one_object.cpp:111-147): no candidates, "no pose".
+    if (c->quad_off.back() == 0) {
+        clear_candidates(c);
+        c->best_lcp = 0; c->best_index = -1;
+        if (n_candidates) *n_candidates = 0;
+        c->timing[1].lap("no congruent sets");
+        return STOCS_OK;
+    }
     // the device starts on the small bases (used whole: materialised and sorted) while the host draws the subsets of the large ones
     if (!c->bases.empty()) { const int rc0 = stocs_internal_prepare_small(c, max_per_base); if (rc0) return rc0; }
     // picks = (base, rank, job slot, sorted?) records; the quads themselves are produced on the device
@@ -298,7 +307,7 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
         // candidates stay on the device: jobs -> transforms -> order-preserving compaction of the accepted ones
         const size_t jb = ((n * sizeof(XformJob) + 255) / 256) * 256, tb = n * 64, ob = (((n + 1) * 4 + 255) / 256) * 256;
         size_t scan_tmp = 0;
-        STOCS_HIP_CHECK(rocprim::exclusive_scan(NULL, scan_tmp, (int32_t*)NULL, (int32_t*)NULL, 0, n + 1, rocprim::plus<int32_t>(), c->stream));
+        STOCS_HIP_CHECK(exclusive_scan(NULL, scan_tmp, (const uint32_t*)NULL, (uint32_t*)NULL, n + 1, c->stream));
         scan_tmp = ((scan_tmp + 255) / 256) * 256;
         const size_t pb = device_picks ? ((n * 16 + 255) / 256) * 256 + ((c->bases.size() * 16 + 255) / 256) * 256 : 0;   // picks + table
         int rc = ensure_scratch(c, jb + 2 * tb + 3 * ob + scan_tmp + pb);
@@ -341,7 +350,7 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
         hipLaunchKernelGGL(rigid_transform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_spos, c->d_mpos, dJ, (int)n,
                            c->centroid_scene, c->centroid_model, dT, dP, dO);
         STOCS_HIP_CHECK(hipGetLastError());
-        STOCS_HIP_CHECK(rocprim::exclusive_scan(dTmp, scan_tmp, dO, dPos, 0, n + 1, rocprim::plus<int32_t>(), c->stream));
+        STOCS_HIP_CHECK(exclusive_scan(dTmp, scan_tmp, (const uint32_t*)dO, (uint32_t*)dPos, n + 1, c->stream));
         hipLaunchKernelGGL(compact_candidates_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float4*)dT, (const float4*)dP, dO, dPos, dB,
                            (int)n, (float4*)cand_T(c), (float4*)cand_P(c), cand_lcp(c), cand_base(c));
         STOCS_HIP_CHECK(hipGetLastError());

@@ -224,6 +224,13 @@ class StocsEstimator:
         capi.check(self.L.stocs_lcp_detail(self.h, pT, hit.ctypes.data_as(capi._ip), counted.ctypes.data_as(capi._u8p)))
         return hit, counted
 
+    def lcp_hit_count(self, dT, n):
+        """(hits, counted) over n device-resident transforms (stocs_lcp_hit_count): point queries that found a scene point within
+        epsilon, and those of them that passed the normal test."""
+        h = C.c_int64(0); k = C.c_int64(0)
+        capi.check(self.L.stocs_lcp_hit_count(self.h, dT, n, C.byref(h), C.byref(k)))
+        return h.value, k.value
+
     def compute_best_transform(self):
         s = C.c_float(0); i = C.c_int(-1)
         P = np.zeros(16, np.float32)

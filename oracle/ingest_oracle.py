@@ -70,7 +70,7 @@ def depth_normals(P, valid, win=5):
 def depth_normals_gradient(depth_u16, K):
     """cv::rgbd::RgbdNormals(..., RGBD_NORMALS_METHOD_LINEMOD) on the raw 16-bit depth image (rgbd.cpp:199-205), restated from the
     published method (Hinterstoisser et al., PAMI 2012, section 2.4): least-squares depth gradient over the 8 neighbours at +-5
-    pixels whose depth differs from the centre by at most 50 raw units; normal of the tangent plane through the back-projected
+    pixels whose depth differs from the centre by less than 50 raw units; normal of the tangent plane through the back-projected
     X, X(x+1), X(y+1); integer sums, float cross product, normalised, pointed at the camera.  OpenCV absent: UNPINNED."""
     fx, cx, fy, cy = (np.float32(v) for v in K)
     D = np.asarray(depth_u16).astype(np.int64)
@@ -82,7 +82,7 @@ def depth_normals_gradient(depth_u16, K):
     for j in (-r, 0, r):
         for i in (-r, 0, r):
             delta = D[r + j:H - r - 1 + j, r + i:W - r - 1 + i] - d
-            ok = np.abs(delta) <= 50
+            ok = np.abs(delta) < 50
             A0[ys, xs] += ok * (i * i); A1[ys, xs] += ok * (i * j); A3[ys, xs] += ok * (j * j)
             b0[ys, xs] += np.where(ok, i * delta, 0); b1[ys, xs] += np.where(ok, j * delta, 0)
     det = A0 * A3 - A1 * A1

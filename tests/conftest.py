@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# harness side: one BLAS thread under the cgroup CPU quota of the GPU boxes; importing the library itself has no side effects
+os.environ.setdefault("STOCS_PIN_BLAS", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

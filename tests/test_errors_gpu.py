@@ -227,9 +227,9 @@ def test_patch_test_entry_points_reject_bad_arguments():
     assert npat.value == 3 and nd.value > 0
     small = np.zeros(8, np.float32)
     assert L.stocs_get_cull_state(est.h, None, None, C.byref(npat), None, small.ctypes.data_as(capi._fp), 8, C.byref(nd)) == -4   # capacity
-    for key, bad in (("lcp_cull", 3), ("lcp_cull", -1), ("lcp_group", 3), ("lcp_group", 16), ("lcp_order", -1)):
+    for key, bad in (("lcp_cull", 3), ("lcp_cull", -1), ("lcp_group", 3), ("lcp_group", 8), ("lcp_group", 16), ("lcp_order", -1)):   # (8 lanes per query: measurement build only)
         assert L.stocs_set_option(est.h, key.encode(), bad) == -1, (key, bad)
-    for key, ok in (("lcp_cull", 0), ("lcp_cull", 2), ("lcp_group", 8), ("lcp_group", 4)):
+    for key, ok in (("lcp_cull", 0), ("lcp_cull", 2), ("lcp_group", 4)):
         assert L.stocs_set_option(est.h, key.encode(), ok) == 0, (key, ok)
     est.close()
     # fewer than 64 model points: no field, scoring works as ever

@@ -222,7 +222,7 @@ def test_all_scan_variants_on_sparse_scene(oracle_lib):
     ref = orc.lcp_batch(T, nthreads=8)
     best = int(np.argmax(ref))
     ho, co = orc.lcp_detail(T[best])
-    for v in (0, 15, 24, 31):
+    for v in (0, 24, 31):                       # (31 is a dense-scene kernel: on this grid it maps to 24)
         est.set_option("lcp_variant", v)
         assert np.abs(est.score_transforms(T) - ref).max() <= LCP_TOL, v
         hg, cg = est.lcp_detail(T[best])
@@ -230,7 +230,7 @@ def test_all_scan_variants_on_sparse_scene(oracle_lib):
     est.set_option("lcp_variant", 99)
     # measurement-only kernels (and the timing ablations of round 1) are not part of the product library
     from model_matching_amd import capi
-    for v in (1, 9, 10, 11, 12, 13, 14, 16, 20, 28, 98, -1):
+    for v in (1, 9, 10, 11, 12, 13, 14, 15, 16, 20, 28, 98, -1):
         with pytest.raises(capi.StocsError):
             est.set_option("lcp_variant", v)
 
@@ -246,7 +246,7 @@ def test_dense_scene_and_all_scan_variants(oracle_lib):
     assert np.abs(got - ref).max() <= LCP_TOL and got.max() > 0.05
     best = int(np.argmax(ref))
     ho, co = orc.lcp_detail(T[best])
-    for v in (0, 31, 39, 15, 24):     # 39: queue-fed scan with early exit (the default here); on a dense (centre-sorted) grid 15 and 24 map to it
+    for v in (0, 31, 39, 24):     # 39: queue-fed scan with early exit (the default here); on a dense (centre-sorted) grid 24 maps to it
         est.set_option("lcp_variant", v)
         gv = est.score_transforms(T)
         assert np.abs(gv - ref).max() <= LCP_TOL, v

@@ -151,6 +151,44 @@ def test_congruent_sets_and_transforms_equal_oracle(setup):
     assert okg == oko == False
 
 
+def test_a_trial_without_congruent_sets_is_a_valid_empty_result(setup):
+    """Zero quads is a result, not an error (the reference's loop appends nothing, stocs_match_one_object.cpp:111-147): after
+    stocs_find_congruent_all found none, stocs_make_transforms gives 0 candidates and compute_best_transform "no pose" -- whether
+    the pair lists were empty, no (base, cell) was occupied by both lists (the early return of the reduced form), or the
+    direction cells simply never matched."""
+    m, s, est, orc = setup
+    est.L.stocs_clear_bases(est.h)
+    valid, ids, inv = est.sample_bases(99, 24)
+    est.find_congruent_all()
+    nq = [est.num_quads(k) for k in range(int(valid.sum()))]
+    a = int(np.nonzero(valid)[0][int(np.argmax(nq))])          # a base that does have congruent sets
+    assert max(nq) > 0
+    far = np.array([int(np.argmin(s.pos[:, 0])), int(np.argmax(s.pos[:, 0])), int(np.argmin(s.pos[:, 1])), int(np.argmax(s.pos[:, 1]))], np.int32)
+    cases = {
+        # both intersection points far outside the unit cube: every entry gets the "no cell" key, no cell is shared
+        "no shared cell": (ids[a], np.array([1000.0, -1000.0], np.float32)),
+        # base points farther apart than the model is long: the PPF keys are not in the index, both lists are empty
+        "empty lists": (far, np.array([0.5, 0.5], np.float32)),
+    }
+    zero = [k for k, n in enumerate(nq) if n == 0]
+    if zero:                                                    # non-empty lists whose entries never match
+        az = int(np.nonzero(valid)[0][zero[0]])
+        cases["no match"] = (ids[az], inv[az])
+    for name, (b, iv) in cases.items():
+        est.set_bases(b.reshape(1, 4), iv.reshape(1, 2))
+        assert est.find_congruent_all() == 0, name
+        assert est.num_quads(0) == 0 and est.get_quads(0).shape == (0, 4), name
+        assert est.make_transforms(200, 5) == 0, name
+        T, P, l, bi = est.get_pose_candidates()
+        assert len(T) == 0, name
+        lcp, idx, pose = est.compute_best_transform()
+        assert (lcp, idx) == (0.0, -1) and not pose.any(), name
+    # and the context is fine afterwards: the same base with its own invariants gives its sets again
+    est.set_bases(ids[a].reshape(1, 4), inv[a].reshape(1, 2))
+    assert est.find_congruent_all() == max(nq)
+    assert est.make_transforms(200, 5) > 0
+
+
 def test_wide_key_path_of_the_pair_lists(setup, monkeypatch):
     """Position grids beyond 32 bits of (base, cell) take 64-bit sort keys; that path (forced here) must give the same
     quads in the same orders."""

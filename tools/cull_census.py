@@ -2,6 +2,7 @@
 """Census (CPU only, scipy kd-tree; no library code): which 64-point steps of the sorted model a sphere test against the scene could rule out, for the Morton and the median-split order.  usage: python tools/cull_census.py [Cm|C5] [candidates]"""
 import numpy as np, sys
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+import os as _os; _os.environ.setdefault("STOCS_PIN_BLAS", "1")   # harness side: one BLAS thread under the cgroup CPU quota (DESIGN.md 3); the library import itself has no side effects
 from model_matching_amd import synth
 from scipy.spatial import cKDTree
 from scipy.ndimage import distance_transform_edt

@@ -15,6 +15,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import os as _os; _os.environ.setdefault("STOCS_PIN_BLAS", "1")   # harness side: one BLAS thread under the cgroup CPU quota; the library import itself has no side effects
 from model_matching_amd import synth  # noqa: E402
 from model_matching_amd.estimator import StocsEstimator  # noqa: E402
 from oracle import pyoracle  # noqa: E402

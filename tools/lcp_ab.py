@@ -8,6 +8,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os; _os.environ.setdefault("STOCS_PIN_BLAS", "1")   # harness side: one BLAS thread under the cgroup CPU quota; the library import itself has no side effects
 from model_matching_amd import capi, synth  # noqa: E402
 # variants beyond 0 / 15 / 24 / 31 exist only in the measurement build (make -C model_matching_amd/csrc tools)
 _tools_lib = os.path.join(os.path.dirname(capi.LIB_PATH), "libstocs_hip_tools.so")

@@ -1,5 +1,6 @@
 import numpy as np, sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import os as _os; _os.environ.setdefault("STOCS_PIN_BLAS", "1")   # harness side: one BLAS thread under the cgroup CPU quota; the library import itself has no side effects
 from model_matching_amd import synth
 from model_matching_amd.estimator import StocsEstimator
 from oracle import pyoracle

@@ -2,6 +2,7 @@
 """Census (CPU only): length of the candidate list a surviving query scans, by cell edge eps / div.  usage: python tools/list_census.py [Cm|C5] [div]"""
 import numpy as np, sys
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+import os as _os; _os.environ.setdefault("STOCS_PIN_BLAS", "1")   # harness side: one BLAS thread under the cgroup CPU quota (DESIGN.md 3); the library import itself has no side effects
 from model_matching_amd import synth
 from scipy.spatial import cKDTree
 name=sys.argv[1] if len(sys.argv)>1 else 'Cm'

@@ -5,6 +5,7 @@ epsilon-cells around a query hold -- the numbers behind the choice of the list l
 usage: python tools/query_census.py [C5|Cm|dense|small]"""
 import numpy as np, sys, time
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+import os as _os; _os.environ.setdefault("STOCS_PIN_BLAS", "1")   # harness side: one BLAS thread under the cgroup CPU quota (DESIGN.md 3); the library import itself has no side effects
 from model_matching_amd import synth
 from scipy.spatial import cKDTree
 name = sys.argv[1] if len(sys.argv)>1 else 'C5'

@@ -1,6 +1,7 @@
 import json, os, sys
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import os as _os; _os.environ.setdefault("STOCS_PIN_BLAS", "1")   # harness side: one BLAS thread under the cgroup CPU quota; the library import itself has no side effects
 from model_matching_amd import synth
 from model_matching_amd.estimator import StocsEstimator
 for nS, nM, K, lattice in [(50000, 12500, 32768, 0.0032), (35000, 8000, 32768, 0.004), (100000, 25000, 16384, 0.0022)]:

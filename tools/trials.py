@@ -20,6 +20,7 @@ import time
 # 1-3 (profiles/r03_stall_root_cause.json).  Must happen before numpy is imported.
 for _v in ("OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
     os.environ.setdefault(_v, "1")
+os.environ.setdefault("STOCS_PIN_BLAS", "1")   # harness side (importing the library itself has no side effects)
 
 import numpy as np
 
