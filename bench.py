@@ -34,7 +34,7 @@ PEAK_HBM_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~
 NEEDED_BYTES_PER_HIT = 28      # one nearest scene record: position 12 + normal 12 + class probability 4
 
 
-def kernel_record(est, dT, kcand, dL, reps, workload, candidates_arg, run_pmc, groups=None, prefix=""):
+def kernel_record(est, dT, kcand, dL, reps, workload, candidates_arg, run_pmc, groups=None, prefix="", count_hits=True):
     """Flat, scalar-only description of the dominant kernel for one workload -- everything a reader needs to recompute it:
     * contract figure: ALGORITHMIC bytes (68 + 52 |M| per pose) / kernel time / HBM peak.  Not a ceiling on
       cache-resident workloads: it charges a scene record to every model point and the model to every pose.
@@ -46,7 +46,7 @@ def kernel_record(est, dT, kcand, dL, reps, workload, candidates_arg, run_pmc, g
       guide: Infinity-Cache hits are counted, so this is NOT pure HBM), L2 -> L1 bytes, unit utilisations, and the binding unit."""
     b_pose = 68 + 52 * est.nM
     k_ms = est.time_score_kernel(dT, kcand, dL, reps)
-    hits, counted = est.lcp_hit_count(dT, kcand)
+    hits, counted = est.lcp_hit_count(dT, kcand) if count_hits else (0, 0)
     needed = float(hits) * NEEDED_BYTES_PER_HIT + 68.0 * kcand
     sec = k_ms * 1e-3
     rec = {
@@ -81,10 +81,10 @@ def add_counters(rec, nested, workload, candidates_arg, groups=None):
         import pmc as pmc_tool
         if shutil.which("rocprofv3"):
             pdir = tempfile.mkdtemp(prefix="stocs_pmc_")
-            child = ["python3", os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pipeline", "--no-pmc", "--no-c5",
+            child = ["python3", os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pipeline", "--no-pmc", "--no-c5", "--no-hits",
                      "--workload", workload] + (["--candidates", str(candidates_arg)] if candidates_arg else [])
             grp = pmc_tool.GROUPS if not groups else type(pmc_tool.GROUPS)((g, pmc_tool.GROUPS[g]) for g in groups if g in pmc_tool.GROUPS)
-            raw = pmc_tool.collect("lcp_coop", child, pdir, groups=grp)
+            raw = pmc_tool.collect("lcp_coopq_kernel<false", child, pdir, groups=grp)   # the scoring kernel, not its per-point detail form (<true, ...>)
             der = pmc_tool.derive(raw, k_ms)
             shutil.rmtree(pdir, ignore_errors=True)
             mem = der.get("hbm_bytes_per_launch")
@@ -162,6 +162,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (roofline.traffic / binding become null)")
     ap.add_argument("--no-c5", action="store_true", help="skip the C5 leg of the roofline record (200 000-point scene, 50 000-point model: the HBM-bound configuration)")
+    ap.add_argument("--no-hits", action="store_true", help="skip the hit census behind needed_bytes (the counter child runs: its per-point detail launches must not be profiled)")
     ap.add_argument("--pmc-groups", default="", help="comma-separated counter groups of tools/pmc.py for the live passes (default: all)")
     args = ap.parse_args()
 
@@ -257,7 +258,7 @@ def main():
     best_i = int(np.argmax(lcp))
     run_pmc = rank == 0 and world == 1 and not args.no_pmc
     groups = [g for g in args.pmc_groups.split(",") if g] or None
-    krec, knest = kernel_record(est, dT, kcand, dL, reps, args.workload, args.candidates, False)   # (counters: after the pipeline section, below)
+    krec, knest = kernel_record(est, dT, kcand, dL, reps, args.workload, args.candidates, False, count_hits=not args.no_hits)   # (counters: after the pipeline section, below)
     k_ms = krec["kernel_ms"]
     achieved = b_pose * kcand / (k_ms * 1e-3) / 1e9   # GB/s
     peak = PEAK_HBM_GBS
