@@ -185,6 +185,35 @@ int stocs_lcp_hit_count(stocs_ctx* ctx, const void* d_T16, int n, int64_t* hits,
 /* compute_best_transform (stocs.cpp:982-1004): score every stored candidate, arg-max with first
  * maximum winning; best_idx = -1 and best_lcp = 0 when every score is 0 */
 int stocs_verify_all(stocs_ctx* ctx, float* best_lcp, int* best_idx, float* best_pose16_camera);
+/* ---- trial batches: N independent StoCS trials in ONE set of launches.  The reference runs one trial per process
+ * (stocs_match_one_object.cpp:81-165: 100 base attempts -> congruent sets -> <= 200 candidates per base -> best candidate);
+ * BASELINE config 4 runs 64 of them.  Trial t of the batch is, bit for bit (bases, congruent sets, candidates, scores, winner),
+ *     stocs_reset_trial; stocs_sample_bases(mode, seeds[t], 0, n_attempts, dispersion); stocs_find_congruent_all;
+ *     stocs_make_transforms(max_per_base, seeds[t]); stocs_verify_all
+ * but the trials share every launch: one sampling launch (class mode: a workgroup per attempt of every trial; instance mode: a
+ * workgroup pair per trial on its own copy of the image-space state), one congruent-set pass over the concatenated base sets, one
+ * transform pass, one scoring launch with a per-trial arg-max.  Batches beyond what one set of launches can key or hold are cut
+ * into pieces of consecutive trials (environment STOCS_TRIALS_MAX_MB: device-memory ceiling of a piece, default 16384).
+ * The context is left as stocs_reset_trial leaves it (no bases, no candidates); the batch's record stays readable through the
+ * getters below until the next batch.  keep_details != 0 also keeps every trial's candidate list (tests; costs a download). ---- */
+typedef struct stocs_trial_result {
+    int32_t n_bases;          /* valid bases among the trial's attempts                                   */
+    int32_t n_candidates;     /* candidates its stocs_make_transforms produced                            */
+    int64_t n_quads;          /* congruent sets over all its bases                                        */
+    float   best_lcp;         /* compute_best_transform of the trial alone (stocs.cpp:982-1004)           */
+    int32_t best_index;       /* index into the trial's own candidate list; -1 (and best_lcp 0): no pose  */
+    float   best_pose16[16];  /* camera frame, column-major; zeros when there is no pose                  */
+} stocs_trial_result;
+int stocs_run_trials(stocs_ctx* ctx, int mode, int n_trials, const uint64_t* seeds, int n_attempts, float dispersion, int max_per_base,
+                     int keep_details, stocs_trial_result* out /* n_trials, may be NULL */);
+/* attempts of one trial of the last batch, as stocs_sample_bases returns them (ids permuted by try_sampled_base, invariants, valid) */
+int stocs_trials_get_bases(stocs_ctx* ctx, int trial, int32_t* base_ids4, float* inv2, int32_t* valid, int cap_attempts, int* n_attempts);
+/* congruent sets of each valid base of the trial (what stocs_get_quads reports as *n for that base slot) */
+int stocs_trials_get_quad_counts(stocs_ctx* ctx, int trial, int64_t* counts, int cap, int* n);
+/* the trial's candidates as stocs_get_candidates returns them after stocs_verify_all (needs keep_details; base_index counts the
+ * trial's own valid bases) */
+int stocs_trials_get_candidates(stocs_ctx* ctx, int trial, float* T16_centred, float* pose16_camera, float* lcp, int32_t* base_index, int cap, int* n);
+
 /* arg-max of n device-resident scores on the device: *key = max over i of
  * stocs_pack_best(lcp[i], id_offset + i), 0 when no score is positive (first maximum wins, as the
  * strict > of stocs.cpp:994).  Synchronises the context's stream; 8 bytes cross PCIe. */
@@ -311,7 +340,7 @@ int stocs_time_score_kernel(stocs_ctx* ctx, const void* d_T16, int n, void* d_lc
  * difference across them is 0. */
 int64_t stocs_device_alloc_count(void);
 /* host wall clock, in milliseconds, of the steps of the context's LAST stocs_find_congruent_all (which = 0),
- * stocs_make_transforms (1) or stocs_verify_all (2): always recorded (a few clock reads per call, no synchronisation of its
+ * stocs_make_transforms (1), stocs_verify_all (2) or stocs_run_trials (3: its phases summed over the pieces of the batch): always recorded (a few clock reads per call, no synchronisation of its
  * own), so that a call that stalls -- tens of milliseconds instead of one -- names the step it stalled in.  Steps are host
  * intervals between the call's existing synchronisation points: "wait for the device" steps hold the GPU work, the others
  * host work and runtime calls; entries whose label starts with "device:" are HIP-event times of the kernel groups that

@@ -28,6 +28,11 @@ class Params(C.Structure):
                 ("number_of_bases", C.c_int), ("maximum_congruent_sets", C.c_int)]
 
 
+class TrialResult(C.Structure):
+    _fields_ = [("n_bases", C.c_int32), ("n_candidates", C.c_int32), ("n_quads", C.c_int64), ("best_lcp", C.c_float), ("best_index", C.c_int32),
+                ("best_pose16", C.c_float * 16)]
+
+
 class Camera(C.Structure):
     _fields_ = [("fx", C.c_float), ("cx", C.c_float), ("fy", C.c_float), ("cy", C.c_float), ("depth_scale", C.c_float),
                 ("width", C.c_int), ("height", C.c_int), ("normal_method", C.c_int)]
@@ -81,6 +86,10 @@ SIGNATURES = {
     "stocs_lcp_detail": (C.c_int, [_vp, _fp, _ip, _u8p]),
     "stocs_lcp_hit_count": (C.c_int, [_vp, _vp, C.c_int, _i64p, _i64p]),
     "stocs_verify_all": (C.c_int, [_vp, _fp, _intp, _fp]),
+    "stocs_run_trials": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_int, C.c_float, C.c_int, C.c_int, C.POINTER(TrialResult)]),
+    "stocs_trials_get_bases": (C.c_int, [_vp, C.c_int, _ip, _fp, _ip, C.c_int, _intp]),
+    "stocs_trials_get_quad_counts": (C.c_int, [_vp, C.c_int, _i64p, C.c_int, _intp]),
+    "stocs_trials_get_candidates": (C.c_int, [_vp, C.c_int, _fp, _fp, _fp, _ip, C.c_int, _intp]),
     "stocs_best_device": (C.c_int, [_vp, _vp, C.c_int, C.c_uint32, C.POINTER(C.c_uint64)]),
     "stocs_pack_best": (C.c_uint64, [C.c_float, C.c_uint32]),
     "stocs_unpack_best": (None, [C.c_uint64, _fp, C.POINTER(C.c_uint32)]),

@@ -110,47 +110,70 @@ __global__ __launch_bounds__(64) void plan_ranges_kernel(const uint32_t* __restr
     }
 }
 
-// One workgroup: offsets of every base in the gathered lists (a base without P pairs or without Q pairs gets neither,
-// stocs.cpp:788), the segment arrays the gather walks, the list offsets patched into the base jobs, the totals for the host.
-// Counts are staged in LDS, scanned there by one thread (nB <= PLAN_MAX_BASES), and everything else is written in parallel.
-#define PLAN_MAX_BASES 2048
-__global__ __launch_bounds__(256) void plan_offsets_kernel(int nB, const uint2* __restrict__ ranges, const uint32_t* __restrict__ n_ranges, const uint32_t* __restrict__ totals,
-                                                           BaseJob* __restrict__ jobs, Segment* __restrict__ psegs, Segment* __restrict__ qsegs,
-                                                           uint32_t* __restrict__ p_off, uint32_t* __restrict__ q_off, PlanOut* __restrict__ out,
-                                                           unsigned int* __restrict__ err) {
-    __shared__ uint32_t s_np[PLAN_MAX_BASES], s_nq[PLAN_MAX_BASES], s_rp[PLAN_MAX_BASES], s_rq[PLAN_MAX_BASES];   // counts, then exclusive offsets
-    for (int b = threadIdx.x; b < nB; b += blockDim.x) {
-        uint32_t np = totals[b], nq = totals[nB + b], rp = n_ranges[b], rq = n_ranges[nB + b];
-        if (np == 0 || nq == 0) { np = 0; nq = 0; rp = 0; rq = 0; }
-        s_np[b] = np; s_nq[b] = nq; s_rp[b] = rp; s_rq[b] = rq;
+// exclusive scan of a[0 .. n) by one workgroup of 1024, in place; emit(i, offset, value) sees every element
+template <class F>
+__device__ __forceinline__ void block_scan_1024(uint32_t* __restrict__ a, uint32_t n, uint32_t* s_part, F emit) {
+    const uint32_t tid = threadIdx.x, chunk = (n + 1023u) / 1024u;
+    const uint32_t lo = min(tid * chunk, n), hi = min(lo + chunk, n);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += a[i];
+    __syncthreads();
+    s_part[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+        const uint32_t v = tid >= d ? s_part[tid - d] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
     }
+    uint32_t run = s_part[tid] - sum;
+    for (uint32_t i = lo; i < hi; ++i) { const uint32_t v = a[i]; a[i] = run; emit(i, run, v); run += v; }
+}
+
+// One workgroup of 1024: offsets of every base in the gathered lists (a base without P pairs or without Q pairs gets neither,
+// stocs.cpp:788), the segment arrays the gather walks, the list offsets patched into the base jobs, the totals for the host.
+// Four in-place scans over arrays of nB + 1 words in device memory (any number of bases: a trial batch brings thousands), then
+// everything else in parallel over the bases.
+#define PLAN_MAX_BASES (1 << 20)
+__global__ __launch_bounds__(1024) void plan_offsets_kernel(int nB, const uint2* __restrict__ ranges, const uint32_t* __restrict__ n_ranges, const uint32_t* __restrict__ totals,
+                                                            BaseJob* __restrict__ jobs, Segment* __restrict__ psegs, Segment* __restrict__ qsegs,
+                                                            uint32_t* __restrict__ p_off, uint32_t* __restrict__ q_off, uint32_t* __restrict__ sp_off, uint32_t* __restrict__ sq_off,
+                                                            PlanOut* __restrict__ out, unsigned int* __restrict__ err) {
+    __shared__ uint32_t s_part[1024];
+    __shared__ unsigned long long s_tot[2];
+    if (threadIdx.x < 2) s_tot[threadIdx.x] = 0ull;
     if (threadIdx.x < 64) err[threadIdx.x] = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long totP = 0, totQ = 0;
-        uint32_t nsp = 0, nsq = 0, overflow = 0;
-        for (int b = 0; b < nB; ++b) {
-            const uint32_t np = s_np[b], nq = s_nq[b], rp = s_rp[b], rq = s_rq[b];
-            s_np[b] = (uint32_t)totP; s_nq[b] = (uint32_t)totQ; s_rp[b] = nsp; s_rq[b] = nsq;
-            totP += np; totQ += nq; nsp += rp; nsq += rq;
-            if (totP >= 0xFFFF0000ull || totQ >= 0xFFFF0000ull) overflow = 1;
-        }
-        p_off[nB] = (uint32_t)totP; q_off[nB] = (uint32_t)totQ;
-        out->totP = totP; out->totQ = totQ; out->n_pseg = nsp; out->n_qseg = nsq; out->overflow = overflow; out->pad = 0;
+    unsigned long long tp = 0, tq = 0;
+    for (int b = threadIdx.x; b <= nB; b += blockDim.x) {
+        uint32_t np = 0, nq = 0, rp = 0, rq = 0;
+        if (b < nB) { np = totals[b]; nq = totals[nB + b]; rp = n_ranges[b]; rq = n_ranges[nB + b]; }
+        if (np == 0 || nq == 0) { np = 0; nq = 0; rp = 0; rq = 0; }
+        p_off[b] = np; q_off[b] = nq; sp_off[b] = rp; sq_off[b] = rq;      // counts now, exclusive offsets after the scans (element nB: the totals)
+        tp += np; tq += nq;
     }
+    for (int off = 32; off > 0; off >>= 1) { tp += __shfl_xor(tp, off, 64); tq += __shfl_xor(tq, off, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_tot[0], tp); atomicAdd(&s_tot[1], tq); }
     __syncthreads();
+    block_scan_1024(p_off, (uint32_t)nB + 1u, s_part, [&](uint32_t b, uint32_t o, uint32_t v) { if (b < (uint32_t)nB) { jobs[b].p_off = o; jobs[b].p_len = v; } });
+    __syncthreads();
+    block_scan_1024(q_off, (uint32_t)nB + 1u, s_part, [&](uint32_t b, uint32_t o, uint32_t v) { if (b < (uint32_t)nB) { jobs[b].q_off = o; jobs[b].q_len = v; } });
+    __syncthreads();
+    block_scan_1024(sp_off, (uint32_t)nB + 1u, s_part, [](uint32_t, uint32_t, uint32_t) {});
+    __syncthreads();
+    block_scan_1024(sq_off, (uint32_t)nB + 1u, s_part, [](uint32_t, uint32_t, uint32_t) {});
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out->totP = s_tot[0]; out->totQ = s_tot[1]; out->n_pseg = sp_off[nB]; out->n_qseg = sq_off[nB];
+        out->overflow = (s_tot[0] >= 0xFFFF0000ull || s_tot[1] >= 0xFFFF0000ull) ? 1u : 0u; out->pad = 0;
+    }
     for (int b = threadIdx.x; b < nB; b += blockDim.x) {
-        uint32_t np = totals[b], nq = totals[nB + b];
-        const bool none = np == 0 || nq == 0;
-        if (none) { np = 0; nq = 0; }
-        p_off[b] = s_np[b]; q_off[b] = s_nq[b];
-        jobs[b].p_off = s_np[b]; jobs[b].p_len = np; jobs[b].q_off = s_nq[b]; jobs[b].q_len = nq;
-        if (none) continue;
+        if (totals[b] == 0 || totals[nB + b] == 0) continue;
 #pragma unroll
         for (int list = 0; list < 2; ++list) {
             const uint2* r = ranges + ((size_t)list * nB + b) * 128;
-            Segment* sg = list ? qsegs + s_rq[b] : psegs + s_rp[b];
-            uint32_t d = list ? s_nq[b] : s_np[b];
+            Segment* sg = list ? qsegs + sq_off[b] : psegs + sp_off[b];
+            uint32_t d = list ? q_off[b] : p_off[b];
             const uint32_t n = n_ranges[(size_t)list * nB + b];
             for (uint32_t k = 0; k < n; ++k) { const uint2 v = r[k]; Segment o = {v.x, v.y - v.x, d, (uint32_t)b}; sg[k] = o; d += o.len; }
         }
@@ -228,26 +251,6 @@ __global__ __launch_bounds__(256) void survivors_count_kernel(const KeyT* __rest
     if (lane == 0) s_w[w] = cnt;
     __syncthreads();
     if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-}
-
-// exclusive scan of a[0 .. n) by one workgroup of 1024, in place; emit(i, offset, value) sees every element
-template <class F>
-__device__ __forceinline__ void block_scan_1024(uint32_t* __restrict__ a, uint32_t n, uint32_t* s_part, F emit) {
-    const uint32_t tid = threadIdx.x, chunk = (n + 1023u) / 1024u;
-    const uint32_t lo = min(tid * chunk, n), hi = min(lo + chunk, n);
-    uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; ++i) sum += a[i];
-    __syncthreads();
-    s_part[tid] = sum;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024u; d <<= 1) {
-        const uint32_t v = tid >= d ? s_part[tid - d] : 0u;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
-    }
-    uint32_t run = s_part[tid] - sum;
-    for (uint32_t i = lo; i < hi; ++i) { const uint32_t v = a[i]; a[i] = run; emit(i, run, v); run += v; }
 }
 
 // workgroup 0: P list, workgroup 1: Q list.  Tile counts -> tile offsets (element n_tiles receives the total)
@@ -1143,8 +1146,11 @@ int stocs_cone_cells_host(const float* n3, float cos_alpha, uint32_t* exact_bits
     return STOCS_OK;
 }
 
-int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
+int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) { return stocs_internal_find_congruent(c, total_quads, 0, NULL); }
+
+int stocs_internal_find_congruent(stocs_ctx* c, int64_t* total_quads, size_t max_bytes, int* too_big) {
     if (!c) return STOCS_ERR_INVALID;
+    if (too_big) *too_big = 0;
     DeviceGuard dev_guard(c->device);
     const bool dbg = getenv("STOCS_DEBUG_TIMING") != NULL;
     double tprev = now_s();
@@ -1179,7 +1185,8 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     const float nepsilon = (float)((double)(1.0f / 7.0f) + 0.00001);  // normalset.h:86
     // ---- key layout ----
     const long long NC = (long long)egSize * egSize * egSize;
-    const bool use_table = NC > 0 && NC * (long long)nB <= (long long)32 * 1024 * 1024;
+    // (8 bytes of run table + 2 of occupancy per (base, cell): up to 2.7 GB -- a trial batch brings thousands of bases, and 288 GB are there for it)
+    const bool use_table = NC > 0 && NC * (long long)nB <= (long long)256 * 1024 * 1024;
     int base_bits = 1, id_bits = 1, cell_bits = 1;
     while ((1 << base_bits) < nB) base_bits++;
     while ((1 << id_bits) < c->nM) id_bits++;
@@ -1190,7 +1197,7 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     }
     const bool wide = base_bits + cell_bits > 32 || getenv("STOCS_CONGRUENT_WIDE_KEYS") != NULL;   // env: keeps the 64-bit path testable
     // both pair lists are reduced to the entries with a partner cell when one byte per (base, cell) is a small table (count_pass)
-    const bool reduce = use_table && ((unsigned long long)nB << cell_bits) <= (1ull << 25) && !getenv("STOCS_CONGRUENT_KEEP_ALL");
+    const bool reduce = use_table && ((unsigned long long)nB << cell_bits) <= (1ull << 29) && !getenv("STOCS_CONGRUENT_KEEP_ALL");
     for (int b = 0; b < nB; ++b) {
         const BaseRec& B = c->bases[b];
         BaseJob& J = jobs[b];
@@ -1206,8 +1213,8 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
     const size_t nb = (size_t)nB;
     const size_t o_jobs = 0, o_bids = o_jobs + al(sizeof(BaseJob) * nb), o_err = o_bids + al(16 * nb), o_rng = o_err + 256, o_nr = o_rng + al(2 * nb * 128 * 8),
                  o_tot = o_nr + al(2 * nb * 4), o_pseg = o_tot + al(2 * nb * 4), o_qseg = o_pseg + al(nb * 128 * sizeof(Segment)),
-                 o_poff = o_qseg + al(nb * 128 * sizeof(Segment)), o_qoff = o_poff + al((nb + 1) * 4), o_spo = o_qoff + al((nb + 2) * 4), o_sqo = o_spo + al(nb * 4),
-                 o_out = o_sqo + al(nb * 4), plan_bytes = o_out + 256, up_bytes = o_err + 256;
+                 o_poff = o_qseg + al(nb * 128 * sizeof(Segment)), o_qoff = o_poff + al((nb + 1) * 4), o_spo = o_qoff + al((nb + 2) * 4), o_sqo = o_spo + al((nb + 1) * 4),
+                 o_out = o_sqo + al((nb + 1) * 4), plan_bytes = o_out + 256, up_bytes = o_err + 256;
     if (S->plan_bytes < plan_bytes) {
         if (S->d_plan) (void)hipFree(S->d_plan);
         S->d_plan = NULL; S->plan_bytes = 0;
@@ -1243,8 +1250,8 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
         STOCS_HIP_CHECK(hipMemcpyAsync(dpl, h, up_bytes, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(plan_ranges_kernel, dim3((unsigned)nB, 2), dim3(64), 0, c->stream, ix.d_bucket_start, ix.tr, ix.rot, ix.NA, ix.nD, plan.bids,
                            (const float4*)c->d_spos, (const float4*)c->d_snrmw, nB, (uint2*)(dpl + o_rng), (uint32_t*)(dpl + o_nr), (uint32_t*)(dpl + o_tot));
-        hipLaunchKernelGGL(plan_offsets_kernel, dim3(1), dim3(256), 0, c->stream, nB, (const uint2*)(dpl + o_rng), (const uint32_t*)(dpl + o_nr), (const uint32_t*)(dpl + o_tot),
-                           plan.jobs, plan.psegs, plan.qsegs, plan.p_off, plan.q_off, (PlanOut*)(dpl + o_out), plan.err);
+        hipLaunchKernelGGL(plan_offsets_kernel, dim3(1), dim3(1024), 0, c->stream, nB, (const uint2*)(dpl + o_rng), (const uint32_t*)(dpl + o_nr), (const uint32_t*)(dpl + o_tot),
+                           plan.jobs, plan.psegs, plan.qsegs, plan.p_off, plan.q_off, (uint32_t*)(dpl + o_spo), (uint32_t*)(dpl + o_sqo), (PlanOut*)(dpl + o_out), plan.err);
         STOCS_HIP_CHECK(hipGetLastError());
         // read-backs land in the pinned block (a copy into pageable memory -- a stack variable, a std::vector -- takes the
         // runtime's staging path): totals in the fixed slot, the Q offsets behind the per-base quad offsets of count_pass
@@ -1258,7 +1265,7 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
         c->timing[0].lap("wait for the device (plan)");
         const PlanOut po = *po_pin;
         if (!reduce) memcpy(q_off.data(), qoff_pin, 4 * (nb + 1));
-        if (po.overflow) { set_error("pair lists exceed 2^32 entries"); return STOCS_ERR_CAPACITY; }
+        if (po.overflow) { if (too_big) { *too_big = 1; return STOCS_OK; } set_error("pair lists exceed 2^32 entries"); return STOCS_ERR_CAPACITY; }
         totP = po.totP; totQ = po.totQ; plan.n_pseg = (int)po.n_pseg; plan.n_qseg = (int)po.n_qseg;
         STOCS_TICK("plan (device)")
     } else {
@@ -1292,7 +1299,7 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
             for (size_t r = 0; r < qr.size(); ++r) { Segment sg = {qr[r].first, qr[r].second - qr[r].first, d, (uint32_t)b}; qsegs.push_back(sg); d += sg.len; }
             q_off[b] = (uint32_t)totQ;
             totP += np; totQ += nq;
-            if (totP >= 0xFFFF0000ull || totQ >= 0xFFFF0000ull) { set_error("pair lists exceed 2^32 entries"); return STOCS_ERR_CAPACITY; }
+            if (totP >= 0xFFFF0000ull || totQ >= 0xFFFF0000ull) { if (too_big) { *too_big = 1; return STOCS_OK; } set_error("pair lists exceed 2^32 entries"); return STOCS_ERR_CAPACITY; }
         }
         q_off[nB] = (uint32_t)totQ;
         if (psegs.size() > nb * 128 || qsegs.size() > nb * 128) { set_error("internal: more than 128 ranges per lookup"); return STOCS_ERR_STATE; }
@@ -1317,7 +1324,9 @@ int stocs_find_congruent_all(stocs_ctx* c, int64_t* total_quads) {
         const size_t tables = use_table ? (size_t)(NC * nB) * 8 : 0;
         const size_t per_entry = 3 * kb + 8 + 16 + 8 + (reduce ? kb + 4 : 0);   // (the compacted copies of the reduced form)
         const size_t occ = reduce ? 2 * ((size_t)nB << cell_bits) : 0;
-        int rc0 = S->arena_state.reserve((size_t)totP * per_entry + (size_t)totQ * per_entry + tables + occ + ((size_t)48 << 20));
+        const size_t need = (size_t)totP * per_entry + (size_t)totQ * per_entry + tables + occ + ((size_t)48 << 20);
+        if (max_bytes && need > max_bytes && nB > 1) { if (too_big) *too_big = 1; return STOCS_OK; }   // the caller splits its base set
+        int rc0 = S->arena_state.reserve(need);
         if (rc0) return rc0;
     }
     c->timing[0].lap("arena reserve");

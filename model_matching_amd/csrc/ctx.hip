@@ -237,6 +237,7 @@ static int load_scene_impl(stocs_ctx* c, const float* sp, const float* sn, const
     if (!rc) rc = build_grid(c);
     lap("grid");
     // per-trial state belongs to the old scene
+    clear_trial_batch(c);
     c->bases.clear(); c->quad_off.clear(); clear_candidates(c);
     c->best_lcp = 0; c->best_index = -1;
     c->scene_scored = 0; c->scene_work = 0.0;
@@ -414,11 +415,12 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     c->nS = nS; c->nM = nM;
     c->d_scratch = NULL; c->scratch_bytes = 0;
     c->h_pin = NULL; c->pin_bytes = 0;
-    for (int k = 0; k < 3; ++k) c->timing[k].n = 0;
+    for (int k = 0; k < 4; ++k) c->timing[k].n = 0;
     c->index.built = false;
     c->index.d_bucket_start = NULL; c->index.d_pairs = NULL; c->index.d_exists = NULL;
     c->cong = NULL; c->quad_id_bits = 16;
     c->inst = NULL;
+    c->trials = NULL; c->snrmw_trial0 = NULL; c->snrmw_stride = 0; c->snrmw_override = NULL;
     c->d_cand = NULL; c->cand_bytes = 0; c->n_cands = 0; c->cand_cap = 0; c->cands_stale = false;
     c->d_best = NULL;
     c->best_lcp = 0; c->best_index = -1;
@@ -546,6 +548,7 @@ int stocs_ctx_destroy(stocs_ctx* c) {
                     c->index.d_pairs, c->index.d_exists, c->d_scratch, c->d_best, c->d_cand, c->d_order};
     stocs_internal_free_congruent(c);
     stocs_internal_free_instance(c);
+    stocs_internal_free_trials(c);
     c->grid_mem.destroy(); c->grid_ws.destroy();
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -641,7 +644,7 @@ int stocs_dev_download(stocs_ctx* c, void* host, const void* dptr, int64_t bytes
 }
 
 int stocs_last_call_timing(const stocs_ctx* c, int which, const char** labels, double* ms, int cap, int* n) {
-    if (!c || which < 0 || which > 2 || !n || cap < 0) return STOCS_ERR_INVALID;
+    if (!c || which < 0 || which > 3 || !n || cap < 0) return STOCS_ERR_INVALID;
     const CallTiming& t = c->timing[which];
     *n = t.n;
     for (int i = 0; i < t.n && i < cap; ++i) {

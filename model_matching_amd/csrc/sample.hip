@@ -405,7 +405,7 @@ __host__ __device__ static bool try_sampled_base(const V3 base[4], float& invari
 }
 
 // rows 6-7 on the device: ordered base + invariants of one attempt (try_sampled_base, stocs.cpp:224-268)
-struct BaseOut { int32_t ids[4]; float inv[2]; int32_t valid; int32_t pad; };
+// (struct BaseOut: stocs_ctx.h)
 
 // ordered base + invariants of one attempt by twelve lanes of one wavefront: the 12 ordered pairings of try_sampled_base
 // (stocs.cpp:224-268) evaluated side by side, then the reference's first-strict-minimum rule in its enumeration order.
@@ -620,6 +620,12 @@ struct InstanceArgs {
     int32_t* q_sv; float* q_w;  // per attempt S slots: the survivors (scene index, weight)
     unsigned int* q_flag;       // per attempt: 1 once the slot is complete
     unsigned int* q_err;        // set when the second workgroup gave up waiting
+    // trial batches (stocs_run_trials): workgroups 2 t and 2 t + 1 are the two roles of trial t.  Every pointer from `cls` down
+    // (except spos_w) then names trial 0's copy inside a block of per-trial state, and trial t's copy lies t * trial_stride bytes
+    // behind it; seeds[t] is the trial's seed.
+    int n_trials;               // 0: one trial on the context's own state (the kernel's seed argument)
+    size_t trial_stride;
+    const uint64_t* seeds;
 };
 
 template <class P>
@@ -729,8 +735,18 @@ __global__ __launch_bounds__(1024) void instance_attempts_kernel(InstanceArgs A,
     sv_t* sv = WLDS ? (sv_t*)(inst_dyn + o_w + (((size_t)S * 4 + 15) & ~(size_t)15)) : (sv_t*)A.sv;   // survivors of pass 1 inside the mask, in scene order
     const float4* spos = A.pa.spos;
     const float4* snrm = A.pa.snrm;
-    if (blockIdx.x != 0 && blockIdx.x + 1 != gridDim.x) return;            // (placement experiments launch idle workgroups in between)
-    const bool first_role = blockIdx.x == 0;
+    bool first_role = blockIdx.x == 0;
+    if (A.n_trials > 0) {
+        const int trial = (int)(blockIdx.x >> 1);
+        if (trial >= A.n_trials) return;
+        first_role = (blockIdx.x & 1u) == 0u;
+        seed = A.seeds[trial];
+        const size_t off = (size_t)trial * A.trial_stride;
+#define INST_ADV(p) p = (decltype(p))((char*)(p) + off)
+        INST_ADV(A.cls); INST_ADV(A.prev_in); INST_ADV(A.label); INST_ADV(A.maskbits); INST_ADV(A.segbits); INST_ADV(A.parent_g); INST_ADV(A.w); INST_ADV(A.sv);
+        INST_ADV(A.snrm_w); INST_ADV(A.res); INST_ADV(A.q_hdr); INST_ADV(A.q_sv); INST_ADV(A.q_w); INST_ADV(A.q_flag); INST_ADV(A.q_err);
+#undef INST_ADV
+    } else if (blockIdx.x != 0 && blockIdx.x + 1 != gridDim.x) return;     // (placement experiments launch idle workgroups in between)
     unsigned long long tprev = A.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     // the thread index is made opaque at the start of every stage: otherwise the compiler hoists per-thread addresses of
     // every array out of the attempt loop, and a hundred registers of them spill to scratch around every stage
@@ -940,7 +956,7 @@ __global__ __launch_bounds__(1024) void instance_attempts_kernel(InstanceArgs A,
     if (n_attempts > 0 && threadIdx.x == 0) __hip_atomic_store(A.q_flag + (n_attempts - 1), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     if (A.stamps && threadIdx.x == 0) { A.stamps[0] += acc0; A.stamps[1] += acc1; A.stamps[2] += acc2; A.stamps[3] += acc3; A.stamps[4] += acc4; }
     // the LCP adds class_probability_, which this sampling decays in place (Q8): refresh the scene arrays it reads
-    for (int i = threadIdx.x; i < S; i += 1024) { const float c = A.cls[i]; A.spos_w[i].w = c; A.snrm_w[i].w = c; }
+    for (int i = threadIdx.x; i < S; i += 1024) { const float c = A.cls[i]; if (A.spos_w) A.spos_w[i].w = c; A.snrm_w[i].w = c; }
     return;
     }
 
@@ -1034,6 +1050,10 @@ struct ClassArgs {
     float* w_g; int32_t* sv_g;  // n_attempts x S each: the working set of scenes too large for LDS
     BaseOut* res;
     unsigned long long* stamps; // STOCS_DEBUG_TIMING only: cycles per stage of the first workgroup (else NULL)
+    // trial batches (stocs_run_trials): workgroup a is attempt a % per_trial of trial a / per_trial and draws with that trial's seed
+    const uint64_t* seeds;      // NULL: one trial, the kernel's seed argument
+    int per_trial;
+    int wg_offset;              // workgroup blockIdx.x is attempt slot wg_offset + blockIdx.x of the batch (launches of big scenes come in pieces)
 };
 
 template <bool WLDS>
@@ -1046,12 +1066,15 @@ __global__ __launch_bounds__(1024) void class_attempts_kernel(ClassArgs A, uint6
     __shared__ int sh_cnt[64], sh_cex[65];
     const int a = blockIdx.x;
     if (a >= n_attempts) return;
-    const int S = A.pa.S, attempt = first_attempt + a;
+    const int S = A.pa.S;
+    int attempt = first_attempt + a;
+    int slot = a;                                                           // where the attempt's result goes
+    if (A.seeds) { slot = A.wg_offset + a; const int tr = slot / A.per_trial; seed = A.seeds[tr]; attempt = first_attempt + (slot - tr * A.per_trial); }
     float* w = WLDS ? (float*)cls_dyn : A.w_g + (size_t)a * S;
     sv_t* sv = WLDS ? (sv_t*)(cls_dyn + (((size_t)S * 4 + 15) & ~(size_t)15)) : (sv_t*)(A.sv_g + (size_t)a * S);
     const float4* spos = A.pa.spos;
     const float4* snrm = A.pa.snrm;
-    BaseOut* out = A.res + a;
+    BaseOut* out = A.res + slot;
     int32_t bidx[4] = {-1, -1, -1, -1};
     int fail = 0;
 #define CLS_THREAD() int t = threadIdx.x; asm volatile("" : "+v"(t)); const int lane = t & 63, wv = t >> 6; (void)lane; (void)wv;
@@ -1215,6 +1238,7 @@ static int sample_class(stocs_ctx* c, uint64_t seed, int first_attempt, int nB, 
     A.w_g = (float*)p; p += b_w;
     A.sv_g = (int32_t*)p;
     A.draw_per_thread = 2;
+    A.seeds = NULL; A.per_trial = 0; A.wg_offset = 0;
     const bool dbg = getenv("STOCS_DEBUG_TIMING") != NULL;
     A.stamps = NULL;
     if (dbg) {   // behind everything else in the scratch area
@@ -1269,6 +1293,7 @@ struct InstanceState {
     int32_t* d_sv = NULL; float* d_w = NULL;
     RunPair* d_pairs = NULL; uint32_t* d_pair_off = NULL;
     char* d_queue = NULL; size_t queue_bytes = 0;   // hand-over slots between the two workgroups (grown on demand)
+    char* d_trials = NULL; size_t trials_bytes = 0; // per-trial copies of the mutable state of a trial batch (stocs_run_trials)
     size_t n_runs = 0;
     std::vector<uint32_t> h_segbits;
 };
@@ -1278,6 +1303,7 @@ static void free_instance_state(stocs_ctx* c) {
     if (!I) return;
     if (I->d_mem) (void)hipFree(I->d_mem);
     if (I->d_queue) (void)hipFree(I->d_queue);
+    if (I->d_trials) (void)hipFree(I->d_trials);
     delete I;
     c->inst = NULL;
 }
@@ -1405,6 +1431,7 @@ static int sample_instance(stocs_ctx* c, uint64_t seed, int first_attempt, int n
     A.stamps = NULL;
     if (dbg) { A.stamps = (unsigned long long*)I->d_parent; STOCS_HIP_CHECK(hipMemsetAsync(I->d_parent, 0, 128, c->stream)); }   // parent_g is idle for small discs
     A.w = I->d_w; A.sv = I->d_sv; A.spos_w = c->d_spos; A.snrm_w = c->d_snrmw; A.res = sb.res;
+    A.n_trials = 0; A.trial_stride = 0; A.seeds = NULL;
     // hand-over slots of the attempts: header, S (index, weight) pairs, flag; one error word
     {
         auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -1459,6 +1486,132 @@ static int sample_instance(stocs_ctx* c, uint64_t seed, int first_attempt, int n
     return record_bases(c, nB, res.data(), ids, inv, valid);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Base sampling of a whole batch of independent trials in ONE launch (stocs_run_trials): trial t is what
+// stocs_sample_bases(mode, seeds[t], 0, n_attempts) gives on a freshly reset context.
+//   class mode: n_trials x n_attempts workgroups of class_attempts_kernel (the attempts are independent anyway);
+//   instance mode: a pair of workgroups per trial (the attempts of ONE trial are sequential, stocs.cpp:572-580,626), every trial
+//   on its own copy of the mutable state -- decaying prior, previous_segment, segmentation buffer, masks, hand-over slots -- and
+//   with its own copy of the scene normals + LCP weights (Q8: the LCP adds the DECAYED class probability of its trial).
+// res_host: n_trials * n_attempts results.  *snrmw0 / *snrmw_stride: trial t's weights for the scoring kernel (instance mode; NULL
+// in class mode: the scene's own).  The context's own per-trial state is not touched.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void init_trial_state_kernel(char* __restrict__ block, size_t stride, size_t zero_words4, size_t o_cls, size_t o_snrm,
+                                                               const float4* __restrict__ snrmw, int S) {
+    char* mine = block + (size_t)blockIdx.y * stride;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < zero_words4) ((uint4*)mine)[i] = make_uint4(0u, 0u, 0u, 0u);   // prev_in | label | masks | segment | flags | error word
+    if (i < (size_t)S) { const float4 v = snrmw[i]; ((float*)(mine + o_cls))[i] = v.w; ((float4*)(mine + o_snrm))[i] = v; }
+}
+
+int sample_trials(stocs_ctx* c, int mode, int nT, const uint64_t* seeds, int nA, float dispersion, BaseOut* res_host, const float4** snrmw0, size_t* snrmw_stride) {
+    *snrmw0 = NULL; *snrmw_stride = 0;
+    const size_t S = (size_t)c->nS, nW = (size_t)nT * (size_t)nA;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    if (mode == 0) {
+        const bool wlds = S <= 26000 && !getenv("STOCS_INSTANCE_NO_LDS");
+        // scenes beyond the LDS working set keep 8 bytes per (attempt, point) in device memory: at most ~1 GB of it per launch
+        const size_t per_launch = wlds ? nW : std::max<size_t>(1, std::min<size_t>(nW, ((size_t)1 << 30) / (S * 8)));
+        const size_t b_res = al(nW * sizeof(BaseOut)), b_seed = al((size_t)nT * 8), b_w = wlds ? 0 : al(per_launch * S * 4);
+        int rc = ensure_scratch(c, b_res + b_seed + 2 * b_w);
+        if (rc) return rc;
+        if ((rc = ensure_pinned(c, (size_t)PIN_VAR + b_seed))) return rc;
+        char* p = (char*)c->d_scratch;
+        ClassArgs A;
+        A.pa = pass_args(c);
+        A.res = (BaseOut*)p;
+        uint64_t* d_seeds = (uint64_t*)(p + b_res);
+        A.w_g = (float*)(p + b_res + b_seed); A.sv_g = (int32_t*)(p + b_res + b_seed + b_w);
+        A.draw_per_thread = 2; A.stamps = NULL;
+        A.seeds = d_seeds; A.per_trial = nA;
+        memcpy((char*)c->h_pin + PIN_VAR, seeds, (size_t)nT * 8);
+        STOCS_HIP_CHECK(hipMemcpyAsync(d_seeds, (char*)c->h_pin + PIN_VAR, (size_t)nT * 8, hipMemcpyHostToDevice, c->stream));
+        const size_t lds = wlds ? ((S * 4 + 15) & ~(size_t)15) + S * 2 + 16 : 0;
+        if (wlds) STOCS_HIP_CHECK(hipFuncSetAttribute((const void*)class_attempts_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+        for (size_t w0 = 0; w0 < nW; w0 += per_launch) {
+            const unsigned n = (unsigned)std::min(per_launch, nW - w0);
+            A.wg_offset = (int)w0;
+            if (wlds) hipLaunchKernelGGL(class_attempts_kernel<true>, dim3(n), dim3(1024), lds, c->stream, A, (uint64_t)0, 0, (int)n);
+            else hipLaunchKernelGGL(class_attempts_kernel<false>, dim3(n), dim3(1024), 0, c->stream, A, (uint64_t)0, 0, (int)n);
+        }
+        STOCS_HIP_CHECK(hipGetLastError());
+        STOCS_HIP_CHECK(hipMemcpyAsync(res_host, A.res, nW * sizeof(BaseOut), hipMemcpyDeviceToHost, c->stream));
+        STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        return STOCS_OK;
+    }
+    // ---- instance mode ----
+    int rc = prepare_instance_state(c);
+    if (rc) return rc;
+    InstanceState* I = (InstanceState*)c->inst;
+    const size_t Sw = (size_t)I->Sw, nr = std::max<size_t>(I->n_runs, 1), nq = (size_t)std::max(nA, 1);
+    // one trial's block: what has to start from zero comes first (one fill), then everything that is written before it is read
+    const size_t o_pi = 0, o_lb = o_pi + al(S), o_mb = o_lb + al(S), o_sb = o_mb + al(256 * Sw * 4), o_fl = o_sb + al(Sw * 4), o_er = o_fl + al(nq * 4), zero_end = o_er + 256,
+                 o_cl = zero_end, o_pa = o_cl + al(S * 4), o_w = o_pa + al((nr + 1) * 4), o_sv = o_w + al(S * 4), o_sn = o_sv + al(S * 4), o_rs = o_sn + al(S * 16),
+                 o_hd = o_rs + al(nq * sizeof(BaseOut)), o_qs = o_hd + al(nq * 16), o_qw = o_qs + al(nq * S * 4), stride = o_qw + al(nq * S * 4);
+    const size_t b_seed = al((size_t)nT * 8), total = b_seed + (size_t)nT * stride;
+    if (I->trials_bytes < total) {
+        if (I->d_trials) { STOCS_HIP_CHECK(hipStreamSynchronize(c->stream)); (void)hipFree(I->d_trials); I->d_trials = NULL; I->trials_bytes = 0; }
+        STOCS_HIP_CHECK(dev_malloc((void**)&I->d_trials, total + total / 8));
+        I->trials_bytes = total + total / 8;
+    }
+    if ((rc = ensure_pinned(c, (size_t)PIN_VAR + b_seed))) return rc;
+    uint64_t* d_seeds = (uint64_t*)I->d_trials;
+    char* blk = I->d_trials + b_seed;
+    memcpy((char*)c->h_pin + PIN_VAR, seeds, (size_t)nT * 8);
+    STOCS_HIP_CHECK(hipMemcpyAsync(d_seeds, (char*)c->h_pin + PIN_VAR, (size_t)nT * 8, hipMemcpyHostToDevice, c->stream));
+    {
+        const size_t zw = zero_end / 16, n = std::max(zw, S);
+        hipLaunchKernelGGL(init_trial_state_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nT), dim3(256), 0, c->stream, blk, stride, zw, o_cl, o_sn,
+                           (const float4*)c->d_snrmw, (int)S);
+    }
+    InstanceArgs A;
+    A.pa = pass_args(c);
+    A.pix = c->d_spix; A.edge_pt = I->d_edge_pt; A.pt_run = I->d_pt_run; A.run_s = I->d_run_s; A.run_e = I->d_run_e; A.row_off = I->d_row_off;
+    A.pairs = I->d_pairs; A.pair_off = I->d_pair_off;
+    A.draw_per_thread = 2;
+    if (const char* e = getenv("STOCS_DRAW_PER_THREAD")) A.draw_per_thread = std::max(1, atoi(e));
+    A.H = c->prm.image_height; A.W = c->prm.image_width; A.Sw = I->Sw;
+    A.cls = (float*)(blk + o_cl); A.prev_in = (uint8_t*)(blk + o_pi); A.label = (uint8_t*)(blk + o_lb); A.maskbits = (uint32_t*)(blk + o_mb);
+    A.segbits = (uint32_t*)(blk + o_sb); A.parent_g = (uint32_t*)(blk + o_pa);
+    A.stamps = NULL;
+    A.w = (float*)(blk + o_w); A.sv = (int32_t*)(blk + o_sv); A.spos_w = NULL; A.snrm_w = (float4*)(blk + o_sn); A.res = (BaseOut*)(blk + o_rs);
+    A.q_hdr = (int4*)(blk + o_hd); A.q_flag = (unsigned int*)(blk + o_fl); A.q_err = (unsigned int*)(blk + o_er);
+    A.q_sv = (int32_t*)(blk + o_qs); A.q_w = (float*)(blk + o_qw);
+    A.n_trials = nT; A.trial_stride = stride; A.seeds = d_seeds;
+    const size_t lds_parent = ((size_t)(INST_MAX_NODES + 1) * 4 + 15) & ~(size_t)15;
+    const bool wlds = c->nS <= INST_LDS_POINTS && !getenv("STOCS_INSTANCE_NO_LDS");
+    const size_t lds = lds_parent + (wlds ? (((S * 4 + 15) & ~(size_t)15) + S * 2 + 16) : 0);
+    {
+        const void* fn = wlds ? (const void*)instance_attempts_kernel<true> : (const void*)instance_attempts_kernel<false>;
+        STOCS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+    }
+    // The two workgroups of a trial wait for each other through device memory (the second polls the first's flags with a bounded
+    // wait): both must be resident together.  A workgroup of 1024 threads with this much LDS takes a whole CU, the chip has 256 and
+    // the hardware starts workgroups in index order: at most 128 trials per launch keeps every pair resident.
+    for (int t0 = 0; t0 < nT; t0 += 128) {
+        const int n = std::min(128, nT - t0);
+        InstanceArgs B = A;
+        B.n_trials = n; B.seeds = d_seeds + t0;
+#define TR_ADV(p) B.p = (decltype(B.p))((char*)(A.p) + (size_t)t0 * stride)
+        TR_ADV(cls); TR_ADV(prev_in); TR_ADV(label); TR_ADV(maskbits); TR_ADV(segbits); TR_ADV(parent_g); TR_ADV(w); TR_ADV(sv); TR_ADV(snrm_w); TR_ADV(res);
+        TR_ADV(q_hdr); TR_ADV(q_sv); TR_ADV(q_w); TR_ADV(q_flag); TR_ADV(q_err);
+#undef TR_ADV
+        if (wlds) hipLaunchKernelGGL(instance_attempts_kernel<true>, dim3(2u * (unsigned)n), dim3(1024), lds, c->stream, B, (uint64_t)0, 0, nA, dispersion);
+        else hipLaunchKernelGGL(instance_attempts_kernel<false>, dim3(2u * (unsigned)n), dim3(1024), lds, c->stream, B, (uint64_t)0, 0, nA, dispersion);
+    }
+    STOCS_HIP_CHECK(hipGetLastError());
+    // results and error words of all trials: strided rows of the block
+    std::vector<unsigned int> q_err((size_t)nT, 0u);
+    STOCS_HIP_CHECK(hipMemcpy2DAsync(res_host, (size_t)nA * sizeof(BaseOut), blk + o_rs, stride, (size_t)nA * sizeof(BaseOut), (size_t)nT, hipMemcpyDeviceToHost, c->stream));
+    STOCS_HIP_CHECK(hipMemcpy2DAsync(q_err.data(), 4, blk + o_er, stride, 4, (size_t)nT, hipMemcpyDeviceToHost, c->stream));
+    STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int t = 0; t < nT; ++t)
+        if (q_err[(size_t)t]) { set_error("instance-mode sampling (trial %d of the batch): the second workgroup gave up waiting for the first", t); return STOCS_ERR_HIP; }
+    *snrmw0 = (const float4*)(blk + o_sn);
+    *snrmw_stride = stride;
+    return STOCS_OK;
+}
+
 }  // namespace stocs
 
 using namespace stocs;
@@ -1470,6 +1623,7 @@ int stocs_sample_bases(stocs_ctx* c, int mode, uint64_t seed, int first_attempt,
     if (!c || n_attempts < 0 || first_attempt < 0 || (mode != 0 && mode != 1)) return STOCS_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
     if (!c->index.built) { set_error("stocs_sample_bases: PPF index not built"); return STOCS_ERR_STATE; }
+    clear_trial_batch(c);
     if (n_attempts == 0) return STOCS_OK;
     if (c->nS == 0) {  // the reference would index an empty vector here (stocs.cpp:386); report no bases
         for (int b = 0; b < n_attempts; ++b) if (valid) valid[b] = 0;
@@ -1499,6 +1653,7 @@ int stocs_reset_trial(stocs_ctx* c) {
     DeviceGuard dev_guard(c->device);
     c->h_sprob = c->h_sprob0;
     c->last_segment.clear();
+    clear_trial_batch(c);
     c->bases.clear(); c->quad_off.clear(); clear_candidates(c);
     c->best_lcp = 0; c->best_index = -1;
     int rc = reset_instance_trial(c);
@@ -1510,6 +1665,7 @@ int stocs_set_bases(stocs_ctx* c, int n, const int32_t* ids, const float* inv) {
     if (!c || n < 0 || (n && (!ids || !inv))) return STOCS_ERR_INVALID;
     for (int i = 0; i < 4 * n; ++i)
         if (ids[i] < 0 || ids[i] >= c->nS) { set_error("stocs_set_bases: scene index out of range"); return STOCS_ERR_INVALID; }
+    clear_trial_batch(c);
     c->bases.clear();
     c->quad_off.clear();
     for (int i = 0; i < n; ++i) {
@@ -1522,6 +1678,7 @@ int stocs_set_bases(stocs_ctx* c, int n, const int32_t* ids, const float* inv) {
 }
 int stocs_clear_bases(stocs_ctx* c) {
     if (!c) return STOCS_ERR_INVALID;
+    clear_trial_batch(c);
     c->bases.clear(); c->quad_off.clear(); clear_candidates(c);
     c->best_lcp = 0; c->best_index = -1;
     return STOCS_OK;

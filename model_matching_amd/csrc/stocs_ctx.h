@@ -173,6 +173,9 @@ struct BaseRec {
     float inv1, inv2;
 };
 
+// rows 6-7 on the device: ordered base + invariants of one attempt (try_sampled_base, stocs.cpp:224-268)
+struct BaseOut { int32_t ids[4]; float inv[2]; int32_t valid; int32_t pad; };
+
 struct Candidate {
     float T[16];     // centred frames (scored), stocs.cpp:923
     float pose[16];  // camera frame (returned), stocs.cpp:925-937
@@ -249,6 +252,16 @@ struct stocs_ctx {
 
     // run state
     std::vector<stocs::BaseRec> bases;
+    // a batch of independent trials in one set of launches (stocs_run_trials, trials.hip): `bases` is then the concatenation of the
+    // trials' base sets, and these say whose each base is.  All empty outside such a batch (one trial, the calls' own seed).
+    std::vector<uint64_t> base_seed;        // per base: seed of its trial
+    std::vector<int32_t> base_local;        // per base: its slot in its own trial's base set
+    std::vector<int32_t> trial_first_base;  // per trial of the batch (+ 1): first base
+    std::vector<int32_t> trial_cand_off;    // per trial of the batch (+ 1): first candidate (filled by stocs_make_transforms)
+    const float4* snrmw_trial0;             // instance-mode batches: trial t scores against the weights at snrmw_trial0 + t * snrmw_stride bytes
+    size_t snrmw_stride;
+    const float4* snrmw_override;           // != NULL: the scoring kernel reads its scene normals + weights here (one trial of such a batch)
+    void* trials;                           // results of the last stocs_run_trials (trials.hip, TrialBatch)
     // congruent quads: only their per-base counts live here (quad_off[b+1] - quad_off[b]); `cong` (congruent.hip,
     // CongruentState) keeps what is needed to produce the quads of a base on demand, packed with quad_id_bits
     // bits per model id below the base id
@@ -271,7 +284,7 @@ struct stocs_ctx {
     // pageable memory goes through the runtime's own staging and is one more thing that can stall (ensure_pinned grows it)
     void* h_pin;
     size_t pin_bytes;
-    stocs::CallTiming timing[3];   // last stocs_find_congruent_all / stocs_make_transforms / stocs_verify_all
+    stocs::CallTiming timing[4];   // last stocs_find_congruent_all / stocs_make_transforms / stocs_verify_all / stocs_run_trials
 
     // scratch
     void* d_scratch;
@@ -280,6 +293,13 @@ struct stocs_ctx {
 
 namespace stocs {
 inline void clear_candidates(stocs_ctx* c) { c->cands.clear(); c->n_cands = 0; c->cands_stale = false; }
+// the base set is (again) one trial's: whoever replaces or extends it outside stocs_run_trials calls this first
+inline void clear_trial_batch(stocs_ctx* c) {
+    if (c->base_seed.empty() && c->trial_first_base.empty()) return;
+    c->base_seed.clear(); c->base_local.clear(); c->trial_first_base.clear(); c->trial_cand_off.clear();
+    c->snrmw_trial0 = NULL; c->snrmw_stride = 0;
+    c->bases.clear(); c->quad_off.clear(); clear_candidates(c);   // what is left of the batch's last piece means nothing to a single trial
+}
 inline float* cand_T(stocs_ctx* c) { return (float*)c->d_cand; }
 inline float* cand_P(stocs_ctx* c) { return (float*)c->d_cand + (size_t)c->cand_cap * 16; }
 inline float* cand_lcp(stocs_ctx* c) { return (float*)c->d_cand + (size_t)c->cand_cap * 32; }
@@ -289,6 +309,7 @@ int ensure_pinned(stocs_ctx* c, size_t bytes);   // c->h_pin of at least `bytes`
 enum { PIN_CONGRUENT = 0, PIN_TRANSFORMS = 256, PIN_VERIFY = 512, PIN_BEST = 768, PIN_VAR = 1024 };   // fixed slots, then the per-call variable part
 // d_best8 != NULL: the kernel's epilogue also takes the arg-max of compute_best_transform over the batch into that word (zeroed in front)
 int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d_hit, uint8_t* d_counted, unsigned long long* d_best8, uint32_t id_offset);
+int sample_trials(stocs_ctx* c, int mode, int nT, const uint64_t* seeds, int nA, float dispersion, BaseOut* res_host, const float4** snrmw0, size_t* snrmw_stride);   // sample.hip
 int build_ppf_index(stocs_ctx* c);
 int build_grid_gpu(stocs_ctx* c, int div, int dense);
 int prepare_cull_field(stocs_ctx* c);   // geometry + memory of SceneGrid::d_dist for the current grid and model (end of a grid build)
@@ -298,6 +319,10 @@ extern "C" int stocs_internal_prepare_small(stocs_ctx* c, int max_per_base);   /
 extern "C" void stocs_internal_free_congruent(stocs_ctx* c);
 extern "C" void stocs_internal_invalidate_congruent(stocs_ctx* c);
 extern "C" void stocs_internal_free_instance(stocs_ctx* c);
+extern "C" void stocs_internal_free_trials(stocs_ctx* c);
+// the congruent phase with a ceiling on its device memory: *too_big != 0 (and STOCS_OK) when the pair lists of the context's base set
+// would need more than max_bytes (0: no ceiling) or exceed 2^32 entries -- a trial batch then splits the base set and tries again
+extern "C" int stocs_internal_find_congruent(stocs_ctx* c, int64_t* total_quads, size_t max_bytes, int* too_big);
 extern "C" void stocs_internal_invalidate_instance(stocs_ctx* c);
 int plan_lookup(const PpfIndex& ix, const int* K, std::vector<std::pair<uint32_t, uint32_t> >* ranges);
 void prefetch_lookup(const PpfIndex& ix, const int* K);

@@ -137,7 +137,9 @@ __global__ __launch_bounds__(64) void winner_pose_kernel(const unsigned long lon
 // partial Fisher-Yates the host form runs (open-addressing table of the touched entries of the identity permutation, here in
 // LDS): the draws r_j are independent and computed by all threads, the swaps are sequential and done by one.  Runs on the
 // auxiliary stream next to the materialisation of the small bases.  table[b] = (first job, quad count lo, hi, unused).
-__global__ __launch_bounds__(256) void draw_picks_kernel(const uint4* __restrict__ table, uint64_t seed, int max_per_base, uint32_t hmask,
+// trial (when != NULL; stocs_run_trials): per base (seed lo, seed hi, slot of the base in ITS trial, 0) -- the draw of a base is
+// rng(seed of its trial, its slot there, j), and its candidates carry that slot, exactly as when the trial runs alone.
+__global__ __launch_bounds__(256) void draw_picks_kernel(const uint4* __restrict__ table, const uint4* __restrict__ trial, uint64_t seed, int max_per_base, uint32_t hmask,
                                                          int4* __restrict__ picks, int32_t* __restrict__ job_base) {
     extern __shared__ uint32_t lds_dyn[];
     int* hkeys = (int*)lds_dyn;                          // hmask + 1
@@ -149,12 +151,14 @@ __global__ __launch_bounds__(256) void draw_picks_kernel(const uint4* __restrict
     const int first = (int)t.x;
     const long long nq = (long long)(((unsigned long long)t.z << 32) | (unsigned long long)t.y);
     if (nq <= 0) return;
+    int b_own = b;                                   // the base's slot in its own trial
+    if (trial) { const uint4 tr = trial[b]; seed = ((uint64_t)tr.y << 32) | (uint64_t)tr.x; b_own = (int)tr.z; }
     if (nq < max_per_base) {   // stocs_match_one_object.cpp:126: strictly fewer -> all, in the std::set order of stocs.cpp:860-866
-        for (int i = threadIdx.x; i < (int)nq; i += blockDim.x) { picks[first + i] = make_int4(b, i, first + i, 1); job_base[first + i] = b; }
+        for (int i = threadIdx.x; i < (int)nq; i += blockDim.x) { picks[first + i] = make_int4(b, i, first + i, 1); job_base[first + i] = b_own; }
         return;
     }
     for (uint32_t h = threadIdx.x; h <= hmask; h += blockDim.x) hkeys[h] = -1;
-    for (int j = threadIdx.x; j < max_per_base; j += blockDim.x) r[j] = rng64(seed, 0x5E1EC7ull + (uint64_t)b, (uint64_t)j);
+    for (int j = threadIdx.x; j < max_per_base; j += blockDim.x) r[j] = rng64(seed, 0x5E1EC7ull + (uint64_t)b_own, (uint64_t)j);
     __syncthreads();
     if (threadIdx.x == 0) {
         auto slot_of = [&](int i) {
@@ -177,7 +181,13 @@ __global__ __launch_bounds__(256) void draw_picks_kernel(const uint4* __restrict
         }
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < max_per_base; j += blockDim.x) { picks[first + j] = make_int4(b, out[j], first + j, 0); job_base[first + j] = b; }
+    for (int j = threadIdx.x; j < max_per_base; j += blockDim.x) { picks[first + j] = make_int4(b, out[j], first + j, 0); job_base[first + j] = b_own; }
+}
+
+// out[k] = a[idx[k]]: the accepted-candidate counts in front of every trial's first job (= where its candidates start)
+__global__ __launch_bounds__(256) void gather_i32_kernel(const int32_t* __restrict__ a, const int32_t* __restrict__ idx, int n, int32_t* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = a[idx[k]];
 }
 
 // accepted candidates (ok != 0) keep their pick order: destination = exclusive scan of the flags
@@ -235,6 +245,7 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
         clear_candidates(c);
         c->best_lcp = 0; c->best_index = -1;
         if (n_candidates) *n_candidates = 0;
+        c->trial_cand_off.assign(c->trial_first_base.size(), 0);
         c->timing[1].lap("no congruent sets");
         return STOCS_OK;
     }
@@ -250,25 +261,37 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
     // the picks are drawn on the device (draw_picks_kernel, on the auxiliary stream next to the small bases' materialisation)
     // while the table of touched entries fits LDS; the host form below is the same draw and serves larger per-base maxima
     const bool device_picks = max_per_base <= 1024 && c->aux_stream && !getenv("STOCS_TRANSFORMS_HOST_PICKS");
+    // a batch of trials (stocs_run_trials): every base draws with the seed of its trial and under its slot there
+    const bool batch = !c->base_seed.empty();
+    if (batch && (c->base_seed.size() != c->bases.size() || c->base_local.size() != c->bases.size())) { set_error("internal: trial tables do not match the base set"); return STOCS_ERR_STATE; }
+    const size_t nbases = c->bases.size(), tab_bytes = (16 * nbases + 255) & ~(size_t)255;
+    const size_t n_tr = batch ? c->trial_first_base.size() : 0;     // trials + 1
+    std::vector<size_t> first_job(nbases + 1, 0);
     size_t n_dev = 0;
     if (device_picks) {
-        const size_t nb = c->bases.size();
-        int rc0 = ensure_pinned(c, (size_t)PIN_VAR + 16 * nb + 256);
+        int rc0 = ensure_pinned(c, (size_t)PIN_VAR + 2 * tab_bytes + 4 * n_tr + 256);
         if (rc0) return rc0;
         uint4* table = (uint4*)((char*)c->h_pin + PIN_VAR);
-        for (size_t b = 0; b < nb; ++b) {
+        uint4* table2 = (uint4*)((char*)c->h_pin + PIN_VAR + tab_bytes);
+        for (size_t b = 0; b < nbases; ++b) {
             const unsigned long long nq64 = c->quad_off[b + 1] - c->quad_off[b];
             if (nq64 > 0x7FFFFFFFull) { set_error("base %zu has %llu congruent quads (more than 2^31 - 1)", b, nq64); return STOCS_ERR_CAPACITY; }
             table[b] = make_uint4((uint32_t)n_dev, (uint32_t)nq64, (uint32_t)(nq64 >> 32), 0u);
+            if (batch) table2[b] = make_uint4((uint32_t)c->base_seed[b], (uint32_t)(c->base_seed[b] >> 32), (uint32_t)c->base_local[b], 0u);
+            first_job[b] = n_dev;
             n_dev += (size_t)std::min<unsigned long long>(nq64, (unsigned long long)max_per_base);
         }
+        first_job[nbases] = n_dev;
     }
     std::vector<int> hkeys(hsize), hvals(hsize);
     auto add_pick = [&](size_t b, int rank, int sorted) {
         picks.push_back((int32_t)b); picks.push_back((int32_t)rank); picks.push_back((int32_t)job_base.size()); picks.push_back(sorted);
-        job_base.push_back((int)b);
+        job_base.push_back(batch ? (int)c->base_local[b] : (int)b);
     };
     for (size_t b = 0; b < c->bases.size() && !device_picks; ++b) {
+        first_job[b] = job_base.size();
+        const uint64_t seed_b = batch ? c->base_seed[b] : seed;
+        const uint64_t slot_b = batch ? (uint64_t)c->base_local[b] : (uint64_t)b;
         const unsigned long long nq64 = c->quad_off[b + 1] - c->quad_off[b];
         if (nq64 > 0x7FFFFFFFull) { set_error("base %zu has %llu congruent quads (more than 2^31 - 1)", b, nq64); return STOCS_ERR_CAPACITY; }
         const long long nq = (long long)nq64;
@@ -290,7 +313,7 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
             auto at = [&](int i) { const uint32_t h = slot_of(i); return hkeys[h] == i ? hvals[h] : i; };
             auto put = [&](int i, int v) { const uint32_t h = slot_of(i); hkeys[h] = i; hvals[h] = v; };
             for (int j = 0; j < max_per_base; ++j) {
-                const uint64_t r = rng64(seed, 0x5E1EC7ull + b, (uint64_t)j);
+                const uint64_t r = rng64(seed_b, 0x5E1EC7ull + slot_b, (uint64_t)j);
                 const int k = j + (int)mulhi64(r, (uint64_t)(nq - j));
                 const int vj = at(j), vk = at(k);
                 put(j, vk); put(k, vj);
@@ -298,6 +321,7 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
             }
         }
     }
+    if (!device_picks) first_job[nbases] = job_base.size();
     const size_t n = device_picks ? n_dev : job_base.size();
     c->timing[1].lap(device_picks ? "small bases enqueued + pick table" : "small bases enqueued + host picks");
     tick("host picks");
@@ -309,10 +333,11 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
         size_t scan_tmp = 0;
         STOCS_HIP_CHECK(exclusive_scan(NULL, scan_tmp, (const uint32_t*)NULL, (uint32_t*)NULL, n + 1, c->stream));
         scan_tmp = ((scan_tmp + 255) / 256) * 256;
-        const size_t pb = device_picks ? ((n * 16 + 255) / 256) * 256 + ((c->bases.size() * 16 + 255) / 256) * 256 : 0;   // picks + table
-        int rc = ensure_scratch(c, jb + 2 * tb + 3 * ob + scan_tmp + pb);
+        const size_t pb = device_picks ? ((n * 16 + 255) / 256) * 256 + 2 * tab_bytes : 0;   // picks + the two tables
+        const size_t trb = batch ? ((8 * n_tr + 255) / 256) * 256 : 0;                        // first jobs of the trials + their candidate offsets
+        int rc = ensure_scratch(c, jb + 2 * tb + 3 * ob + scan_tmp + pb + trb);
         if (rc) return rc;
-        if (!device_picks && (rc = ensure_pinned(c, PIN_VAR))) return rc;
+        if (!device_picks && (rc = ensure_pinned(c, (size_t)PIN_VAR + 2 * tab_bytes + 4 * n_tr + 256))) return rc;
         if ((size_t)c->cand_cap < n) {
             if (c->d_cand) { STOCS_HIP_CHECK(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_cand); c->d_cand = NULL; }
             c->cand_cap = (int)(n + n / 4 + 1024);
@@ -335,9 +360,9 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
             d_picks = (const int32_t*)pk;
             const size_t lds = (size_t)(2 * (hmask + 1) + ((max_per_base + 1) & ~1)) * 4 + (size_t)max_per_base * 8;
             // on the auxiliary stream: nothing it touches is in use on the main one (the scratch block is idle between calls)
-            STOCS_HIP_CHECK(hipMemcpyAsync(d_table, (char*)c->h_pin + PIN_VAR, 16 * c->bases.size(), hipMemcpyHostToDevice, c->aux_stream));
-            hipLaunchKernelGGL(draw_picks_kernel, dim3((unsigned)c->bases.size()), dim3(256), lds, c->aux_stream, (const uint4*)d_table, seed, max_per_base, hmask,
-                               (int4*)pk, dB);
+            STOCS_HIP_CHECK(hipMemcpyAsync(d_table, (char*)c->h_pin + PIN_VAR, batch ? 2 * tab_bytes : 16 * nbases, hipMemcpyHostToDevice, c->aux_stream));
+            hipLaunchKernelGGL(draw_picks_kernel, dim3((unsigned)c->bases.size()), dim3(256), lds, c->aux_stream, (const uint4*)d_table,
+                               batch ? (const uint4*)((char*)d_table + tab_bytes) : (const uint4*)NULL, seed, max_per_base, hmask, (int4*)pk, dB);
             STOCS_HIP_CHECK(hipGetLastError());
             STOCS_HIP_CHECK(hipEventRecord(c->ev_join, c->aux_stream));
             STOCS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
@@ -356,6 +381,15 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
         STOCS_HIP_CHECK(hipGetLastError());
         int32_t* rb = (int32_t*)((char*)c->h_pin + PIN_TRANSFORMS);   // pinned read-back slot: accepted count, unresolved picks
         rb[0] = 0; rb[1] = 0;
+        int32_t* tr_pin = (int32_t*)((char*)c->h_pin + PIN_VAR + 2 * tab_bytes);   // batch: first job of every trial in, first candidate of every trial out
+        if (batch) {
+            int32_t* d_tr = (int32_t*)(base + jb + 2 * tb + 3 * ob + scan_tmp + pb);
+            for (size_t t = 0; t < n_tr; ++t) tr_pin[t] = (int32_t)first_job[(size_t)c->trial_first_base[t]];
+            STOCS_HIP_CHECK(hipMemcpyAsync(d_tr, tr_pin, 4 * n_tr, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(gather_i32_kernel, dim3((unsigned)((n_tr + 255) / 256)), dim3(256), 0, c->stream, (const int32_t*)dPos, (const int32_t*)d_tr, (int)n_tr, d_tr + n_tr);
+            STOCS_HIP_CHECK(hipGetLastError());
+            STOCS_HIP_CHECK(hipMemcpyAsync(tr_pin, d_tr + n_tr, 4 * n_tr, hipMemcpyDeviceToHost, c->stream));
+        }
         STOCS_HIP_CHECK(hipMemcpyAsync(&rb[0], dPos + n, 4, hipMemcpyDeviceToHost, c->stream));
         if (d_unresolved) STOCS_HIP_CHECK(hipMemcpyAsync(&rb[1], d_unresolved, 4, hipMemcpyDeviceToHost, c->stream));
         c->timing[1].lap("enqueue resolve/transform/compact");
@@ -366,6 +400,7 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
         if (n_unresolved) { set_error("stocs_make_transforms: %u picks could not be resolved (internal inconsistency)", n_unresolved); return STOCS_ERR_STATE; }
         c->n_cands = n_ok;
         c->cands_stale = n_ok > 0;
+        if (batch) c->trial_cand_off.assign(tr_pin, tr_pin + n_tr);
         tick("transform+compact");
     }
     if (n_candidates) *n_candidates = c->n_cands;

@@ -238,6 +238,42 @@ class StocsEstimator:
         self.best_lcp, self.best_index, self.best_pose = s.value, i.value, P
         return s.value, i.value, P
 
+    # ---- trial batches: N independent trials in one set of launches (stocs_run_trials) ----
+    def run_trials(self, seeds, n_attempts=100, mode=0, dispersion=0.9, max_per_base=200, keep_details=False):
+        """-> list of dicts (n_bases, n_candidates, n_quads, best_lcp, best_index, best_pose 16 floats), one per seed."""
+        sd = np.ascontiguousarray(seeds, np.uint64)
+        res = (capi.TrialResult * max(len(sd), 1))()
+        capi.check(self.L.stocs_run_trials(self.h, mode, len(sd), sd.ctypes.data_as(C.POINTER(C.c_uint64)), n_attempts, dispersion, max_per_base,
+                                           1 if keep_details else 0, res))
+        return [dict(n_bases=r.n_bases, n_candidates=r.n_candidates, n_quads=r.n_quads, best_lcp=r.best_lcp, best_index=r.best_index,
+                     best_pose=np.array(r.best_pose16, np.float32)) for r in res[:len(sd)]]
+
+    def trial_bases(self, trial):
+        n = C.c_int(0)
+        capi.check(self.L.stocs_trials_get_bases(self.h, trial, None, None, None, 0, C.byref(n)))
+        ids = np.zeros((n.value, 4), np.int32); inv = np.zeros((n.value, 2), np.float32); valid = np.zeros(n.value, np.int32)
+        capi.check(self.L.stocs_trials_get_bases(self.h, trial, ids.ctypes.data_as(capi._ip), inv.ctypes.data_as(capi._fp), valid.ctypes.data_as(capi._ip),
+                                                 n.value, C.byref(n)))
+        return valid.astype(bool), ids, inv
+
+    def trial_quad_counts(self, trial):
+        n = C.c_int(0)
+        capi.check(self.L.stocs_trials_get_quad_counts(self.h, trial, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.int64)
+        if n.value:
+            capi.check(self.L.stocs_trials_get_quad_counts(self.h, trial, out.ctypes.data_as(capi._i64p), n.value, C.byref(n)))
+        return out
+
+    def trial_candidates(self, trial):
+        n = C.c_int(0)
+        capi.check(self.L.stocs_trials_get_candidates(self.h, trial, None, None, None, None, 0, C.byref(n)))
+        T = np.zeros((n.value, 16), np.float32); P = np.zeros((n.value, 16), np.float32)
+        l = np.zeros(n.value, np.float32); b = np.zeros(n.value, np.int32)
+        if n.value:
+            capi.check(self.L.stocs_trials_get_candidates(self.h, trial, T.ctypes.data_as(capi._fp), P.ctypes.data_as(capi._fp), l.ctypes.data_as(capi._fp),
+                                                          b.ctypes.data_as(capi._ip), n.value, C.byref(n)))
+        return T, P, l, b
+
     # ---- device-resident scoring for the benchmark ----
     def dev_alloc(self, nbytes):
         p = C.c_void_p()
@@ -328,7 +364,7 @@ class StocsEstimator:
     def last_call_timing(self, which):
         """[(step, milliseconds)] of the last find_congruent_all (0), make_transforms (1) or compute_best_transform (2):
         host wall clock between the call's own synchronisation points, always recorded by the library."""
-        labels = (C.c_char_p * 18)()
+        labels = (C.c_char_p * 18)()   # which = 3: the phases of the last run_trials
         ms = (C.c_double * 18)()
         n = C.c_int(0)
         capi.check(self.L.stocs_last_call_timing(self.h, which, labels, ms, 18, C.byref(n)))

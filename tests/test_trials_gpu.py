@@ -1,0 +1,158 @@
+"""Trial batches (stocs_run_trials): N independent StoCS trials in one set of launches -- the intra-GPU form of BASELINE config 4
+("64 parallel StoCS trials"; the reference runs one trial per process, src/stocs_match_one_object.cpp:81-165).
+
+The contract: trial t of a batch is BIT FOR BIT the trial that
+    stocs_reset_trial; stocs_sample_bases(mode, seed_t, 0, n_attempts); stocs_find_congruent_all; stocs_make_transforms(max, seed_t);
+    stocs_verify_all
+gives alone on the same context -- attempts (ids, invariants, validity), congruent sets per base, candidate transforms (centred and
+camera frame), their base indices, every score, the winner and its pose.  The single-trial path is what the other GPU tests pin
+against the oracle (test_pipeline_gpu.py, test_examples.py, test_driver_gpu.py); one trial here is checked against `orc.run` directly."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _single(est, seed, n_attempts, mode, max_per_base):
+    est.reset_trial()
+    valid, ids, inv = est.sample_bases(seed, n_attempts, mode=mode, dispersion=0.9)
+    nq = est.find_congruent_all()
+    counts = np.array([est.num_quads(k) for k in range(int(valid.sum()))], np.int64)
+    nc = est.make_transforms(max_per_base, seed)
+    lcp, idx, pose = est.compute_best_transform()
+    T, P, l, b = est.get_pose_candidates()
+    return dict(valid=valid, ids=ids, inv=inv, n_quads=nq, counts=counts, n_candidates=nc, best_lcp=lcp, best_index=idx, best_pose=pose.copy(),
+                T=T, P=P, lcp=l, base=b)
+
+
+def _assert_trials_equal_singles(est, seeds, n_attempts, mode, max_per_base, min_candidates=1):
+    res = est.run_trials(seeds, n_attempts, mode=mode, dispersion=0.9, max_per_base=max_per_base, keep_details=True)
+    got = []
+    for t in range(len(seeds)):
+        valid, ids, inv = est.trial_bases(t)
+        T, P, l, b = est.trial_candidates(t)
+        got.append(dict(res[t], valid=valid, ids=ids, inv=inv, counts=est.trial_quad_counts(t), T=T, P=P, lcp=l, base=b))
+    assert est.L.stocs_num_bases(est.h) == 0                       # the context is left as stocs_reset_trial leaves it
+    total = 0
+    for t, seed in enumerate(seeds):
+        ref, g = _single(est, int(seed), n_attempts, mode, max_per_base), got[t]
+        assert np.array_equal(ref["valid"], g["valid"]), t
+        v = ref["valid"]
+        assert np.array_equal(ref["ids"][v], g["ids"][v]) and np.array_equal(ref["inv"][v].view(np.uint32), g["inv"][v].view(np.uint32)), t
+        assert g["n_bases"] == int(v.sum()) and g["n_quads"] == ref["n_quads"] and np.array_equal(ref["counts"], g["counts"]), t
+        assert g["n_candidates"] == ref["n_candidates"] == len(g["T"]), t
+        assert np.array_equal(ref["T"].view(np.uint32), g["T"].view(np.uint32)) and np.array_equal(ref["P"].view(np.uint32), g["P"].view(np.uint32)), t
+        assert np.array_equal(ref["base"], g["base"]), t
+        assert np.array_equal(ref["lcp"].view(np.uint32), g["lcp"].view(np.uint32)), t     # integer accumulation: a score does not depend on its batch
+        assert g["best_index"] == ref["best_index"] and g["best_lcp"] == ref["best_lcp"], t
+        assert np.array_equal(ref["best_pose"].view(np.uint32), g["best_pose"].view(np.uint32)), t
+        total += g["n_candidates"]
+    assert total >= min_candidates
+    return res
+
+
+@pytest.fixture(scope="module")
+def tiny_est():
+    from model_matching_amd import synth
+    from model_matching_amd.estimator import StocsEstimator
+    m, s, k = synth.workload("tiny")
+    est = StocsEstimator(s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm, build_index=True)
+    return m, s, est
+
+
+def test_class_mode_batch_equals_the_trials_run_alone(tiny_est, oracle_lib):
+    m, s, est = tiny_est
+    seeds = [1234, 7, 99, 2**40 + 5, 1234, 31337]              # (a repeated seed gives the same trial twice)
+    res = _assert_trials_equal_singles(est, seeds, 40, 0, 50, min_candidates=100)
+    assert res[0]["best_lcp"] == res[4]["best_lcp"] and res[0]["n_candidates"] == res[4]["n_candidates"]
+    # and one trial straight against the restated run_stocs_estimation (stocs_match_one_object.cpp:51-185)
+    orc = oracle_lib.Oracle(s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm, build_index=True)
+    r = orc.run(1234, 40, 50)
+    assert (res[0]["n_bases"], res[0]["n_quads"], res[0]["n_candidates"]) == (r.n_bases, r.n_quads_total, r.n_candidates)
+    assert abs(res[0]["best_lcp"] - r.best_lcp) <= 1e-5
+
+
+def test_batch_cut_into_pieces_gives_the_same_trials(tiny_est, monkeypatch):
+    """A batch beyond what one set of launches can key or hold is cut into pieces of consecutive trials: forced here."""
+    m, s, est = tiny_est
+    seeds = [11, 12, 13, 14, 15]
+    whole = est.run_trials(seeds, 30, max_per_base=40)
+    assert est.last_call_timing(3)[-1][1] == 1.0               # one piece
+    for knob, value in (("STOCS_TRIALS_PER_PIECE", "2"), ("STOCS_TRIALS_MAX_MB", "1")):
+        monkeypatch.setenv(knob, value)
+        cut = est.run_trials(seeds, 30, max_per_base=40)
+        monkeypatch.delenv(knob)
+        assert est.last_call_timing(3)[-1][1] >= 3.0, knob     # pieces of at most two trials / of one trial each (1 MB ceiling)
+        for a, b in zip(whole, cut):
+            assert a["n_bases"] == b["n_bases"] and a["n_quads"] == b["n_quads"] and a["n_candidates"] == b["n_candidates"]
+            assert a["best_lcp"] == b["best_lcp"] and a["best_index"] == b["best_index"] and np.array_equal(a["best_pose"], b["best_pose"])
+
+
+def test_subset_rule_per_trial(tiny_est):
+    """Bases with >= max quads draw their subset with the seed of THEIR trial and under their slot there (Q5 divergence: seeded)."""
+    m, s, est = tiny_est
+    _assert_trials_equal_singles(est, [5, 6, 7], 30, 0, 3, min_candidates=30)      # max_per_base 3: nearly every base is sub-sampled
+    # host-drawn picks (per-base maxima beyond the LDS table): same candidates
+    a = est.run_trials([5, 6, 7], 30, max_per_base=3, keep_details=True)
+    Ta = [est.trial_candidates(t)[0] for t in range(3)]
+    os.environ["STOCS_TRANSFORMS_HOST_PICKS"] = "1"
+    try:
+        b = est.run_trials([5, 6, 7], 30, max_per_base=3, keep_details=True)
+        Tb = [est.trial_candidates(t)[0] for t in range(3)]
+    finally:
+        del os.environ["STOCS_TRANSFORMS_HOST_PICKS"]
+    for t in range(3):
+        assert a[t]["best_lcp"] == b[t]["best_lcp"] and np.array_equal(Ta[t], Tb[t])
+
+
+def test_instance_mode_batch_equals_the_trials_run_alone():
+    """Instance mode (edge map present, stocs.cpp:559-751): the attempts of one trial are sequential, so a batch runs a workgroup
+    pair per trial, every trial on its own copy of the image-space state; and each trial's candidates are scored against ITS
+    decayed class probabilities (Q8)."""
+    from model_matching_amd.estimator import StocsEstimator
+    d = np.load(os.path.join(GOLD, "example_packed_dove.npz"))
+    est = StocsEstimator(d["scene_pos"], d["scene_nrm"], d["scene_prob"], d["scene_pixel"], d["model_pos"], d["model_nrm"], build_index=True)
+    est.set_edge_map(d["edge_map"])
+    res = _assert_trials_equal_singles(est, [1, 2, 3, 4, 5], 24, 1, 200, min_candidates=500)
+    assert len({r["best_lcp"] for r in res}) > 1               # different seeds, different trials
+    # the context's own scene state is untouched by a batch: its class probabilities are the ones given at construction
+    est.run_trials([9, 10], 24, mode=1)
+    assert np.array_equal(est.get_scene()[2], d["scene_prob"].astype(np.float32))
+    # a decayed prior left behind by a single instance-mode trial does not leak into the next batch
+    est.sample_bases(1, 24, mode=1)
+    again = est.run_trials([1, 2, 3, 4, 5], 24, mode=1)
+    assert [r["best_lcp"] for r in again] == [r["best_lcp"] for r in res]
+
+
+@pytest.mark.parametrize("name", ["ycb_024_bowl", "linemod_obj_06"])
+def test_example_frames_in_batches(name):
+    from model_matching_amd.estimator import StocsEstimator
+    d = np.load(os.path.join(GOLD, "example_%s.npz" % name))
+    est = StocsEstimator(d["scene_pos"], d["scene_nrm"], d["scene_prob"], d["scene_pixel"], d["model_pos"], d["model_nrm"], build_index=True)
+    _assert_trials_equal_singles(est, [1, 2, 3], 100, 0, 200, min_candidates=300)   # (linemod: ~120 congruent sets per trial)
+
+
+def test_edge_cases_and_errors(tiny_est):
+    from model_matching_amd import capi
+    m, s, est = tiny_est
+    assert est.run_trials([], 10) == []
+    r = est.run_trials([3, 4], 0)                               # no attempts: no bases, no pose
+    assert all(x["n_bases"] == 0 and x["n_candidates"] == 0 and x["best_index"] == -1 and x["best_lcp"] == 0.0 and not x["best_pose"].any() for x in r)
+    with pytest.raises(capi.StocsError):
+        est.run_trials([1], 10, max_per_base=0)
+    with pytest.raises(capi.StocsError):
+        est.run_trials([1], 10, mode=2)
+    with pytest.raises(capi.StocsError):
+        est.run_trials([1], 300, mode=1)                        # u8 segment labels (Q14)
+    est.run_trials([1, 2], 10)
+    with pytest.raises(capi.StocsError):
+        est.trial_bases(2)                                      # only two trials in the last batch
+    with pytest.raises(capi.StocsError):
+        est.trial_candidates(0)                                 # run without keep_details
+    # single-trial calls after a batch start from a clean context
+    assert est.L.stocs_num_bases(est.h) == 0
+    valid, ids, inv = est.sample_bases(1, 10)
+    assert est.L.stocs_num_bases(est.h) == int(valid.sum())

@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--bases", type=int, default=100)
     ap.add_argument("--max-sets", type=int, default=200)
     ap.add_argument("--streams", type=int, default=1, help="trial streams in flight per GPU (one context + HIP stream + host thread each)")
+    ap.add_argument("--batch", type=int, default=0, help="B > 0: the rank's trials go through stocs_run_trials in batches of B -- all trials of a batch in ONE set of launches "
+                                                         "(0: one trial after the other through the single-trial calls)")
     ap.add_argument("--gpus", type=int, default=0, help="N > 1 without a launcher: start N rank processes (one per GPU) as children and relay their output")
     args = ap.parse_args()
     from model_matching_amd import dist as sd
@@ -116,7 +118,33 @@ def main():
                 b = (lcp, gid, pose.copy())
         return b, nc
 
-    if n_streams == 1:
+    def run_batched():
+        # the rank's trials lo .. hi in batches of args.batch: every trial of a batch shares every launch (stocs_run_trials)
+        est, b, nc = ests[0], (0.0, -1, None), 0
+        for b0 in range(lo, hi, args.batch):
+            ts = list(range(b0, min(b0 + args.batch, hi)))
+            res = est.run_trials([args.seed + t for t in ts], args.bases, mode=mode, dispersion=0.9, max_per_base=args.max_sets)
+            tm = dict(est.last_call_timing(3))
+            for i, key in enumerate(("sampling", "congruent", "transforms", "verification")):
+                phase_s[0][i] += sum(v for k, v in tm.items() if k.startswith(key)) * 1e-3
+            for t, r in zip(ts, res):
+                nc += r["n_candidates"]
+                gid = (t << 16) | r["best_index"]
+                if r["best_index"] >= 0 and (r["best_lcp"] > b[0] or (r["best_lcp"] == b[0] and gid < b[1])):
+                    b = (r["best_lcp"], gid, r["best_pose"].copy())
+        return b, nc
+
+    if args.batch > 0:
+        run_batched()                      # untimed: sizes the arenas of the batched form (as the single trial above did for the other)
+        est0 = ests[0]; est0.sync()
+        for k in range(4):
+            phase_s[0][k] = 0.0
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        results = [run_batched()]
+    elif n_streams == 1:
         results = [run_trials(0)]
     else:
         from concurrent.futures import ThreadPoolExecutor
@@ -152,7 +180,7 @@ def main():
         dist.all_gather_object(ranks, me)
     if rank == 0:
         print(json.dumps({"world_size": world, "backend": (dist.get_backend() if world > 1 else None), "ranks": ranks,
-                          "setup_seconds_outside_the_timed_span_rank0": setup_s, "example": args.example, "mode": "instance" if mode else "class", "trials": args.trials, "streams_per_gpu": n_streams, "n_gpus": world, "rehearsal": rehearsal,
+                          "setup_seconds_outside_the_timed_span_rank0": setup_s, "example": args.example, "mode": "instance" if mode else "class", "trials": args.trials, "streams_per_gpu": n_streams, "batch": args.batch, "n_gpus": world, "rehearsal": rehearsal,
                           "seconds": dt, "trials_per_s": args.trials / dt,
                           "rank0_phase_seconds_sample_congruent_transforms_verify": [sum(p[i] for p in phase_s) for i in range(4)], "candidates_verified": n_cand, "candidates_per_s": n_cand / dt,
                           "best_lcp": g_lcp, "best_trial": (g_id >> 16) if g_id >= 0 else -1, "best_candidate": (g_id & 0xFFFF) if g_id >= 0 else -1,
