@@ -249,8 +249,6 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
         c->timing[1].lap("no congruent sets");
         return STOCS_OK;
     }
-    // the device starts on the small bases (used whole: materialised and sorted) while the host draws the subsets of the large ones
-    if (!c->bases.empty()) { const int rc0 = stocs_internal_prepare_small(c, max_per_base); if (rc0) return rc0; }
     // picks = (base, rank, job slot, sorted?) records; the quads themselves are produced on the device
     std::vector<int32_t> picks;
     std::vector<int> job_base;
@@ -261,6 +259,9 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
     // the picks are drawn on the device (draw_picks_kernel, on the auxiliary stream next to the small bases' materialisation)
     // while the table of touched entries fits LDS; the host form below is the same draw and serves larger per-base maxima
     const bool device_picks = max_per_base <= 1024 && c->aux_stream && !getenv("STOCS_TRANSFORMS_HOST_PICKS");
+    // host-drawn picks: the device starts on the small bases (used whole: materialised and sorted) while the host draws the subsets
+    // of the large ones; device-drawn picks: behind the upload of the pick table, further down
+    if (!device_picks && !c->bases.empty()) { const int rc0 = stocs_internal_prepare_small(c, max_per_base); if (rc0) return rc0; }
     // a batch of trials (stocs_run_trials): every base draws with the seed of its trial and under its slot there
     const bool batch = !c->base_seed.empty();
     if (batch && (c->base_seed.size() != c->bases.size() || c->base_local.size() != c->bases.size())) { set_error("internal: trial tables do not match the base set"); return STOCS_ERR_STATE; }
@@ -323,7 +324,7 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
     }
     if (!device_picks) first_job[nbases] = job_base.size();
     const size_t n = device_picks ? n_dev : job_base.size();
-    c->timing[1].lap(device_picks ? "small bases enqueued + pick table" : "small bases enqueued + host picks");
+    c->timing[1].lap(device_picks ? "pick table (host)" : "small bases enqueued + host picks");
     tick("host picks");
     clear_candidates(c);
     c->best_lcp = 0; c->best_index = -1;
@@ -344,6 +345,7 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
             c->cand_bytes = (size_t)c->cand_cap * (16 + 16 + 1 + 1) * 4;
             STOCS_HIP_CHECK(dev_malloc((void**)&c->d_cand, c->cand_bytes));
         }
+        c->timing[1].lap("buffers (scratch, pinned, candidate block)");
         char* base = (char*)c->d_scratch;
         XformJob* dJ = (XformJob*)base;
         float* dT = (float*)(base + jb);
@@ -359,16 +361,24 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
             uint4* d_table = (uint4*)(pk + ((n * 16 + 255) / 256) * 256);
             d_picks = (const int32_t*)pk;
             const size_t lds = (size_t)(2 * (hmask + 1) + ((max_per_base + 1) & ~1)) * 4 + (size_t)max_per_base * 8;
-            // on the auxiliary stream: nothing it touches is in use on the main one (the scratch block is idle between calls)
-            STOCS_HIP_CHECK(hipMemcpyAsync(d_table, (char*)c->h_pin + PIN_VAR, batch ? 2 * tab_bytes : 16 * nbases, hipMemcpyHostToDevice, c->aux_stream));
+            // The table goes up on the MAIN stream: a host-to-device copy of a few hundred kilobytes enqueued on the otherwise idle auxiliary
+            // stream blocked the calling thread for 5.6 ms (64 trials of the ycb frame: 195 KB; measured, profiles/r04_trials_steps.json),
+            // the same copy on the stream that carries the rest of the call's work returns at once.  The draws then run on the auxiliary
+            // stream behind an event, next to the small bases' materialisation, which is enqueued behind the copy.
+            STOCS_HIP_CHECK(hipMemcpyAsync(d_table, (char*)c->h_pin + PIN_VAR, batch ? 2 * tab_bytes : 16 * nbases, hipMemcpyHostToDevice, c->stream));
+            STOCS_HIP_CHECK(hipEventRecord(c->ev_fork, c->stream));
+            STOCS_HIP_CHECK(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+            if (!c->bases.empty()) { const int rc0 = stocs_internal_prepare_small(c, max_per_base); if (rc0) return rc0; }
             hipLaunchKernelGGL(draw_picks_kernel, dim3((unsigned)c->bases.size()), dim3(256), lds, c->aux_stream, (const uint4*)d_table,
                                batch ? (const uint4*)((char*)d_table + tab_bytes) : (const uint4*)NULL, seed, max_per_base, hmask, (int4*)pk, dB);
             STOCS_HIP_CHECK(hipGetLastError());
             STOCS_HIP_CHECK(hipEventRecord(c->ev_join, c->aux_stream));
             STOCS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
         }
+        c->timing[1].lap("enqueue pick table upload + small bases + draws (auxiliary stream)");
         rc = stocs_internal_make_jobs(c, device_picks ? NULL : picks.data(), d_picks, (int)n, dJ, &d_unresolved);
         if (rc) return rc;
+        c->timing[1].lap("enqueue resolve");
         tick("resolve picks");
         if (!device_picks) STOCS_HIP_CHECK(hipMemcpyAsync(dB, job_base.data(), n * 4, hipMemcpyHostToDevice, c->stream));
         STOCS_HIP_CHECK(hipMemsetAsync(dO + n, 0, 4, c->stream));
@@ -392,7 +402,7 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
         }
         STOCS_HIP_CHECK(hipMemcpyAsync(&rb[0], dPos + n, 4, hipMemcpyDeviceToHost, c->stream));
         if (d_unresolved) STOCS_HIP_CHECK(hipMemcpyAsync(&rb[1], d_unresolved, 4, hipMemcpyDeviceToHost, c->stream));
-        c->timing[1].lap("enqueue resolve/transform/compact");
+        c->timing[1].lap("enqueue transform/scan/compact + read-backs");
         STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));   // the one synchronisation point of this call
         c->timing[1].lap("wait for the device");
         const int32_t n_ok = rb[0];

@@ -180,7 +180,9 @@ def main():
         dist.all_gather_object(ranks, me)
     if rank == 0:
         print(json.dumps({"world_size": world, "backend": (dist.get_backend() if world > 1 else None), "ranks": ranks,
-                          "setup_seconds_outside_the_timed_span_rank0": setup_s, "example": args.example, "mode": "instance" if mode else "class", "trials": args.trials, "streams_per_gpu": n_streams, "batch": args.batch, "n_gpus": world, "rehearsal": rehearsal,
+                          "setup_seconds_outside_the_timed_span_rank0": setup_s, "example": args.example, "mode": "instance" if mode else "class", "trials": args.trials, "streams_per_gpu": n_streams, "batch": args.batch,
+                          "last_call_steps_ms": {name: [[lab, round(ms, 4)] for lab, ms in ests[0].last_call_timing(w)]
+                                                 for w, name in ((0, "find_congruent_all"), (1, "make_transforms"), (2, "verify_all"), (3, "run_trials"))}, "n_gpus": world, "rehearsal": rehearsal,
                           "seconds": dt, "trials_per_s": args.trials / dt,
                           "rank0_phase_seconds_sample_congruent_transforms_verify": [sum(p[i] for p in phase_s) for i in range(4)], "candidates_verified": n_cand, "candidates_per_s": n_cand / dt,
                           "best_lcp": g_lcp, "best_trial": (g_id >> 16) if g_id >= 0 else -1, "best_candidate": (g_id & 0xFFFF) if g_id >= 0 else -1,
