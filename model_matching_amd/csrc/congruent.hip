@@ -192,14 +192,22 @@ __device__ __forceinline__ int64_t index_pos(V3 p, float cell, int eg) {
 // with its sort key (base << cell_bits | position cell).  P entries sit at p1 + inv1 (p2 - p1) (nset.addElement,
 // stocs.cpp:810-818), Q entries query at p1 + inv2 (p2 - p1) (stocs.cpp:827-836).  A cell the table cannot hold -- it
 // cannot occur for points of the unit cube -- gets the all-ones cell: never queried, never matched.
+// po != NULL: the launch was sized by a CAPACITY (the host has not read the plan yet, see stocs_internal_find_congruent): the
+// list's length and segment count are the planned ones, read here, and the workgroups beyond them leave at once.
 template <class KeyT>
 __global__ __launch_bounds__(256) void gather_key_kernel(const uint32_t* __restrict__ pairs, const Segment* __restrict__ segs, int nseg, uint32_t total,
                                                          const BaseJob* __restrict__ jobs, const float4* __restrict__ munit, int is_q, int cell_bits,
                                                          long long cell_limit, KeyT* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                         uint8_t* __restrict__ occ) {
+                                                         uint8_t* __restrict__ occ, const PlanOut* __restrict__ po) {
+    if (po) {
+        const unsigned long long t = is_q ? po->totQ : po->totP;
+        total = t < (unsigned long long)total ? (uint32_t)t : total;      // never beyond the buffers (a plan beyond the capacity is redone by the host)
+        nseg = (int)(is_q ? po->n_qseg : po->n_pseg);
+    }
     // segment of the workgroup's first entry: one uniform binary search (scalar loads); a segment holds thousands of
     // entries, so the lanes then step forward zero or one segment
     const uint32_t e0 = blockIdx.x * blockDim.x;
+    if (e0 >= total) return;
     int lo = 0, hi = nseg - 1;  // last segment with dst <= e0
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -238,8 +246,9 @@ __device__ __forceinline__ bool occ_test(const uint8_t* __restrict__ occ, KeyT k
 // per tile of SURV_TILE entries: how many survive
 template <class KeyT>
 __global__ __launch_bounds__(256) void survivors_count_kernel(const KeyT* __restrict__ keys, uint32_t n, const uint8_t* __restrict__ other,
-                                                              uint32_t* __restrict__ tile_cnt) {
+                                                              uint32_t* __restrict__ tile_cnt, const PlanOut* __restrict__ po, int is_q) {
     __shared__ uint32_t s_w[4];
+    if (po) { const unsigned long long t = is_q ? po->totQ : po->totP; n = t < (unsigned long long)n ? (uint32_t)t : n; }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t cnt = 0;
 #pragma unroll
@@ -297,8 +306,10 @@ __global__ __launch_bounds__(256) void survivors_base_offsets_kernel(const KeyT*
 template <class KeyT>
 __global__ __launch_bounds__(256) void survivors_compact_kernel(const KeyT* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n,
                                                                 const uint8_t* __restrict__ other, const uint32_t* __restrict__ tile_off,
-                                                                KeyT* __restrict__ okeys, uint32_t* __restrict__ ovals) {
+                                                                KeyT* __restrict__ okeys, uint32_t* __restrict__ ovals, const PlanOut* __restrict__ po, int is_q) {
     constexpr int R = SURV_TILE / 256;
+    if (po) { const unsigned long long t = is_q ? po->totQ : po->totP; n = t < (unsigned long long)n ? (uint32_t)t : n; }
+    if (blockIdx.x * SURV_TILE >= n) return;
     __shared__ uint32_t s_c[R][4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     KeyT key[R];
@@ -796,6 +807,8 @@ struct CongruentState {
     std::vector<unsigned long long> h_out_base, h_off;
     std::vector<uint32_t> h_qoff;          // Q range of every base (host copy of d_qoff)
     bool reduce = false;                   // this trial's lists are reduced to the entries with a partner cell
+    unsigned long long hist_P = 0, hist_Q = 0;   // planned list lengths of the last trial on this scene (capacities of the next one)
+    int hist_nB = 0;
     bool no_quads = false;                 // the last count found no (base, cell) that both lists occupy
     std::vector<uint2> h_blocks;           // workgroup -> Q range of the last materialise
     void* h_stage = NULL;         // pinned staging of the per-trial tables (one upload per trial)
@@ -920,10 +933,14 @@ struct PlanDev {
     int n_pseg, n_qseg;
 };
 
+// d_po != NULL ("optimistic"): the host has NOT read the plan -- S->totP / S->totQ are capacities the buffers and launches are
+// sized by, the kernels read the planned totals from *d_po, and the plan's totals arrive with the survivors' in ONE read-back
+// (po_pin).  Returns 1 (not an error) when the plan turned out larger than the capacities: the caller redoes the pass with the
+// exact sizes it now knows.
 template <class KeyT>
-static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool dbg, double& tprev) {
+static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool dbg, double& tprev, const PlanOut* d_po = NULL, const PlanOut* po_pin = NULL) {
     const int nB = S->nB;
-    const size_t totP0 = S->totP, totQ0 = S->totQ;   // the gathered lists as planned
+    const size_t totP0 = S->totP, totQ0 = S->totQ;   // the gathered lists as planned (d_po: their capacities)
     size_t totP = totP0, totQ = totQ0;               // the lists that are sorted and joined (the survivors, when the lists are reduced)
     hipStream_t st = c->stream;
     hipStream_t sq = c->aux_stream ? c->aux_stream : st;
@@ -964,15 +981,15 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
             STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_fork, 0));
         }
         hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totQ0 + 255) / 256)), dim3(256), 0, sq, ix.d_pairs, d_qsegs, n_qseg, (uint32_t)totQ0,
-                           S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p, occ_q);
+                           S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p, occ_q, d_po);
         STOCS_HIP_CHECK(hipEventRecord(c->ev_t[8], sq));             // Q's cells are marked
         hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totP0 + 255) / 256)), dim3(256), 0, st, ix.d_pairs, d_psegs, n_pseg, (uint32_t)totP0,
-                           S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p, occ_p);
+                           S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p, occ_p, d_po);
         STOCS_HIP_CHECK(hipEventRecord(c->ev_t[9], st));             // P's cells are marked
         if (sq != st) { STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_t[9], 0)); STOCS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_t[8], 0)); }
-        hipLaunchKernelGGL(survivors_count_kernel<KeyT>, dim3(ntq), dim3(256), 0, sq, (const KeyT*)d_qk_raw.p, (uint32_t)totQ0, (const uint8_t*)occ_p, d_surv.p + o_tq);
+        hipLaunchKernelGGL(survivors_count_kernel<KeyT>, dim3(ntq), dim3(256), 0, sq, (const KeyT*)d_qk_raw.p, (uint32_t)totQ0, (const uint8_t*)occ_p, d_surv.p + o_tq, d_po, 1);
         if (sq != st) STOCS_HIP_CHECK(hipEventRecord(c->ev_join, sq));
-        hipLaunchKernelGGL(survivors_count_kernel<KeyT>, dim3(ntp), dim3(256), 0, st, (const KeyT*)d_pk_raw.p, (uint32_t)totP0, (const uint8_t*)occ_q, d_surv.p + o_tp);
+        hipLaunchKernelGGL(survivors_count_kernel<KeyT>, dim3(ntp), dim3(256), 0, st, (const KeyT*)d_pk_raw.p, (uint32_t)totP0, (const uint8_t*)occ_q, d_surv.p + o_tp, d_po, 0);
         if (sq != st) STOCS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_join, 0));
         hipLaunchKernelGGL(survivors_scan_kernel, dim3(2), dim3(1024), 0, st, d_surv.p + o_tp, ntp, d_surv.p + o_tq, ntq);
         hipLaunchKernelGGL(survivors_base_offsets_kernel<KeyT>, dim3((unsigned)nB, 2), dim3(256), 0, st, (const KeyT*)d_pk_raw.p, (uint32_t)totP0, (const uint8_t*)occ_q,
@@ -991,14 +1008,21 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
             STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_fork, 0));
         }
         hipLaunchKernelGGL(survivors_compact_kernel<KeyT>, dim3(ntq), dim3(256), 0, sq, (const KeyT*)d_qk_raw.p, (const uint32_t*)d_qv_raw.p, (uint32_t)totQ0,
-                           (const uint8_t*)occ_p, (const uint32_t*)(d_surv.p + o_tq), d_qk_c.p, d_qv_c.p);
+                           (const uint8_t*)occ_p, (const uint32_t*)(d_surv.p + o_tq), d_qk_c.p, d_qv_c.p, d_po, 1);
         hipLaunchKernelGGL(survivors_compact_kernel<KeyT>, dim3(ntp), dim3(256), 0, st, (const KeyT*)d_pk_raw.p, (const uint32_t*)d_pv_raw.p, (uint32_t)totP0,
-                           (const uint8_t*)occ_q, (const uint32_t*)(d_surv.p + o_tp), d_pk_c.p, d_pv_c.p);
+                           (const uint8_t*)occ_q, (const uint32_t*)(d_surv.p + o_tp), d_pk_c.p, d_pv_c.p, d_po, 0);
         STOCS_HIP_CHECK(hipGetLastError());
         c->timing[0].lap("enqueue gather + occupancy + survivor counts");
         STOCS_HIP_CHECK(hipEventSynchronize(c->ev_t[7]));   // the read-back, not the compaction behind it
         c->timing[0].lap("wait for the device (survivors)");
         have_surv_clock = true;
+        if (po_pin) {   // the plan's own totals came with this read-back: were the capacities enough?
+            if (po_pin->overflow || po_pin->totP > (unsigned long long)totP0 || po_pin->totQ > (unsigned long long)totQ0) {
+                STOCS_HIP_CHECK(hipStreamSynchronize(st));            // the compaction behind the read-back: nothing may still touch the arena
+                if (sq != st) STOCS_HIP_CHECK(hipStreamSynchronize(sq));
+                return 1;
+            }
+        }
         totP = qoff_pin[nB + 1]; totQ = qoff_pin[nB];
         memcpy(S->h_qoff.data(), qoff_pin, 4 * ((size_t)nB + 1));
         if (dbg) fprintf(stderr, "[stocs congruent] survivors: P %zu of %zu, Q %zu of %zu\n", totP, totP0, totQ, totQ0);
@@ -1029,13 +1053,13 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     }
     if (!reduce)
         hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totQ + 255) / 256)), dim3(256), 0, sq, ix.d_pairs, d_qsegs, n_qseg, (uint32_t)totQ,
-                           S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p, (uint8_t*)NULL);
+                           S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p, (uint8_t*)NULL, (const PlanOut*)NULL);
     STOCS_HIP_CHECK(sort_pairs(d_tmp2.p, tb2, qk_in, (KeyT*)S->d_qkeys.p, qv_in, S->d_qvals.p, totQ, 0, end_bit, sq));
     STOCS_HIP_CHECK(hipEventRecord(c->ev_t[1], sq));
     if (sq != st) STOCS_HIP_CHECK(hipEventRecord(c->ev_join, sq));
     if (!reduce)
         hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, ix.d_pairs, d_psegs, n_pseg, (uint32_t)totP,
-                           S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p, (uint8_t*)NULL);
+                           S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p, (uint8_t*)NULL, (const PlanOut*)NULL);
     STOCS_HIP_CHECK(hipGetLastError());
     // one stable sort per list: (base, position cell); inside a cell the entries keep the index order of the gather
     STOCS_HIP_CHECK(sort_pairs(d_tmp.p, tb1, pk_in, (KeyT*)S->d_pkeys.p, pv_in, S->d_pvals.p, totP, 0, end_bit_p, st));
@@ -1114,7 +1138,7 @@ void stocs_internal_free_congruent(stocs_ctx* c) {   // stocs_ctx_destroy: nothi
 }
 
 void stocs_internal_invalidate_congruent(stocs_ctx* c) {   // the counted state refers to bases of another scene
-    if (c && c->cong) ((CongruentState*)c->cong)->valid = false;
+    if (c && c->cong) { CongruentState* S = (CongruentState*)c->cong; S->valid = false; S->hist_nB = 0; S->hist_P = S->hist_Q = 0; }
 }
 
 // Host evaluation of one cone query with both evaluations of cone_cells.h (no device needed): the direction-cell bitset
@@ -1236,6 +1260,8 @@ int stocs_internal_find_congruent(stocs_ctx* c, int64_t* total_quads, size_t max
     plan.psegs = (Segment*)(dpl + o_pseg); plan.qsegs = (Segment*)(dpl + o_qseg); plan.p_off = (uint32_t*)(dpl + o_poff); plan.q_off = (uint32_t*)(dpl + o_qoff);
     plan.n_pseg = 0; plan.n_qseg = 0;
     uint64_t totP = 0, totQ = 0;
+    bool optimistic = false;
+    const PlanOut* d_po = NULL; const PlanOut* po_pinned = NULL;
     std::vector<uint32_t>& q_off = S->h_qoff;
     q_off.assign(nB + 1, 0);
     {
@@ -1261,12 +1287,27 @@ int stocs_internal_find_congruent(stocs_ctx* c, int64_t* total_quads, size_t max
         STOCS_HIP_CHECK(hipMemcpyAsync(po_pin, dpl + o_out, sizeof(PlanOut), hipMemcpyDeviceToHost, c->stream));
         if (!reduce) STOCS_HIP_CHECK(hipMemcpyAsync(qoff_pin, plan.q_off, 4 * (nb + 1), hipMemcpyDeviceToHost, c->stream));   // (reduced lists: their own offsets come later)
         c->timing[0].lap("enqueue plan upload + kernels + read-back");
-        STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
-        c->timing[0].lap("wait for the device (plan)");
-        const PlanOut po = *po_pin;
-        if (!reduce) memcpy(q_off.data(), qoff_pin, 4 * (nb + 1));
-        if (po.overflow) { if (too_big) { *too_big = 1; return STOCS_OK; } set_error("pair lists exceed 2^32 entries"); return STOCS_ERR_CAPACITY; }
-        totP = po.totP; totQ = po.totQ; plan.n_pseg = (int)po.n_pseg; plan.n_qseg = (int)po.n_qseg;
+        // ONE sizing synchronisation point instead of two (plan totals, then survivors' totals): when an earlier trial of this scene
+        // has shown how long the lists get, buffers and launches are sized by a capacity (1.6 x that, per base), the kernels read the
+        // planned totals from the device, and the plan's totals come back together with the survivors' (count_pass).  A plan beyond
+        // the capacity is detected there and redone with exact sizes.  Not for a trial batch under a memory ceiling (its caller
+        // needs the totals first) and not for the first trial of a scene.
+        optimistic = reduce && !too_big && S->hist_nB > 0 && !getenv("STOCS_CONGRUENT_EXACT_SIZES");
+        if (optimistic) {
+            d_po = (const PlanOut*)(dpl + o_out); po_pinned = po_pin;
+            const char* ce = getenv("STOCS_CONGRUENT_CAPACITY");     // (tests: a factor below 1 forces the redo with exact sizes)
+            const double scale = (ce ? atof(ce) : 1.6) * (double)nB / (double)S->hist_nB, slack = ce ? 1.0 : 1048576.0;
+            totP = (uint64_t)std::min(4.0e9, (double)S->hist_P * scale + slack);
+            totQ = (uint64_t)std::min(4.0e9, (double)S->hist_Q * scale + slack);
+        } else {
+            STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+            c->timing[0].lap("wait for the device (plan)");
+            const PlanOut po = *po_pin;
+            if (!reduce) memcpy(q_off.data(), qoff_pin, 4 * (nb + 1));
+            if (po.overflow) { if (too_big) { *too_big = 1; return STOCS_OK; } set_error("pair lists exceed 2^32 entries"); return STOCS_ERR_CAPACITY; }
+            totP = po.totP; totQ = po.totQ; plan.n_pseg = (int)po.n_pseg; plan.n_qseg = (int)po.n_qseg;
+            S->hist_P = po.totP; S->hist_Q = po.totQ; S->hist_nB = nB;
+        }
         STOCS_TICK("plan (device)")
     } else {
         // on the host (kept for very many bases and for A/B): the same ranges from the host copy of the bucket table
@@ -1315,19 +1356,25 @@ int stocs_internal_find_congruent(stocs_ctx* c, int64_t* total_quads, size_t max
         c->timing[0].lap("plan on the host + upload");
         STOCS_TICK("plan (host)")
     }
-    if (dbg) fprintf(stderr, "[stocs congruent] totP %llu totQ %llu segs %d %d\n", (unsigned long long)totP, (unsigned long long)totQ, plan.n_pseg, plan.n_qseg);
+    if (dbg) fprintf(stderr, "[stocs congruent] %s totP %llu totQ %llu segs %d %d\n", optimistic ? "capacities" : "planned", (unsigned long long)totP, (unsigned long long)totQ, plan.n_pseg, plan.n_qseg);
     if (totP == 0 || totQ == 0) return STOCS_OK;
     if (id_bits > 16) { set_error("|M| = %d: model ids beyond 16 bits do not fit the packed pairs and quads", c->nM); return STOCS_ERR_CAPACITY; }
 
-    {   // everything this call allocates, estimated up front: one slab, one hipMalloc in a context's lifetime (if sizes stay put)
+    auto reserve_arena = [&](uint64_t nP, uint64_t nQ, bool* over) -> int {
+        // everything this call allocates, estimated up front: one slab, one hipMalloc in a context's lifetime (if sizes stay put)
         const size_t kb = wide ? 8 : 4;
         const size_t tables = use_table ? (size_t)(NC * nB) * 8 : 0;
         const size_t per_entry = 3 * kb + 8 + 16 + 8 + (reduce ? kb + 4 : 0);   // (the compacted copies of the reduced form)
         const size_t occ = reduce ? 2 * ((size_t)nB << cell_bits) : 0;
-        const size_t need = (size_t)totP * per_entry + (size_t)totQ * per_entry + tables + occ + ((size_t)48 << 20);
-        if (max_bytes && need > max_bytes && nB > 1) { if (too_big) *too_big = 1; return STOCS_OK; }   // the caller splits its base set
-        int rc0 = S->arena_state.reserve(need);
+        const size_t need = (size_t)nP * per_entry + (size_t)nQ * per_entry + tables + occ + ((size_t)48 << 20);
+        if (max_bytes && need > max_bytes && nB > 1) { *over = true; return STOCS_OK; }
+        return S->arena_state.reserve(need);
+    };
+    {
+        bool over = false;
+        int rc0 = reserve_arena(totP, totQ, &over);
         if (rc0) return rc0;
+        if (over) { if (too_big) *too_big = 1; return STOCS_OK; }   // the caller splits its base set
     }
     c->timing[0].lap("arena reserve");
     S->nB = nB; S->totP = (uint32_t)totP; S->totQ = (uint32_t)totQ; S->nepsilon = nepsilon;
@@ -1341,7 +1388,37 @@ int stocs_internal_find_congruent(stocs_ctx* c, int64_t* total_quads, size_t max
     S->id_bits = id_bits; S->base_bits = base_bits; S->cell_bits = cell_bits;
     S->base_in_key = 4 * id_bits + base_bits <= 64;
     S->no_quads = false;
-    int rc = wide ? count_pass<uint64_t>(c, S, plan, dbg, tprev) : count_pass<uint32_t>(c, S, plan, dbg, tprev);
+    int rc = wide ? count_pass<uint64_t>(c, S, plan, dbg, tprev, d_po, po_pinned) : count_pass<uint32_t>(c, S, plan, dbg, tprev, d_po, po_pinned);
+    if (optimistic && rc <= 1) {   // (the read-back of count_pass brought the plan's totals)
+        const PlanOut po = *po_pinned;
+        if (po.overflow) { set_error("pair lists exceed 2^32 entries"); return STOCS_ERR_CAPACITY; }
+        S->hist_P = po.totP; S->hist_Q = po.totQ; S->hist_nB = nB;
+        if (rc == 1) {
+            // the plan outgrew the capacities: once more with the sizes now known.  The base jobs carry the survivors' offsets by now:
+            // the layout kernel writes the planned ones again (its inputs are still in the planning buffer)
+            c->timing[0].lap("plan beyond the capacities: redone with exact sizes");
+            const size_t nb2 = (size_t)nB;
+            char* dpl2 = S->d_plan;
+            auto al2 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+            const size_t o_bids2 = al2(sizeof(BaseJob) * nb2), o_err2 = o_bids2 + al2(16 * nb2), o_rng2 = o_err2 + 256, o_nr2 = o_rng2 + al2(2 * nb2 * 128 * 8),
+                         o_tot2 = o_nr2 + al2(2 * nb2 * 4), o_pseg2 = o_tot2 + al2(2 * nb2 * 4), o_qseg2 = o_pseg2 + al2(nb2 * 128 * sizeof(Segment)),
+                         o_poff2 = o_qseg2 + al2(nb2 * 128 * sizeof(Segment)), o_qoff2 = o_poff2 + al2((nb2 + 1) * 4), o_spo2 = o_qoff2 + al2((nb2 + 2) * 4),
+                         o_sqo2 = o_spo2 + al2((nb2 + 1) * 4), o_out2 = o_sqo2 + al2((nb2 + 1) * 4);
+            hipLaunchKernelGGL(plan_offsets_kernel, dim3(1), dim3(1024), 0, c->stream, nB, (const uint2*)(dpl2 + o_rng2), (const uint32_t*)(dpl2 + o_nr2), (const uint32_t*)(dpl2 + o_tot2),
+                               plan.jobs, plan.psegs, plan.qsegs, plan.p_off, plan.q_off, (uint32_t*)(dpl2 + o_spo2), (uint32_t*)(dpl2 + o_sqo2), (PlanOut*)(dpl2 + o_out2), plan.err);
+            STOCS_HIP_CHECK(hipGetLastError());
+            { int rc0 = S->arena_state.reset(); if (rc0) return rc0; }
+            tl_arena = &S->arena_state;
+            bool over = false;
+            int rc0 = reserve_arena(po.totP, po.totQ, &over);
+            if (rc0) return rc0;
+            plan.n_pseg = (int)po.n_pseg; plan.n_qseg = (int)po.n_qseg;
+            S->totP = (uint32_t)po.totP; S->totQ = (uint32_t)po.totQ;
+            S->no_quads = false;
+            if (po.totP == 0 || po.totQ == 0) return STOCS_OK;
+            rc = wide ? count_pass<uint64_t>(c, S, plan, dbg, tprev) : count_pass<uint32_t>(c, S, plan, dbg, tprev);
+        }
+    }
     if (rc) return rc;
     if (S->no_quads) return STOCS_OK;   // as with empty lists: nothing to materialise, every base has zero quads
     S->valid = true;

@@ -920,6 +920,8 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
         const bool lists_huge = (double)c->grid.n_entries * 16.0 >= 512.0e6;
         a.xcd_blocks = c->lcp_order >= 2 ? (c->lcp_order == 2 ? 1 : c->lcp_order) : (lists_huge ? 128 : 0);
     }
+    if (d_best8 && d_best8 == c->d_best && c->best_is_zero) best_zeroed = true;   // stocs_make_transforms left the word zeroed for this launch
+    if (d_best8 == c->d_best) c->best_is_zero = false;
     if (d_best8 && !best_zeroed) STOCS_HIP_CHECK(hipMemsetAsync(d_best8, 0, 8, c->stream));
     int variant = c->lcp_variant >= 0 ? c->lcp_variant : lcp_variant();
     // dense grids keep their lists sorted by distance from the cell centre (not by index): only kernels
@@ -1131,6 +1133,7 @@ int stocs_best_device(stocs_ctx* c, const void* d_lcp, int n, uint32_t id_offset
     *key = 0;
     if (n == 0) return STOCS_OK;
     if (!c->d_best) STOCS_HIP_CHECK(dev_malloc((void**)&c->d_best, 8));
+    c->best_is_zero = false;
     if (n <= (1 << 18)) {
         hipLaunchKernelGGL(best_single_kernel, dim3(1), dim3(1024), 0, c->stream, (const float*)d_lcp, n, id_offset, c->d_best);
     } else {

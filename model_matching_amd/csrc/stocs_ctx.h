@@ -279,6 +279,7 @@ struct stocs_ctx {
     int best_index;
 
     unsigned long long* d_best;   // 8-byte arg-max key
+    bool best_is_zero;            // *d_best was zeroed on the stream by the last stocs_make_transforms and not used since
 
     // pinned host block for the small device-to-host read-backs of the entry points (totals, offsets, keys): a copy into
     // pageable memory goes through the runtime's own staging and is one more thing that can stall (ensure_pinned grows it)

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void rigid_transform_kernel(const float4* __re
                                                               float* __restrict__ T_out, float* __restrict__ P_out,
                                                               int32_t* __restrict__ ok_out) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) ok_out[n] = 0;   // the flag array is scanned over n + 1 entries so that the last output is the accepted count
     if (j >= n) return;
     const XformJob job = jobs[j];
     const V3 p0 = ld3(spos, job.s[0]), p1 = ld3(spos, job.s[1]), p2 = ld3(spos, job.s[2]);
@@ -194,8 +195,9 @@ __global__ __launch_bounds__(256) void gather_i32_kernel(const int32_t* __restri
 __global__ __launch_bounds__(256) void compact_candidates_kernel(const float4* __restrict__ T, const float4* __restrict__ P, const int32_t* __restrict__ ok,
                                                                  const int32_t* __restrict__ pos, const int32_t* __restrict__ job_base, int n,
                                                                  float4* __restrict__ To, float4* __restrict__ Po, float* __restrict__ lcp,
-                                                                 int32_t* __restrict__ base_out) {
+                                                                 int32_t* __restrict__ base_out, unsigned long long* __restrict__ best) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0 && best) *best = 0ull;   // the arg-max word of the verification that follows (stocs_verify_all): no fill of its own there
     if (j >= n || !ok[j]) return;
     const int d = pos[j];
 #pragma unroll
@@ -346,6 +348,7 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
             STOCS_HIP_CHECK(dev_malloc((void**)&c->d_cand, c->cand_bytes));
         }
         c->timing[1].lap("buffers (scratch, pinned, candidate block)");
+        if (!c->d_best) STOCS_HIP_CHECK(dev_malloc((void**)&c->d_best, 8));
         char* base = (char*)c->d_scratch;
         XformJob* dJ = (XformJob*)base;
         float* dT = (float*)(base + jb);
@@ -381,13 +384,13 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
         c->timing[1].lap("enqueue resolve");
         tick("resolve picks");
         if (!device_picks) STOCS_HIP_CHECK(hipMemcpyAsync(dB, job_base.data(), n * 4, hipMemcpyHostToDevice, c->stream));
-        STOCS_HIP_CHECK(hipMemsetAsync(dO + n, 0, 4, c->stream));
         hipLaunchKernelGGL(rigid_transform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_spos, c->d_mpos, dJ, (int)n,
                            c->centroid_scene, c->centroid_model, dT, dP, dO);
         STOCS_HIP_CHECK(hipGetLastError());
         STOCS_HIP_CHECK(exclusive_scan(dTmp, scan_tmp, (const uint32_t*)dO, (uint32_t*)dPos, n + 1, c->stream));
         hipLaunchKernelGGL(compact_candidates_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float4*)dT, (const float4*)dP, dO, dPos, dB,
-                           (int)n, (float4*)cand_T(c), (float4*)cand_P(c), cand_lcp(c), cand_base(c));
+                           (int)n, (float4*)cand_T(c), (float4*)cand_P(c), cand_lcp(c), cand_base(c), c->d_best);
+        c->best_is_zero = true;
         STOCS_HIP_CHECK(hipGetLastError());
         int32_t* rb = (int32_t*)((char*)c->h_pin + PIN_TRANSFORMS);   // pinned read-back slot: accepted count, unresolved picks
         rb[0] = 0; rb[1] = 0;

@@ -273,7 +273,7 @@ def test_unreduced_pair_lists_give_the_same_sets(setup, monkeypatch):
     nv = int(valid.sum())
     quads = [est.get_quads(k) for k in range(nv)]
     walk = [est.get_quads_at(k, np.arange(min(len(quads[k]), 300))) for k in range(nv)]
-    assert len(est.last_call_timing(0)) >= 16     # the reduced form has its own synchronisation point and device group
+    assert len(est.last_call_timing(0)) >= 15     # the reduced form has its own synchronisation point and device group
     for wide in ("", "1"):
         monkeypatch.setenv("STOCS_CONGRUENT_KEEP_ALL", "1")
         if wide:
@@ -288,6 +288,41 @@ def test_unreduced_pair_lists_give_the_same_sets(setup, monkeypatch):
             continue
         assert np.array_equal(quads[slot], orc.find_congruent(ids[a], float(inv[a][0]), float(inv[a][1])))
         slot += 1
+
+
+def test_one_sizing_synchronisation_point_and_its_fallback(setup, monkeypatch):
+    """From the second trial of a scene on, stocs_find_congruent_all sizes its buffers and launches by a capacity learnt from the
+    trial before and reads the plan's totals together with the survivors' (one sizing synchronisation point instead of two).
+    Same sets as with the exact sizes; a plan beyond the capacity is redone with exact sizes, again with the same sets."""
+    m, s, est, orc = setup
+    est.L.stocs_clear_bases(est.h)
+    valid, ids, inv = est.sample_bases(4243, 24)
+    nv = int(valid.sum())
+    monkeypatch.setenv("STOCS_CONGRUENT_EXACT_SIZES", "1")
+    n_exact = est.find_congruent_all()
+    steps = [lab for lab, _ in est.last_call_timing(0)]
+    assert "wait for the device (plan)" in steps
+    quads = [est.get_quads(k) for k in range(nv)]
+    monkeypatch.delenv("STOCS_CONGRUENT_EXACT_SIZES")
+    assert est.find_congruent_all() == n_exact and n_exact > 0          # capacities from the call before
+    steps = [lab for lab, _ in est.last_call_timing(0)]
+    assert "wait for the device (plan)" not in steps and "wait for the device (survivors)" in steps
+    for k in range(nv):
+        assert np.array_equal(est.get_quads(k), quads[k])
+    n_cand = est.make_transforms(50, 3)
+    monkeypatch.setenv("STOCS_CONGRUENT_CAPACITY", "0.05")              # far too small: detected, redone
+    assert est.find_congruent_all() == n_exact
+    steps = [lab for lab, _ in est.last_call_timing(0)]
+    assert "plan beyond the capacities: redone with exact sizes" in steps
+    for k in range(nv):
+        assert np.array_equal(est.get_quads(k), quads[k])
+    assert est.make_transforms(50, 3) == n_cand
+    monkeypatch.delenv("STOCS_CONGRUENT_CAPACITY")
+    # a smaller base set after a larger one (capacities scale with the number of bases), and an empty one
+    est.set_bases(ids[valid][:3], inv[valid][:3])
+    assert est.find_congruent_all() == sum(len(q) for q in quads[:3])
+    est.L.stocs_clear_bases(est.h)
+    assert est.find_congruent_all() == 0
 
 
 def test_distance_gate_path_of_the_count(setup, monkeypatch):
