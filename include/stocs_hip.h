@@ -305,6 +305,11 @@ int stocs_icp_point_to_plane(const float* src_pos3, int nsrc, const float* tgt_p
  *   than epsilon from every scene point cannot add to the score and is skipped after one look-up in a distance field of
  *   the scene.  0 = off, 1 (default) = on once the field pays (1e9 candidates x model points scored against the scene so
  *   far: the field costs ~0.25 ms per scene and takes ~6 % off a launch), 2 = from the first call.  Same scores, bitwise.
+ * "lcp_cull_after": that threshold of "lcp_cull" = 1 in MILLIONS of point queries (candidates x model points scored against
+ *   the current scene); default 1000, 0 = from the first call.  One trial of a 640x480 frame is 1-40 million: a caller that
+ *   scores a single trial per frame never fills the field, a trial batch (stocs_run_trials) or a stream of candidate batches
+ *   crosses the threshold within a call or two.  When the scene BEFORE the current one crossed it, stocs_ctx_set_scene fills
+ *   the new scene's field at once, on the context's auxiliary stream (a frame stream on a fixed camera will cross it again).
  * "lcp_group": lanes that verify one queued query together in the queue-fed kernels: 4 (two entries of a 128-byte list line per
  *   lane, sixteen queries per trip).  The only value of the product library (8, one entry per lane, is the form of rounds 1-3a
  *   and lives in the measurement build). ---- */

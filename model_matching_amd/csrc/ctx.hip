@@ -190,6 +190,10 @@ static int load_scene_impl(stocs_ctx* c, const float* sp, const float* sn, const
         fprintf(stderr, "[stocs scene] %-22s %8.3f ms\n", what, (t.tv_sec - ts_a.tv_sec) * 1e3 + (t.tv_nsec - ts_a.tv_nsec) * 1e-6);
         ts_a = t;
     };
+    // a frame stream on a fixed camera: when the frame before this one was scored often enough for its distance field to pay, this
+    // one will be too -- its field is filled at once, next to whatever the caller does first (sampling), instead of after a warm-up
+    c->prev_scene_warm = c->lcp_cull == 1 && c->grid.d_dist != NULL && c->scene_work >= c->lcp_cull_after;
+    if (c->cull_pending && c->aux_stream) { STOCS_HIP_CHECK(hipStreamSynchronize(c->aux_stream)); c->cull_pending = false; }   // the old field's memory is about to be recycled
     c->nS = nS;
     c->h_spos.resize(nS); c->h_snrm.resize(nS); c->h_sprob.assign(sprob, sprob + nS); c->h_sprob0 = c->h_sprob; c->h_spix.assign((size_t)2 * nS, 0);
     for (int i = 0; i < nS; ++i) {
@@ -236,6 +240,11 @@ static int load_scene_impl(stocs_ctx* c, const float* sp, const float* sn, const
     lap("upload");
     if (!rc) rc = build_grid(c);
     lap("grid");
+    if (!rc && c->prev_scene_warm && c->lcp_cull == 1 && c->grid.d_dist && c->d_mpatch && c->aux_stream) {
+        // (the grid build has synchronised c->stream: the scene arrays the fill reads are in place)
+        rc = fill_cull_field(c, c->aux_stream);
+        if (!rc) { STOCS_HIP_CHECK(hipEventRecord(c->ev_cull, c->aux_stream)); c->cull_pending = true; }
+    }
     // per-trial state belongs to the old scene
     clear_trial_batch(c);
     c->bases.clear(); c->quad_off.clear(); clear_candidates(c);
@@ -437,10 +446,12 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     c->patch_r_ref = 0.0f; c->scene_scored = 0; c->scene_work = 0.0;
     c->lcp_group = getenv("STOCS_LCP_GROUP") ? atoi(getenv("STOCS_LCP_GROUP")) : 4;
     c->lcp_cull = getenv("STOCS_LCP_CULL") ? atoi(getenv("STOCS_LCP_CULL")) : 1;
+    c->lcp_cull_after = 1.0e9; c->prev_scene_warm = false; c->cull_pending = false; c->ev_cull = NULL;
     c->stream = NULL; c->own_stream = NULL; c->aux_stream = NULL;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_cull, hipEventDisableTiming) != hipSuccess) {
         set_error("stream/event creation failed");
         delete c;
         return STOCS_ERR_NO_DEVICE;
@@ -556,6 +567,7 @@ int stocs_ctx_destroy(stocs_ctx* c) {
     (void)hipEventDestroy(c->ev1);
     (void)hipEventDestroy(c->ev_fork);
     (void)hipEventDestroy(c->ev_join);
+    if (c->ev_cull) (void)hipEventDestroy(c->ev_cull);
     for (int k = 0; k < 10; ++k) (void)hipEventDestroy(c->ev_t[k]);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

@@ -488,16 +488,17 @@ int prepare_cull_field(stocs_ctx* c) {
     return c->grid_mem.take((size_t)n[0] * n[1] * n[2] * sizeof(float), (void**)&g.d_dist);
 }
 
-int fill_cull_field(stocs_ctx* c) {
+int fill_cull_field(stocs_ctx* c, hipStream_t st) {
     SceneGrid& g = c->grid;
     if (!g.d_dist || g.dist_ready) return STOCS_OK;
+    if (!st) st = c->stream;
     CullGeom G;
     G.o[0] = g.cg_ox; G.o[1] = g.cg_oy; G.o[2] = g.cg_oz;   // the float origin and edge the scan kernels use, widened
     G.g = g.cg_g; G.cap = g.cg_cap;
     G.n[0] = g.cg_nx; G.n[1] = g.cg_ny; G.n[2] = g.cg_nz; G.w = g.cg_w;
     const size_t n = (size_t)g.cg_nx * g.cg_ny * g.cg_nz;
-    hipLaunchKernelGGL(dist_fill_kernel, dim3(grid_of(n)), dim3(256), 0, c->stream, g.d_dist, n, g.cg_cap);
-    hipLaunchKernelGGL(dist_splat_kernel, dim3((unsigned)((c->nS + 3) / 4)), dim3(256), 0, c->stream, G, g.cg_ox, g.cg_oy, g.cg_oz, g.cg_g, g.cg_cap,
+    hipLaunchKernelGGL(dist_fill_kernel, dim3(grid_of(n)), dim3(256), 0, st, g.d_dist, n, g.cg_cap);
+    hipLaunchKernelGGL(dist_splat_kernel, dim3((unsigned)((c->nS + 3) / 4)), dim3(256), 0, st, G, g.cg_ox, g.cg_oy, g.cg_oz, g.cg_g, g.cg_cap,
                        c->d_spos, c->nS, (uint32_t*)g.d_dist);
     STOCS_HIP_CHECK(hipGetLastError());
     g.dist_ready = true;

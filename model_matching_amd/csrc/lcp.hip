@@ -874,9 +874,10 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
     a.gox = a.goy = a.goz = 0.f; a.g = a.inv_g = a.cap = 0.f; a.gnx = a.gny = a.gnz = 0;
     c->scene_scored++;
     c->scene_work += (double)n * (double)c->nM;
-    if (c->lcp_cull && c->grid.d_dist && c->d_mpatch && (c->grid.dist_ready || c->lcp_cull >= 2 || c->scene_work >= 1.0e9)) {
+    if (c->lcp_cull && c->grid.d_dist && c->d_mpatch && (c->grid.dist_ready || c->lcp_cull >= 2 || c->scene_work >= c->lcp_cull_after)) {
         int rc = fill_cull_field(c);
         if (rc) return rc;
+        if (c->cull_pending) { STOCS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_cull, 0)); c->cull_pending = false; }   // filled at stocs_ctx_set_scene, on the auxiliary stream
         a.patch = c->d_mpatch; a.dist = c->grid.d_dist;
         a.gox = c->grid.cg_ox; a.goy = c->grid.cg_oy; a.goz = c->grid.cg_oz; a.g = c->grid.cg_g; a.inv_g = c->grid.cg_inv_g; a.cap = c->grid.cg_cap;
         a.gnx = c->grid.cg_nx; a.gny = c->grid.cg_ny; a.gnz = c->grid.cg_nz;
@@ -1202,6 +1203,9 @@ int stocs_set_option(stocs_ctx* c, const char* key, int value) {
     // 0: every 64-point step is walked; 1 (default): steps whose bounding sphere is out of reach of the scene are skipped once the scene's
     // distance field pays (1e9 point queries against the scene so far); 2: from the first call (same scores in every case)
     if (!strcmp(key, "lcp_cull") && value >= 0 && value <= 2) { c->lcp_cull = value; return STOCS_OK; }
+    // the threshold of lcp_cull = 1, in MILLIONS of point queries (candidates x model points) scored against the current scene:
+    // default 1000 (= 1e9: the field costs ~0.25 ms at 20 000 scene points and takes ~6 % off a launch); 0 = from the first call
+    if (!strcmp(key, "lcp_cull_after") && value >= 0) { c->lcp_cull_after = (double)value * 1.0e6; return STOCS_OK; }
     // lanes that verify one queued query together: 4 (two list entries per lane); the eight-lane form of rounds 1-3a lost its A/B and lives in the tools build
     if (!strcmp(key, "lcp_group")) {
         bool ok = value == 4;
@@ -1227,6 +1231,7 @@ int stocs_get_cull_state(stocs_ctx* c, float* patches4, int32_t* perm, int* n_pa
         if (dist_cap < nd) return STOCS_ERR_CAPACITY;
         int rc = fill_cull_field(c);
         if (rc) return rc;
+        if (c->cull_pending) { STOCS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_cull, 0)); c->cull_pending = false; }
     }
     if (patches4 && np) STOCS_HIP_CHECK(hipMemcpyAsync(patches4, c->d_mpatch, (size_t)np * 16, hipMemcpyDeviceToHost, c->stream));
     if (perm) for (int i = 0; i < c->nM; ++i) perm[i] = c->h_mperm[i];

@@ -227,6 +227,11 @@ struct stocs_ctx {
     float patch_r_ref; // the radius most patches stay below (sizes the cap of the scene's distance field)
     int lcp_cull;      // 1: the scan kernels skip the 64-point steps whose bounding sphere is farther than epsilon from every scene point
     int lcp_group;     // lanes per queued query in the verify trips: 4 (default, two list entries per lane) or 8 (one entry per lane)
+    double lcp_cull_after;   // lcp_cull == 1: the distance field is filled once this many point queries were scored against the scene (default 1e9)
+    bool prev_scene_warm;    // the scene before this one crossed that threshold: a stream of frames will again, so the field of a new frame
+                             // is filled right away, on the auxiliary stream (cull_pending: the scoring stream has not waited for it yet)
+    bool cull_pending;
+    hipEvent_t ev_cull;
     int scene_scored;  // scoring launches against the current scene
     double scene_work; // candidates x model points scored against the current scene so far (the distance field is filled when it pays)
 
@@ -314,7 +319,7 @@ int sample_trials(stocs_ctx* c, int mode, int nT, const uint64_t* seeds, int nA,
 int build_ppf_index(stocs_ctx* c);
 int build_grid_gpu(stocs_ctx* c, int div, int dense);
 int prepare_cull_field(stocs_ctx* c);   // geometry + memory of SceneGrid::d_dist for the current grid and model (end of a grid build)
-int fill_cull_field(stocs_ctx* c);      // the values, on c->stream (no synchronisation)
+int fill_cull_field(stocs_ctx* c, hipStream_t st = NULL);      // the values, on st (NULL: c->stream); no synchronisation
 extern "C" int stocs_internal_make_jobs(stocs_ctx* c, const int32_t* picks4_host, const int32_t* picks4_dev, int n, void* d_jobs_out, const unsigned int** d_unresolved_out);
 extern "C" int stocs_internal_prepare_small(stocs_ctx* c, int max_per_base);   // small bases materialised while the host draws the picks
 extern "C" void stocs_internal_free_congruent(stocs_ctx* c);

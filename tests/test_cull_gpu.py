@@ -139,6 +139,36 @@ def test_metric_size_bitwise_and_default_policy(oracle_lib):
     assert np.abs(moved - off[:8192]).max() < 0.05
 
 
+def test_threshold_option_and_early_fill_on_a_frame_stream():
+    """stocs_set_option("lcp_cull_after"): the threshold of the default policy, in millions of point queries; and when the frame
+    BEFORE the current one crossed it, stocs_ctx_set_scene fills the new frame's field at once on the auxiliary stream (the first
+    scoring call waits for it through an event).  Scores never change: compared bitwise with the test off."""
+    from model_matching_amd import capi, synth
+    m, s, k, est, _, Tgt = _setup("small")
+    T = synth.make_candidates(Tgt, 4096)
+    _, _, _, dist0 = est.cull_state(with_field=False)
+    est.set_option("lcp_cull", 0)
+    off = est.score_transforms(T)
+    est.set_option("lcp_cull", 1)
+    est.set_option("lcp_cull_after", 0)                       # from the first call on
+    assert np.array_equal(est.score_transforms(T).view(np.uint32), off.view(np.uint32))
+    est.set_option("lcp_cull_after", 1)                       # one million point queries: this batch alone crosses it
+    for shift in ([0.004, 0.0, -0.003], [0.0, 0.006, 0.002], [-0.005, 0.001, 0.0]):      # three more frames of the stream
+        est.set_scene(s.pos + np.array(shift, np.float32), s.nrm, s.prob, s.pixel)         # (the frame before was warm: filled here, on the auxiliary stream)
+        got = est.score_transforms(T)
+        est.set_option("lcp_cull", 0)
+        ref = est.score_transforms(T)
+        est.set_option("lcp_cull", 1)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), shift
+        assert ref.max() > 0.05
+    # two frames in a row without any scoring in between: the pending fill of the first is waited for before its memory is recycled
+    est.set_scene(s.pos, s.nrm, s.prob, s.pixel)
+    est.set_scene(s.pos, s.nrm, s.prob, s.pixel)
+    assert np.array_equal(est.score_transforms(T).view(np.uint32), off.view(np.uint32))
+    with pytest.raises(capi.StocsError):
+        est.set_option("lcp_cull_after", -1)
+
+
 @pytest.mark.parametrize("name,n", [("Cm", 2048), ("C5", 256)])
 def test_step_lists_longer_than_one_ballot(name, n):
     """A wavefront tests 64 steps per ballot: with one wavefront per candidate (lcp_split 0) the 79 steps of the Cm model take two
