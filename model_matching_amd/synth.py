@@ -81,6 +81,46 @@ def make_model(n: int = 5000, seed: int = SEED_MODEL, scale: float = 1.0) -> Clo
     return Cloud(np.ascontiguousarray(pos, np.float32), np.ascontiguousarray(nrm, np.float32))
 
 
+def make_model_asym(n: int = 5000, seed: int = SEED_MODEL + 101) -> Cloud:
+    """A model without any symmetry, for pose-quality reports: tri-axial ellipsoid (0.08, 0.055, 0.03) m with two spherical bumps of
+    different size off every symmetry plane -- r = 0.02 m at (0.05, 0.01, 0.02) and r = 0.012 m at (-0.035, 0.03, -0.012).  Every
+    rotation of it is observable (the metric model "Cm", SURVEY 8d, is an ellipsoid of revolution with one bump: a rotation about
+    its axis barely changes it, so the rotation error of its winners says little).  Same sampling as make_model."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    abc = np.array([0.08, 0.055, 0.03])
+    bumps = [(np.array([0.05, 0.01, 0.02]), 0.02), (np.array([-0.035, 0.03, -0.012]), 0.012)]
+    n0 = max(20 * n, 20000)
+    u = _fibonacci_sphere(n0)
+    a, b, c = abc
+    g = np.sqrt((b * c * u[:, 0]) ** 2 + (a * c * u[:, 1]) ** 2 + (a * b * u[:, 2]) ** 2)
+    keep = rng.random(n0) < g / g.max()
+    pe = u[keep] * abc
+    ne = pe / (abc ** 2)
+    ne /= np.linalg.norm(ne, axis=1, keepdims=True)
+    area_e = 4 * np.pi * ((((a * b) ** 1.6075 + (a * c) ** 1.6075 + (b * c) ** 1.6075) / 3) ** (1 / 1.6075))
+    dens = keep.sum() / area_e
+    inside_any = np.zeros(len(pe), bool)
+    for bc, br in bumps:
+        inside_any |= np.linalg.norm(pe - bc, axis=1) < br
+    parts_p, parts_n = [pe[~inside_any]], [ne[~inside_any]]
+    for k, (bc, br) in enumerate(bumps):
+        us = _fibonacci_sphere(int(dens * 4 * np.pi * br * br) + 1)
+        ps = us * br + bc
+        hidden = ((ps / abc) ** 2).sum(axis=1) < 1.0
+        for j, (oc, orr) in enumerate(bumps):
+            if j != k:
+                hidden |= np.linalg.norm(ps - oc, axis=1) < orr
+        parts_p.append(ps[~hidden]); parts_n.append(us[~hidden])
+    pos = np.concatenate(parts_p); nrm = np.concatenate(parts_n)
+    perm = rng.permutation(len(pos))[:n]
+    if len(perm) < n:
+        raise ValueError("oversampling factor too small")
+    pos, nrm = pos[perm], nrm[perm]
+    pos = pos + rng.normal(0.0, 0.0003, pos.shape)
+    pos = pos - pos.mean(axis=0)
+    return Cloud(np.ascontiguousarray(pos, np.float32), np.ascontiguousarray(nrm, np.float32))
+
+
 def random_rotation(rng: np.random.Generator) -> np.ndarray:
     q = rng.normal(size=4)
     q /= np.linalg.norm(q)
@@ -238,6 +278,9 @@ def workload(name: str = "Cm"):
     if name == "Cm":
         m = make_model(5000)
         return m, make_scene(m, 20000), 65536
+    if name == "Cm_asym":   # the metric sizes with a model without symmetry (pose-quality reports; not the metric workload)
+        m = make_model_asym(5000)
+        return m, make_scene(m, 20000, seed=SEED_SCENE + 101), 65536
     if name == "C5":
         m = make_model(50000)
         return m, make_scene(m, 200000, lattice=0.0016), 16384

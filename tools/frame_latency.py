@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import os as _os; _os.environ.setdefault("STOCS_PIN_BLAS", "1")   # harness side: one BLAS thread under the cgroup CPU quota; the library import itself has no side effects
 from model_matching_amd.estimator import StocsEstimator, ingest_scene, preprocess_model  # noqa: E402
+from pose_check import depth_agreement, pose_matrix_from_colmajor16  # noqa: E402  (tools/pose_check.py)
 
 
 def main():
@@ -40,7 +41,7 @@ def main():
         est = StocsEstimator(pos, nrm, prob, pix, mpos, mnrm, build_index=True)
         est.sync()
         t_ctx = (time.perf_counter() - t) * 1e3
-        rows = []
+        rows, agree = [], []
         for f in range(frames):
             t0 = time.perf_counter()
             pos, nrm, prob, pix = ingest_scene(depth, cprob, K, dscale)
@@ -56,11 +57,25 @@ def main():
             lcp, idx, pose = est.compute_best_transform()
             t4 = time.perf_counter()
             rows.append([(t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (t4 - t0) * 1e3, int(nq), int(nc), float(lcp)])
+            # (outside the clock) the winner against the frame's own depth image and class-probability map: tools/pose_check.py
+            agree.append(depth_agreement(pose_matrix_from_colmajor16(pose), mpos, mnrm, depth, cprob, K, dscale) if idx >= 0 else None)
+        # 64 independent trials of the same frame in one set of launches (stocs_run_trials), the best of them against the same evidence
+        est.run_trials(list(range(1000, 1064)), 100, mode=mode, dispersion=0.9)          # (sizes the arenas of the batched form)
+        tb = time.perf_counter()
+        res = est.run_trials(list(range(1000, 1064)), 100, mode=mode, dispersion=0.9)
+        t_batch = (time.perf_counter() - tb) * 1e3
+        best = max(res, key=lambda x: x["best_lcp"])
+        batch = {"trials": 64, "ms": t_batch, "trials_per_s": 64e3 / t_batch, "best_lcp_of_the_batch": best["best_lcp"],
+                 "median_best_lcp_of_its_trials": float(np.median([x["best_lcp"] for x in res])),
+                 "winner_vs_the_frames_own_depth_and_class_maps": depth_agreement(pose_matrix_from_colmajor16(best["best_pose"]), mpos, mnrm, depth, cprob, K, dscale)
+                 if best["best_index"] >= 0 else None}
         r = np.array(rows[1:])   # the first frame warms the arenas up
         out[name] = {"mode": "instance" if mode else "class", "scene_points": int(len(pos)), "model_points": int(len(mpos)),
                      "context_create_incl_index_ms": t_ctx,
                      "median_ms": {"ingest": float(np.median(r[:, 0])), "set_scene": float(np.median(r[:, 1])), "sample_100_bases": float(np.median(r[:, 2])),
                                    "congruent+transforms+verify": float(np.median(r[:, 3])), "frame_total": float(np.median(r[:, 4]))},
+                     "winner_vs_the_frames_own_depth_and_class_maps": agree[1:],
+                     "batch_of_64_trials_in_one_set_of_launches": batch,
                      "quads": [int(x) for x in r[:, 5]], "candidates": [int(x) for x in r[:, 6]], "best_lcp": [float(x) for x in r[:, 7]]}
         est.close()
     print(json.dumps(out, indent=1))
