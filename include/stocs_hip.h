@@ -340,6 +340,13 @@ void* stocs_stream(stocs_ctx* ctx);          /* hipStream_t */
  * events on the context's stream; returns the average milliseconds per launch */
 int stocs_time_score_kernel(stocs_ctx* ctx, const void* d_T16, int n, void* d_lcp, int reps,
                             float* avg_ms);
+/* Debug aid: with STOCS_DEBUG_STREAMS=1 in the environment stocs_find_congruent_all and stocs_make_transforms -- the two entry
+ * points that use the context's auxiliary stream -- check on the host, step by step, that every buffer used on both streams is
+ * ordered by an event edge (main -> aux before its first use there, aux -> main before its next use or before its arena is
+ * recycled) and return STOCS_ERR_STATE naming buffer and step otherwise.  The launches are the same with and without it.  This
+ * runs the checker itself on canned sequences (no device): scenario 0 = the library's fork / join pattern (returns 0), 1-4 = one
+ * missing edge each (return >= 1; first_msg receives the report). */
+int stocs_debug_stream_audit_selftest(int scenario, char* first_msg, int cap);
 /* number of device (hipMalloc) and pinned-host (hipHostMalloc) allocations the library has made in this process so far.
  * A warm context -- one that has run a trial of the current scene -- runs further trials without allocating: the
  * difference across them is 0. */

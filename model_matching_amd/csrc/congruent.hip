@@ -957,6 +957,8 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     S->d_err.p = plan.err;
     const int n_pseg = plan.n_pseg, n_qseg = plan.n_qseg;
     const PpfIndex& ix = c->index;
+    StreamAudit& AU = c->audit;                       // STOCS_DEBUG_STREAMS: every two-stream step below says what it reads and writes
+    const int s0 = 0, s1 = sq != st ? 1 : 0;
     const long long cell_limit = S->use_table ? S->NC : ((long long)1 << 31);
     const unsigned end_bit = (unsigned)(S->cell_bits + S->base_bits);
     const unsigned long long occ_bits = (unsigned long long)nB << S->cell_bits;   // (base, cell) values = bytes of an occupancy table
@@ -975,22 +977,37 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         uint8_t* occ_p = (uint8_t*)d_surv.p;
         uint8_t* occ_q = (uint8_t*)(d_surv.p + W);
         hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, d_surv.p, n_words, (uint32_t*)NULL);
+        const uint32_t* tiles_p = d_surv.p + o_tp; const uint32_t* tiles_q = d_surv.p + o_tq;
+        AU.use(s0, occ_p, true, "occupancy of P", "zero fill"); AU.use(s0, occ_q, true, "occupancy of Q", "zero fill");
+        AU.use(s0, tiles_p, true, "tile counts of P", "zero fill"); AU.use(s0, tiles_q, true, "tile counts of Q", "zero fill");
+        AU.use(s0, plan.jobs, true, "base jobs", "plan kernels"); AU.use(s0, plan.psegs, true, "P segments", "plan kernels"); AU.use(s0, plan.qsegs, true, "Q segments", "plan kernels");
         STOCS_HIP_CHECK(hipEventRecord(c->ev_t[6], st));
         if (sq != st) {
             STOCS_HIP_CHECK(hipEventRecord(c->ev_fork, st));          // the plan upload and the zero fill are on st
             STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_fork, 0));
+            AU.record(c->ev_fork, s0); AU.wait(s1, c->ev_fork);
         }
         hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totQ0 + 255) / 256)), dim3(256), 0, sq, ix.d_pairs, d_qsegs, n_qseg, (uint32_t)totQ0,
                            S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p, occ_q, d_po);
+        AU.use(s1, plan.qsegs, false, "Q segments", "gather Q"); AU.use(s1, plan.jobs, false, "base jobs", "gather Q");
+        AU.use(s1, d_qk_raw.p, true, "gathered Q keys", "gather Q"); AU.use(s1, d_qv_raw.p, true, "gathered Q pairs", "gather Q"); AU.use(s1, occ_q, true, "occupancy of Q", "gather Q");
         STOCS_HIP_CHECK(hipEventRecord(c->ev_t[8], sq));             // Q's cells are marked
+        AU.record(c->ev_t[8], s1);
         hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totP0 + 255) / 256)), dim3(256), 0, st, ix.d_pairs, d_psegs, n_pseg, (uint32_t)totP0,
                            S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p, occ_p, d_po);
+        AU.use(s0, plan.psegs, false, "P segments", "gather P"); AU.use(s0, plan.jobs, false, "base jobs", "gather P");
+        AU.use(s0, d_pk_raw.p, true, "gathered P keys", "gather P"); AU.use(s0, d_pv_raw.p, true, "gathered P pairs", "gather P"); AU.use(s0, occ_p, true, "occupancy of P", "gather P");
         STOCS_HIP_CHECK(hipEventRecord(c->ev_t[9], st));             // P's cells are marked
-        if (sq != st) { STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_t[9], 0)); STOCS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_t[8], 0)); }
+        AU.record(c->ev_t[9], s0);
+        if (sq != st) { STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_t[9], 0)); STOCS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_t[8], 0)); AU.wait(s1, c->ev_t[9]); AU.wait(s0, c->ev_t[8]); }
         hipLaunchKernelGGL(survivors_count_kernel<KeyT>, dim3(ntq), dim3(256), 0, sq, (const KeyT*)d_qk_raw.p, (uint32_t)totQ0, (const uint8_t*)occ_p, d_surv.p + o_tq, d_po, 1);
-        if (sq != st) STOCS_HIP_CHECK(hipEventRecord(c->ev_join, sq));
+        AU.use(s1, d_qk_raw.p, false, "gathered Q keys", "survivors count Q"); AU.use(s1, occ_p, false, "occupancy of P", "survivors count Q"); AU.use(s1, tiles_q, true, "tile counts of Q", "survivors count Q");
+        if (sq != st) { STOCS_HIP_CHECK(hipEventRecord(c->ev_join, sq)); AU.record(c->ev_join, s1); }
         hipLaunchKernelGGL(survivors_count_kernel<KeyT>, dim3(ntp), dim3(256), 0, st, (const KeyT*)d_pk_raw.p, (uint32_t)totP0, (const uint8_t*)occ_q, d_surv.p + o_tp, d_po, 0);
-        if (sq != st) STOCS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_join, 0));
+        AU.use(s0, d_pk_raw.p, false, "gathered P keys", "survivors count P"); AU.use(s0, occ_q, false, "occupancy of Q", "survivors count P"); AU.use(s0, tiles_p, true, "tile counts of P", "survivors count P");
+        if (sq != st) { STOCS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_join, 0)); AU.wait(s0, c->ev_join); }
+        AU.use(s0, tiles_p, true, "tile counts of P", "tile scan"); AU.use(s0, tiles_q, true, "tile counts of Q", "tile scan");
+        AU.use(s0, d_qk_raw.p, false, "gathered Q keys", "base offsets"); AU.use(s0, occ_p, false, "occupancy of P", "base offsets"); AU.use(s0, plan.jobs, true, "base jobs", "base offsets");
         hipLaunchKernelGGL(survivors_scan_kernel, dim3(2), dim3(1024), 0, st, d_surv.p + o_tp, ntp, d_surv.p + o_tq, ntq);
         hipLaunchKernelGGL(survivors_base_offsets_kernel<KeyT>, dim3((unsigned)nB, 2), dim3(256), 0, st, (const KeyT*)d_pk_raw.p, (uint32_t)totP0, (const uint8_t*)occ_q,
                            (const uint32_t*)(d_surv.p + o_tp), (const KeyT*)d_qk_raw.p, (uint32_t)totQ0, (const uint8_t*)occ_p, (const uint32_t*)(d_surv.p + o_tq), nB,
@@ -1000,13 +1017,19 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         uint32_t* qoff_pin = (uint32_t*)((char*)c->h_pin + PIN_VAR + 8 * ((size_t)nB + 1));
         STOCS_HIP_CHECK(hipMemcpyAsync(qoff_pin, plan.q_off, 4 * ((size_t)nB + 2), hipMemcpyDeviceToHost, st));   // Q offsets, Q total, P total
         STOCS_HIP_CHECK(hipEventRecord(c->ev_t[7], st));
+        AU.record(c->ev_t[7], s0);
         // the survivors move behind their tiles' offsets while the host waits for the totals: the compacted lists are sized by
         // the gathered ones here (the totals are what the wait is for)
         if ((rc = d_pk_c.alloc(totP0)) || (rc = d_pv_c.alloc(totP0)) || (rc = d_qk_c.alloc(totQ0)) || (rc = d_qv_c.alloc(totQ0))) return rc;
         if (sq != st) {
             STOCS_HIP_CHECK(hipEventRecord(c->ev_fork, st));          // tile offsets are scanned on st
             STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_fork, 0));
+            AU.record(c->ev_fork, s0); AU.wait(s1, c->ev_fork);
         }
+        AU.use(s1, d_qk_raw.p, false, "gathered Q keys", "compact Q"); AU.use(s1, d_qv_raw.p, false, "gathered Q pairs", "compact Q"); AU.use(s1, occ_p, false, "occupancy of P", "compact Q");
+        AU.use(s1, tiles_q, false, "tile counts of Q", "compact Q"); AU.use(s1, d_qk_c.p, true, "surviving Q keys", "compact Q"); AU.use(s1, d_qv_c.p, true, "surviving Q pairs", "compact Q");
+        AU.use(s0, d_pk_raw.p, false, "gathered P keys", "compact P"); AU.use(s0, d_pv_raw.p, false, "gathered P pairs", "compact P"); AU.use(s0, occ_q, false, "occupancy of Q", "compact P");
+        AU.use(s0, tiles_p, false, "tile counts of P", "compact P"); AU.use(s0, d_pk_c.p, true, "surviving P keys", "compact P"); AU.use(s0, d_pv_c.p, true, "surviving P pairs", "compact P");
         hipLaunchKernelGGL(survivors_compact_kernel<KeyT>, dim3(ntq), dim3(256), 0, sq, (const KeyT*)d_qk_raw.p, (const uint32_t*)d_qv_raw.p, (uint32_t)totQ0,
                            (const uint8_t*)occ_p, (const uint32_t*)(d_surv.p + o_tq), d_qk_c.p, d_qv_c.p, d_po, 1);
         hipLaunchKernelGGL(survivors_compact_kernel<KeyT>, dim3(ntp), dim3(256), 0, st, (const KeyT*)d_pk_raw.p, (const uint32_t*)d_pv_raw.p, (uint32_t)totP0,
@@ -1014,12 +1037,14 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         STOCS_HIP_CHECK(hipGetLastError());
         c->timing[0].lap("enqueue gather + occupancy + survivor counts");
         STOCS_HIP_CHECK(hipEventSynchronize(c->ev_t[7]));   // the read-back, not the compaction behind it
+        AU.host_sync_event(c->ev_t[7]);
         c->timing[0].lap("wait for the device (survivors)");
         have_surv_clock = true;
         if (po_pin) {   // the plan's own totals came with this read-back: were the capacities enough?
             if (po_pin->overflow || po_pin->totP > (unsigned long long)totP0 || po_pin->totQ > (unsigned long long)totQ0) {
                 STOCS_HIP_CHECK(hipStreamSynchronize(st));            // the compaction behind the read-back: nothing may still touch the arena
                 if (sq != st) STOCS_HIP_CHECK(hipStreamSynchronize(sq));
+                AU.host_sync(s0); AU.host_sync(s1);
                 return 1;
             }
         }
@@ -1050,13 +1075,16 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     if (sq != st) {
         STOCS_HIP_CHECK(hipEventRecord(c->ev_fork, st));          // the upload above is on st
         STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_fork, 0));
+        AU.record(c->ev_fork, s0); AU.wait(s1, c->ev_fork);
     }
     if (!reduce)
         hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totQ + 255) / 256)), dim3(256), 0, sq, ix.d_pairs, d_qsegs, n_qseg, (uint32_t)totQ,
                            S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p, (uint8_t*)NULL, (const PlanOut*)NULL);
     STOCS_HIP_CHECK(sort_pairs(d_tmp2.p, tb2, qk_in, (KeyT*)S->d_qkeys.p, qv_in, S->d_qvals.p, totQ, 0, end_bit, sq));
+    AU.use(s1, qk_in, false, "Q keys to sort", "sort Q"); AU.use(s1, qv_in, false, "Q pairs to sort", "sort Q");
+    AU.use(s1, S->d_qkeys.p, true, "sorted Q keys", "sort Q"); AU.use(s1, S->d_qvals.p, true, "sorted Q pairs", "sort Q"); AU.use(s1, d_tmp2.p, true, "sort scratch Q", "sort Q");
     STOCS_HIP_CHECK(hipEventRecord(c->ev_t[1], sq));
-    if (sq != st) STOCS_HIP_CHECK(hipEventRecord(c->ev_join, sq));
+    if (sq != st) { STOCS_HIP_CHECK(hipEventRecord(c->ev_join, sq)); AU.record(c->ev_join, s1); }
     if (!reduce)
         hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, ix.d_pairs, d_psegs, n_pseg, (uint32_t)totP,
                            S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p, (uint8_t*)NULL, (const PlanOut*)NULL);
@@ -1076,7 +1104,10 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
                        S->use_table ? S->d_cfirst.p : (uint32_t*)NULL,
                        S->use_table ? S->d_cend.p : (uint32_t*)NULL);
     STOCS_HIP_CHECK(hipGetLastError());
-    if (sq != st) STOCS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_join, 0));   // the join needs both sides
+    AU.use(s0, pk_in, false, "P keys to sort", "sort P"); AU.use(s0, pv_in, false, "P pairs to sort", "sort P");
+    AU.use(s0, S->d_pkeys.p, true, "sorted P keys", "sort P + records"); AU.use(s0, S->d_pvals.p, true, "sorted P pairs", "sort P + records"); AU.use(s0, plan.jobs, false, "base jobs", "P records");
+    if (sq != st) { STOCS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_join, 0)); AU.wait(s0, c->ev_join); }   // the join needs both sides
+    AU.use(s0, S->d_qkeys.p, false, "sorted Q keys", "join count"); AU.use(s0, S->d_qvals.p, false, "sorted Q pairs", "join count"); AU.use(s0, plan.jobs, false, "base jobs", "join count");
     STOCS_HIP_CHECK(hipEventRecord(c->ev_t[3], st));
     STOCS_TICK("gather+sort+records")
     // join: count pass + exclusive scan.  The quads themselves are produced on demand (materialise / resolve_picks_kernel)
@@ -1100,6 +1131,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     STOCS_HIP_CHECK(hipEventRecord(c->ev_t[5], st));
     c->timing[0].lap(reduce ? "enqueue compact/sort/records/join/scan" : "enqueue gather/sort/records/join/scan");
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
+    AU.host_sync(s0);
     c->timing[0].lap("wait for the device (counts)");
     {   // the device's own account of that wait (every event has completed: the stream is idle, the Q side was joined into it)
         static const char* const what_all[5] = {"device: Q gather + sort (aux stream, from the fork)", "device: P gather + sort", "device: P records + wait for Q",
@@ -1186,6 +1218,9 @@ int stocs_internal_find_congruent(stocs_ctx* c, int64_t* total_quads, size_t max
     S->valid = false;
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));   // the previous trial's buffers are about to be reused
     if (c->aux_stream) STOCS_HIP_CHECK(hipStreamSynchronize(c->aux_stream));   // (idle unless an earlier call failed half way)
+    c->audit.on = getenv("STOCS_DEBUG_STREAMS") != NULL;
+    c->audit.host_sync(0); if (c->aux_stream) c->audit.host_sync(1);
+    c->audit.retire_all("stocs_find_congruent_all: the arena is recycled");
     c->timing[0].lap("entry synchronisation");
     { int rc0 = S->arena_state.reset(); if (rc0) return rc0; }
     tl_arena = &S->arena_state;
@@ -1420,6 +1455,11 @@ int stocs_internal_find_congruent(stocs_ctx* c, int64_t* total_quads, size_t max
         }
     }
     if (rc) return rc;
+    if (!c->audit.violations.empty()) {   // STOCS_DEBUG_STREAMS: a use without an event edge between the two streams
+        set_error("stocs_find_congruent_all: %zu stream-ordering violation(s); first: %s", c->audit.violations.size(), c->audit.violations[0].c_str());
+        c->audit.violations.clear();
+        return STOCS_ERR_STATE;
+    }
     if (S->no_quads) return STOCS_OK;   // as with empty lists: nothing to materialise, every base has zero quads
     S->valid = true;
     c->quad_id_bits = id_bits;

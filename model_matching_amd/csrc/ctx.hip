@@ -666,6 +666,27 @@ int stocs_last_call_timing(const stocs_ctx* c, int which, const char** labels, d
     return t.n > cap ? STOCS_ERR_CAPACITY : STOCS_OK;
 }
 
+// CPU-only self test of the STOCS_DEBUG_STREAMS checker (stream_audit.h) on canned two-stream sequences: 0 = the fork / join
+// pattern of the library (no violation), 1 = a use on the auxiliary stream without the main -> aux edge, 2 = the main stream reads
+// what the auxiliary stream wrote without the aux -> main edge, 3 = the arena is recycled while the auxiliary stream still writes,
+// 4 = a write behind a read of the other stream without an edge.  Returns the number of violations found.
+int stocs_debug_stream_audit_selftest(int scenario, char* first_msg, int cap) {
+    StreamAudit A;
+    A.begin(true);
+    int buf_a = 0, buf_b = 0, ev_fork = 0, ev_join = 0;
+    A.use(0, &buf_a, true, "a", "produce a (main)");
+    if (scenario != 1) { A.record(&ev_fork, 0); A.wait(1, &ev_fork); }
+    A.use(1, &buf_a, false, "a", "consume a (aux)");
+    A.use(1, &buf_b, true, "b", "produce b (aux)");
+    if (scenario == 4) A.use(0, &buf_a, true, "a", "overwrite a (main)");
+    if (scenario != 2 && scenario != 3) { A.record(&ev_join, 1); A.wait(0, &ev_join); }
+    if (scenario != 3) A.use(0, &buf_b, false, "b", "consume b (main)");
+    if (scenario == 3) { A.host_sync(0); A.retire_all("arena reset"); }
+    else { A.host_sync(0); if (scenario == 0) A.retire_all("arena reset"); }
+    if (first_msg && cap > 0) { first_msg[0] = 0; if (!A.violations.empty()) snprintf(first_msg, (size_t)cap, "%s", A.violations[0].c_str()); }
+    return (int)A.violations.size();
+}
+
 int64_t stocs_device_alloc_count(void) { return (int64_t)__atomic_load_n(&g_dev_allocs, __ATOMIC_RELAXED); }
 
 uint64_t stocs_pack_best(float lcp, uint32_t id) {

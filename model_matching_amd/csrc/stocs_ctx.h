@@ -15,6 +15,7 @@
 
 #include "../../include/stocs_hip.h"
 #include "stocs_math.h"
+#include "stream_audit.h"
 
 namespace stocs {
 
@@ -291,6 +292,8 @@ struct stocs_ctx {
     void* h_pin;
     size_t pin_bytes;
     stocs::CallTiming timing[4];   // last stocs_find_congruent_all / stocs_make_transforms / stocs_verify_all / stocs_run_trials
+
+    stocs::StreamAudit audit;   // STOCS_DEBUG_STREAMS=1: happens-before check of the two-stream sections (stream_audit.h); off otherwise
 
     // scratch
     void* d_scratch;

@@ -371,12 +371,15 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
             STOCS_HIP_CHECK(hipMemcpyAsync(d_table, (char*)c->h_pin + PIN_VAR, batch ? 2 * tab_bytes : 16 * nbases, hipMemcpyHostToDevice, c->stream));
             STOCS_HIP_CHECK(hipEventRecord(c->ev_fork, c->stream));
             STOCS_HIP_CHECK(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+            c->audit.use(0, d_table, true, "pick table", "table upload"); c->audit.record(c->ev_fork, 0); c->audit.wait(1, c->ev_fork);
             if (!c->bases.empty()) { const int rc0 = stocs_internal_prepare_small(c, max_per_base); if (rc0) return rc0; }
             hipLaunchKernelGGL(draw_picks_kernel, dim3((unsigned)c->bases.size()), dim3(256), lds, c->aux_stream, (const uint4*)d_table,
                                batch ? (const uint4*)((char*)d_table + tab_bytes) : (const uint4*)NULL, seed, max_per_base, hmask, (int4*)pk, dB);
             STOCS_HIP_CHECK(hipGetLastError());
             STOCS_HIP_CHECK(hipEventRecord(c->ev_join, c->aux_stream));
             STOCS_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+            c->audit.use(1, d_table, false, "pick table", "draw picks"); c->audit.use(1, pk, true, "picks", "draw picks"); c->audit.use(1, dB, true, "job bases", "draw picks");
+            c->audit.record(c->ev_join, 1); c->audit.wait(0, c->ev_join);
         }
         c->timing[1].lap("enqueue pick table upload + small bases + draws (auxiliary stream)");
         rc = stocs_internal_make_jobs(c, device_picks ? NULL : picks.data(), d_picks, (int)n, dJ, &d_unresolved);
@@ -405,8 +408,15 @@ int stocs_make_transforms(stocs_ctx* c, int max_per_base, uint64_t seed, int* n_
         }
         STOCS_HIP_CHECK(hipMemcpyAsync(&rb[0], dPos + n, 4, hipMemcpyDeviceToHost, c->stream));
         if (d_unresolved) STOCS_HIP_CHECK(hipMemcpyAsync(&rb[1], d_unresolved, 4, hipMemcpyDeviceToHost, c->stream));
+        c->audit.use(0, d_picks, false, "picks", "resolve picks"); c->audit.use(0, dB, false, "job bases", "compact candidates");
         c->timing[1].lap("enqueue transform/scan/compact + read-backs");
         STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));   // the one synchronisation point of this call
+        c->audit.host_sync(0);
+        if (!c->audit.violations.empty()) {
+            set_error("stocs_make_transforms: %zu stream-ordering violation(s); first: %s", c->audit.violations.size(), c->audit.violations[0].c_str());
+            c->audit.violations.clear();
+            return STOCS_ERR_STATE;
+        }
         c->timing[1].lap("wait for the device");
         const int32_t n_ok = rb[0];
         const unsigned int n_unresolved = (unsigned int)rb[1];

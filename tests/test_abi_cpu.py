@@ -375,3 +375,17 @@ def test_model_patch_order_on_the_host(capi):
                 del os.environ["STOCS_MODEL_ORDER"]
             assert np.median(pat[:, 3]) < 0.85 * np.median(pat_m[:, 3])
             assert pat[:, 3].max() < 0.6 * pat_m[:, 3].max()
+
+
+def test_stream_audit_selftest():
+    """STOCS_DEBUG_STREAMS (model_matching_amd/csrc/stream_audit.h): the host-side happens-before checker of the library's two-stream
+    sections, on canned sequences -- the fork / join pattern the library uses passes, every missing event edge is reported."""
+    import ctypes as C
+    from model_matching_amd import capi
+    L = capi.load()
+    msg = C.create_string_buffer(512)
+    assert L.stocs_debug_stream_audit_selftest(0, msg, 512) == 0 and msg.value == b""
+    expect = {1: b"read after write", 2: b"read after write", 3: b"recycled while", 4: b"write after read"}
+    for scenario, text in expect.items():
+        assert L.stocs_debug_stream_audit_selftest(scenario, msg, 512) >= 1, scenario
+        assert text in msg.value, (scenario, msg.value)

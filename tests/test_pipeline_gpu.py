@@ -325,6 +325,26 @@ def test_one_sizing_synchronisation_point_and_its_fallback(setup, monkeypatch):
     assert est.find_congruent_all() == 0
 
 
+def test_two_stream_sections_pass_the_happens_before_audit(setup, monkeypatch):
+    """STOCS_DEBUG_STREAMS=1: stocs_find_congruent_all and stocs_make_transforms describe every buffer their two streams share and
+    the event edges between them to a host-side checker (stream_audit.h) and fail on a use without an edge.  The reduced and the
+    unreduced form, the optimistic and the exact sizing, single trials and a trial batch: no violation, same results."""
+    m, s, est, orc = setup
+    est.L.stocs_clear_bases(est.h)
+    valid, ids, inv = est.sample_bases(515, 24)
+    n0 = est.find_congruent_all(); c0 = est.make_transforms(40, 9)
+    monkeypatch.setenv("STOCS_DEBUG_STREAMS", "1")
+    for extra in ({}, {"STOCS_CONGRUENT_EXACT_SIZES": "1"}, {"STOCS_CONGRUENT_KEEP_ALL": "1"}, {"STOCS_CONGRUENT_CAPACITY": "0.05"}):
+        for k, v in extra.items():
+            monkeypatch.setenv(k, v)
+        assert est.find_congruent_all() == n0 and est.make_transforms(40, 9) == c0, extra
+        assert est.find_congruent_all() == n0 and est.make_transforms(40, 9) == c0, extra      # (and again: the arenas are recycled under the audit)
+        for k in extra:
+            monkeypatch.delenv(k)
+    res = est.run_trials([1, 2, 3], 24, max_per_base=40)
+    assert all(r["n_candidates"] > 0 for r in res)
+
+
 def test_distance_gate_path_of_the_count(setup, monkeypatch):
     """The count pass normally tests direction cells alone: inside one position cell the gate of stocs.cpp:854 (squared
     metres against epsilon, Q1) cannot fail while 12 epsilon^2 < epsilon.  The general path -- the gate evaluated per
