@@ -445,7 +445,14 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
     constexpr int EPL = 8 / GL, NG = 64 / GL, E0 = EPL * FIRST;
     static_assert(!EARLY || FIRST == 1, "early exit decides line by line");
     const int sub = lane & (GL - 1), grp = lane / GL;
+#if defined(STOCS_TOOLS_BUILD) && defined(STOCS_LCP_W_UNIFORM)
+    // measurement build only (profiles/r04_lcp_w_uniform_isa.md): the wavefront index forced into an SGPR.  63 VGPRs, 8 waves -- and
+    // 12 % SLOWER: every LDS address of the per-wavefront queue (qt[w][..], qn[w][..], ri[w][..]) is then formed as "scalar base +
+    // vector index" with the scalar part re-materialised into a VGPR at each use instead of living in one address VGPR
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#else
     const int w = threadIdx.x >> 6;
+#endif
     const int cand = SPLIT ? lcp_candidate(a, n, 0, 1) : lcp_candidate(a, n, w, WPB);
     if (cand < 0 && !TILE) return;   // SPLIT: the whole workgroup leaves together; TILE: the wavefront stays for the barriers
     const float* T = T16 + (size_t)(cand < 0 ? 0 : cand) * 16;
