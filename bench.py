@@ -301,17 +301,35 @@ def main():
     est.dev_upload(dT, T)
     lcp = np.zeros(kcand, np.float32)
 
-    # All work of a step is enqueued on PyTorch's current HIP stream: LCP kernel, device arg-max into an
-    # 8-byte torch tensor and (N > 1) the RCCL max all-reduce of that key -- no host round trip per step.
+    # All work of a step is enqueued on PyTorch's current HIP stream: LCP kernel with the device arg-max in its epilogue into an
+    # 8-byte torch tensor -- no host round trip per step.  With N > 1 the RCCL max all-reduce of that key (8 bytes over xGMI,
+    # latency-bound) runs on a SIDE stream behind an event, on the buffer of step k, while the compute stream already scores step
+    # k + 1 into the other buffer: the collective is off the critical path (round 3 enqueued it on the compute stream: ~30 us per
+    # 1.1 ms step).  A buffer is rewritten at step k + 2 only behind the event that closes its all-reduce.
     est.set_stream(torch.cuda.current_stream().cuda_stream)
-    key = torch.zeros(1, dtype=torch.int64, device="cuda")
+    keys = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(2)]
+    overlap = world > 1 and not rehearsal
+    comm_stream = torch.cuda.Stream() if overlap else None
+    scored = [torch.cuda.Event() for _ in range(2)] if overlap else None
+    reduced = [torch.cuda.Event() for _ in range(2)] if overlap else None
+    state = {"k": 0}
 
     def step():
+        i = state["k"] & 1
+        state["k"] += 1
+        key = keys[i]
+        compute = torch.cuda.current_stream()
+        if overlap and state["k"] > 2:
+            compute.wait_event(reduced[i])                                    # the all-reduce of step k - 2 has read and written this buffer
         # the metric kernel; its epilogue takes compute_best_transform's arg-max (first maximum wins, stocs.cpp:994) into `key`
         est.score_best_device_async(dT, kcand, dL, rank * kcand, key.data_ptr())
-        if world > 1 and not rehearsal:
-            dist.all_reduce(key, op=dist.ReduceOp.MAX)                    # 8 bytes over xGMI
-        elif world > 1:
+        if overlap:
+            scored[i].record(compute)
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(scored[i])
+                dist.all_reduce(key, op=dist.ReduceOp.MAX)                    # 8 bytes over xGMI, next to the next step's kernel
+                reduced[i].record(comm_stream)
+        elif world > 1:                                                       # rehearsal: gloo on the host, synchronous
             k = key.cpu()
             dist.all_reduce(k, op=dist.ReduceOp.MAX)
             key.copy_(k)
@@ -338,6 +356,7 @@ def main():
 
     # roofline of the dominant kernel: HIP events on the context's stream, resident inputs
     est.dev_download(dL, lcp)
+    key = keys[(state["k"] - 1) & 1]                      # the last step's buffer (torch.cuda.synchronize above covers the side stream)
     final_key = int(key.item())
     final_lcp, final_gid = sdist.unpack_best(final_key) if final_key else (0.0, -1)
     if world == 1:
@@ -369,7 +388,7 @@ def main():
         "config": {"workload": "%s: synthetic %d-pt scene vs %d-pt model, %d candidate transforms per step per GPU, "
                                "eps=5mm" % (args.workload, est.nS, est.nM, kcand),
                    "candidates_per_step_per_gpu": kcand, "scene_points": est.nS, "model_points": est.nM,
-                   "parallelism": "independent trial batches, one per GPU; 8-byte RCCL max all-reduce per step"},
+                   "parallelism": "independent trial batches, one per GPU; 8-byte RCCL max all-reduce per step, on a side stream next to the following step"},
         "rehearsal": rehearsal,
         "final_lcp_percent": float(final_lcp) * 100.0,
         "best_global_candidate_id": int(final_gid),

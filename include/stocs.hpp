@@ -467,7 +467,45 @@ public:
         return n;
     }
 
+    // N independent runs of that whole loop (base attempts -> congruent sets -> <= maximum_congruent_sets transforms per base ->
+    // compute_best_transform) with seeds first_seed, first_seed + 1, ... in ONE set of GPU launches (stocs_run_trials): what
+    // BASELINE config 4 ("64 parallel StoCS trials") runs.  Trial t equals, bit for bit, the run a fresh estimator with
+    // set_seed(first_seed + t) gives through the three calls above + compute_best_transform.  The best trial's pose becomes the
+    // estimator's best pose (get_best_score / get_best_pose); returns the index of that trial, -1 when no trial found a pose.
+    struct TrialResult { int n_bases, n_candidates; long long n_congruent_sets; float best_lcp; int best_index; MatrixType best_pose; };
+    int run_trials(int n_trials, uint64_t first_seed, int number_of_bases, int maximum_congruent_sets, float dispersion, std::vector<TrialResult>* results = NULL) {
+        std::vector<uint64_t> seeds((size_t)std::max(n_trials, 0));
+        for (int t = 0; t < n_trials; ++t) seeds[(size_t)t] = first_seed + (uint64_t)t;
+        std::vector<stocs_trial_result> r((size_t)std::max(n_trials, 1));
+        la_n_ = 0; la_in_ctx_ = false; batched_ = false; fetched_ = false; n_batched_ = 0;
+        if (stocs_run_trials(ctx_, has_edge_map() ? 1 : 0, n_trials, seeds.data(), number_of_bases, dispersion, maximum_congruent_sets, 0, r.data()) != STOCS_OK) return -1;
+        int best = -1;
+        if (results) results->clear();
+        for (int t = 0; t < n_trials; ++t) {
+            if (r[(size_t)t].best_index >= 0 && (best < 0 || r[(size_t)t].best_lcp > r[(size_t)best].best_lcp)) best = t;   // strict >: the first best trial wins
+            if (results) {
+                TrialResult x;
+                x.n_bases = r[(size_t)t].n_bases; x.n_candidates = r[(size_t)t].n_candidates; x.n_congruent_sets = (long long)r[(size_t)t].n_quads;
+                x.best_lcp = r[(size_t)t].best_lcp; x.best_index = r[(size_t)t].best_index;
+                memcpy(x.best_pose.data(), r[(size_t)t].best_pose16, 64);
+                results->push_back(x);
+            }
+        }
+        trial_best_.reset();
+        best_lcp = 0; best_index = -1;
+        if (best >= 0) {
+            MatrixType m;
+            memcpy(m.data(), r[(size_t)best].best_pose16, 64);
+            trial_best_.reset(new PoseCandidate(m, r[(size_t)best].best_lcp, -1.0f));
+            best_lcp = r[(size_t)best].best_lcp;
+        }
+        return best;
+    }
+    // the winner of the last run_trials (camera frame), NULL when no trial found a pose; owned by the estimator
+    PoseCandidate* get_best_trial_pose() const { return trial_best_.get(); }
+
 protected:
+    std::unique_ptr<PoseCandidate> trial_best_;
     void reset_members(const std::string& dbg, int w, int h, float dist, int tr, int rot, float edge_thr, float class_thr) {
         ctx_ = NULL; best_lcp = 0; best_index = -1; seed_ = 0; attempt_ = 0; batched_ = false; fetched_ = false; n_batched_ = 0;
         la_n_ = 0; la_first_ = 0; la_seed_ = 0; la_cursor_ = 0; la_in_ctx_ = false; la_congruent_done_ = false; la_mode_ = 0; la_nvalid_ = 0;

@@ -67,7 +67,7 @@ int main(int argc, char** argv) {
     const std::string a1 = argv[clouds ? 2 : 1], a2 = argv[clouds ? 3 : 2];
     if (const char* e = getenv("STOCS_REPO_PATH")) repo_path = e;
     std::string edge_path, out_path, dbg_dir;
-    int do_cluster = 0;
+    int do_cluster = 0, n_trials = 0;
     uint64_t seed = 1;
     for (int i = clouds ? 4 : 3; i + 1 < argc; i += 2) {
         const std::string k = argv[i], v = argv[i + 1];
@@ -78,6 +78,7 @@ int main(int argc, char** argv) {
         else if (k == "--max-sets") maximum_congruent_sets = atoi(v.c_str());
         else if (k == "--dbg") dbg_dir = v;
         else if (k == "--cluster") do_cluster = atoi(v.c_str());
+        else if (k == "--trials") n_trials = atoi(v.c_str());   // N independent runs (seeds seed, seed + 1, ...) in one set of GPU launches; the best one is written
         else if (k == "--repo") repo_path = v;
         else if (k == "--voxel") voxel_size = (float)atof(v.c_str());
         else if (k == "--depth-scale") depth_scale = (float)atof(v.c_str());
@@ -130,6 +131,37 @@ int main(int argc, char** argv) {
     }
     stocs::stocs_estimator& stocs_ptr = *est;
     stocs_ptr.set_seed(seed);
+
+    if (n_trials > 0) {
+        // BASELINE config 4: N independent StoCS trials -- each the whole loop of run_stocs_estimation (:79-165) with its own seed --
+        // in ONE set of launches (stocs_run_trials); the best pose over the trials is the result
+        std::vector<stocs::stocs_estimator::TrialResult> res;
+        auto t0 = std::chrono::high_resolution_clock::now();
+        const int best = stocs_ptr.run_trials(n_trials, seed, number_of_bases, maximum_congruent_sets, sample_dispersion, &res);
+        auto t1 = std::chrono::high_resolution_clock::now();
+        long long cand = 0;
+        for (size_t t = 0; t < res.size(); ++t) {
+            cand += res[t].n_candidates;
+            std::cout << "trial " << t << ": bases " << res[t].n_bases << " congruent sets " << res[t].n_congruent_sets << " candidates " << res[t].n_candidates
+                      << " best lcp " << res[t].best_lcp << std::endl;
+        }
+        const long long us = (long long)std::chrono::duration_cast<micro>(t1 - t0).count();
+        char tl[256];
+        snprintf(tl, sizeof(tl), "trials: n=%d best_trial=%d best_lcp=%.9g candidates=%lld total_microseconds=%lld", n_trials, best,
+                 best >= 0 ? (double)res[(size_t)best].best_lcp : 0.0, cand, us);
+        if (PoseCandidate* bp = stocs_ptr.get_best_trial_pose()) {
+            std::ofstream o(out_path, std::ofstream::out);
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) o << bp->transform(r, c) << (r == 2 && c == 3 ? "" : " ");
+            o << std::endl;
+            std::cout << "pose:";
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) { char b[32]; snprintf(b, sizeof(b), " %.9g", (double)bp->transform(r, c)); std::cout << b; }
+            std::cout << std::endl;
+        } else {
+            std::cout << "no pose found" << std::endl;
+        }
+        std::cout << tl << std::endl;
+        return 0;
+    }
 
     // Step 1: sample n bases on the scene (:79-105)
     auto start = std::chrono::high_resolution_clock::now();

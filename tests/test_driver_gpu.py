@@ -271,3 +271,32 @@ def test_stocs_single_instance_mode_on_packed_dove(tmp_path):
     da = depth_agreement(P, d["model_pos"], d["model_nrm"], raw["depth"], raw["prob"], [float(x) for x in raw["K"]], float(raw["depth_scale"]))
     assert da["visible_points"] >= 100 and da["in_image"] >= 0.95 and da["with_depth"] >= 0.8, da
     assert da["within_10mm"] >= 0.45 and da["on_mask"] >= 0.70, da
+
+
+@pytest.mark.gpu
+def test_stocs_single_trials_option_equals_the_library_batch(tmp_path):
+    """stocs_single --trials N: N independent runs of the reference's loop (seeds seed, seed + 1, ...) through the facade's
+    run_trials = one stocs_run_trials call; per-trial counts and best scores equal the ctypes mirror's, the best trial's pose is
+    what gets written."""
+    from model_matching_amd import cloudio
+    from model_matching_amd.estimator import StocsEstimator
+    d = np.load(os.path.join(ROOT, "tests", "golden", "example_ycb_024_bowl.npz"))
+    cloudio.write_stcl(tmp_path / "scene.stcl", d["scene_pos"], d["scene_nrm"], d["scene_prob"], d["scene_pixel"])
+    cloudio.write_stcl(tmp_path / "model.stcl", d["model_pos"], d["model_nrm"])
+    out = tmp_path / "pose.txt"
+    r = subprocess.run([APP, "--clouds", str(tmp_path / "scene.stcl"), str(tmp_path / "model.stcl"), "--seed", "40", "--trials", "6", "--out", str(out)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    est = StocsEstimator(d["scene_pos"], d["scene_nrm"], d["scene_prob"], d["scene_pixel"], d["model_pos"], d["model_nrm"], build_index=True)
+    res = est.run_trials([40 + t for t in range(6)], 100, max_per_base=200)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("trial ")]
+    assert len(lines) == 6
+    for t, l in enumerate(lines):
+        w = l.split()
+        assert (int(w[3]), int(w[6]), int(w[8])) == (res[t]["n_bases"], res[t]["n_quads"], res[t]["n_candidates"]), l
+        assert abs(float(w[11]) - res[t]["best_lcp"]) <= 1e-5 * max(1.0, res[t]["best_lcp"]), l
+    best = max(range(6), key=lambda t: (res[t]["best_lcp"], -t))
+    summ = [l for l in r.stdout.splitlines() if l.startswith("trials: ")][0]
+    assert ("best_trial=%d " % best) in summ
+    P = np.array(out.read_text().split(), float).reshape(3, 4)
+    assert np.allclose(P, res[best]["best_pose"].reshape(4, 4).T[:3], rtol=2e-5, atol=2e-6)
