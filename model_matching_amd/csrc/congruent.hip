@@ -33,6 +33,7 @@
 // then ascending (id1, id2)).  The oracle enumerates the same way.
 // The join is irregular integer/gather work: HBM/L2-bound, no MFMA.
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -53,7 +54,11 @@ struct BaseJob {
     int egSize;
     int nb;           // cone samples
     uint32_t p_off, p_len, q_off, q_len;   // runs in the gathered P / Q arrays
-    float dirs[STOCS_MAX_CONE][3];
+    float sin_alpha;  // the cone samples of the base are (sin_alpha * cos theta_a, sin_alpha * sin theta_a, cos_alpha), a < nb, with cos / sin of
+                      // theta_a = a * angleStep(nb) from ONE table shared by all bases (cone_trig: they depend on nb alone).  Round 3 carried the
+                      // 56 products per base in the job record: 808 bytes per base to fill and upload -- 0.7 ms of host time for the 6 000
+                      // bases of a 64-trial batch; the one float product per sample is the same IEEE operation on the device.
+    float pad;
 };
 
 struct Segment { uint32_t src, len, dst, base; };
@@ -388,6 +393,7 @@ struct JoinArgs {
     const uint16_t* pdc;   // direction cells alone when the distance gate of stocs.cpp:854 cannot fail inside a position cell (else NULL)
     const uint32_t* cfirst; const uint32_t* cend; long long NC;
     float nepsilon, half_inv_neps, dist_thr;
+    const float2* trig;    // [STOCS_MAX_CONE + 1][STOCS_MAX_CONE]: (cos, sin) of theta_a for every sample count
     int id_bits, cell_bits;
     int base_in_key;   // the packed quad key carries the base above the four ids (it does whenever 4 id_bits + base_bits <= 64)
 #ifdef STOCS_TOOLS_BUILD
@@ -486,7 +492,9 @@ __device__ __forceinline__ uint32_t join_one(const JoinArgs<KeyT>& A, uint32_t i
             d = dn;
         }
     } else {
-        for (int a = 0; a < nb; ++a) colour(J.dirs[a][0], J.dirs[a][1]);
+        const float2* tr = A.trig + (size_t)nb * STOCS_MAX_CONE;
+        const float sa = J.sin_alpha;
+        for (int a = 0; a < nb; ++a) { const float2 t = tr[a]; colour(sa * t.x, sa * t.y); }
     }
     // one linear pass over the position cell's P entries against the direction bitset, four records in flight
     uint32_t local = 0;
@@ -539,7 +547,9 @@ __device__ __forceinline__ uint32_t join_stage_tables(const JoinArgs<KeyT>& A, J
     for (int t = threadIdx.x; t < JOIN_LDS_BASES * STOCS_MAX_CONE; t += blockDim.x) {
         const uint32_t b = b0 + (uint32_t)(t / STOCS_MAX_CONE);
         const int a = t % STOCS_MAX_CONE;
-        lds.dirs[t / STOCS_MAX_CONE][a] = b < (uint32_t)A.nB ? make_float2(A.jobs[b].dirs[a][0], A.jobs[b].dirs[a][1]) : make_float2(0.f, 0.f);
+        float2 d = make_float2(0.f, 0.f);
+        if (b < (uint32_t)A.nB && a < A.jobs[b].nb) { const float2 tr = A.trig[(size_t)A.jobs[b].nb * STOCS_MAX_CONE + a]; const float sa = A.jobs[b].sin_alpha; d = make_float2(sa * tr.x, sa * tr.y); }
+        lds.dirs[t / STOCS_MAX_CONE][a] = d;
     }
     __syncthreads();
     return b0;
@@ -719,7 +729,8 @@ __global__ __launch_bounds__(256) void resolve_picks_kernel(JoinArgs<KeyT> A, co
         float q[4];
         quat_from_z(queryn, q);
         if (lane < J.nb) {
-            const int id = cone_cell_exact(q, mk3(J.dirs[lane][0], J.dirs[lane][1], J.dirs[lane][2]), A.nepsilon);
+            const float2 tr = A.trig[(size_t)J.nb * STOCS_MAX_CONE + lane];
+            const int id = cone_cell_exact(q, mk3(J.sin_alpha * tr.x, J.sin_alpha * tr.y, J.cos_alpha), A.nepsilon);
             if (id >= 0) atomicOr(&seen[id >> 5], 1u << (id & 31));
         }
         __threadfence_block(); __builtin_amdgcn_wave_barrier();
@@ -813,6 +824,7 @@ struct CongruentState {
     std::vector<uint2> h_blocks;           // workgroup -> Q range of the last materialise
     void* h_stage = NULL;         // pinned staging of the per-trial tables (one upload per trial)
     size_t stage_bytes = 0;
+    float2* d_trig = NULL;        // the shared (cos, sin) table of the cone samples, uploaded once per context
     char* d_plan = NULL;          // persistent planning buffer: jobs, base ids, ranges, segments, offsets (outside the arenas:
     size_t plan_bytes = 0;        // it is written before the trial's sizes -- and with them the arena's -- are known)
     template <class KeyT>
@@ -823,6 +835,7 @@ struct CongruentState {
         A.pkeys = (const KeyT*)d_pkeys.p; A.pvals = d_pvals.p; A.prec = d_prec.p; A.pdc = close_cells ? d_pdc.p : NULL;
         A.cfirst = use_table ? d_cfirst.p : NULL; A.cend = use_table ? d_cend.p : NULL; A.NC = NC;
         A.nepsilon = nepsilon; A.half_inv_neps = half_inv_neps; A.dist_thr = c->prm.distance_threshold; A.id_bits = id_bits; A.cell_bits = cell_bits;
+        A.trig = d_trig;
         A.base_in_key = base_in_key ? 1 : 0;
 #ifdef STOCS_TOOLS_BUILD
         A.gmin = JOIN_GROUP_MIN; A.rmin = JOIN_RUN_MIN;
@@ -892,30 +905,37 @@ static int materialise(stocs_ctx* c, CongruentState* S, const std::vector<char>&
     return S->wide ? materialise_t<uint64_t>(c, S, sel, out, off) : materialise_t<uint32_t>(c, S, sel, out, off);
 }
 
-// cone sample table of a base: normalset.hpp:178-190 (float libm calls on per-base scalars: exactly the reference's values).
-// theta_a = a * angleStep depends on the sample count alone, so cosf / sinf of it are computed once per count.
+// (cos, sin) of the sample angles theta_a = a * angleStep for every sample count nb (normalset.hpp:183-188: float libm on per-count
+// scalars, exactly the reference's values); row nb of [STOCS_MAX_CONE + 1][STOCS_MAX_CONE]
+static const float* cone_trig() {
+    static float trig[STOCS_MAX_CONE + 1][STOCS_MAX_CONE][2];
+    static bool ready = false;
+    static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    pthread_mutex_lock(&mu);
+    if (!ready) {
+        memset(trig, 0, sizeof(trig));
+        for (unsigned nb = 1; nb <= STOCS_MAX_CONE; ++nb) {
+            const float angleStep = (float)((double)2.0f * M_PI / (double)(float)nb);
+            for (unsigned a = 0; a < nb; ++a) {
+                const float theta = (float)a * angleStep;
+                trig[nb][a][0] = cosf(theta);
+                trig[nb][a][1] = sinf(theta);
+            }
+        }
+        ready = true;
+    }
+    pthread_mutex_unlock(&mu);
+    return &trig[0][0][0];
+}
+
+// cone samples of a base: normalset.hpp:178-190 (float libm calls on per-base scalars: exactly the reference's values): their
+// number and sin(alpha); sample a is (sin_alpha * cos theta_a, sin_alpha * sin theta_a, cos_alpha) with the shared table above
 static void fill_cone_table(BaseJob* J) {
-    static thread_local float trig[STOCS_MAX_CONE + 1][STOCS_MAX_CONE][2];
-    static thread_local bool have[STOCS_MAX_CONE + 1] = {false};
     const float alpha = acosf(J->cos_alpha);
     const float perimeter = (float)((double)2.0f * M_PI * (double)atanf(alpha));  // sic (Q10)
     const unsigned nb = (unsigned)(2 * ceilf(perimeter * 7.0f / 2.0f));
-    const float sinAlpha = sinf(alpha);
+    J->sin_alpha = sinf(alpha);
     J->nb = (nb > STOCS_MAX_CONE || !(alpha == alpha)) ? 0 : (int)nb;  // nb <= 56 for any alpha in [0, pi]; NaN alpha -> no samples
-    if (J->nb && !have[J->nb]) {
-        const float angleStep = (float)((double)2.0f * M_PI / (double)(float)nb);
-        for (int a = 0; a < J->nb; ++a) {
-            const float theta = (float)a * angleStep;
-            trig[J->nb][a][0] = cosf(theta);
-            trig[J->nb][a][1] = sinf(theta);
-        }
-        have[J->nb] = true;
-    }
-    for (int a = 0; a < J->nb; ++a) {
-        J->dirs[a][0] = sinAlpha * trig[J->nb][a][0];
-        J->dirs[a][1] = sinAlpha * trig[J->nb][a][1];
-        J->dirs[a][2] = J->cos_alpha;
-    }
 }
 
 static double now_s() {
@@ -1164,6 +1184,7 @@ void stocs_internal_free_congruent(stocs_ctx* c) {   // stocs_ctx_destroy: nothi
         S->arena_state.destroy(); S->arena_tmp.destroy();
         if (S->h_stage) (void)hipHostFree(S->h_stage);
         if (S->d_plan) (void)hipFree(S->d_plan);
+        if (S->d_trig) (void)hipFree(S->d_trig);
         delete S;
         c->cong = NULL;
     }
@@ -1189,8 +1210,9 @@ int stocs_cone_cells_host(const float* n3, float cos_alpha, uint32_t* exact_bits
     quat_from_z(mk3(n3[0], n3[1], n3[2]), q);
     const ConeFilter cf = cone_filter_setup(q, J.cos_alpha, half_inv_neps);
     int undecided = 0;
+    const float* trig = cone_trig() + (size_t)J.nb * STOCS_MAX_CONE * 2;
     for (int a = 0; a < J.nb; ++a) {
-        const V3 d = mk3(J.dirs[a][0], J.dirs[a][1], J.dirs[a][2]);
+        const V3 d = mk3(J.sin_alpha * trig[2 * a], J.sin_alpha * trig[2 * a + 1], J.cos_alpha);
         const int ie = cone_cell_exact(q, d, nepsilon);
         if (ie >= 0) exact_bits11[ie >> 5] |= 1u << (ie & 31);
         int ik = cone_cell_filtered(cf, d.x, d.y);
@@ -1224,6 +1246,10 @@ int stocs_internal_find_congruent(stocs_ctx* c, int64_t* total_quads, size_t max
     c->timing[0].lap("entry synchronisation");
     { int rc0 = S->arena_state.reset(); if (rc0) return rc0; }
     tl_arena = &S->arena_state;
+    if (!S->d_trig) {   // once per context (synchronous copy from static host memory)
+        STOCS_HIP_CHECK(dev_malloc((void**)&S->d_trig, sizeof(float2) * (STOCS_MAX_CONE + 1) * STOCS_MAX_CONE));
+        STOCS_HIP_CHECK(hipMemcpy(S->d_trig, cone_trig(), sizeof(float2) * (STOCS_MAX_CONE + 1) * STOCS_MAX_CONE, hipMemcpyHostToDevice));
+    }
     // pinned block for everything this call reads back: plan totals, Q offsets (4 B per base), per-base quad offsets (8 B)
     { int rc0 = ensure_pinned(c, (size_t)PIN_VAR + 12 * ((size_t)nB + 1) + 256); if (rc0) return rc0; }
     c->timing[0].lap("arena reset + pinned block");

@@ -6,7 +6,9 @@ With --instance the workloads also get a random edge map (passable background, r
 some in-between values, an isolated pocket around some points) and the sampling runs in instance mode (persistent
 device kernel with the union-find flood fill) against the oracle's literal BFS, attempt by attempt, plus the segment of
 the last attempt and the decayed class prior.
-usage: python tools/fuzz_parity.py [N] [first_seed] [--instance]"""
+With --batch every workload also runs four trials as ONE batch (stocs_run_trials): trial 0 against the oracle's run, trials 1-3
+against the same seeds run alone through the single-trial calls (bitwise: counts, candidates, scores, winner).
+usage: python tools/fuzz_parity.py [N] [first_seed] [--instance] [--batch]"""
 import json
 import os
 import sys
@@ -64,12 +66,14 @@ def instance_leg(est, orc, rng, s, seed, nb):
 
 def main():
     instance = "--instance" in sys.argv
-    argv = [a for a in sys.argv if a != "--instance"]
+    batch = "--batch" in sys.argv
+    argv = [a for a in sys.argv if a not in ("--instance", "--batch")]
     n = int(argv[1]) if len(argv) > 1 else 20
     first = int(argv[2]) if len(argv) > 2 else 1000
     pyoracle.build()
     bad = 0
     n_inst_bases = 0
+    n_batch_trials = 0
     stats = []
     for k in range(n):
         rng = np.random.default_rng(first + k)
@@ -101,6 +105,24 @@ def main():
             ok &= dmax <= 1e-5
         else:
             dmax = 0.0
+        if batch:
+            seeds = [seed + j for j in range(4)]
+            res = est.run_trials(seeds, nb, mode=0, max_per_base=200, keep_details=True)
+            bok = (res[0]["n_bases"], res[0]["n_quads"], res[0]["n_candidates"]) == (r.n_bases, r.n_quads_total, r.n_candidates) and abs(res[0]["best_lcp"] - r.best_lcp) <= 1e-5
+            bok &= bool(np.array_equal(est.trial_candidates(0)[0], To))
+            kept = [est.trial_candidates(j) for j in range(4)]
+            for j in range(1, 4):
+                est.reset_trial()
+                v1, _, _ = est.sample_bases(seeds[j], nb)
+                q1 = est.find_congruent_all(); c1 = est.make_transforms(200, seeds[j]); l1, i1, p1 = est.compute_best_transform()
+                T1, P1, s1, b1 = est.get_pose_candidates()
+                bok &= (res[j]["n_bases"], res[j]["n_quads"], res[j]["n_candidates"], res[j]["best_index"]) == (int(v1.sum()), q1, c1, i1) and res[j]["best_lcp"] == l1
+                bok &= bool(np.array_equal(kept[j][0], T1) and np.array_equal(kept[j][2].view(np.uint32), s1.view(np.uint32)) and np.array_equal(kept[j][3], b1)
+                            and np.array_equal(res[j]["best_pose"], p1))
+            if not bok:
+                print("BATCH MISMATCH", dict(k=k, nm=nm, ns=ns, seed=seed, nb=nb), flush=True)
+            ok &= bok
+            n_batch_trials += 4
         if instance:
             iok, nv = instance_leg(est, orc, rng, s, seed + 1, nb)
             if not iok:
@@ -113,7 +135,9 @@ def main():
             print("MISMATCH", dict(k=k, nm=nm, ns=ns, seed=seed, nb=nb, bases=(int(valid.sum()), r.n_bases), quads=(int(tot), r.n_quads_total),
                                    cands=(int(nc), r.n_candidates), dl=dl, dmax=dmax), flush=True)
         est.close()
-    print(json.dumps({"workloads": n, "instance_mode": instance, "instance_bases": n_inst_bases, "mismatches": bad, "total_quads": int(sum(x[4] for x in stats)), "total_candidates": int(sum(x[5] for x in stats)),
+        if (k + 1) % 25 == 0:
+            print("... %d workloads, %d mismatches" % (k + 1, bad), file=sys.stderr, flush=True)
+    print(json.dumps({"workloads": n, "batched_trials_checked": n_batch_trials, "instance_mode": instance, "instance_bases": n_inst_bases, "mismatches": bad, "total_quads": int(sum(x[4] for x in stats)), "total_candidates": int(sum(x[5] for x in stats)),
                       "max_abs_lcp_diff": max(x[6] for x in stats)}))
 
 
