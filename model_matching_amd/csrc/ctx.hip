@@ -429,7 +429,7 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     c->index.d_bucket_start = NULL; c->index.d_pairs = NULL; c->index.d_exists = NULL;
     c->cong = NULL; c->quad_id_bits = 16;
     c->inst = NULL;
-    c->trials = NULL; c->snrmw_trial0 = NULL; c->snrmw_stride = 0; c->snrmw_override = NULL;
+    c->trials = NULL; c->snrmw_trial0 = NULL; c->snrmw_stride = 0; c->snrmw_override = NULL; c->lcp_cand_trial = NULL;
     c->d_cand = NULL; c->cand_bytes = 0; c->n_cands = 0; c->cand_cap = 0; c->cands_stale = false;
     c->d_best = NULL; c->best_is_zero = false;
     c->best_lcp = 0; c->best_index = -1;

@@ -43,6 +43,10 @@ struct LcpArgs {
     const uint4* flat;    // cell words addressed by (cz*ny + cy)*nx + cx, or NULL (brick look-up through top / cells)
     const float4* list;
     const float4* snrmw;  // scene unit normal + class-probability weight
+    // instance-mode trial batches (stocs_run_trials): candidate i belongs to trial cand_trial[i] of the batch and adds the class
+    // probabilities as ITS trial's sampling decayed them (Q8): that trial's copy lies cand_trial[i] * snrmw_stride bytes behind snrmw
+    const int32_t* cand_trial;   // NULL: every candidate scores against snrmw itself
+    size_t snrmw_stride;
     const float* chunk_r; // per 8-entry chunk: lower bound of |entry - cell centre| (dense scenes), else NULL
     float ox, oy, oz, inv_h, inv_h4, h;
     int nx, ny, nz, nbx, nby;
@@ -89,6 +93,14 @@ __device__ __forceinline__ int lcp_candidate(const LcpArgs& a, int n, int w, int
     return a.order ? __builtin_amdgcn_readfirstlane(a.order[slot]) : slot;
 }
 
+
+// the scene normals + weights candidate `cand` scores against (wave-uniform: scalar loads)
+__device__ __forceinline__ const float4* lcp_weights_of(const LcpArgs& a, int cand) {
+    if (!a.cand_trial) return a.snrmw;
+    const int t = __builtin_amdgcn_readfirstlane(a.cand_trial[cand < 0 ? 0 : cand]);
+    return (const float4*)((const char*)a.snrmw + (size_t)t * a.snrmw_stride);
+}
+
 #define DPP_QUAD_XOR1 0xB1   /* quad_perm [1,0,3,2] */
 #define DPP_QUAD_XOR2 0x4E   /* quad_perm [2,3,0,1] */
 #define DPP_HALF_MIRROR 0x141 /* lane k <-> 7-k inside each group of 8 */
@@ -133,6 +145,7 @@ __global__ __launch_bounds__(256) void lcp_kernel(LcpArgs a, const float* __rest
     const int cand = lcp_candidate(a, n, threadIdx.x >> 6);
     if (cand < 0) return;
     const float* T = T16 + (size_t)cand * 16;
+    const float4* __restrict__ snrmw = lcp_weights_of(a, cand);
     const float t0 = T[0], t1 = T[1], t2 = T[2], t4 = T[4], t5 = T[5], t6 = T[6], t8 = T[8], t9 = T[9], t10 = T[10],
                 t12 = T[12], t13 = T[13], t14 = T[14];
     unsigned long long acc = 0ull;
@@ -167,7 +180,7 @@ __global__ __launch_bounds__(256) void lcp_kernel(LcpArgs a, const float* __rest
             const float nx = t0 * nm.x + (t4 * nm.y + t8 * nm.z);
             const float ny = t1 * nm.x + (t5 * nm.y + t9 * nm.z);
             const float nz = t2 * nm.x + (t6 * nm.y + t10 * nm.z);
-            const float4 sn = a.snrmw[best];
+            const float4 sn = snrmw[best];
             const float d = sn.x * nx + (sn.y * ny + sn.z * nz);
             // acos(d)*180/pi < 30 as an exact threshold; d > 1 -> NaN angle -> not counted (Q7)
             counted = (d >= a.dot_lo) && (d <= 1.0f);
@@ -234,6 +247,7 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coop_kernel(LcpArgs a, const flo
     const int cand = SPLIT ? lcp_candidate(a, n, 0, 1) : lcp_candidate(a, n, w, WPB);
     if (cand < 0) return;
     const int first = SPLIT ? 64 * w : 0, stride = SPLIT ? 64 * WPB : 64;
+    const float4* __restrict__ snrmw = lcp_weights_of(a, cand);
     const float* T = T16 + (size_t)cand * 16;
     const float t0 = T[0], t1 = T[1], t2 = T[2], t4 = T[4], t5 = T[5], t6 = T[6], t8 = T[8], t9 = T[9], t10 = T[10],
                 t12 = T[12], t13 = T[13], t14 = T[14];
@@ -353,7 +367,7 @@ __global__ __launch_bounds__(64 * WPB) void lcp_coop_kernel(LcpArgs a, const flo
             const float nx = t0 * nm.x + (t4 * nm.y + t8 * nm.z);
             const float ny = t1 * nm.x + (t5 * nm.y + t9 * nm.z);
             const float nz = t2 * nm.x + (t6 * nm.y + t10 * nm.z);
-            const float4 sn = a.snrmw[best];
+            const float4 sn = snrmw[best];
             const float d = sn.x * nx + (sn.y * ny + sn.z * nz);
             counted = (d >= a.dot_lo) && (d <= 1.0f);
             if (counted) lcp_add(acc, sn.w);
@@ -455,6 +469,7 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
 #endif
     const int cand = SPLIT ? lcp_candidate(a, n, 0, 1) : lcp_candidate(a, n, w, WPB);
     if (cand < 0 && !TILE) return;   // SPLIT: the whole workgroup leaves together; TILE: the wavefront stays for the barriers
+    const float4* __restrict__ snrmw = lcp_weights_of(a, cand);
     const float* T = T16 + (size_t)(cand < 0 ? 0 : cand) * 16;
     const float t0 = T[0], t1 = T[1], t2 = T[2], t4 = T[4], t5 = T[5], t6 = T[6], t8 = T[8], t9 = T[9], t10 = T[10],
                 t12 = T[12], t13 = T[13], t14 = T[14];
@@ -615,7 +630,7 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
                 const float nx = t0 * nm.x + (t4 * nm.y + t8 * nm.z);
                 const float ny = t1 * nm.x + (t5 * nm.y + t9 * nm.z);
                 const float nz = t2 * nm.x + (t6 * nm.y + t10 * nm.z);
-                const float4 sn = STOCS_ABLATE(a, 32) ? make_float4(nx, ny, nz, 0.5f) : a.snrmw[best];         // 32: no scene-normal gather
+                const float4 sn = STOCS_ABLATE(a, 32) ? make_float4(nx, ny, nz, 0.5f) : snrmw[best];         // 32: no scene-normal gather
                 const float d = sn.x * nx + (sn.y * ny + sn.z * nz);
                 counted = (d >= a.dot_lo) && (d <= 1.0f);
                 if (counted) lcp_add(acc, sn.w);
@@ -863,6 +878,7 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
     a.best = d_best8; a.id_offset = id_offset;
     a.mpos = c->d_mpos_s; a.mnrm = c->d_mnrm_s; a.mperm = c->d_mperm; a.M = c->nM;
     a.top = c->grid.d_top; a.cells = c->grid.d_cells; a.flat = c->grid.d_flat; a.list = c->grid.d_list; a.snrmw = c->snrmw_override ? c->snrmw_override : c->d_snrmw;
+    a.cand_trial = c->lcp_cand_trial; a.snrmw_stride = c->lcp_cand_trial ? c->snrmw_stride : 0;
     a.ox = c->grid.ox; a.oy = c->grid.oy; a.oz = c->grid.oz; a.inv_h = c->grid.inv_h; a.inv_h4 = c->grid.inv_h * 4.0f; a.h = c->grid.h; a.chunk_r = c->grid.d_chunk_r;
     a.nx = c->grid.nx; a.ny = c->grid.ny; a.nz = c->grid.nz; a.nbx = c->grid.nbx; a.nby = c->grid.nby;
     a.sq_eps = c->prm.distance_threshold * c->prm.distance_threshold;  // sq_eps = epsilon*epsilon, stocs.cpp:1014

@@ -266,6 +266,7 @@ struct stocs_ctx {
     std::vector<int32_t> trial_cand_off;    // per trial of the batch (+ 1): first candidate (filled by stocs_make_transforms)
     const float4* snrmw_trial0;             // instance-mode batches: trial t scores against the weights at snrmw_trial0 + t * snrmw_stride bytes
     size_t snrmw_stride;
+    const int32_t* lcp_cand_trial;          // != NULL (with snrmw_override = trial 0's copy): candidate i of the launch scores against trial lcp_cand_trial[i]'s copy
     const float4* snrmw_override;           // != NULL: the scoring kernel reads its scene normals + weights here (one trial of such a batch)
     void* trials;                           // results of the last stocs_run_trials (trials.hip, TrialBatch)
     // congruent quads: only their per-base counts live here (quad_off[b+1] - quad_off[b]); `cong` (congruent.hip,

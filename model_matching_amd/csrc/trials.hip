@@ -68,6 +68,15 @@ __global__ __launch_bounds__(256) void trial_best_kernel(const float* __restrict
     }
 }
 
+// candidate -> trial of the piece (candidates come out trial by trial: a binary search in the per-trial offsets)
+__global__ __launch_bounds__(256) void cand_trial_kernel(const int32_t* __restrict__ cand_off, int n_trials, int first_trial, int n, int32_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int lo = 0, hi = n_trials - 1;           // last t with cand_off[t] <= i
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (cand_off[mid] <= i) lo = mid; else hi = mid - 1; }
+    out[i] = first_trial + lo;
+}
+
 static double now_ms() { return CallTiming::now_s() * 1e3; }
 
 }  // namespace stocs
@@ -183,32 +192,37 @@ int stocs_run_trials(stocs_ctx* c, int mode, int n_trials, const uint64_t* seeds
         // ---- verification: every candidate of the piece scored, then the arg-max of each trial ----
         std::vector<float> out18((size_t)nTp * 18, 0.0f);
         if (n_cand > 0) {
-            if (mode == 0 || !snrmw0) {
-                if ((rc = launch_lcp(c, cand_T(c), n_cand, cand_lcp(c), NULL, NULL, NULL, 0))) break;
-            } else {
-                for (int t = 0; t < nTp && !rc; ++t) {      // each trial against ITS decayed class probabilities (Q8)
-                    const int o0 = c->trial_cand_off[(size_t)t], n_t = c->trial_cand_off[(size_t)t + 1] - o0;
-                    if (n_t <= 0) continue;
-                    c->snrmw_override = (const float4*)((const char*)snrmw0 + (size_t)(t0 + t) * snrmw_stride);
-                    rc = launch_lcp(c, cand_T(c) + (size_t)o0 * 16, n_t, cand_lcp(c) + o0, NULL, NULL, NULL, 0);
-                }
-                c->snrmw_override = NULL;
-                if (rc) break;
-            }
-            const size_t ob = (((size_t)nTp + 1) * 4 + 255) & ~(size_t)255, rb = (size_t)nTp * 18 * 4;
-            if ((rc = ensure_scratch(c, ob + rb + 256))) break;   // (the transform jobs of this piece are done with the scratch area)
+            // scratch of this step (the transform jobs of the piece are done with the area): per-trial candidate offsets | per-trial
+            // results | (instance mode) the trial of every candidate
+            const bool per_trial_weights = mode == 1 && snrmw0 != NULL;
+            const size_t ob = (((size_t)nTp + 1) * 4 + 255) & ~(size_t)255, rb = (((size_t)nTp * 18 * 4) + 255) & ~(size_t)255,
+                         tb = per_trial_weights ? (((size_t)n_cand * 4 + 255) & ~(size_t)255) : 0;
+            if ((rc = ensure_scratch(c, ob + rb + tb + 256))) break;
             if ((rc = ensure_pinned(c, (size_t)PIN_VAR + ob + rb + 256))) break;
             int32_t* d_off = (int32_t*)c->d_scratch;
             float* d_out = (float*)((char*)c->d_scratch + ob);
+            int32_t* d_ct = (int32_t*)((char*)c->d_scratch + ob + rb);
             int32_t* off_pin = (int32_t*)((char*)c->h_pin + PIN_VAR);
             float* out_pin = (float*)((char*)c->h_pin + PIN_VAR + ob);
             memcpy(off_pin, c->trial_cand_off.data(), 4 * ((size_t)nTp + 1));
             STOCS_HIP_CHECK(hipMemcpyAsync(d_off, off_pin, 4 * ((size_t)nTp + 1), hipMemcpyHostToDevice, c->stream));
+            if (!per_trial_weights) {
+                if ((rc = launch_lcp(c, cand_T(c), n_cand, cand_lcp(c), NULL, NULL, NULL, 0))) break;
+            } else {
+                // instance mode: every candidate against the class probabilities as ITS trial's sampling decayed them (Q8) -- still ONE
+                // launch: the kernel picks the trial's copy of the scene normals + weights per candidate (LcpArgs::cand_trial)
+                hipLaunchKernelGGL(cand_trial_kernel, dim3((unsigned)((n_cand + 255) / 256)), dim3(256), 0, c->stream, (const int32_t*)d_off, nTp, t0, n_cand, d_ct);
+                STOCS_HIP_CHECK(hipGetLastError());
+                c->snrmw_override = snrmw0; c->lcp_cand_trial = d_ct;
+                rc = launch_lcp(c, cand_T(c), n_cand, cand_lcp(c), NULL, NULL, NULL, 0);
+                c->snrmw_override = NULL; c->lcp_cand_trial = NULL;
+                if (rc) break;
+            }
             hipLaunchKernelGGL(trial_best_kernel, dim3((unsigned)nTp), dim3(256), 0, c->stream, (const float*)cand_lcp(c), (const float*)cand_P(c), (const int32_t*)d_off, d_out);
             STOCS_HIP_CHECK(hipGetLastError());
-            STOCS_HIP_CHECK(hipMemcpyAsync(out_pin, d_out, rb, hipMemcpyDeviceToHost, c->stream));
+            STOCS_HIP_CHECK(hipMemcpyAsync(out_pin, d_out, (size_t)nTp * 18 * 4, hipMemcpyDeviceToHost, c->stream));
             STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
-            memcpy(out18.data(), out_pin, rb);
+            memcpy(out18.data(), out_pin, (size_t)nTp * 18 * 4);
             c->cands_stale = true;
         }
         ms_ver += now_ms() - ta;
