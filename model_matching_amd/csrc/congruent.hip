@@ -197,6 +197,7 @@ __device__ __forceinline__ int64_t index_pos(V3 p, float cell, int eg) {
 // with its sort key (base << cell_bits | position cell).  P entries sit at p1 + inv1 (p2 - p1) (nset.addElement,
 // stocs.cpp:810-818), Q entries query at p1 + inv2 (p2 - p1) (stocs.cpp:827-836).  A cell the table cannot hold -- it
 // cannot occur for points of the unit cube -- gets the all-ones cell: never queried, never matched.
+#define GATHER_EPT 4
 // po != NULL: the launch was sized by a CAPACITY (the host has not read the plan yet, see stocs_internal_find_congruent): the
 // list's length and segment count are the planned ones, read here, and the workgroups beyond them leave at once.
 template <class KeyT>
@@ -209,32 +210,54 @@ __global__ __launch_bounds__(256) void gather_key_kernel(const uint32_t* __restr
         total = t < (unsigned long long)total ? (uint32_t)t : total;      // never beyond the buffers (a plan beyond the capacity is redone by the host)
         nseg = (int)(is_q ? po->n_qseg : po->n_pseg);
     }
-    // segment of the workgroup's first entry: one uniform binary search (scalar loads); a segment holds thousands of
-    // entries, so the lanes then step forward zero or one segment
-    const uint32_t e0 = blockIdx.x * blockDim.x;
+    // A workgroup takes GATHER_EPT * 256 consecutive entries, a thread GATHER_EPT of them 256 apart (coalesced), with the loads of
+    // all its entries issued before the first use: the kernel is a chain of dependent look-ups (segment -> pair -> two model
+    // points -> base job) and was bound by their latency with one entry per thread (95 us per 9.5 M entries at Cm; round 4).
+    // Segment of the workgroup's first entry: one uniform binary search (scalar loads); a segment holds thousands of entries, so
+    // the lanes then step forward a few segments at most.
+    const uint32_t e0 = blockIdx.x * (blockDim.x * GATHER_EPT);
     if (e0 >= total) return;
     int lo = 0, hi = nseg - 1;  // last segment with dst <= e0
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (segs[mid].dst <= e0) lo = mid; else hi = mid - 1;
     }
-    const uint32_t e = e0 + threadIdx.x;
-    if (e >= total) return;
+    uint32_t e[GATHER_EPT], pr[GATHER_EPT], base[GATHER_EPT];
+    bool live[GATHER_EPT];
     int sgi = lo;
-    while (sgi + 1 < nseg && segs[sgi + 1].dst <= e) ++sgi;
-    const Segment sg = segs[sgi];
-    const uint32_t pr = pairs[sg.src + (e - sg.dst)];
-    const BaseJob& J = jobs[sg.base];
-    const V3 p1 = ld3c(munit, pr >> 16), p2 = ld3c(munit, pr & 0xFFFF);
-    const float inv = is_q ? J.inv2 : J.inv1;
-    const int64_t pc = index_pos(p1 + inv * (p2 - p1), J.cell, J.egSize);
+#pragma unroll
+    for (int k = 0; k < GATHER_EPT; ++k) {
+        e[k] = e0 + (uint32_t)k * blockDim.x + threadIdx.x;
+        live[k] = e[k] < total;
+        pr[k] = 0; base[k] = 0;
+        if (live[k]) {
+            while (sgi + 1 < nseg && segs[sgi + 1].dst <= e[k]) ++sgi;
+            const Segment sg = segs[sgi];
+            pr[k] = pairs[sg.src + (e[k] - sg.dst)];
+            base[k] = sg.base;
+        }
+    }
+    float4 a1[GATHER_EPT], a2[GATHER_EPT];
+    float inv[GATHER_EPT]; int eg[GATHER_EPT];
+#pragma unroll
+    for (int k = 0; k < GATHER_EPT; ++k) {
+        a1[k] = munit[pr[k] >> 16]; a2[k] = munit[pr[k] & 0xFFFF];
+        const BaseJob& J = jobs[base[k]];
+        inv[k] = is_q ? J.inv2 : J.inv1; eg[k] = J.egSize;
+    }
     const KeyT cmask = ((KeyT)1 << cell_bits) - (KeyT)1;
-    const bool no_cell = pc < 0 || pc >= cell_limit;
-    const KeyT key = ((KeyT)sg.base << cell_bits) | (no_cell ? cmask : (KeyT)pc);
-    keys[e] = key;
-    vals[e] = pr;
-    if (occ && !no_cell) occ[(size_t)key] = 1;   // which (base, cell) this list occupies: a byte each, plain stores (every writer writes 1;
-                                                 // neighbours in the index share a first point, not a cell, and 18 M atomics took 1.7 ms)
+#pragma unroll
+    for (int k = 0; k < GATHER_EPT; ++k) {
+        if (!live[k]) continue;
+        const V3 p1 = mk3(a1[k].x, a1[k].y, a1[k].z), p2 = mk3(a2[k].x, a2[k].y, a2[k].z);
+        const int64_t pc = index_pos(p1 + inv[k] * (p2 - p1), 0.0f, eg[k]);
+        const bool no_cell = pc < 0 || pc >= cell_limit;
+        const KeyT key = ((KeyT)base[k] << cell_bits) | (no_cell ? cmask : (KeyT)pc);
+        keys[e[k]] = key;
+        vals[e[k]] = pr[k];
+        if (occ && !no_cell) occ[(size_t)key] = 1;   // which (base, cell) this list occupies: a byte each, plain stores (every writer writes 1;
+                                                     // neighbours in the index share a first point, not a cell, and 18 M atomics took 1.7 ms)
+    }
 }
 
 // ---- survivors ----
@@ -1007,13 +1030,13 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
             STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_fork, 0));
             AU.record(c->ev_fork, s0); AU.wait(s1, c->ev_fork);
         }
-        hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totQ0 + 255) / 256)), dim3(256), 0, sq, ix.d_pairs, d_qsegs, n_qseg, (uint32_t)totQ0,
+        hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totQ0 + 256 * GATHER_EPT - 1) / (256 * GATHER_EPT))), dim3(256), 0, sq, ix.d_pairs, d_qsegs, n_qseg, (uint32_t)totQ0,
                            S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p, occ_q, d_po);
         AU.use(s1, plan.qsegs, false, "Q segments", "gather Q"); AU.use(s1, plan.jobs, false, "base jobs", "gather Q");
         AU.use(s1, d_qk_raw.p, true, "gathered Q keys", "gather Q"); AU.use(s1, d_qv_raw.p, true, "gathered Q pairs", "gather Q"); AU.use(s1, occ_q, true, "occupancy of Q", "gather Q");
         STOCS_HIP_CHECK(hipEventRecord(c->ev_t[8], sq));             // Q's cells are marked
         AU.record(c->ev_t[8], s1);
-        hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totP0 + 255) / 256)), dim3(256), 0, st, ix.d_pairs, d_psegs, n_pseg, (uint32_t)totP0,
+        hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totP0 + 256 * GATHER_EPT - 1) / (256 * GATHER_EPT))), dim3(256), 0, st, ix.d_pairs, d_psegs, n_pseg, (uint32_t)totP0,
                            S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p, occ_p, d_po);
         AU.use(s0, plan.psegs, false, "P segments", "gather P"); AU.use(s0, plan.jobs, false, "base jobs", "gather P");
         AU.use(s0, d_pk_raw.p, true, "gathered P keys", "gather P"); AU.use(s0, d_pv_raw.p, true, "gathered P pairs", "gather P"); AU.use(s0, occ_p, true, "occupancy of P", "gather P");
@@ -1098,7 +1121,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         AU.record(c->ev_fork, s0); AU.wait(s1, c->ev_fork);
     }
     if (!reduce)
-        hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totQ + 255) / 256)), dim3(256), 0, sq, ix.d_pairs, d_qsegs, n_qseg, (uint32_t)totQ,
+        hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totQ + 256 * GATHER_EPT - 1) / (256 * GATHER_EPT))), dim3(256), 0, sq, ix.d_pairs, d_qsegs, n_qseg, (uint32_t)totQ,
                            S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p, (uint8_t*)NULL, (const PlanOut*)NULL);
     STOCS_HIP_CHECK(sort_pairs(d_tmp2.p, tb2, qk_in, (KeyT*)S->d_qkeys.p, qv_in, S->d_qvals.p, totQ, 0, end_bit, sq));
     AU.use(s1, qk_in, false, "Q keys to sort", "sort Q"); AU.use(s1, qv_in, false, "Q pairs to sort", "sort Q");
@@ -1106,7 +1129,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     STOCS_HIP_CHECK(hipEventRecord(c->ev_t[1], sq));
     if (sq != st) { STOCS_HIP_CHECK(hipEventRecord(c->ev_join, sq)); AU.record(c->ev_join, s1); }
     if (!reduce)
-        hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, ix.d_pairs, d_psegs, n_pseg, (uint32_t)totP,
+        hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totP + 256 * GATHER_EPT - 1) / (256 * GATHER_EPT))), dim3(256), 0, st, ix.d_pairs, d_psegs, n_pseg, (uint32_t)totP,
                            S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p, (uint8_t*)NULL, (const PlanOut*)NULL);
     STOCS_HIP_CHECK(hipGetLastError());
     // one stable sort per list: (base, position cell); inside a cell the entries keep the index order of the gather
