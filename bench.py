@@ -34,7 +34,7 @@ PEAK_HBM_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~
 NEEDED_BYTES_PER_HIT = 28      # one nearest scene record: position 12 + normal 12 + class probability 4
 
 
-def kernel_record(est, dT, kcand, dL, reps, workload, candidates_arg, run_pmc, groups=None, prefix="", count_hits=True):
+def kernel_record(est, dT, kcand, dL, reps, workload, candidates_arg, run_pmc, groups=None, prefix="", count_hits=True, hits_counted=None):
     """Flat, scalar-only description of the dominant kernel for one workload -- everything a reader needs to recompute it:
     * contract figure: ALGORITHMIC bytes (68 + 52 |M| per pose) / kernel time / HBM peak.  Not a ceiling on
       cache-resident workloads: it charges a scene record to every model point and the model to every pose.
@@ -46,7 +46,7 @@ def kernel_record(est, dT, kcand, dL, reps, workload, candidates_arg, run_pmc, g
       guide: Infinity-Cache hits are counted, so this is NOT pure HBM), L2 -> L1 bytes, unit utilisations, and the binding unit."""
     b_pose = 68 + 52 * est.nM
     k_ms = est.time_score_kernel(dT, kcand, dL, reps)
-    hits, counted = est.lcp_hit_count(dT, kcand) if count_hits else (0, 0)
+    hits, counted = hits_counted if hits_counted is not None else (est.lcp_hit_count(dT, kcand) if count_hits else (0, 0))
     needed = float(hits) * NEEDED_BYTES_PER_HIT + 68.0 * kcand
     sec = k_ms * 1e-3
     rec = {
@@ -334,12 +334,11 @@ def main():
             dist.all_reduce(k, op=dist.ReduceOp.MAX)
             key.copy_(k)
 
-    # The dominant kernel's own clock (HIP events around `reps` back-to-back launches on the context's stream) and the hit census
-    # behind needed_bytes come first: they are measurements of the same kernel on the same batch, and taking them in front leaves the
-    # chip at its working clocks for the W warm-up steps and the K timed ones (a 20-step timed region is 24 ms: after 5 warm-up steps
-    # from idle it ran 7 % below the 400-step rate in round 3).  The timed region below is unchanged: W untimed steps, then exactly K.
-    reps = max(5, min(args.steps, 400))
-    krec, knest = kernel_record(est, dT, kcand, dL, reps, args.workload, args.candidates, False, count_hits=not args.no_hits)   # (counters: after the pipeline section, below)
+    # The hit census behind needed_bytes (the per-point detail form of the kernel over the whole batch, ~30 ms of device work) comes
+    # first: it is a measurement of the same batch, and taking it in front leaves the chip at its working clocks for the W warm-up steps
+    # and the K timed ones (a 20-step timed region is 24 ms: after 5 warm-up steps from idle it ran 7 % below the 400-step rate in
+    # round 3).  The timed region below is unchanged: W untimed steps, then exactly K; the kernel's own clock is taken after it.
+    hits_counted = est.lcp_hit_count(dT, kcand) if not args.no_hits else (0, 0)
     for _ in range(args.warmup):
         step()
     if world > 1:
@@ -372,6 +371,8 @@ def main():
     best_i = int(np.argmax(lcp))
     run_pmc = rank == 0 and world == 1 and not args.no_pmc
     groups = [g for g in args.pmc_groups.split(",") if g] or None
+    reps = max(5, min(args.steps, 400))
+    krec, knest = kernel_record(est, dT, kcand, dL, reps, args.workload, args.candidates, False, hits_counted=hits_counted)   # (counters: after the pipeline section, below)
     k_ms = krec["kernel_ms"]
     achieved = b_pose * kcand / (k_ms * 1e-3) / 1e9   # GB/s
     peak = PEAK_HBM_GBS

@@ -172,16 +172,32 @@ __global__ __launch_bounds__(1024) void plan_offsets_kernel(int nB, const uint2*
         out->totP = s_tot[0]; out->totQ = s_tot[1]; out->n_pseg = sp_off[nB]; out->n_qseg = sq_off[nB];
         out->overflow = (s_tot[0] >= 0xFFFF0000ull || s_tot[1] >= 0xFFFF0000ull) ? 1u : 0u; out->pad = 0;
     }
-    for (int b = threadIdx.x; b < nB; b += blockDim.x) {
-        if (totals[b] == 0 || totals[nB + b] == 0) continue;
-#pragma unroll
-        for (int list = 0; list < 2; ++list) {
-            const uint2* r = ranges + ((size_t)list * nB + b) * 128;
-            Segment* sg = list ? qsegs + sq_off[b] : psegs + sp_off[b];
-            uint32_t d = list ? q_off[b] : p_off[b];
-            const uint32_t n = n_ranges[(size_t)list * nB + b];
-            for (uint32_t k = 0; k < n; ++k) { const uint2 v = r[k]; Segment o = {v.x, v.y - v.x, d, (uint32_t)b}; sg[k] = o; d += o.len; }
-        }
+}
+
+// The segment arrays the gathers walk, from the offsets laid out above: one wavefront per (base, list) -- the <= 128 ranges of a
+// lookup, two per lane, their destinations an exclusive wavefront scan of their lengths.  (Inside plan_offsets_kernel, one thread
+// per base, this loop was 170 us for the 6 000 bases of a 64-trial batch.)
+__global__ __launch_bounds__(256) void plan_segments_kernel(int nB, const uint2* __restrict__ ranges, const uint32_t* __restrict__ n_ranges, const uint32_t* __restrict__ totals,
+                                                            Segment* __restrict__ psegs, Segment* __restrict__ qsegs, const uint32_t* __restrict__ p_off,
+                                                            const uint32_t* __restrict__ q_off, const uint32_t* __restrict__ sp_off, const uint32_t* __restrict__ sq_off) {
+    const int lane = threadIdx.x & 63;
+    const int job = blockIdx.x * 4 + (threadIdx.x >> 6);       // (base, list)
+    if (job >= 2 * nB) return;
+    const int b = job >> 1, list = job & 1;
+    if (totals[b] == 0 || totals[nB + b] == 0) return;          // a base without P pairs or without Q pairs gets neither (stocs.cpp:788)
+    const uint2* r = ranges + ((size_t)list * nB + b) * 128;
+    Segment* sg = list ? qsegs + sq_off[b] : psegs + sp_off[b];
+    const uint32_t d0 = list ? q_off[b] : p_off[b];
+    const uint32_t n = n_ranges[(size_t)list * nB + b];
+    uint32_t carry = 0;
+    for (uint32_t k0 = 0; k0 < n; k0 += 64) {
+        const uint32_t k = k0 + (uint32_t)lane;
+        const uint2 v = k < n ? r[k] : make_uint2(0u, 0u);
+        const uint32_t len = v.y - v.x;
+        uint32_t inc = len;
+        for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t o = __shfl_up(inc, dd, 64); if (lane >= dd) inc += o; }
+        if (k < n) { Segment o = {v.x, len, d0 + carry + (inc - len), (uint32_t)b}; sg[k] = o; }
+        carry += __shfl(inc, 63, 64);
     }
 }
 
@@ -1362,6 +1378,9 @@ int stocs_internal_find_congruent(stocs_ctx* c, int64_t* total_quads, size_t max
                            (const float4*)c->d_spos, (const float4*)c->d_snrmw, nB, (uint2*)(dpl + o_rng), (uint32_t*)(dpl + o_nr), (uint32_t*)(dpl + o_tot));
         hipLaunchKernelGGL(plan_offsets_kernel, dim3(1), dim3(1024), 0, c->stream, nB, (const uint2*)(dpl + o_rng), (const uint32_t*)(dpl + o_nr), (const uint32_t*)(dpl + o_tot),
                            plan.jobs, plan.psegs, plan.qsegs, plan.p_off, plan.q_off, (uint32_t*)(dpl + o_spo), (uint32_t*)(dpl + o_sqo), (PlanOut*)(dpl + o_out), plan.err);
+        hipLaunchKernelGGL(plan_segments_kernel, dim3((unsigned)((2 * nB + 3) / 4)), dim3(256), 0, c->stream, nB, (const uint2*)(dpl + o_rng), (const uint32_t*)(dpl + o_nr),
+                           (const uint32_t*)(dpl + o_tot), plan.psegs, plan.qsegs, (const uint32_t*)plan.p_off, (const uint32_t*)plan.q_off, (const uint32_t*)(dpl + o_spo),
+                           (const uint32_t*)(dpl + o_sqo));
         STOCS_HIP_CHECK(hipGetLastError());
         // read-backs land in the pinned block (a copy into pageable memory -- a stack variable, a std::vector -- takes the
         // runtime's staging path): totals in the fixed slot, the Q offsets behind the per-base quad offsets of count_pass
