@@ -238,29 +238,45 @@ __global__ __launch_bounds__(256) void gather_key_kernel(const uint32_t* __restr
         const int mid = (lo + hi + 1) >> 1;
         if (segs[mid].dst <= e0) lo = mid; else hi = mid - 1;
     }
+    // The kernel is bound by the texture addresser (0.89 busy in a 16-trial Cm batch: ~12 lane addresses per entry), so the common case
+    // is kept off it: the 64 consecutive entries of a wavefront nearly always lie in ONE segment (a segment holds thousands), found
+    // with scalar loads; segment, base, invariant and grid size are then wave-uniform (SGPRs) and a lane issues only its pair load, the
+    // two model-point gathers and its three stores.  A wavefront that straddles a boundary takes the per-lane search.
     uint32_t e[GATHER_EPT], pr[GATHER_EPT], base[GATHER_EPT];
     bool live[GATHER_EPT];
-    int sgi = lo;
+    float inv[GATHER_EPT]; int eg[GATHER_EPT];
+    const int wave = (int)(threadIdx.x >> 6);
+    int sgu = lo;                                      // wave-uniform running segment index
 #pragma unroll
     for (int k = 0; k < GATHER_EPT; ++k) {
         e[k] = e0 + (uint32_t)k * blockDim.x + threadIdx.x;
         live[k] = e[k] < total;
-        pr[k] = 0; base[k] = 0;
-        if (live[k]) {
+        pr[k] = 0; base[k] = 0; inv[k] = 0.0f; eg[k] = 1;
+        const uint32_t ef = __builtin_amdgcn_readfirstlane(e0 + (uint32_t)k * blockDim.x + (uint32_t)wave * 64u);   // the wavefront's first entry
+        if (ef >= total) continue;                                                                               // (uniform)
+        const uint32_t el = min(ef + 63u, total - 1u);
+        sgu = __builtin_amdgcn_readfirstlane(sgu);
+        while (sgu + 1 < nseg && segs[sgu + 1].dst <= ef) ++sgu;
+        const bool one = sgu + 1 >= nseg || segs[sgu + 1].dst > el;
+        if (one) {
+            const Segment sg = segs[sgu];               // scalar loads
+            const BaseJob& J = jobs[sg.base];
+            const float ju = is_q ? J.inv2 : J.inv1;
+            const int gu = J.egSize;
+            if (live[k]) { pr[k] = pairs[sg.src + (e[k] - sg.dst)]; base[k] = sg.base; inv[k] = ju; eg[k] = gu; }
+        } else if (live[k]) {
+            int sgi = sgu;
             while (sgi + 1 < nseg && segs[sgi + 1].dst <= e[k]) ++sgi;
             const Segment sg = segs[sgi];
             pr[k] = pairs[sg.src + (e[k] - sg.dst)];
             base[k] = sg.base;
+            const BaseJob& J = jobs[sg.base];
+            inv[k] = is_q ? J.inv2 : J.inv1; eg[k] = J.egSize;
         }
     }
     float4 a1[GATHER_EPT], a2[GATHER_EPT];
-    float inv[GATHER_EPT]; int eg[GATHER_EPT];
 #pragma unroll
-    for (int k = 0; k < GATHER_EPT; ++k) {
-        a1[k] = munit[pr[k] >> 16]; a2[k] = munit[pr[k] & 0xFFFF];
-        const BaseJob& J = jobs[base[k]];
-        inv[k] = is_q ? J.inv2 : J.inv1; eg[k] = J.egSize;
-    }
+    for (int k = 0; k < GATHER_EPT; ++k) { a1[k] = munit[pr[k] >> 16]; a2[k] = munit[pr[k] & 0xFFFF]; }
     const KeyT cmask = ((KeyT)1 << cell_bits) - (KeyT)1;
 #pragma unroll
     for (int k = 0; k < GATHER_EPT; ++k) {
@@ -295,10 +311,18 @@ __global__ __launch_bounds__(256) void survivors_count_kernel(const KeyT* __rest
     if (po) { const unsigned long long t = is_q ? po->totQ : po->totP; n = t < (unsigned long long)n ? (uint32_t)t : n; }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t cnt = 0;
+    // (keys first, then the occupancy bytes -- dependent, scattered loads that miss the L2 half of the time -- all in flight together:
+    //  with one ballot per load the wavefronts waited 95 % of their time)
+    constexpr int R = SURV_TILE / 256;
+    KeyT key[R]; uint8_t ob[R];
 #pragma unroll
-    for (int k = 0; k < SURV_TILE / 256; ++k) {
+    for (int k = 0; k < R; ++k) { const uint32_t e = blockIdx.x * SURV_TILE + k * 256 + threadIdx.x; key[k] = e < n ? keys[e] : (KeyT)0; }
+#pragma unroll
+    for (int k = 0; k < R; ++k) ob[k] = other[(size_t)key[k]];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
         const uint32_t e = blockIdx.x * SURV_TILE + k * 256 + threadIdx.x;
-        const bool alive = e < n && occ_test(other, keys[e]);   // the all-ones cell is never marked
+        const bool alive = e < n && ob[k] != 0;   // the all-ones cell is never marked
         cnt += (uint32_t)__popcll(__ballot(alive));
     }
     if (lane == 0) s_w[w] = cnt;
@@ -357,14 +381,18 @@ __global__ __launch_bounds__(256) void survivors_compact_kernel(const KeyT* __re
     __shared__ uint32_t s_c[R][4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     KeyT key[R];
-    uint32_t rank[R];
+    uint32_t rank[R], val[R];
+    uint8_t ob[R];
     bool alive[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) { const uint32_t e = blockIdx.x * SURV_TILE + k * 256 + threadIdx.x; key[k] = e < n ? keys[e] : (KeyT)0; val[k] = e < n ? vals[e] : 0u; }
+#pragma unroll
+    for (int k = 0; k < R; ++k) ob[k] = other[(size_t)key[k]];       // all four scattered byte loads in flight together
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const uint32_t e = blockIdx.x * SURV_TILE + k * 256 + threadIdx.x;
         const bool in = e < n;
-        key[k] = in ? keys[e] : (KeyT)0;
-        alive[k] = in && occ_test(other, key[k]);
+        alive[k] = in && ob[k] != 0;
         const unsigned long long am = __ballot(alive[k]);
         rank[k] = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
         if (lane == 0) s_c[k][w] = (uint32_t)__popcll(am);
@@ -377,9 +405,8 @@ __global__ __launch_bounds__(256) void survivors_compact_kernel(const KeyT* __re
 #pragma unroll
         for (int ww = 0; ww < 4; ++ww) { if (ww < w) o += s_c[k][ww]; base += s_c[k][ww]; }
         if (alive[k]) {
-            const uint32_t e = blockIdx.x * SURV_TILE + k * 256 + threadIdx.x;
             okeys[o + rank[k]] = key[k];
-            ovals[o + rank[k]] = vals[e];
+            ovals[o + rank[k]] = val[k];
         }
     }
 }
