@@ -306,7 +306,8 @@ __device__ __forceinline__ bool occ_test(const uint8_t* __restrict__ occ, KeyT k
 // per tile of SURV_TILE entries: how many survive
 template <class KeyT>
 __global__ __launch_bounds__(256) void survivors_count_kernel(const KeyT* __restrict__ keys, uint32_t n, const uint8_t* __restrict__ other,
-                                                              uint32_t* __restrict__ tile_cnt, const PlanOut* __restrict__ po, int is_q) {
+                                                              uint32_t* __restrict__ tile_cnt, const PlanOut* __restrict__ po, int is_q,
+                                                              unsigned long long* __restrict__ alive_bits) {
     __shared__ uint32_t s_w[4];
     if (po) { const unsigned long long t = is_q ? po->totQ : po->totP; n = t < (unsigned long long)n ? (uint32_t)t : n; }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -323,7 +324,11 @@ __global__ __launch_bounds__(256) void survivors_count_kernel(const KeyT* __rest
     for (int k = 0; k < R; ++k) {
         const uint32_t e = blockIdx.x * SURV_TILE + k * 256 + threadIdx.x;
         const bool alive = e < n && ob[k] != 0;   // the all-ones cell is never marked
-        cnt += (uint32_t)__popcll(__ballot(alive));
+        const unsigned long long am = __ballot(alive);
+        // one bit per entry, kept for the compaction: it then reads 8 bytes per wavefront instead of gathering the occupancy bytes again,
+        // and loads the keys and pairs of the survivors only (a quarter of the entries)
+        if (lane == 0) alive_bits[(size_t)blockIdx.x * (SURV_TILE / 64) + (size_t)k * 4 + (size_t)w] = am;
+        cnt += (uint32_t)__popcll(am);
     }
     if (lane == 0) s_w[w] = cnt;
     __syncthreads();
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(256) void survivors_base_offsets_kernel(const KeyT*
 // the survivors of a tile, in order, behind the tile's offset
 template <class KeyT>
 __global__ __launch_bounds__(256) void survivors_compact_kernel(const KeyT* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n,
-                                                                const uint8_t* __restrict__ other, const uint32_t* __restrict__ tile_off,
+                                                                const unsigned long long* __restrict__ alive_bits, const uint32_t* __restrict__ tile_off,
                                                                 KeyT* __restrict__ okeys, uint32_t* __restrict__ ovals, const PlanOut* __restrict__ po, int is_q) {
     constexpr int R = SURV_TILE / 256;
     if (po) { const unsigned long long t = is_q ? po->totQ : po->totP; n = t < (unsigned long long)n ? (uint32_t)t : n; }
@@ -382,18 +387,20 @@ __global__ __launch_bounds__(256) void survivors_compact_kernel(const KeyT* __re
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     KeyT key[R];
     uint32_t rank[R], val[R];
-    uint8_t ob[R];
+    unsigned long long bm[R];
     bool alive[R];
 #pragma unroll
-    for (int k = 0; k < R; ++k) { const uint32_t e = blockIdx.x * SURV_TILE + k * 256 + threadIdx.x; key[k] = e < n ? keys[e] : (KeyT)0; val[k] = e < n ? vals[e] : 0u; }
-#pragma unroll
-    for (int k = 0; k < R; ++k) ob[k] = other[(size_t)key[k]];       // all four scattered byte loads in flight together
+    for (int k = 0; k < R; ++k) bm[k] = alive_bits[(size_t)blockIdx.x * (SURV_TILE / 64) + (size_t)k * 4 + (size_t)w];   // the count pass's ballots (wave-uniform)
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const uint32_t e = blockIdx.x * SURV_TILE + k * 256 + threadIdx.x;
-        const bool in = e < n;
-        alive[k] = in && ob[k] != 0;
-        const unsigned long long am = __ballot(alive[k]);
+        alive[k] = (bm[k] >> lane) & 1ull;
+        key[k] = (KeyT)0; val[k] = 0u;
+        if (alive[k]) { key[k] = keys[e]; val[k] = vals[e]; }       // survivors only
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const unsigned long long am = bm[k];
         rank[k] = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
         if (lane == 0) s_c[k][w] = (uint32_t)__popcll(am);
     }
@@ -1060,6 +1067,8 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         const uint32_t ntp = (uint32_t)((totP0 + SURV_TILE - 1) / SURV_TILE), ntq = (uint32_t)((totQ0 + SURV_TILE - 1) / SURV_TILE);
         const size_t o_tp = 2 * W, o_tq = o_tp + ntp + 1, n_words = o_tq + ntq + 1;
         if ((rc = d_surv.alloc(n_words))) return rc;
+        DevBuf<unsigned long long> d_bits_p, d_bits_q;   // one bit per gathered entry: survives (written by the count pass, read by the compaction)
+        if ((rc = d_bits_p.alloc((size_t)std::max(ntp, 1u) * (SURV_TILE / 64))) || (rc = d_bits_q.alloc((size_t)std::max(ntq, 1u) * (SURV_TILE / 64)))) return rc;
         uint8_t* occ_p = (uint8_t*)d_surv.p;
         uint8_t* occ_q = (uint8_t*)(d_surv.p + W);
         hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, d_surv.p, n_words, (uint32_t*)NULL);
@@ -1086,11 +1095,11 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         STOCS_HIP_CHECK(hipEventRecord(c->ev_t[9], st));             // P's cells are marked
         AU.record(c->ev_t[9], s0);
         if (sq != st) { STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_t[9], 0)); STOCS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_t[8], 0)); AU.wait(s1, c->ev_t[9]); AU.wait(s0, c->ev_t[8]); }
-        hipLaunchKernelGGL(survivors_count_kernel<KeyT>, dim3(ntq), dim3(256), 0, sq, (const KeyT*)d_qk_raw.p, (uint32_t)totQ0, (const uint8_t*)occ_p, d_surv.p + o_tq, d_po, 1);
-        AU.use(s1, d_qk_raw.p, false, "gathered Q keys", "survivors count Q"); AU.use(s1, occ_p, false, "occupancy of P", "survivors count Q"); AU.use(s1, tiles_q, true, "tile counts of Q", "survivors count Q");
+        hipLaunchKernelGGL(survivors_count_kernel<KeyT>, dim3(ntq), dim3(256), 0, sq, (const KeyT*)d_qk_raw.p, (uint32_t)totQ0, (const uint8_t*)occ_p, d_surv.p + o_tq, d_po, 1, d_bits_q.p);
+        AU.use(s1, d_qk_raw.p, false, "gathered Q keys", "survivors count Q"); AU.use(s1, occ_p, false, "occupancy of P", "survivors count Q"); AU.use(s1, tiles_q, true, "tile counts of Q", "survivors count Q"); AU.use(s1, d_bits_q.p, true, "alive bits of Q", "survivors count Q");
         if (sq != st) { STOCS_HIP_CHECK(hipEventRecord(c->ev_join, sq)); AU.record(c->ev_join, s1); }
-        hipLaunchKernelGGL(survivors_count_kernel<KeyT>, dim3(ntp), dim3(256), 0, st, (const KeyT*)d_pk_raw.p, (uint32_t)totP0, (const uint8_t*)occ_q, d_surv.p + o_tp, d_po, 0);
-        AU.use(s0, d_pk_raw.p, false, "gathered P keys", "survivors count P"); AU.use(s0, occ_q, false, "occupancy of Q", "survivors count P"); AU.use(s0, tiles_p, true, "tile counts of P", "survivors count P");
+        hipLaunchKernelGGL(survivors_count_kernel<KeyT>, dim3(ntp), dim3(256), 0, st, (const KeyT*)d_pk_raw.p, (uint32_t)totP0, (const uint8_t*)occ_q, d_surv.p + o_tp, d_po, 0, d_bits_p.p);
+        AU.use(s0, d_pk_raw.p, false, "gathered P keys", "survivors count P"); AU.use(s0, occ_q, false, "occupancy of Q", "survivors count P"); AU.use(s0, tiles_p, true, "tile counts of P", "survivors count P"); AU.use(s0, d_bits_p.p, true, "alive bits of P", "survivors count P");
         if (sq != st) { STOCS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_join, 0)); AU.wait(s0, c->ev_join); }
         AU.use(s0, tiles_p, true, "tile counts of P", "tile scan"); AU.use(s0, tiles_q, true, "tile counts of Q", "tile scan");
         AU.use(s0, d_qk_raw.p, false, "gathered Q keys", "base offsets"); AU.use(s0, occ_p, false, "occupancy of P", "base offsets"); AU.use(s0, plan.jobs, true, "base jobs", "base offsets");
@@ -1112,14 +1121,14 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
             STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_fork, 0));
             AU.record(c->ev_fork, s0); AU.wait(s1, c->ev_fork);
         }
-        AU.use(s1, d_qk_raw.p, false, "gathered Q keys", "compact Q"); AU.use(s1, d_qv_raw.p, false, "gathered Q pairs", "compact Q"); AU.use(s1, occ_p, false, "occupancy of P", "compact Q");
+        AU.use(s1, d_qk_raw.p, false, "gathered Q keys", "compact Q"); AU.use(s1, d_qv_raw.p, false, "gathered Q pairs", "compact Q"); AU.use(s1, d_bits_q.p, false, "alive bits of Q", "compact Q");
         AU.use(s1, tiles_q, false, "tile counts of Q", "compact Q"); AU.use(s1, d_qk_c.p, true, "surviving Q keys", "compact Q"); AU.use(s1, d_qv_c.p, true, "surviving Q pairs", "compact Q");
-        AU.use(s0, d_pk_raw.p, false, "gathered P keys", "compact P"); AU.use(s0, d_pv_raw.p, false, "gathered P pairs", "compact P"); AU.use(s0, occ_q, false, "occupancy of Q", "compact P");
+        AU.use(s0, d_pk_raw.p, false, "gathered P keys", "compact P"); AU.use(s0, d_pv_raw.p, false, "gathered P pairs", "compact P"); AU.use(s0, d_bits_p.p, false, "alive bits of P", "compact P");
         AU.use(s0, tiles_p, false, "tile counts of P", "compact P"); AU.use(s0, d_pk_c.p, true, "surviving P keys", "compact P"); AU.use(s0, d_pv_c.p, true, "surviving P pairs", "compact P");
         hipLaunchKernelGGL(survivors_compact_kernel<KeyT>, dim3(ntq), dim3(256), 0, sq, (const KeyT*)d_qk_raw.p, (const uint32_t*)d_qv_raw.p, (uint32_t)totQ0,
-                           (const uint8_t*)occ_p, (const uint32_t*)(d_surv.p + o_tq), d_qk_c.p, d_qv_c.p, d_po, 1);
+                           (const unsigned long long*)d_bits_q.p, (const uint32_t*)(d_surv.p + o_tq), d_qk_c.p, d_qv_c.p, d_po, 1);
         hipLaunchKernelGGL(survivors_compact_kernel<KeyT>, dim3(ntp), dim3(256), 0, st, (const KeyT*)d_pk_raw.p, (const uint32_t*)d_pv_raw.p, (uint32_t)totP0,
-                           (const uint8_t*)occ_q, (const uint32_t*)(d_surv.p + o_tp), d_pk_c.p, d_pv_c.p, d_po, 0);
+                           (const unsigned long long*)d_bits_p.p, (const uint32_t*)(d_surv.p + o_tp), d_pk_c.p, d_pv_c.p, d_po, 0);
         STOCS_HIP_CHECK(hipGetLastError());
         c->timing[0].lap("enqueue gather + occupancy + survivor counts");
         STOCS_HIP_CHECK(hipEventSynchronize(c->ev_t[7]));   // the read-back, not the compaction behind it
