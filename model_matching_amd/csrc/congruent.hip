@@ -214,82 +214,130 @@ __device__ __forceinline__ int64_t index_pos(V3 p, float cell, int eg) {
 // stocs.cpp:810-818), Q entries query at p1 + inv2 (p2 - p1) (stocs.cpp:827-836).  A cell the table cannot hold -- it
 // cannot occur for points of the unit cube -- gets the all-ones cell: never queried, never matched.
 #define GATHER_EPT 4
+#define GATHER_TILE (256u * GATHER_EPT)
+#define GATHER_MAX_WGS 2048u   // 256 CUs x 8 workgroups of 256 threads
+static inline unsigned gather_grid(unsigned long long total) { const unsigned long long t = (total + GATHER_TILE - 1) / GATHER_TILE; return (unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>(t, GATHER_MAX_WGS)); }
 // po != NULL: the launch was sized by a CAPACITY (the host has not read the plan yet, see stocs_internal_find_congruent): the
 // list's length and segment count are the planned ones, read here, and the workgroups beyond them leave at once.
 template <class KeyT>
 __global__ __launch_bounds__(256) void gather_key_kernel(const uint32_t* __restrict__ pairs, const Segment* __restrict__ segs, int nseg, uint32_t total,
                                                          const BaseJob* __restrict__ jobs, const float4* __restrict__ munit, int is_q, int cell_bits,
                                                          long long cell_limit, KeyT* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                         uint8_t* __restrict__ occ, const PlanOut* __restrict__ po) {
+                                                         uint32_t* __restrict__ occ, const PlanOut* __restrict__ po, uint32_t lds_words, uint32_t n_bases) {
+    // occ: ONE BIT per (base, cell) value of the key -- which (base, cell) this list occupies.  lds_words > 0 (= 2^cell_bits / 32, the
+    // words of one base): the bits of the base the workgroup's current tile starts in are collected in LDS and OR-ed into the table
+    // when the workgroup moves on to the next base or ends (a base's stretch is ~88 tiles at Cm: one atomic per word and workgroup
+    // instead of one scattered store per entry); entries of another base in the same tile (a boundary tile) go to the table directly.
+    extern __shared__ uint32_t s_occ[];
     if (po) {
         const unsigned long long t = is_q ? po->totQ : po->totP;
         total = t < (unsigned long long)total ? (uint32_t)t : total;      // never beyond the buffers (a plan beyond the capacity is redone by the host)
         nseg = (int)(is_q ? po->n_qseg : po->n_pseg);
     }
-    // A workgroup takes GATHER_EPT * 256 consecutive entries, a thread GATHER_EPT of them 256 apart (coalesced), with the loads of
-    // all its entries issued before the first use: the kernel is a chain of dependent look-ups (segment -> pair -> two model
-    // points -> base job) and was bound by their latency with one entry per thread (95 us per 9.5 M entries at Cm; round 4).
-    // Segment of the workgroup's first entry: one uniform binary search (scalar loads); a segment holds thousands of entries, so
-    // the lanes then step forward a few segments at most.
-    const uint32_t e0 = blockIdx.x * (blockDim.x * GATHER_EPT);
-    if (e0 >= total) return;
-    int lo = 0, hi = nseg - 1;  // last segment with dst <= e0
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (segs[mid].dst <= e0) lo = mid; else hi = mid - 1;
+    // A workgroup takes a contiguous run of tiles (GATHER_EPT * 256 entries each; a thread GATHER_EPT of them 256 apart, coalesced),
+    // the launch at most GATHER_MAX_WGS workgroups.  One workgroup per tile made this kernel a chain of dependent look-ups per
+    // workgroup -- a binary search over the segments (12 scalar loads one after the other), segment -> base job -> pair -> two model
+    // points -- paid 9 000 times at Cm: 103 us for 9.5 M entries, of which 62 us remained with the pair load as the ONLY memory
+    // access (ablation, round 4).  Now the search runs once per workgroup and the segment of a wavefront's entries is wave-uniform
+    // STATE carried from tile to tile (a segment holds thousands of entries: the next boundary is compared, not loaded), so the
+    // steady state is pair load -> model points -> stores.
+    const uint32_t n_tiles = (total + GATHER_TILE - 1u) / GATHER_TILE;
+    const uint32_t per_wg = (n_tiles + gridDim.x - 1u) / gridDim.x;
+    const uint32_t t_begin = blockIdx.x * per_wg, t_end = min(n_tiles, t_begin + per_wg);
+    if (t_begin >= t_end) return;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t w0 = t_begin * GATHER_TILE + wave * 64u;      // the wavefront's first entry
+    const bool mark_lds = occ != NULL && lds_words != 0u;
+    if (mark_lds) { for (uint32_t w = threadIdx.x; w < lds_words; w += blockDim.x) s_occ[w] = 0u; __syncthreads(); }
+    // the base the current TILE starts in, followed through the base jobs (uniform over the workgroup: it depends on the tile alone)
+    uint32_t cur_b = 0, cur_end = 0;
+    if (mark_lds) {
+        const uint32_t ts = t_begin * GATHER_TILE;
+        int blo = 0, bhi = (int)n_bases - 1;       // last base whose stretch begins at or before ts
+        while (blo < bhi) {
+            const int mid = (blo + bhi + 1) >> 1;
+            const uint32_t off = is_q ? jobs[mid].q_off : jobs[mid].p_off;
+            if (off <= ts) blo = mid; else bhi = mid - 1;
+        }
+        cur_b = (uint32_t)blo;
+        cur_end = blo + 1 < (int)n_bases ? (is_q ? jobs[blo + 1].q_off : jobs[blo + 1].p_off) : 0xFFFFFFFFu;
     }
-    // The kernel is bound by the texture addresser (0.89 busy in a 16-trial Cm batch: ~12 lane addresses per entry), so the common case
-    // is kept off it: the 64 consecutive entries of a wavefront nearly always lie in ONE segment (a segment holds thousands), found
-    // with scalar loads; segment, base, invariant and grid size are then wave-uniform (SGPRs) and a lane issues only its pair load, the
-    // two model-point gathers and its three stores.  A wavefront that straddles a boundary takes the per-lane search.
-    uint32_t e[GATHER_EPT], pr[GATHER_EPT], base[GATHER_EPT];
-    bool live[GATHER_EPT];
-    float inv[GATHER_EPT]; int eg[GATHER_EPT];
-    const int wave = (int)(threadIdx.x >> 6);
-    int sgu = lo;                                      // wave-uniform running segment index
-#pragma unroll
-    for (int k = 0; k < GATHER_EPT; ++k) {
-        e[k] = e0 + (uint32_t)k * blockDim.x + threadIdx.x;
-        live[k] = e[k] < total;
-        pr[k] = 0; base[k] = 0; inv[k] = 0.0f; eg[k] = 1;
-        const uint32_t ef = __builtin_amdgcn_readfirstlane(e0 + (uint32_t)k * blockDim.x + (uint32_t)wave * 64u);   // the wavefront's first entry
-        if (ef >= total) continue;                                                                               // (uniform)
-        const uint32_t el = min(ef + 63u, total - 1u);
-        sgu = __builtin_amdgcn_readfirstlane(sgu);
-        while (sgu + 1 < nseg && segs[sgu + 1].dst <= ef) ++sgu;
-        const bool one = sgu + 1 >= nseg || segs[sgu + 1].dst > el;
-        if (one) {
-            const Segment sg = segs[sgu];               // scalar loads
-            const BaseJob& J = jobs[sg.base];
-            const float ju = is_q ? J.inv2 : J.inv1;
-            const int gu = J.egSize;
-            if (live[k]) { pr[k] = pairs[sg.src + (e[k] - sg.dst)]; base[k] = sg.base; inv[k] = ju; eg[k] = gu; }
-        } else if (live[k]) {
-            int sgi = sgu;
-            while (sgi + 1 < nseg && segs[sgi + 1].dst <= e[k]) ++sgi;
-            const Segment sg = segs[sgi];
-            pr[k] = pairs[sg.src + (e[k] - sg.dst)];
-            base[k] = sg.base;
-            const BaseJob& J = jobs[sg.base];
-            inv[k] = is_q ? J.inv2 : J.inv1; eg[k] = J.egSize;
+    auto flush = [&](uint32_t b) {
+        __syncthreads();
+        for (uint32_t w = threadIdx.x; w < lds_words; w += blockDim.x) {
+            const uint32_t v = s_occ[w];
+            if (v) { atomicOr(&occ[(size_t)b * lds_words + w], v); s_occ[w] = 0u; }
+        }
+        __syncthreads();
+    };
+    int lo = 0, hi = nseg - 1;                                    // last segment with dst <= w0 (uniform binary search, scalar loads)
+    if (w0 < total) {
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (segs[mid].dst <= w0) lo = mid; else hi = mid - 1;
         }
     }
-    float4 a1[GATHER_EPT], a2[GATHER_EPT];
-#pragma unroll
-    for (int k = 0; k < GATHER_EPT; ++k) { a1[k] = munit[pr[k] >> 16]; a2[k] = munit[pr[k] & 0xFFFF]; }
+    // wave-uniform segment state
+    int sgu = lo;
+    uint32_t sg_src = 0, sg_dst = 0, sg_base = 0, next_dst = 0xFFFFFFFFu, gu = 1;
+    float ju = 0.0f;
+    auto load_segment = [&](int i) {
+        const Segment sg = segs[i];
+        sg_src = __builtin_amdgcn_readfirstlane(sg.src); sg_dst = __builtin_amdgcn_readfirstlane(sg.dst); sg_base = __builtin_amdgcn_readfirstlane(sg.base);
+        next_dst = i + 1 < nseg ? __builtin_amdgcn_readfirstlane(segs[i + 1].dst) : 0xFFFFFFFFu;
+        const BaseJob& J = jobs[sg_base];
+        ju = is_q ? J.inv2 : J.inv1; gu = (uint32_t)J.egSize;
+    };
+    if (nseg > 0) load_segment(sgu);
     const KeyT cmask = ((KeyT)1 << cell_bits) - (KeyT)1;
+    for (uint32_t tile = t_begin; tile < t_end; ++tile) {
+        if (mark_lds && tile * GATHER_TILE >= cur_end) {            // (uniform over the workgroup)
+            flush(cur_b);
+            while (tile * GATHER_TILE >= cur_end) { ++cur_b; cur_end = cur_b + 1 < n_bases ? (is_q ? jobs[cur_b + 1].q_off : jobs[cur_b + 1].p_off) : 0xFFFFFFFFu; }
+        }
+        uint32_t e[GATHER_EPT], pr[GATHER_EPT], base[GATHER_EPT];
+        bool live[GATHER_EPT];
+        float inv[GATHER_EPT]; int eg[GATHER_EPT];
 #pragma unroll
-    for (int k = 0; k < GATHER_EPT; ++k) {
-        if (!live[k]) continue;
-        const V3 p1 = mk3(a1[k].x, a1[k].y, a1[k].z), p2 = mk3(a2[k].x, a2[k].y, a2[k].z);
-        const int64_t pc = index_pos(p1 + inv[k] * (p2 - p1), 0.0f, eg[k]);
-        const bool no_cell = pc < 0 || pc >= cell_limit;
-        const KeyT key = ((KeyT)base[k] << cell_bits) | (no_cell ? cmask : (KeyT)pc);
-        keys[e[k]] = key;
-        vals[e[k]] = pr[k];
-        if (occ && !no_cell) occ[(size_t)key] = 1;   // which (base, cell) this list occupies: a byte each, plain stores (every writer writes 1;
-                                                     // neighbours in the index share a first point, not a cell, and 18 M atomics took 1.7 ms)
+        for (int k = 0; k < GATHER_EPT; ++k) {
+            const uint32_t ef = tile * GATHER_TILE + (uint32_t)k * 256u + wave * 64u;   // (uniform)
+            e[k] = ef + lane;
+            live[k] = e[k] < total;
+            pr[k] = 0; base[k] = 0; inv[k] = 0.0f; eg[k] = 1;
+            if (ef >= total) continue;
+            const uint32_t el = min(ef + 63u, total - 1u);
+            while (next_dst <= ef) load_segment(++sgu);
+            if (el < next_dst) {                    // the 64 entries lie in one segment: nothing but the pair load
+                if (live[k]) { pr[k] = pairs[sg_src + (e[k] - sg_dst)]; base[k] = sg_base; inv[k] = ju; eg[k] = (int)gu; }
+            } else if (live[k]) {                   // a wavefront across a boundary: per-lane walk from the uniform segment
+                int sgi = sgu;
+                while (sgi + 1 < nseg && segs[sgi + 1].dst <= e[k]) ++sgi;
+                const Segment sg = segs[sgi];
+                pr[k] = pairs[sg.src + (e[k] - sg.dst)];
+                base[k] = sg.base;
+                const BaseJob& J = jobs[sg.base];
+                inv[k] = is_q ? J.inv2 : J.inv1; eg[k] = J.egSize;
+            }
+        }
+        float4 a1[GATHER_EPT], a2[GATHER_EPT];
+#pragma unroll
+        for (int k = 0; k < GATHER_EPT; ++k) { a1[k] = munit[pr[k] >> 16]; a2[k] = munit[pr[k] & 0xFFFF]; }
+#pragma unroll
+        for (int k = 0; k < GATHER_EPT; ++k) {
+            if (!live[k]) continue;
+            const V3 p1 = mk3(a1[k].x, a1[k].y, a1[k].z), p2 = mk3(a2[k].x, a2[k].y, a2[k].z);
+            const int64_t pc = index_pos(p1 + inv[k] * (p2 - p1), 0.0f, eg[k]);
+            const bool no_cell = pc < 0 || pc >= cell_limit;
+            const KeyT key = ((KeyT)base[k] << cell_bits) | (no_cell ? cmask : (KeyT)pc);
+            keys[e[k]] = key;
+            vals[e[k]] = pr[k];
+            if (occ && !no_cell) {
+                if (mark_lds && base[k] == cur_b) atomicOr(&s_occ[(uint32_t)pc >> 5], 1u << ((uint32_t)pc & 31u));
+                else atomicOr(&occ[(size_t)(key >> 5)], 1u << ((uint32_t)key & 31u));
+            }
+        }
     }
+    if (mark_lds) flush(cur_b);
 }
 
 // ---- survivors ----
@@ -301,38 +349,60 @@ __global__ __launch_bounds__(256) void gather_key_kernel(const uint32_t* __restr
 // the entries.  Entries dropped here have an empty partner run: they contribute no quad and no rank of the walk order.
 #define SURV_TILE 1024
 template <class KeyT>
-__device__ __forceinline__ bool occ_test(const uint8_t* __restrict__ occ, KeyT key) { return occ[(size_t)key] != 0; }
+__device__ __forceinline__ bool occ_test(const uint32_t* __restrict__ occ, KeyT key) { return (occ[(size_t)(key >> 5)] >> ((uint32_t)key & 31u)) & 1u; }
 
-// per tile of SURV_TILE entries: how many survive
+// per tile of SURV_TILE entries: how many survive.  A workgroup takes a run of consecutive tiles; lds_words > 0: the OTHER list's bits of
+// the base its current tile starts in sit in LDS (2^cell_bits / 8 bytes, loaded when the base changes), so the test of an entry is an
+// LDS read -- the byte table of rounds 3-4a was gathered from device memory per entry and missed the L2 half of the time (3.2 MB per
+// list and trial against a 4 MB L2 that the lists stream through).  Entries of another base in the tile read the table directly.
 template <class KeyT>
-__global__ __launch_bounds__(256) void survivors_count_kernel(const KeyT* __restrict__ keys, uint32_t n, const uint8_t* __restrict__ other,
+__global__ __launch_bounds__(256) void survivors_count_kernel(const KeyT* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ other,
                                                               uint32_t* __restrict__ tile_cnt, const PlanOut* __restrict__ po, int is_q,
-                                                              unsigned long long* __restrict__ alive_bits) {
+                                                              unsigned long long* __restrict__ alive_bits, uint32_t lds_words, int cell_bits) {
+    extern __shared__ uint32_t s_occ[];
     __shared__ uint32_t s_w[4];
     if (po) { const unsigned long long t = is_q ? po->totQ : po->totP; n = t < (unsigned long long)n ? (uint32_t)t : n; }
+    const uint32_t n_tiles = (n + SURV_TILE - 1u) / SURV_TILE;
+    const uint32_t per_wg = (n_tiles + gridDim.x - 1u) / gridDim.x;
+    const uint32_t t_begin = blockIdx.x * per_wg, t_end = min(n_tiles, t_begin + per_wg);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t cnt = 0;
-    // (keys first, then the occupancy bytes -- dependent, scattered loads that miss the L2 half of the time -- all in flight together:
-    //  with one ballot per load the wavefronts waited 95 % of their time)
     constexpr int R = SURV_TILE / 256;
-    KeyT key[R]; uint8_t ob[R];
+    const KeyT cmask = ((KeyT)1 << cell_bits) - (KeyT)1;
+    KeyT cur = ~(KeyT)0;                 // base whose bits are in LDS
+    for (uint32_t tile = t_begin; tile < t_end; ++tile) {
+        if (lds_words) {
+            const KeyT tb = keys[(size_t)tile * SURV_TILE] >> cell_bits;      // (uniform: the tile's first entry exists)
+            if (tb != cur) {
+                __syncthreads();
+                cur = tb;
+                for (uint32_t i = threadIdx.x; i < lds_words; i += blockDim.x) s_occ[i] = other[(size_t)cur * lds_words + i];
+                __syncthreads();
+            }
+        }
+        uint32_t cnt = 0;
+        KeyT key[R]; bool ob[R];
 #pragma unroll
-    for (int k = 0; k < R; ++k) { const uint32_t e = blockIdx.x * SURV_TILE + k * 256 + threadIdx.x; key[k] = e < n ? keys[e] : (KeyT)0; }
+        for (int k = 0; k < R; ++k) { const uint32_t e = tile * SURV_TILE + k * 256 + threadIdx.x; key[k] = e < n ? keys[e] : ~(KeyT)0; }
 #pragma unroll
-    for (int k = 0; k < R; ++k) ob[k] = other[(size_t)key[k]];
+        for (int k = 0; k < R; ++k) {
+            const uint32_t e = tile * SURV_TILE + k * 256 + threadIdx.x;
+            if (e >= n) ob[k] = false;
+            else if (lds_words && (key[k] >> cell_bits) == cur) { const uint32_t cl = (uint32_t)(key[k] & cmask); ob[k] = (s_occ[cl >> 5] >> (cl & 31u)) & 1u; }
+            else ob[k] = occ_test(other, key[k]);
+        }
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const uint32_t e = blockIdx.x * SURV_TILE + k * 256 + threadIdx.x;
-        const bool alive = e < n && ob[k] != 0;   // the all-ones cell is never marked
-        const unsigned long long am = __ballot(alive);
-        // one bit per entry, kept for the compaction: it then reads 8 bytes per wavefront instead of gathering the occupancy bytes again,
-        // and loads the keys and pairs of the survivors only (a quarter of the entries)
-        if (lane == 0) alive_bits[(size_t)blockIdx.x * (SURV_TILE / 64) + (size_t)k * 4 + (size_t)w] = am;
-        cnt += (uint32_t)__popcll(am);
+        for (int k = 0; k < R; ++k) {
+            const unsigned long long am = __ballot(ob[k]);   // (the all-ones cell is never marked)
+            // one bit per entry, kept for the compaction: it then reads 8 bytes per wavefront instead of testing again,
+            // and loads the keys and pairs of the survivors only (a quarter of the entries)
+            if (lane == 0) alive_bits[(size_t)tile * (SURV_TILE / 64) + (size_t)k * 4 + (size_t)w] = am;
+            cnt += (uint32_t)__popcll(am);
+        }
+        if (lane == 0) s_w[w] = cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) tile_cnt[tile] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
     }
-    if (lane == 0) s_w[w] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
 // workgroup 0: P list, workgroup 1: Q list.  Tile counts -> tile offsets (element n_tiles receives the total)
@@ -346,15 +416,15 @@ __global__ __launch_bounds__(1024) void survivors_scan_kernel(uint32_t* __restri
 // survivors in front of the stretch's old bounds: the offset of the tile a bound falls into plus the survivors of that
 // tile in front of it), patched into the base jobs and the offset arrays the join reads.  Workgroup (b, list).
 template <class KeyT>
-__global__ __launch_bounds__(256) void survivors_base_offsets_kernel(const KeyT* __restrict__ pkeys, uint32_t nP, const uint8_t* __restrict__ occ_q,
+__global__ __launch_bounds__(256) void survivors_base_offsets_kernel(const KeyT* __restrict__ pkeys, uint32_t nP, const uint32_t* __restrict__ occ_q,
                                                                      const uint32_t* __restrict__ tiles_p, const KeyT* __restrict__ qkeys, uint32_t nQ,
-                                                                     const uint8_t* __restrict__ occ_p, const uint32_t* __restrict__ tiles_q, int nB,
+                                                                     const uint32_t* __restrict__ occ_p, const uint32_t* __restrict__ tiles_q, int nB,
                                                                      BaseJob* __restrict__ jobs, uint32_t* __restrict__ p_off, uint32_t* __restrict__ q_off) {
     __shared__ uint32_t s_w[2][4];
     const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool q = blockIdx.y == 1;
     const KeyT* keys = q ? qkeys : pkeys;
-    const uint8_t* other = q ? occ_p : occ_q;
+    const uint32_t* other = q ? occ_p : occ_q;
     const uint32_t* tiles = q ? tiles_q : tiles_p;
     const uint32_t r0 = q ? jobs[b].q_off : jobs[b].p_off, r1 = r0 + (q ? jobs[b].q_len : jobs[b].p_len);
     uint32_t got[2];
@@ -1054,7 +1124,9 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     const int s0 = 0, s1 = sq != st ? 1 : 0;
     const long long cell_limit = S->use_table ? S->NC : ((long long)1 << 31);
     const unsigned end_bit = (unsigned)(S->cell_bits + S->base_bits);
-    const unsigned long long occ_bits = (unsigned long long)nB << S->cell_bits;   // (base, cell) values = bytes of an occupancy table
+    const unsigned long long occ_bits = (unsigned long long)nB << S->cell_bits;   // (base, cell) values = BITS of an occupancy table
+    // one base's bits in LDS (gather: collected there; count: the other list's, tested there) while they fit 32 KB
+    const uint32_t lds_words = (S->cell_bits >= 5 && S->cell_bits <= 18 && !getenv("STOCS_CONGRUENT_NO_LDS_BITS")) ? (1u << (S->cell_bits - 5)) : 0u;
     const bool reduce = S->reduce;
     const KeyT* pk_in = d_pk_raw.p; const uint32_t* pv_in = d_pv_raw.p;   // what the sorts read
     const KeyT* qk_in = d_qk_raw.p; const uint32_t* qv_in = d_qv_raw.p;
@@ -1063,14 +1135,14 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     bool have_surv_clock = false;
     if (reduce) {
         // one zeroed block: occupancy of P | occupancy of Q | P tile counts (+ total) | Q tile counts (+ total)
-        const size_t W = (size_t)((occ_bits + 3) >> 2);   // words of one occupancy table
+        const size_t W = (size_t)((occ_bits + 31) >> 5) + 1;   // words of one occupancy table
         const uint32_t ntp = (uint32_t)((totP0 + SURV_TILE - 1) / SURV_TILE), ntq = (uint32_t)((totQ0 + SURV_TILE - 1) / SURV_TILE);
         const size_t o_tp = 2 * W, o_tq = o_tp + ntp + 1, n_words = o_tq + ntq + 1;
         if ((rc = d_surv.alloc(n_words))) return rc;
         DevBuf<unsigned long long> d_bits_p, d_bits_q;   // one bit per gathered entry: survives (written by the count pass, read by the compaction)
         if ((rc = d_bits_p.alloc((size_t)std::max(ntp, 1u) * (SURV_TILE / 64))) || (rc = d_bits_q.alloc((size_t)std::max(ntq, 1u) * (SURV_TILE / 64)))) return rc;
-        uint8_t* occ_p = (uint8_t*)d_surv.p;
-        uint8_t* occ_q = (uint8_t*)(d_surv.p + W);
+        uint32_t* occ_p = d_surv.p;
+        uint32_t* occ_q = d_surv.p + W;
         hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, d_surv.p, n_words, (uint32_t*)NULL);
         const uint32_t* tiles_p = d_surv.p + o_tp; const uint32_t* tiles_q = d_surv.p + o_tq;
         AU.use(s0, occ_p, true, "occupancy of P", "zero fill"); AU.use(s0, occ_q, true, "occupancy of Q", "zero fill");
@@ -1082,30 +1154,30 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
             STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_fork, 0));
             AU.record(c->ev_fork, s0); AU.wait(s1, c->ev_fork);
         }
-        hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totQ0 + 256 * GATHER_EPT - 1) / (256 * GATHER_EPT))), dim3(256), 0, sq, ix.d_pairs, d_qsegs, n_qseg, (uint32_t)totQ0,
-                           S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p, occ_q, d_po);
+        hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3(gather_grid(totQ0)), dim3(256), lds_words * 4, sq, ix.d_pairs, d_qsegs, n_qseg, (uint32_t)totQ0,
+                           S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p, occ_q, d_po, lds_words, (uint32_t)nB);
         AU.use(s1, plan.qsegs, false, "Q segments", "gather Q"); AU.use(s1, plan.jobs, false, "base jobs", "gather Q");
         AU.use(s1, d_qk_raw.p, true, "gathered Q keys", "gather Q"); AU.use(s1, d_qv_raw.p, true, "gathered Q pairs", "gather Q"); AU.use(s1, occ_q, true, "occupancy of Q", "gather Q");
         STOCS_HIP_CHECK(hipEventRecord(c->ev_t[8], sq));             // Q's cells are marked
         AU.record(c->ev_t[8], s1);
-        hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totP0 + 256 * GATHER_EPT - 1) / (256 * GATHER_EPT))), dim3(256), 0, st, ix.d_pairs, d_psegs, n_pseg, (uint32_t)totP0,
-                           S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p, occ_p, d_po);
+        hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3(gather_grid(totP0)), dim3(256), lds_words * 4, st, ix.d_pairs, d_psegs, n_pseg, (uint32_t)totP0,
+                           S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p, occ_p, d_po, lds_words, (uint32_t)nB);
         AU.use(s0, plan.psegs, false, "P segments", "gather P"); AU.use(s0, plan.jobs, false, "base jobs", "gather P");
         AU.use(s0, d_pk_raw.p, true, "gathered P keys", "gather P"); AU.use(s0, d_pv_raw.p, true, "gathered P pairs", "gather P"); AU.use(s0, occ_p, true, "occupancy of P", "gather P");
         STOCS_HIP_CHECK(hipEventRecord(c->ev_t[9], st));             // P's cells are marked
         AU.record(c->ev_t[9], s0);
         if (sq != st) { STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_t[9], 0)); STOCS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_t[8], 0)); AU.wait(s1, c->ev_t[9]); AU.wait(s0, c->ev_t[8]); }
-        hipLaunchKernelGGL(survivors_count_kernel<KeyT>, dim3(ntq), dim3(256), 0, sq, (const KeyT*)d_qk_raw.p, (uint32_t)totQ0, (const uint8_t*)occ_p, d_surv.p + o_tq, d_po, 1, d_bits_q.p);
+        hipLaunchKernelGGL(survivors_count_kernel<KeyT>, dim3(std::max(1u, std::min(ntq, GATHER_MAX_WGS))), dim3(256), lds_words * 4, sq, (const KeyT*)d_qk_raw.p, (uint32_t)totQ0, (const uint32_t*)occ_p, d_surv.p + o_tq, d_po, 1, d_bits_q.p, lds_words, S->cell_bits);
         AU.use(s1, d_qk_raw.p, false, "gathered Q keys", "survivors count Q"); AU.use(s1, occ_p, false, "occupancy of P", "survivors count Q"); AU.use(s1, tiles_q, true, "tile counts of Q", "survivors count Q"); AU.use(s1, d_bits_q.p, true, "alive bits of Q", "survivors count Q");
         if (sq != st) { STOCS_HIP_CHECK(hipEventRecord(c->ev_join, sq)); AU.record(c->ev_join, s1); }
-        hipLaunchKernelGGL(survivors_count_kernel<KeyT>, dim3(ntp), dim3(256), 0, st, (const KeyT*)d_pk_raw.p, (uint32_t)totP0, (const uint8_t*)occ_q, d_surv.p + o_tp, d_po, 0, d_bits_p.p);
+        hipLaunchKernelGGL(survivors_count_kernel<KeyT>, dim3(std::max(1u, std::min(ntp, GATHER_MAX_WGS))), dim3(256), lds_words * 4, st, (const KeyT*)d_pk_raw.p, (uint32_t)totP0, (const uint32_t*)occ_q, d_surv.p + o_tp, d_po, 0, d_bits_p.p, lds_words, S->cell_bits);
         AU.use(s0, d_pk_raw.p, false, "gathered P keys", "survivors count P"); AU.use(s0, occ_q, false, "occupancy of Q", "survivors count P"); AU.use(s0, tiles_p, true, "tile counts of P", "survivors count P"); AU.use(s0, d_bits_p.p, true, "alive bits of P", "survivors count P");
         if (sq != st) { STOCS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_join, 0)); AU.wait(s0, c->ev_join); }
         AU.use(s0, tiles_p, true, "tile counts of P", "tile scan"); AU.use(s0, tiles_q, true, "tile counts of Q", "tile scan");
         AU.use(s0, d_qk_raw.p, false, "gathered Q keys", "base offsets"); AU.use(s0, occ_p, false, "occupancy of P", "base offsets"); AU.use(s0, plan.jobs, true, "base jobs", "base offsets");
         hipLaunchKernelGGL(survivors_scan_kernel, dim3(2), dim3(1024), 0, st, d_surv.p + o_tp, ntp, d_surv.p + o_tq, ntq);
-        hipLaunchKernelGGL(survivors_base_offsets_kernel<KeyT>, dim3((unsigned)nB, 2), dim3(256), 0, st, (const KeyT*)d_pk_raw.p, (uint32_t)totP0, (const uint8_t*)occ_q,
-                           (const uint32_t*)(d_surv.p + o_tp), (const KeyT*)d_qk_raw.p, (uint32_t)totQ0, (const uint8_t*)occ_p, (const uint32_t*)(d_surv.p + o_tq), nB,
+        hipLaunchKernelGGL(survivors_base_offsets_kernel<KeyT>, dim3((unsigned)nB, 2), dim3(256), 0, st, (const KeyT*)d_pk_raw.p, (uint32_t)totP0, (const uint32_t*)occ_q,
+                           (const uint32_t*)(d_surv.p + o_tp), (const KeyT*)d_qk_raw.p, (uint32_t)totQ0, (const uint32_t*)occ_p, (const uint32_t*)(d_surv.p + o_tq), nB,
                            S->d_jobs.p, plan.p_off, plan.q_off);
         STOCS_HIP_CHECK(hipGetLastError());
         // the host sizes the sorts and the join with the survivors' totals and lays the materialise blocks out with their Q offsets
@@ -1173,16 +1245,16 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         AU.record(c->ev_fork, s0); AU.wait(s1, c->ev_fork);
     }
     if (!reduce)
-        hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totQ + 256 * GATHER_EPT - 1) / (256 * GATHER_EPT))), dim3(256), 0, sq, ix.d_pairs, d_qsegs, n_qseg, (uint32_t)totQ,
-                           S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p, (uint8_t*)NULL, (const PlanOut*)NULL);
+        hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3(gather_grid(totQ)), dim3(256), 0, sq, ix.d_pairs, d_qsegs, n_qseg, (uint32_t)totQ,
+                           S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p, (uint32_t*)NULL, (const PlanOut*)NULL, 0u, (uint32_t)nB);
     STOCS_HIP_CHECK(sort_pairs(d_tmp2.p, tb2, qk_in, (KeyT*)S->d_qkeys.p, qv_in, S->d_qvals.p, totQ, 0, end_bit, sq));
     AU.use(s1, qk_in, false, "Q keys to sort", "sort Q"); AU.use(s1, qv_in, false, "Q pairs to sort", "sort Q");
     AU.use(s1, S->d_qkeys.p, true, "sorted Q keys", "sort Q"); AU.use(s1, S->d_qvals.p, true, "sorted Q pairs", "sort Q"); AU.use(s1, d_tmp2.p, true, "sort scratch Q", "sort Q");
     STOCS_HIP_CHECK(hipEventRecord(c->ev_t[1], sq));
     if (sq != st) { STOCS_HIP_CHECK(hipEventRecord(c->ev_join, sq)); AU.record(c->ev_join, s1); }
     if (!reduce)
-        hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3((unsigned)((totP + 256 * GATHER_EPT - 1) / (256 * GATHER_EPT))), dim3(256), 0, st, ix.d_pairs, d_psegs, n_pseg, (uint32_t)totP,
-                           S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p, (uint8_t*)NULL, (const PlanOut*)NULL);
+        hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3(gather_grid(totP)), dim3(256), 0, st, ix.d_pairs, d_psegs, n_pseg, (uint32_t)totP,
+                           S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p, (uint32_t*)NULL, (const PlanOut*)NULL, 0u, (uint32_t)nB);
     STOCS_HIP_CHECK(hipGetLastError());
     // one stable sort per list: (base, position cell); inside a cell the entries keep the index order of the gather
     STOCS_HIP_CHECK(sort_pairs(d_tmp.p, tb1, pk_in, (KeyT*)S->d_pkeys.p, pv_in, S->d_pvals.p, totP, 0, end_bit_p, st));
@@ -1504,7 +1576,7 @@ int stocs_internal_find_congruent(stocs_ctx* c, int64_t* total_quads, size_t max
         const size_t kb = wide ? 8 : 4;
         const size_t tables = use_table ? (size_t)(NC * nB) * 8 : 0;
         const size_t per_entry = 3 * kb + 8 + 16 + 8 + (reduce ? kb + 4 : 0);   // (the compacted copies of the reduced form)
-        const size_t occ = reduce ? 2 * ((size_t)nB << cell_bits) : 0;
+        const size_t occ = reduce ? 2 * (((size_t)nB << cell_bits) / 8 + 8) : 0;
         const size_t need = (size_t)nP * per_entry + (size_t)nQ * per_entry + tables + occ + ((size_t)48 << 20);
         if (max_bytes && need > max_bytes && nB > 1) { *over = true; return STOCS_OK; }
         return S->arena_state.reserve(need);

@@ -93,6 +93,7 @@ int stocs_run_trials(stocs_ctx* c, int mode, int n_trials, const uint64_t* seeds
                      stocs_trial_result* out) {
     if (!c || n_trials < 0 || n_attempts < 0 || max_per_base <= 0 || (mode != 0 && mode != 1) || (n_trials && !seeds)) return STOCS_ERR_INVALID;
     DeviceGuard dev_guard(c->device);
+    const double t_entry = now_ms();
     if (!c->index.built) { set_error("stocs_run_trials: PPF index not built"); return STOCS_ERR_STATE; }
     if (mode == 1 && n_attempts > 254) { set_error("instance mode labels segments with a u8 (<= 254 attempts, Q14)"); return STOCS_ERR_INVALID; }
     if ((long long)n_trials * (long long)std::max(n_attempts, 1) > (1ll << 24)) { set_error("stocs_run_trials: more than 2^24 attempts in one batch"); return STOCS_ERR_INVALID; }
@@ -115,13 +116,14 @@ int stocs_run_trials(stocs_ctx* c, int mode, int n_trials, const uint64_t* seeds
     for (int t = 0; t < nT; ++t) { memset(&B->out[(size_t)t], 0, sizeof(stocs_trial_result)); B->out[(size_t)t].best_index = -1; }
     CallTiming& TM = c->timing[3];
     TM.begin();
-    double ms_cong = 0, ms_xf = 0, ms_ver = 0;
+    double ms_cong = 0, ms_xf = 0, ms_ver = 0, ms_asm = 0, ms_res = 0;
+    const double ms_setup = now_ms() - t_entry;
     if (nT == 0) return STOCS_OK;
     if (nA > 0 && c->nS > 0) {
         const int rc = sample_trials(c, mode, nT, seeds, nA, dispersion, B->res.data(), &c->snrmw_trial0, &c->snrmw_stride);
         if (rc) { clear_trial_batch(c); return rc; }
     }
-    const float4* snrmw0 = c->snrmw_trial0; const size_t snrmw_stride = c->snrmw_stride;
+    const float4* snrmw0 = c->snrmw_trial0;
     TM.lap("sampling: every attempt of every trial in one launch + read-back");
     // ---- how many bases one set of launches can take (congruent.hip: 32-bit (base, cell) sort keys with the run table, packed
     //      64-bit quads with the base above the four model ids) ----
@@ -154,6 +156,7 @@ int stocs_run_trials(stocs_ctx* c, int mode, int n_trials, const uint64_t* seeds
         while (t1 < nT && t1 - t0 < piece_cap && (t1 == t0 || nb + n_valid[(size_t)t1] <= max_bases)) { nb += n_valid[(size_t)t1]; ++t1; }
         int64_t total_quads = 0;
         for (;;) {   // the piece t0 .. t1: halved until its pair lists fit the ceiling
+            const double t_asm = now_ms();
             c->bases.clear(); c->base_seed.clear(); c->base_local.clear(); c->trial_first_base.clear(); c->trial_cand_off.clear();
             c->quad_off.clear(); clear_candidates(c);
             for (int t = t0; t < t1; ++t) {
@@ -172,6 +175,7 @@ int stocs_run_trials(stocs_ctx* c, int mode, int n_trials, const uint64_t* seeds
             }
             c->trial_first_base.push_back((int32_t)c->bases.size());
             const double ta = now_ms();
+            ms_asm += ta - t_asm;
             int too_big = 0;
             rc = stocs_internal_find_congruent(c, &total_quads, t1 - t0 > 1 ? max_bytes : 0, &too_big);   // (one trial alone always goes, as it does through the single calls)
             ms_cong += now_ms() - ta;
@@ -226,6 +230,7 @@ int stocs_run_trials(stocs_ctx* c, int mode, int n_trials, const uint64_t* seeds
             c->cands_stale = true;
         }
         ms_ver += now_ms() - ta;
+        ta = now_ms();
         // ---- results of the piece ----
         std::vector<float> hT, hP, hL; std::vector<int32_t> hB;
         if (B->keep && n_cand > 0) {
@@ -267,6 +272,7 @@ int stocs_run_trials(stocs_ctx* c, int mode, int n_trials, const uint64_t* seeds
                 B->cbase[(size_t)(t0 + t)].assign(hB.begin() + o0, hB.begin() + o1);
             }
         }
+        ms_res += now_ms() - ta;
         t0 = t1;
     }
     // the context is left as stocs_reset_trial leaves it: no bases, no candidates (the batch's results live in the batch record)
@@ -280,6 +286,10 @@ int stocs_run_trials(stocs_ctx* c, int mode, int n_trials, const uint64_t* seeds
         put("congruent sets of all trials (stocs_find_congruent_all over the concatenated base sets, all pieces)", ms_cong);
         put("transforms of all trials (stocs_make_transforms, all pieces)", ms_xf);
         put("verification: scoring launch(es) + per-trial arg-max + read-back, all pieces", ms_ver);
+        put("host: batch record set-up", ms_setup);
+        put("host: base sets of the pieces assembled", ms_asm);
+        put("host: per-trial results (+ candidate read-back with keep_details)", ms_res);
+        put("whole call by the host clock", now_ms() - t_entry);
         put("pieces (sets of launches) the batch was cut into", (double)B->pieces);
         TM.t_last = t_end;
     }
