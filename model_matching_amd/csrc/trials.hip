@@ -143,7 +143,7 @@ int stocs_run_trials(stocs_ctx* c, int mode, int n_trials, const uint64_t* seeds
         if (4 * id_bits < 64) max_bases = std::min(max_bases, 1ll << std::min(20, 64 - 4 * id_bits));
         max_bases = std::max(max_bases, (long long)std::max(nA, 1));     // a single trial always goes through (as it does alone)
     }
-    size_t max_bytes = (size_t)16 << 30;
+    size_t max_bytes = (size_t)48 << 30;      // of 288 GB: a Cm trial is ~0.9 GB of pair lists, and at Cm a piece is then what the 64-bit quads can key (40 trials)
     if (const char* e = getenv("STOCS_TRIALS_MAX_MB")) max_bytes = (size_t)std::max(1, atoi(e)) << 20;
     int piece_cap = nT;
     if (const char* e = getenv("STOCS_TRIALS_PER_PIECE")) piece_cap = std::max(1, atoi(e));   // (tests: forces several pieces)
