@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity sweep: N small random workloads (model size, scene size, clutter, seeds all drawn), the whole
 hot path on the GPU against the CPU oracle: bases + invariants, per-base quad counts, candidate transforms
-(bit-exact) and scores (1e-5).  Prints one line per mismatch and a summary.
+(bit-exact) and scores (1e-5; a score beyond it counts as an exact-distance tie, divergence Q11, when the per-point matches show
+two scene points equally far from the model point -- reported separately).  Prints one line per mismatch and a summary.
 With --instance the workloads also get a random edge map (passable background, random edge segments and speckle,
 some in-between values, an isolated pocket around some points) and the sampling runs in instance mode (persistent
 device kernel with the union-find flood fill) against the oracle's literal BFS, attempt by attempt, plus the segment of
@@ -15,6 +16,7 @@ import sys
 
 import numpy as np
 
+n_ties = 0
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import os as _os; _os.environ.setdefault("STOCS_PIN_BLAS", "1")   # harness side: one BLAS thread under the cgroup CPU quota; the library import itself has no side effects
@@ -64,7 +66,27 @@ def instance_leg(est, orc, rng, s, seed, nb):
     return ok, int(valid.sum())
 
 
+def is_distance_tie(est, orc, m, T16):
+    """A score beyond the tolerance is the documented divergence Q11 when every model point whose match differs has a match on
+    both sides and the two scene points are equally far from it (equal in float32: 1e-8 m apart at most in float64)."""
+    hg, cg = est.lcp_detail(T16); ho, co = orc.lcp_detail(T16)
+    bad = np.nonzero(hg != ho)[0]
+    if len(bad) == 0 or not np.array_equal(np.delete(cg, bad), np.delete(co, bad)):
+        return False
+    pos = orc.scene_centred().astype(np.float64)
+    mc = m.pos.astype(np.float32) - est.get_model_centroid().astype(np.float32)
+    T = np.asarray(T16, np.float64).reshape(4, 4).T
+    for i in bad:
+        if hg[i] < 0 or ho[i] < 0:
+            return False
+        p = T[:3, :3] @ mc[i].astype(np.float64) + T[:3, 3]
+        if abs(np.linalg.norm(p - pos[hg[i]]) - np.linalg.norm(p - pos[ho[i]])) > 1e-8:
+            return False
+    return True
+
+
 def main():
+    global n_ties
     instance = "--instance" in sys.argv
     batch = "--batch" in sys.argv
     argv = [a for a in sys.argv if a not in ("--instance", "--batch")]
@@ -101,7 +123,12 @@ def main():
         ok &= dl <= 1e-5
         if len(To):
             lo = orc.lcp_batch(To, nthreads=8)
-            dmax = float(np.abs(est.get_pose_candidates()[2] - lo).max())
+            dd = np.abs(est.get_pose_candidates()[2] - lo)
+            over = np.nonzero(dd > 1e-5)[0]
+            if len(over) and all(is_distance_tie(est, orc, m, To[c]) for c in over):
+                n_ties += len(over)            # (Q11: two scene points at the same f32 distance, the kd-tree's visiting order picks the other one)
+                dd[over] = 0.0
+            dmax = float(dd.max())
             ok &= dmax <= 1e-5
         else:
             dmax = 0.0
@@ -137,7 +164,7 @@ def main():
         est.close()
         if (k + 1) % 25 == 0:
             print("... %d workloads, %d mismatches" % (k + 1, bad), file=sys.stderr, flush=True)
-    print(json.dumps({"workloads": n, "batched_trials_checked": n_batch_trials, "instance_mode": instance, "instance_bases": n_inst_bases, "mismatches": bad, "total_quads": int(sum(x[4] for x in stats)), "total_candidates": int(sum(x[5] for x in stats)),
+    print(json.dumps({"workloads": n, "batched_trials_checked": n_batch_trials, "instance_mode": instance, "instance_bases": n_inst_bases, "mismatches": bad, "exact_distance_ties_q11": n_ties, "total_quads": int(sum(x[4] for x in stats)), "total_candidates": int(sum(x[5] for x in stats)),
                       "max_abs_lcp_diff": max(x[6] for x in stats)}))
 
 
