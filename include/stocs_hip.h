@@ -347,6 +347,12 @@ int stocs_time_score_kernel(stocs_ctx* ctx, const void* d_T16, int n, void* d_lc
  * runs the checker itself on canned sequences (no device): scenario 0 = the library's fork / join pattern (returns 0), 1-4 = one
  * missing edge each (return >= 1; first_msg receives the report). */
 int stocs_debug_stream_audit_selftest(int scenario, char* first_msg, int cap);
+/* Do the context's two streams run side by side?  1 = a kernel on the auxiliary stream ran WHILE one on the main stream was waiting
+ * for it, 0 = it did not (both streams sit on one hardware queue of the runtime, GPU_MAX_HW_QUEUES: the two-stream sections of
+ * stocs_find_congruent_all / stocs_make_transforms then run one after the other -- correct, ~13 % slower at Cm), < 0 = error.
+ * stocs_ctx_create asks the same question and takes another auxiliary stream (up to four candidates) until the answer is 1;
+ * STOCS_NO_STREAM_PROBE=1 in the environment skips that.  The context must be idle. */
+int stocs_debug_streams_overlap(stocs_ctx* ctx);
 /* number of device (hipMalloc) and pinned-host (hipHostMalloc) allocations the library has made in this process so far.
  * A warm context -- one that has run a trial of the current scene -- runs further trials without allocating: the
  * difference across them is 0. */

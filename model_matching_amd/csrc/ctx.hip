@@ -26,6 +26,39 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- do two streams run side by side? ----
+// A context runs parts of stocs_find_congruent_all / stocs_make_transforms on its auxiliary stream next to the main one.  The runtime
+// multiplexes the streams of a process onto a few hardware queues (4 per priority class by default, GPU_MAX_HW_QUEUES) and two streams on
+// one queue run one after the other: with another context and torch's streams in the process, both streams of a context shared a queue
+// and a Cm trial lost 13 % (bench.py's pipeline section: 5.9 M poses/s against 6.7 M in a trial-only process; GPU_MAX_HW_QUEUES=8 or 2, or
+// closing the other context, brought it back -- round 4).  Another priority class for the auxiliary stream separates the two for certain
+// but costs eight host threads with a context each a third of their throughput.  So the context asks the device: a one-thread kernel
+// on the first stream waits (at most 100 us) for a flag that a kernel on the second sets; it sees the flag only if the second kernel ran
+// while it was waiting.
+__global__ void overlap_wait_kernel(unsigned int* flag, unsigned int* seen) {
+    const unsigned long long t0 = wall_clock64();      // 100 MHz
+    unsigned int v = 0;
+    while ((v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u && wall_clock64() - t0 < 10000ull) __builtin_amdgcn_s_sleep(8);
+    *seen = v;
+}
+__global__ void overlap_set_kernel(unsigned int* flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// 1: the streams overlap, 0: they do not (or the probe could not run: the caller keeps what it has)
+static int streams_run_side_by_side(hipStream_t a, hipStream_t b) {
+    unsigned int* d = NULL;
+    if (dev_malloc((void**)&d, 256) != hipSuccess) return 0;
+    unsigned int h[2] = {0u, 0u};
+    int ok = 0;
+    if (hipMemsetAsync(d, 0, 8, a) == hipSuccess && hipStreamSynchronize(a) == hipSuccess) {
+        hipLaunchKernelGGL(overlap_wait_kernel, dim3(1), dim3(1), 0, a, d, d + 1);
+        hipLaunchKernelGGL(overlap_set_kernel, dim3(1), dim3(1), 0, b, d);
+        if (hipStreamSynchronize(a) == hipSuccess && hipStreamSynchronize(b) == hipSuccess && hipMemcpy(h, d, 8, hipMemcpyDeviceToHost) == hipSuccess) ok = h[1] != 0u;
+    }
+    (void)hipGetLastError();
+    (void)hipFree(d);
+    return ok;
+}
+
 static inline int32_t float_ord(float f) {
     int32_t i;
     memcpy(&i, &f, 4);
@@ -458,6 +491,17 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     }
     for (int k = 0; k < 10; ++k)
         if (hipEventCreate(&c->ev_t[k]) != hipSuccess) { set_error("event creation failed"); delete c; return STOCS_ERR_NO_DEVICE; }
+    if (!getenv("STOCS_NO_STREAM_PROBE")) {   // an auxiliary stream that runs NEXT to the main one (see streams_run_side_by_side): up to four candidates
+        hipStream_t spare[4]; int n_spare = 0;
+        while (!streams_run_side_by_side(c->own_stream, c->aux_stream) && n_spare < 4) {
+            hipStream_t s2 = NULL;
+            if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+            spare[n_spare++] = c->aux_stream;      // (kept alive until the choice is made: the runtime hands the next stream another queue)
+            c->aux_stream = s2;
+        }
+        for (int k = 0; k < n_spare; ++k) (void)hipStreamDestroy(spare[k]);
+        if (getenv("STOCS_DEBUG_TIMING")) fprintf(stderr, "[stocs ctx] auxiliary stream: candidate %d runs next to the main stream\n", n_spare + 1);
+    }
     c->stream = c->own_stream;
     compute_thresholds(c->prm, &c->thr);
 
@@ -670,6 +714,15 @@ int stocs_last_call_timing(const stocs_ctx* c, int which, const char** labels, d
 // pattern of the library (no violation), 1 = a use on the auxiliary stream without the main -> aux edge, 2 = the main stream reads
 // what the auxiliary stream wrote without the aux -> main edge, 3 = the arena is recycled while the auxiliary stream still writes,
 // 4 = a write behind a read of the other stream without an edge.  Returns the number of violations found.
+int stocs_debug_streams_overlap(stocs_ctx* c) {
+    if (!c) return STOCS_ERR_INVALID;
+    DeviceGuard dev_guard(c->device);
+    if (!c->own_stream || !c->aux_stream) return 0;
+    STOCS_HIP_CHECK(hipStreamSynchronize(c->own_stream));
+    STOCS_HIP_CHECK(hipStreamSynchronize(c->aux_stream));
+    return streams_run_side_by_side(c->own_stream, c->aux_stream);
+}
+
 int stocs_debug_stream_audit_selftest(int scenario, char* first_msg, int cap) {
     StreamAudit A;
     A.begin(true);

@@ -325,6 +325,23 @@ def test_one_sizing_synchronisation_point_and_its_fallback(setup, monkeypatch):
     assert est.find_congruent_all() == 0
 
 
+def test_the_two_streams_of_every_context_run_side_by_side(setup):
+    """The runtime multiplexes a process's streams onto a few hardware queues; two streams on one queue run one after the other, and
+    with several contexts in a process a context's own two ended up there (a Cm trial 13 % slower, round 4).  stocs_ctx_create probes
+    its auxiliary stream against the main one and takes another candidate until a kernel on the one runs while a kernel on the other
+    waits for it: true for the module's context and for three more created next to it."""
+    m, s, est, orc = setup
+    from model_matching_amd.estimator import StocsEstimator
+    more = [StocsEstimator(s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm, build_index=False) for _ in range(3)]
+    try:
+        for e in [est] + more:
+            e.sync()
+            assert e.L.stocs_debug_streams_overlap(e.h) == 1
+    finally:
+        for e in more:
+            e.close()
+
+
 def test_two_stream_sections_pass_the_happens_before_audit(setup, monkeypatch):
     """STOCS_DEBUG_STREAMS=1: stocs_find_congruent_all and stocs_make_transforms describe every buffer their two streams share and
     the event edges between them to a host-side checker (stream_audit.h) and fail on a use without an edge.  The reduced and the

@@ -45,6 +45,13 @@ def main():
     est.sync()
     t_ctx = time.perf_counter() - t
     rep = {"workload": name, "nS": est.nS, "nM": est.nM, "ctx_create_incl_index_s": t_ctx, "index": est.index_stats(), "runs": []}
+    if os.environ.get("PT_BURN") and T_gt is not None:      # A/B: what bench.py has done to the chip before its pipeline section -- PT_BURN launches of the 65 536-candidate metric batch on a second context
+        est2 = StocsEstimator(*args, build_index=False)
+        T = synth.make_candidates(T_gt, k)
+        for _ in range(int(os.environ["PT_BURN"])):
+            est2.score_transforms(T)
+        if os.environ.get("PT_BURN_CLOSE"):
+            est2.close()
     for r in range(reps):
         est.L.stocs_clear_bases(est.h)
         t0 = time.perf_counter()
