@@ -325,6 +325,30 @@ def test_one_sizing_synchronisation_point_and_its_fallback(setup, monkeypatch):
     assert est.find_congruent_all() == 0
 
 
+def test_occupancy_bits_in_device_memory_give_the_same_sets(setup, monkeypatch):
+    """The occupancy of a (base, cell) is one bit; while the bits of one base fit 32 KB the gather collects them in LDS and the count tests them
+    there (round 4).  A finer position grid keeps them in device memory (atomicOr per entry, one read per entry): forced here, same counts,
+    same quads, single trial and batch."""
+    m, s, est, orc = setup
+    est.L.stocs_clear_bases(est.h)
+    valid, ids, inv = est.sample_bases(9091, 24)
+    nv = int(valid.sum())
+    n_lds = est.find_congruent_all()
+    quads = [est.get_quads(k) for k in range(nv)]
+    res = est.run_trials([11, 12, 13], 24, max_per_base=40, keep_details=True)
+    cands = [est.trial_candidates(t)[0] for t in range(3)]
+    monkeypatch.setenv("STOCS_CONGRUENT_NO_LDS_BITS", "1")
+    est.L.stocs_clear_bases(est.h)
+    est.sample_bases(9091, 24)
+    assert est.find_congruent_all() == n_lds and n_lds > 0
+    for k in range(nv):
+        assert np.array_equal(est.get_quads(k), quads[k])
+    res2 = est.run_trials([11, 12, 13], 24, max_per_base=40, keep_details=True)
+    for t in range(3):
+        assert (res2[t]["n_quads"], res2[t]["n_candidates"], res2[t]["best_index"], res2[t]["best_lcp"]) == (res[t]["n_quads"], res[t]["n_candidates"], res[t]["best_index"], res[t]["best_lcp"])
+        assert np.array_equal(est.trial_candidates(t)[0], cands[t])
+
+
 def test_the_two_streams_of_every_context_run_side_by_side(setup):
     """The runtime multiplexes a process's streams onto a few hardware queues; two streams on one queue run one after the other, and
     with several contexts in a process a context's own two ended up there (a Cm trial 13 % slower, round 4).  stocs_ctx_create probes
