@@ -1579,7 +1579,10 @@ int stocs_internal_find_congruent(stocs_ctx* c, int64_t* total_quads, size_t max
         const size_t occ = reduce ? 2 * (((size_t)nB << cell_bits) / 8 + 8) : 0;
         const size_t need = (size_t)nP * per_entry + (size_t)nQ * per_entry + tables + occ + ((size_t)48 << 20);
         if (max_bytes && need > max_bytes && nB > 1) { *over = true; return STOCS_OK; }
-        return S->arena_state.reserve(need);
+        // (under a ceiling -- a piece of a trial batch -- the slab is 1.5 x the need, not twice it: 40 Cm trials need 36 GB)
+        const int rc_r = S->arena_state.reserve(need, max_bytes ? 1.5 : 2.0);
+        if (rc_r == STOCS_ERR_NOMEM && max_bytes && nB > 1) { *over = true; return STOCS_OK; }   // the device is fuller than the ceiling assumes: the caller halves the piece
+        return rc_r;
     };
     {
         bool over = false;

@@ -96,13 +96,17 @@ struct Arena {
         return STOCS_OK;
     }
     // right after reset(): make sure ONE slab can hold `bytes` (a good estimate up front avoids growing in pieces)
-    int reserve(size_t bytes) {
+    // headroom 2: a later trial of the same scene with more pair-list entries must not regrow the slab (a 0.6 GB
+    // hipFree + hipMalloc inside a trial was the 78 ms outlier of BENCH_r01's pipeline run 4).  A piece of a trial batch is sized
+    // against a memory ceiling and asks for little more than it needs; when the device cannot give that either the caller gets
+    // STOCS_ERR_NOMEM and cuts the piece (stocs_run_trials).
+    int reserve(size_t bytes, double headroom = 2.0) {
         if (slabs.size() == 1 && slabs[0].cap >= bytes) return STOCS_OK;
         destroy();
-        // twice the need: a later trial of the same scene with more pair-list entries must not regrow the slab (a 0.6 GB
-        // hipFree + hipMalloc inside a trial was the 78 ms outlier of BENCH_r01's pipeline run 4)
-        Slab sl = {NULL, 2 * bytes, 0};
-        STOCS_HIP_CHECK(dev_malloc((void**)&sl.p, sl.cap));
+        Slab sl = {NULL, (size_t)((double)bytes * headroom), 0};
+        const hipError_t e = dev_malloc((void**)&sl.p, sl.cap);
+        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); stocs::set_error("arena of %zu bytes: out of device memory", sl.cap); return STOCS_ERR_NOMEM; }
+        STOCS_HIP_CHECK(e);
         slabs.push_back(sl);
         return STOCS_OK;
     }
