@@ -235,12 +235,14 @@ __global__ __launch_bounds__(256) void gather_key_kernel(const uint32_t* __restr
         nseg = (int)(is_q ? po->n_qseg : po->n_pseg);
     }
     // A workgroup takes a contiguous run of tiles (GATHER_EPT * 256 entries each; a thread GATHER_EPT of them 256 apart, coalesced),
-    // the launch at most GATHER_MAX_WGS workgroups.  One workgroup per tile made this kernel a chain of dependent look-ups per
-    // workgroup -- a binary search over the segments (12 scalar loads one after the other), segment -> base job -> pair -> two model
-    // points -- paid 9 000 times at Cm: 103 us for 9.5 M entries, of which 62 us remained with the pair load as the ONLY memory
-    // access (ablation, round 4).  Now the search runs once per workgroup and the segment of a wavefront's entries is wave-uniform
-    // STATE carried from tile to tile (a segment holds thousands of entries: the next boundary is compared, not loaded), so the
-    // steady state is pair load -> model points -> stores.
+    // the launch at most GATHER_MAX_WGS workgroups: the binary search over the segments (12 scalar loads one after the other) runs once
+    // per workgroup, the segment of a wavefront's entries is wave-uniform STATE carried from tile to tile (a segment holds thousands
+    // of entries: the next boundary is compared, not loaded), and the workgroup owns the LDS bits of "its" base across its tiles.  The
+    // steady state is pair load -> two model points -> stores: three dependent round trips per tile, ~10 us per tile with eight
+    // workgroups on a CU (device clock of one workgroup, round 4).  The kernel is bound by the bytes its waves keep in flight (1.5 TB/s
+    // over both lists, waves waiting 53 %, no unit above 0.65 busy); by ablation (one list, 9.5 M entries, 103 us): without the
+    // occupancy marks 83, without the (key, pair) stores 83, with nothing but the pair load 62.  Prefetching the next tile's pairs,
+    // the model in LDS and 64-bit products as shifts were measured and not kept.
     const uint32_t n_tiles = (total + GATHER_TILE - 1u) / GATHER_TILE;
     const uint32_t per_wg = (n_tiles + gridDim.x - 1u) / gridDim.x;
     const uint32_t t_begin = blockIdx.x * per_wg, t_end = min(n_tiles, t_begin + per_wg);
