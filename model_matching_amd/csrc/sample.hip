@@ -1044,6 +1044,7 @@ __global__ __launch_bounds__(1024) void instance_attempts_kernel(InstanceArgs A,
 // exceeds r is a non-zero one), so drawing among the compacted survivors equals drawing among all points.
 // Replaces nine launches (init, 4 x draw, 3 x pass, finalize) whose passes each walked every scene point of every attempt.
 // ---------------------------------------------------------------------------------------------------------------
+#define CLASS_TWO_LDS ((size_t)78 * 1024)     // two workgroups of class_attempts_kernel<true, true> on a CU: 2 x (this + ~1 KB of static LDS) <= 160 KB
 struct ClassArgs {
     PassArgs pa;
     int draw_per_thread;        // (the prior every attempt starts from, stocs.cpp:372-381, is the .w of the scene positions)
@@ -1056,8 +1057,12 @@ struct ClassArgs {
     int wg_offset;              // workgroup blockIdx.x is attempt slot wg_offset + blockIdx.x of the batch (launches of big scenes come in pieces)
 };
 
-template <bool WLDS>
-__global__ __launch_bounds__(1024) void class_attempts_kernel(ClassArgs A, uint64_t seed, int first_attempt, int n_attempts) {
+// TWO: built for 64 VGPRs (a few spills) so that TWO workgroups share a CU when the attempt's LDS image allows it (scenes up to ~13 000
+// points): the kernel waits on its bitmap probes and barriers most of the time, and a trial batch brings thousands of workgroups -- 64
+// linemod trials 0.90 -> 0.65 ms of sampling (33 000 -> 36 600 trials/s; 1 024 trials in one call 45 900 -> 53 500).  The 80-VGPR build
+// serves larger scenes (one workgroup per CU either way).
+template <bool WLDS, bool TWO = false>
+__global__ __launch_bounds__(1024, TWO ? 8 : 4) void class_attempts_kernel(ClassArgs A, uint64_t seed, int first_attempt, int n_attempts) {
     typedef typename InstTypes<WLDS>::sv_t sv_t;
     extern __shared__ __align__(16) unsigned char cls_dyn[];
     __shared__ uint64_t sh16[32];
@@ -1250,7 +1255,10 @@ static int sample_class(stocs_ctx* c, uint64_t seed, int first_attempt, int nB, 
         STOCS_HIP_CHECK(hipMemsetAsync(A.stamps, 0, 128, c->stream));
     }
     const size_t lds = wlds ? ((S * 4 + 15) & ~(size_t)15) + S * 2 + 16 : 0;
-    if (wlds) {
+    if (wlds && lds <= CLASS_TWO_LDS && nB > 256) {     // (more workgroups than CUs: two per CU pay)
+        STOCS_HIP_CHECK(hipFuncSetAttribute((const void*)class_attempts_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CLASS_TWO_LDS));
+        hipLaunchKernelGGL((class_attempts_kernel<true, true>), dim3((unsigned)nB), dim3(1024), lds, c->stream, A, seed, first_attempt, nB);
+    } else if (wlds) {
         STOCS_HIP_CHECK(hipFuncSetAttribute((const void*)class_attempts_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
         hipLaunchKernelGGL(class_attempts_kernel<true>, dim3((unsigned)nB), dim3(1024), lds, c->stream, A, seed, first_attempt, nB);
     } else {
@@ -1528,10 +1536,12 @@ int sample_trials(stocs_ctx* c, int mode, int nT, const uint64_t* seeds, int nA,
         STOCS_HIP_CHECK(hipMemcpyAsync(d_seeds, (char*)c->h_pin + PIN_VAR, (size_t)nT * 8, hipMemcpyHostToDevice, c->stream));
         const size_t lds = wlds ? ((S * 4 + 15) & ~(size_t)15) + S * 2 + 16 : 0;
         if (wlds) STOCS_HIP_CHECK(hipFuncSetAttribute((const void*)class_attempts_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+        if (wlds && lds <= CLASS_TWO_LDS) STOCS_HIP_CHECK(hipFuncSetAttribute((const void*)class_attempts_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CLASS_TWO_LDS));
         for (size_t w0 = 0; w0 < nW; w0 += per_launch) {
             const unsigned n = (unsigned)std::min(per_launch, nW - w0);
             A.wg_offset = (int)w0;
-            if (wlds) hipLaunchKernelGGL(class_attempts_kernel<true>, dim3(n), dim3(1024), lds, c->stream, A, (uint64_t)0, 0, (int)n);
+            if (wlds && lds <= CLASS_TWO_LDS && n > 256) hipLaunchKernelGGL((class_attempts_kernel<true, true>), dim3(n), dim3(1024), lds, c->stream, A, (uint64_t)0, 0, (int)n);
+            else if (wlds) hipLaunchKernelGGL(class_attempts_kernel<true>, dim3(n), dim3(1024), lds, c->stream, A, (uint64_t)0, 0, (int)n);
             else hipLaunchKernelGGL(class_attempts_kernel<false>, dim3(n), dim3(1024), 0, c->stream, A, (uint64_t)0, 0, (int)n);
         }
         STOCS_HIP_CHECK(hipGetLastError());
