@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256) void gather_key_kernel(const uint32_t* __restr
     // instead of one scattered store per entry); entries of another base in the same tile (a boundary tile) go to the table directly.
     extern __shared__ uint32_t s_occ[];
     if (po) {
+        if (po->overflow) return;          // >= 2^32 planned entries: the segments' 32-bit destinations have wrapped; the host reports STOCS_ERR_CAPACITY
         const unsigned long long t = is_q ? po->totQ : po->totP;
         total = t < (unsigned long long)total ? (uint32_t)t : total;      // never beyond the buffers (a plan beyond the capacity is redone by the host)
         nseg = (int)(is_q ? po->n_qseg : po->n_pseg);
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(256) void survivors_count_kernel(const KeyT* __rest
                                                               unsigned long long* __restrict__ alive_bits, uint32_t lds_words, int cell_bits) {
     extern __shared__ uint32_t s_occ[];
     __shared__ uint32_t s_w[4];
-    if (po) { const unsigned long long t = is_q ? po->totQ : po->totP; n = t < (unsigned long long)n ? (uint32_t)t : n; }
+    if (po) { if (po->overflow) return; const unsigned long long t = is_q ? po->totQ : po->totP; n = t < (unsigned long long)n ? (uint32_t)t : n; }   // (overflow: the gather wrote nothing)
     const uint32_t n_tiles = (n + SURV_TILE - 1u) / SURV_TILE;
     const uint32_t per_wg = (n_tiles + gridDim.x - 1u) / gridDim.x;
     const uint32_t t_begin = blockIdx.x * per_wg, t_end = min(n_tiles, t_begin + per_wg);
@@ -421,14 +422,23 @@ template <class KeyT>
 __global__ __launch_bounds__(256) void survivors_base_offsets_kernel(const KeyT* __restrict__ pkeys, uint32_t nP, const uint32_t* __restrict__ occ_q,
                                                                      const uint32_t* __restrict__ tiles_p, const KeyT* __restrict__ qkeys, uint32_t nQ,
                                                                      const uint32_t* __restrict__ occ_p, const uint32_t* __restrict__ tiles_q, int nB,
-                                                                     BaseJob* __restrict__ jobs, uint32_t* __restrict__ p_off, uint32_t* __restrict__ q_off) {
+                                                                     BaseJob* __restrict__ jobs, uint32_t* __restrict__ p_off, uint32_t* __restrict__ q_off,
+                                                                     const PlanOut* __restrict__ po) {
     __shared__ uint32_t s_w[2][4];
     const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool q = blockIdx.y == 1;
+    // po != NULL: nP / nQ are the CAPACITIES the key buffers and the tile arrays were sized by, the base jobs carry the PLANNED
+    // stretches.  A plan beyond a capacity is redone by the host with exact sizes (count_pass returns 1 at its read-back), so this
+    // launch has nothing to deliver -- and must not follow planned offsets past the gathered keys and the scanned tiles (the
+    // unguarded form of round 4 read keys[e] beyond d_pk_raw / d_qk_raw and used what it found there as an occupancy index, up to
+    // 512 MB past the table).  The test is uniform over the grid: either every workgroup works or none does.
+    if (po && (po->overflow || po->totP > (unsigned long long)nP || po->totQ > (unsigned long long)nQ)) return;
     const KeyT* keys = q ? qkeys : pkeys;
     const uint32_t* other = q ? occ_p : occ_q;
     const uint32_t* tiles = q ? tiles_q : tiles_p;
-    const uint32_t r0 = q ? jobs[b].q_off : jobs[b].p_off, r1 = r0 + (q ? jobs[b].q_len : jobs[b].p_len);
+    const uint32_t cap = q ? nQ : nP;
+    uint32_t r0 = q ? jobs[b].q_off : jobs[b].p_off, r1 = r0 + (q ? jobs[b].q_len : jobs[b].p_len);
+    r0 = min(r0, cap); r1 = min(max(r1, r0), cap);      // (belt and braces: tiles[] holds cap / SURV_TILE + 1 entries, keys[] cap)
     uint32_t got[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -453,7 +463,7 @@ __global__ __launch_bounds__(256) void survivors_compact_kernel(const KeyT* __re
                                                                 const unsigned long long* __restrict__ alive_bits, const uint32_t* __restrict__ tile_off,
                                                                 KeyT* __restrict__ okeys, uint32_t* __restrict__ ovals, const PlanOut* __restrict__ po, int is_q) {
     constexpr int R = SURV_TILE / 256;
-    if (po) { const unsigned long long t = is_q ? po->totQ : po->totP; n = t < (unsigned long long)n ? (uint32_t)t : n; }
+    if (po) { if (po->overflow) return; const unsigned long long t = is_q ? po->totQ : po->totP; n = t < (unsigned long long)n ? (uint32_t)t : n; }
     if (blockIdx.x * SURV_TILE >= n) return;
     __shared__ uint32_t s_c[R][4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1180,7 +1190,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         hipLaunchKernelGGL(survivors_scan_kernel, dim3(2), dim3(1024), 0, st, d_surv.p + o_tp, ntp, d_surv.p + o_tq, ntq);
         hipLaunchKernelGGL(survivors_base_offsets_kernel<KeyT>, dim3((unsigned)nB, 2), dim3(256), 0, st, (const KeyT*)d_pk_raw.p, (uint32_t)totP0, (const uint32_t*)occ_q,
                            (const uint32_t*)(d_surv.p + o_tp), (const KeyT*)d_qk_raw.p, (uint32_t)totQ0, (const uint32_t*)occ_p, (const uint32_t*)(d_surv.p + o_tq), nB,
-                           S->d_jobs.p, plan.p_off, plan.q_off);
+                           S->d_jobs.p, plan.p_off, plan.q_off, d_po);
         STOCS_HIP_CHECK(hipGetLastError());
         // the host sizes the sorts and the join with the survivors' totals and lays the materialise blocks out with their Q offsets
         uint32_t* qoff_pin = (uint32_t*)((char*)c->h_pin + PIN_VAR + 8 * ((size_t)nB + 1));
@@ -1605,7 +1615,7 @@ int stocs_internal_find_congruent(stocs_ctx* c, int64_t* total_quads, size_t max
     S->base_in_key = 4 * id_bits + base_bits <= 64;
     S->no_quads = false;
     int rc = wide ? count_pass<uint64_t>(c, S, plan, dbg, tprev, d_po, po_pinned) : count_pass<uint32_t>(c, S, plan, dbg, tprev, d_po, po_pinned);
-    if (optimistic && rc <= 1) {   // (the read-back of count_pass brought the plan's totals)
+    if (optimistic && (rc == STOCS_OK || rc == 1)) {   // (the read-back of count_pass brought the plan's totals; on an error the copy may not have landed: the history stays as it was)
         const PlanOut po = *po_pinned;
         if (po.overflow) { set_error("pair lists exceed 2^32 entries"); return STOCS_ERR_CAPACITY; }
         S->hist_P = po.totP; S->hist_Q = po.totQ; S->hist_nB = nB;

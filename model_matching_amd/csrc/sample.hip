@@ -967,13 +967,18 @@ __global__ __launch_bounds__(1024) void instance_attempts_kernel(InstanceArgs A,
     for (int a = 0; a < n_attempts; ++a) {
         const int attempt = first_attempt + a;
         BaseOut* out = A.res + a;
-        if (threadIdx.x == 0) {                                               // bounded wait for the slot (a few seconds at the outside)
-            unsigned spins = 0;
-            // relaxed polls (a coherent read of the one flag word); the acquire is the fence every thread executes behind the
+        if (threadIdx.x == 0) {
+            // Wait for the slot.  The producer of this pair has the lower workgroup index, so it was dispatched BEFORE this workgroup
+            // and is resident (or done) whatever the number of CUs, partitions or other contexts on the device: it never waits for
+            // anybody, so a busy device can only delay it.  The bound is therefore in wall-clock time of the constant 100 MHz counter
+            // (20 s: an exit condition every wave reaches, far beyond any delay a shared device produces), not in polls -- round 4
+            // counted 2^21 polls, ~2-4 s, which another context's 1024-thread workgroups on the same CUs could have exhausted.
+            // Relaxed polls (a coherent read of the one flag word); the acquire is the fence every thread executes behind the
             // barrier below -- an acquire per poll would invalidate this XCD's L2 a million times a second under whoever shares it
+            const unsigned long long t_wait0 = wall_clock64();
             while (__hip_atomic_load(A.q_flag + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                 __builtin_amdgcn_s_sleep(16);
-                if (++spins > (1u << 21)) { sh_abort = 1; break; }
+                if (wall_clock64() - t_wait0 > 2000000000ull) { sh_abort = 1; break; }
             }
         }
         __syncthreads();
@@ -1595,11 +1600,15 @@ int sample_trials(stocs_ctx* c, int mode, int nT, const uint64_t* seeds, int nA,
         const void* fn = wlds ? (const void*)instance_attempts_kernel<true> : (const void*)instance_attempts_kernel<false>;
         STOCS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
     }
-    // The two workgroups of a trial wait for each other through device memory (the second polls the first's flags with a bounded
-    // wait): both must be resident together.  A workgroup of 1024 threads with this much LDS takes a whole CU, the chip has 256 and
-    // the hardware starts workgroups in index order: at most 128 trials per launch keeps every pair resident.
-    for (int t0 = 0; t0 < nT; t0 += 128) {
-        const int n = std::min(128, nT - t0);
+    // The second workgroup of a trial polls the first's flags.  Correctness does not depend on the launch size: a consumer only waits
+    // for the producer with the next-lower workgroup index, which the hardware has dispatched before it (workgroups start in index
+    // order).  The launch is cut to one workgroup per CU of THIS device (a 1024-thread workgroup with this much LDS takes a whole
+    // CU) so that every pair of a launch starts together instead of consumers idling on CUs that later producers are waiting for.
+    int n_cu = 256;
+    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && v > 0) n_cu = v; }
+    const int per_launch = std::max(1, n_cu / 2);
+    for (int t0 = 0; t0 < nT; t0 += per_launch) {
+        const int n = std::min(per_launch, nT - t0);
         InstanceArgs B = A;
         B.n_trials = n; B.seeds = d_seeds + t0;
 #define TR_ADV(p) B.p = (decltype(B.p))((char*)(A.p) + (size_t)t0 * stride)

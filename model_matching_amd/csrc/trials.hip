@@ -121,7 +121,7 @@ int stocs_run_trials(stocs_ctx* c, int mode, int n_trials, const uint64_t* seeds
     if (nT == 0) return STOCS_OK;
     if (nA > 0 && c->nS > 0) {
         const int rc = sample_trials(c, mode, nT, seeds, nA, dispersion, B->res.data(), &c->snrmw_trial0, &c->snrmw_stride);
-        if (rc) { clear_trial_batch(c); return rc; }
+        if (rc) { clear_trial_batch(c); B->nT = 0; B->out.clear(); return rc; }
     }
     const float4* snrmw0 = c->snrmw_trial0;
     TM.lap("sampling: every attempt of every trial in one launch + read-back");
@@ -149,6 +149,9 @@ int stocs_run_trials(stocs_ctx* c, int mode, int n_trials, const uint64_t* seeds
     if (const char* e = getenv("STOCS_TRIALS_PER_PIECE")) piece_cap = std::max(1, atoi(e));   // (tests: forces several pieces)
     std::vector<int32_t> n_valid((size_t)nT, 0);
     for (int t = 0; t < nT; ++t) for (int a = 0; a < nA; ++a) n_valid[(size_t)t] += B->res[(size_t)t * nA + a].valid ? 1 : 0;
+    // A HIP error inside a piece leaves through the common epilogue below (batch state cleared, context reset, the batch record
+    // marked invalid) instead of returning from the middle of the loop with a half-filled record that the getters would serve.
+#define TRIALS_HIP_TRY(expr) { const hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); rc = STOCS_ERR_HIP; break; } }
     int rc = STOCS_OK;
     for (int t0 = 0; t0 < nT && !rc;) {
         int t1 = t0;
@@ -209,23 +212,23 @@ int stocs_run_trials(stocs_ctx* c, int mode, int n_trials, const uint64_t* seeds
             int32_t* off_pin = (int32_t*)((char*)c->h_pin + PIN_VAR);
             float* out_pin = (float*)((char*)c->h_pin + PIN_VAR + ob);
             memcpy(off_pin, c->trial_cand_off.data(), 4 * ((size_t)nTp + 1));
-            STOCS_HIP_CHECK(hipMemcpyAsync(d_off, off_pin, 4 * ((size_t)nTp + 1), hipMemcpyHostToDevice, c->stream));
+            TRIALS_HIP_TRY(hipMemcpyAsync(d_off, off_pin, 4 * ((size_t)nTp + 1), hipMemcpyHostToDevice, c->stream));
             if (!per_trial_weights) {
                 if ((rc = launch_lcp(c, cand_T(c), n_cand, cand_lcp(c), NULL, NULL, NULL, 0))) break;
             } else {
                 // instance mode: every candidate against the class probabilities as ITS trial's sampling decayed them (Q8) -- still ONE
                 // launch: the kernel picks the trial's copy of the scene normals + weights per candidate (LcpArgs::cand_trial)
                 hipLaunchKernelGGL(cand_trial_kernel, dim3((unsigned)((n_cand + 255) / 256)), dim3(256), 0, c->stream, (const int32_t*)d_off, nTp, t0, n_cand, d_ct);
-                STOCS_HIP_CHECK(hipGetLastError());
+                TRIALS_HIP_TRY(hipGetLastError());
                 c->snrmw_override = snrmw0; c->lcp_cand_trial = d_ct;
                 rc = launch_lcp(c, cand_T(c), n_cand, cand_lcp(c), NULL, NULL, NULL, 0);
                 c->snrmw_override = NULL; c->lcp_cand_trial = NULL;
                 if (rc) break;
             }
             hipLaunchKernelGGL(trial_best_kernel, dim3((unsigned)nTp), dim3(256), 0, c->stream, (const float*)cand_lcp(c), (const float*)cand_P(c), (const int32_t*)d_off, d_out);
-            STOCS_HIP_CHECK(hipGetLastError());
-            STOCS_HIP_CHECK(hipMemcpyAsync(out_pin, d_out, (size_t)nTp * 18 * 4, hipMemcpyDeviceToHost, c->stream));
-            STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+            TRIALS_HIP_TRY(hipGetLastError());
+            TRIALS_HIP_TRY(hipMemcpyAsync(out_pin, d_out, (size_t)nTp * 18 * 4, hipMemcpyDeviceToHost, c->stream));
+            TRIALS_HIP_TRY(hipStreamSynchronize(c->stream));
             memcpy(out18.data(), out_pin, (size_t)nTp * 18 * 4);
             c->cands_stale = true;
         }
@@ -235,11 +238,11 @@ int stocs_run_trials(stocs_ctx* c, int mode, int n_trials, const uint64_t* seeds
         std::vector<float> hT, hP, hL; std::vector<int32_t> hB;
         if (B->keep && n_cand > 0) {
             hT.resize((size_t)n_cand * 16); hP.resize((size_t)n_cand * 16); hL.resize((size_t)n_cand); hB.resize((size_t)n_cand);
-            STOCS_HIP_CHECK(hipMemcpyAsync(hT.data(), cand_T(c), (size_t)n_cand * 64, hipMemcpyDeviceToHost, c->stream));
-            STOCS_HIP_CHECK(hipMemcpyAsync(hP.data(), cand_P(c), (size_t)n_cand * 64, hipMemcpyDeviceToHost, c->stream));
-            STOCS_HIP_CHECK(hipMemcpyAsync(hL.data(), cand_lcp(c), (size_t)n_cand * 4, hipMemcpyDeviceToHost, c->stream));
-            STOCS_HIP_CHECK(hipMemcpyAsync(hB.data(), cand_base(c), (size_t)n_cand * 4, hipMemcpyDeviceToHost, c->stream));
-            STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+            TRIALS_HIP_TRY(hipMemcpyAsync(hT.data(), cand_T(c), (size_t)n_cand * 64, hipMemcpyDeviceToHost, c->stream));
+            TRIALS_HIP_TRY(hipMemcpyAsync(hP.data(), cand_P(c), (size_t)n_cand * 64, hipMemcpyDeviceToHost, c->stream));
+            TRIALS_HIP_TRY(hipMemcpyAsync(hL.data(), cand_lcp(c), (size_t)n_cand * 4, hipMemcpyDeviceToHost, c->stream));
+            TRIALS_HIP_TRY(hipMemcpyAsync(hB.data(), cand_base(c), (size_t)n_cand * 4, hipMemcpyDeviceToHost, c->stream));
+            TRIALS_HIP_TRY(hipStreamSynchronize(c->stream));
         }
         for (int t = 0; t < nTp; ++t) {
             stocs_trial_result& R = B->out[(size_t)(t0 + t)];
@@ -275,11 +278,12 @@ int stocs_run_trials(stocs_ctx* c, int mode, int n_trials, const uint64_t* seeds
         ms_res += now_ms() - ta;
         t0 = t1;
     }
+#undef TRIALS_HIP_TRY
     // the context is left as stocs_reset_trial leaves it: no bases, no candidates (the batch's results live in the batch record)
     clear_trial_batch(c);
     c->bases.clear(); c->quad_off.clear(); clear_candidates(c);
     c->best_lcp = 0; c->best_index = -1;
-    if (rc) return rc;
+    if (rc) { B->nT = 0; B->out.clear(); return rc; }     // no results: stocs_trials_get_* answer STOCS_ERR_STATE ("trial out of range") for a failed batch
     {
         const double t_end = CallTiming::now_s();
         auto put = [&](const char* what, double ms) { if (TM.n < CallTiming::MAX_STEPS) { TM.label[TM.n] = what; TM.ms[TM.n] = ms; ++TM.n; } };
