@@ -82,7 +82,7 @@ def add_counters(rec, nested, workload, candidates_arg, groups=None):
         if shutil.which("rocprofv3"):
             pdir = tempfile.mkdtemp(prefix="stocs_pmc_")
             child = ["python3", os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pipeline", "--no-pmc", "--no-c5", "--no-hits",
-                     "--workload", workload] + (["--candidates", str(candidates_arg)] if candidates_arg else [])
+                     "--details", os.devnull, "--workload", workload] + (["--candidates", str(candidates_arg)] if candidates_arg else [])
             grp = pmc_tool.GROUPS if not groups else type(pmc_tool.GROUPS)((g, pmc_tool.GROUPS[g]) for g in groups if g in pmc_tool.GROUPS)
             raw = pmc_tool.collect("lcp_coopq_kernel<false", child, pdir, groups=grp)   # the scoring kernel, not its per-point detail form (<true, ...>)
             der = pmc_tool.derive(raw, k_ms)
@@ -240,6 +240,155 @@ def pipeline_report(model, scene, device, n_runs=8, batch_trials=16):
     return rep
 
 
+
+def _sig(x, n=6):
+    """Floats to n significant digits (the contract line must stay small); everything else unchanged."""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (n, x))
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, n) for v in x]
+    if isinstance(x, dict):
+        return {k: _sig(v, n) for k, v in x.items()}
+    if isinstance(x, (np.floating,)):
+        return _sig(float(x), n)
+    if isinstance(x, (np.integer,)):
+        return int(x)
+    return x
+
+
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "contract_frac", "needed_frac", "memory_side_frac",
+                 "traffic_over_needed", "binding_unit", "binding_frac", "hits_per_pose", "ta_busy_frac", "valu_issue_frac", "l2_to_l1_frac_128B",
+                 "c5_kernel_ms", "c5_kernel_poses_per_s", "c5_contract_frac", "c5_needed_frac", "c5_memory_side_bytes_per_launch", "c5_memory_side_frac",
+                 "c5_traffic_over_needed", "c5_binding_unit", "c5_binding_frac", "c5_hits_per_pose", "c5_oracle_max_abs_lcp_diff")
+COMPACT_LIMIT = 4096
+
+
+def compact_line(full):
+    """The contract line: ONE small JSON object (< 4 KB) with scalars only -- the contract keys, a flat roofline, the CPU baselines, the
+    oracle check and the medians of the whole-path sections.  Everything else (per-run tables, step records, counter nests, notes) lives
+    in bench_details.json next to this script.  Round 4's line had grown to 34 KB and the driver could not parse it."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    out = {k: full.get(k) for k in keep}
+    cfg = full.get("config", {})
+    out["config"] = {k: cfg.get(k) for k in ("workload", "candidates_per_step_per_gpu", "scene_points", "model_points", "parallelism")}
+    out["final_lcp_percent"] = full.get("final_lcp_percent")
+    if full.get("rehearsal"):
+        out["rehearsal"] = True                                 # (ranks sharing one GPU over gloo: never a measurement)
+    di = full.get("distributed")
+    if di:
+        out["distributed"] = {"world_size": di.get("world_size"), "backend": di.get("backend"), "ranks_reporting": [r.get("rank") for r in di.get("ranks", [])][:8]}
+    rf = full.get("roofline", {})
+    out["roofline"] = {k: rf.get(k) for k in ROOFLINE_KEYS if k in rf}
+    cb = full.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")}
+    ca = full.get("cpu_baseline_all_cores")
+    if ca:
+        out["cpu_baseline_all_cores"] = {"value": ca.get("value"), "cores": ca.get("cores")}
+    oc = full.get("oracle_check")
+    if oc:
+        out["oracle_check"] = {k: oc.get(k) for k in ("candidates_compared", "max_abs_lcp_diff_vs_gpu", "within_tolerance")}
+    pl = full.get("pipeline")
+    if pl:
+        runs = [r for r in pl.get("runs", []) if not r.get("warmup")]
+        if runs:
+            out["pipeline_poses_per_s_phases_2_4"] = float(np.median([r["poses_per_s_phases_2_4"] for r in runs]))
+            out["pipeline_ms"] = [float(np.median([r[k] for r in runs])) for k in ("sample_ms", "congruent_ms", "transforms_ms", "verify_ms")]
+            out["pipeline_candidates_per_trial"] = float(np.median([r["candidates"] for r in runs]))
+        bt = pl.get("batched_trials")
+        if bt:
+            out["batched_trials_per_s"] = bt.get("trials_per_s")
+            out["batched_poses_per_s_all_phases"] = bt.get("poses_per_s_all_phases")
+    pa = full.get("pipeline_asymmetric_model")
+    if pa:
+        runs = [r for r in pa.get("runs", []) if not r.get("warmup")]
+        if runs:
+            out["winner_single_trial_rot_err_deg"] = float(np.median([r["winner_rot_err_deg_vs_gt"] for r in runs]))
+            out["winner_single_trial_add_mm"] = float(np.median([r["winner_add_mm_vs_gt"] for r in runs]))
+        bt = pa.get("batched_trials")
+        if bt:
+            out["winner_best_of_batch_rot_err_deg"] = bt.get("best_rot_err_deg_vs_gt")
+            out["winner_best_of_batch_add_mm"] = bt.get("best_add_mm_vs_gt")
+    cp = full.get("cpu_baseline_pipeline")
+    if cp:
+        for k in ("cpu_pipeline_ms", "cpu_pipeline_poses_per_s_phases_2_4", "cpu_pipeline_attempts", "cpu_pipeline_cores",
+                  "ycb_cpu_trial_ms", "ycb_cpu_trials_per_s", "ycb_gpu_trial_ms", "ycb_gpu_trials_per_s_single", "ycb_gpu_trials_per_s_batch64"):
+            if k in cp:
+                out[k] = cp[k]
+    out["details"] = full.get("details_file")
+    out = _sig(out)
+    # never over the limit: drop the optional tail first, the contract keys never
+    for victim in ("winner_best_of_batch_add_mm", "winner_best_of_batch_rot_err_deg", "winner_single_trial_add_mm", "winner_single_trial_rot_err_deg",
+                   "pipeline_candidates_per_trial", "ycb_gpu_trial_ms", "ycb_cpu_trial_ms", "pipeline_ms", "cpu_pipeline_ms", "oracle_check", "cpu_baseline_all_cores"):
+        if len(json.dumps(out)) < COMPACT_LIMIT:
+            break
+        out.pop(victim, None)
+    return out
+
+
+def cpu_pipeline_baseline(model, scene, device, threads, cm_attempts=8):
+    """The reference's CPU path over the WHOLE path, beside the GPU's whole-path numbers: the oracle's restated run_stocs_estimation
+    (oracle/stocs_oracle.cpp orc_run_mode, one thread like the reference) reports the same three spans the reference's driver prints --
+    base sampling / congruent sets + transforms / verification (src/stocs_match_one_object.cpp:80-105,110-151,156-163).
+    * Cm: `cm_attempts` of the 100 base attempts (a Cm trial takes the CPU about a minute: 45-190 M congruent sets are materialised),
+      spans scaled to 100 attempts; candidate poses / s over phases 2-4 = candidates / (congruent + verify span).
+    * the ycb 024_bowl frame (BASELINE configs 1/2; tests/golden fixture): one whole trial, 100 attempts, <= 200 per base, next to the
+      same trial on the GPU -- through the four calls, and 64 of them as one batch."""
+    from oracle import pyoracle
+    from model_matching_amd.estimator import StocsEstimator
+    pyoracle.build()
+    pyoracle.set_index_build_threads(threads)
+    rec = {"cpu_pipeline_cores": 1, "cpu_pipeline_attempts": cm_attempts, "kind": "port",
+           "what": "oracle run_stocs_estimation, one core; index build (offline in the reference) not in any span"}
+    t = time.perf_counter()
+    orc = pyoracle.Oracle(scene.pos, scene.nrm, scene.prob, scene.pixel, model.pos, model.nrm, build_index=True)
+    rec["cm_cpu_index_build_s"] = time.perf_counter() - t
+    rec["cm_cpu_index_build_threads"] = threads
+    r = orc.run(1234, cm_attempts, 200)
+    sc = 100.0 / max(cm_attempts, 1)
+    rec["cm_cpu_spans_s"] = [r.t_sample_s, r.t_congruent_s, r.t_verify_s]
+    rec["cm_cpu_bases_quads_candidates"] = [int(r.n_bases), int(r.n_quads_total), int(r.n_candidates)]
+    rec["cpu_pipeline_ms"] = [r.t_sample_s * sc * 1e3, r.t_congruent_s * sc * 1e3, r.t_verify_s * sc * 1e3]
+    rec["cpu_pipeline_poses_per_s_phases_2_4"] = r.n_candidates / max(r.t_congruent_s + r.t_verify_s, 1e-9)
+    del orc
+    gold = os.path.join(ROOT, "tests", "golden", "example_ycb_024_bowl.npz")
+    if os.path.exists(gold):
+        d = np.load(gold)
+        orc = pyoracle.Oracle(d["scene_pos"], d["scene_nrm"], d["scene_prob"], d["scene_pixel"], d["model_pos"], d["model_nrm"], build_index=True)
+        t = time.perf_counter()
+        r = orc.run(1234, 100, 200)
+        dt = time.perf_counter() - t
+        rec["ycb_cpu_trial_ms"] = [r.t_sample_s * 1e3, r.t_congruent_s * 1e3, r.t_verify_s * 1e3]
+        rec["ycb_cpu_trials_per_s"] = 1.0 / max(dt, 1e-9)
+        rec["ycb_cpu_bases_quads_candidates_lcp"] = [int(r.n_bases), int(r.n_quads_total), int(r.n_candidates), float(r.best_lcp)]
+        del orc
+        est = StocsEstimator(d["scene_pos"], d["scene_nrm"], d["scene_prob"], d["scene_pixel"], d["model_pos"], d["model_nrm"], build_index=True, device=device)
+        spans = []
+        for k in range(6):
+            est.reset_trial()
+            t0 = time.perf_counter(); est.sample_bases(1234 + k, 100)
+            t1 = time.perf_counter(); est.find_congruent_all()
+            t2 = time.perf_counter(); est.make_transforms(200, 1234 + k)
+            t3 = time.perf_counter(); bl, bi, P = est.compute_best_transform()
+            t4 = time.perf_counter()
+            spans.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3))
+            if k == 0:
+                rec["ycb_gpu_same_seed_bases_quads_candidates_lcp"] = [int(est.L.stocs_num_bases(est.h)), None, None, float(bl)]
+        med = [float(np.median([s_[i] for s_ in spans[2:]])) for i in range(4)]
+        rec["ycb_gpu_trial_ms"] = med
+        rec["ycb_gpu_trials_per_s_single"] = 1e3 / max(sum(med), 1e-9)
+        seeds = [7000 + i for i in range(64)]
+        est.run_trials(seeds, 100)
+        t0 = time.perf_counter(); est.run_trials(seeds, 100); dtb = time.perf_counter() - t0
+        rec["ycb_gpu_trials_per_s_batch64"] = 64.0 / dtb
+        est.close()
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -249,10 +398,12 @@ def main():
     ap.add_argument("--candidates", type=int, default=0, help="override candidates per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the untimed phases 1-4 report")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (roofline.traffic / binding become null)")
     ap.add_argument("--no-c5", action="store_true", help="skip the C5 leg of the roofline record (200 000-point scene, 50 000-point model: the HBM-bound configuration)")
     ap.add_argument("--no-hits", action="store_true", help="skip the hit census behind needed_bytes (the counter child runs: its per-point detail launches must not be profiled)")
+    ap.add_argument("--no-cpu-pipeline", action="store_true", help="skip the CPU whole-path baseline (oracle run_stocs_estimation at Cm and on the ycb frame)")
+    ap.add_argument("--details", default="", help="where the full record goes (default: bench_details.json next to this script, and gpurun_out/ when it exists)")
     ap.add_argument("--pmc-groups", default="", help="comma-separated counter groups of tools/pmc.py for the live passes (default: all)")
     args = ap.parse_args()
 
@@ -435,8 +586,8 @@ def main():
         add_counters(krec, knest, args.workload, args.candidates, groups)
         out["roofline"].update(krec)
         out["roofline"]["traffic"] = krec["memory_side_bytes_per_launch"]
-        if krec["binding_unit"]:
-            out["roofline"]["bound"] = krec["binding_unit"]
+        # `bound` keeps the contract's vocabulary ("hbm" | "mfma": this path is byte work, never MFMA); the unit the counters
+        # show busiest is `binding_unit` / `binding_frac` next to it
         out["roofline"]["binding"] = knest["binding"]
         out["roofline"]["pmc"] = knest["pmc"]
     # the same record on C5 (the configuration where the memory side IS the bound): flat c5_* keys in the same object
@@ -534,10 +685,30 @@ def main():
                                "oracle_float_sum_vs_its_own_exact_sum": float(np.abs(ref_all - exact_all).max()),
                                "note": "the GPU adds the weights as integers and returns the exact mean; the reference's running float sum drifts "
                                        "from the exact mean by the last figure; a flipped exact-distance tie (Q11) moves a score by weight / |M|"}
+        if not args.no_cpu_pipeline and not args.no_pipeline and est.nM <= 8192:
+            try:
+                out["cpu_baseline_pipeline"] = cpu_pipeline_baseline(model, scene, local_rank, ncore)
+            except Exception as e:   # the contract line must not depend on it
+                out["cpu_baseline_pipeline"] = {"error": repr(e)}
     est.dev_free(dT)
     est.dev_free(dL)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        # the full record goes to a file; stdout carries ONE small contract line, last
+        paths = [args.details] if args.details else [os.path.join(ROOT, "bench_details.json")]
+        if not args.details and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+            paths.append(os.path.join(ROOT, "gpurun_out", "bench_details.json"))
+        written = None
+        for pth in paths:
+            try:
+                with open(pth, "w") as f:
+                    json.dump(out, f)
+                written = written or os.path.relpath(pth, ROOT)
+            except Exception:
+                pass
+        out["details_file"] = written
+        line = json.dumps(compact_line(out))
+        assert len(line) < COMPACT_LIMIT, len(line)
+        print(line, flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -50,6 +50,8 @@ def lib():
         L.orc_ppf_compute.argtypes = [fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, ip]
         L.orc_index_build.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int]
         L.orc_index_build.restype = vp
+        L.orc_set_index_build_threads.argtypes = [C.c_int]
+        L.orc_set_index_build_threads.restype = None
         L.orc_index_free.argtypes = [vp]
         L.orc_index_lookup.argtypes = [vp, ip, ip, C.c_int64]
         L.orc_index_lookup.restype = C.c_int64
@@ -405,3 +407,8 @@ def pose_diff(test16, base16, sym):
     r = C.c_float(0); t = C.c_float(0)
     lib().orc_pose_diff(pa, pb, ps, C.byref(r), C.byref(t))
     return r.value, t.value
+
+
+def set_index_build_threads(n):
+    """Threads for the feature evaluation of the oracle's index build (the index itself does not depend on the count)."""
+    lib().orc_set_index_build_threads(int(n))

@@ -1013,19 +1013,66 @@ void orc_ppf_compute(const float* p1, const float* n1, const float* p2, const fl
     ppf_compute(ld(p1), ld(n1), ld(p2), ld(n2), tr, rot, mode, out4);
 }
 
+// Threads for the feature evaluation of orc_index_build (default 1).  The insertion stays sequential in the reference's loop order, so
+// the index is the same whatever the count; bench.py raises it to the cgroup's CPU share so that the CPU whole-path baseline does not
+// spend ten seconds of the bench run on the (offline, untimed) 25 M-pair index of the metric model.
+static int g_index_build_threads = 1;
+void orc_set_index_build_threads(int n) { g_index_build_threads = n > 1 ? n : 1; }
+
 orc_index* orc_index_build(const float* pos3, const float* nrm3, int n, int tr, int rot) {
     orc_index* ix = new orc_index;
     ix->tr = tr; ix->rot = rot; ix->npairs = 0;
-    // stocs.cpp:63-78: ordered pairs, id1 outer, id2 inner, id1 != id2
-    for (int id1 = 0; id1 < n; ++id1)
-        for (int id2 = 0; id2 < n; ++id2) {
-            if (id1 == id2) continue;
-            int f[4];
-            ppf_compute(ld(pos3 + 3 * id1), ld(nrm3 + 3 * id1), ld(pos3 + 3 * id2), ld(nrm3 + 3 * id2), tr, rot, 0, f);
-            std::array<int, 4> F = {{f[0], f[1], f[2], f[3]}};
-            ix->base[F].push_back(IPair(id1, id2));
-            ix->npairs++;
-        }
+    const bool dbg_t = getenv("ORC_DEBUG_TIMING") != NULL;
+    double t_feat = 0, t_ins = 0; const double t_begin = omp_get_wtime();
+    // stocs.cpp:63-78: ordered pairs, id1 outer, id2 inner, id1 != id2 -- the features of a block of id1 rows are evaluated side by
+    // side, then appended to their feature's list in exactly that order.  While the features stay inside a small box (they do: a
+    // distance bin and three angle bins) the list of a feature is found through a dense table instead of a hash look-up per pair;
+    // the map the look-ups use is filled from the lists at the end -- same content, same order inside every list.
+    const int ROWS = 64;
+    std::vector<std::array<int, 4> > feat((size_t)ROWS * (size_t)(n > 0 ? n : 1));
+    const int NA = 180 / (rot > 0 ? rot : 1) + 3, ND = 4096;                 // dense box: angles 0 .. 180 + 2 rot, distance bins 0 .. 4095
+    const bool dense_ok = tr > 0 && rot > 0 && (size_t)NA * NA * NA * 64 <= ((size_t)1 << 31);
+    std::vector<int32_t> slot;                                               // (grown by distance bin) dense cell -> list id + 1
+    std::vector<std::array<int, 4> > list_key;
+    std::vector<std::vector<IPair> > lists;
+    const size_t per_d = (size_t)NA * NA * NA;
+    for (int r0 = 0; r0 < n; r0 += ROWS) {
+        const int r1 = std::min(n, r0 + ROWS);
+        const double ta = omp_get_wtime();
+#pragma omp parallel for num_threads(g_index_build_threads) schedule(static)
+        for (int id1 = r0; id1 < r1; ++id1)
+            for (int id2 = 0; id2 < n; ++id2) {
+                if (id1 == id2) continue;
+                int f[4];
+                ppf_compute(ld(pos3 + 3 * id1), ld(nrm3 + 3 * id1), ld(pos3 + 3 * id2), ld(nrm3 + 3 * id2), tr, rot, 0, f);
+                feat[(size_t)(id1 - r0) * n + id2] = {{f[0], f[1], f[2], f[3]}};
+            }
+        const double tb = omp_get_wtime(); t_feat += tb - ta;
+        for (int id1 = r0; id1 < r1; ++id1)
+            for (int id2 = 0; id2 < n; ++id2) {
+                if (id1 == id2) continue;
+                const std::array<int, 4>& F = feat[(size_t)(id1 - r0) * n + id2];
+                bool in_box = dense_ok && F[0] >= 0 && F[0] % tr == 0 && F[0] / tr < ND;
+                for (int k = 1; k < 4 && in_box; ++k) in_box = F[k] >= 0 && F[k] % rot == 0 && F[k] / rot < NA;
+                if (in_box) {
+                    const size_t cell = (((size_t)(F[0] / tr) * NA + (size_t)(F[1] / rot)) * NA + (size_t)(F[2] / rot)) * NA + (size_t)(F[3] / rot);
+                    if (cell >= slot.size()) slot.resize(((size_t)(F[0] / tr) + 8) * per_d, 0);
+                    int32_t& sl = slot[cell];
+                    if (!sl) { lists.push_back(std::vector<IPair>()); list_key.push_back(F); sl = (int32_t)lists.size(); }
+                    lists[(size_t)sl - 1].push_back(IPair(id1, id2));
+                } else {
+                    ix->base[F].push_back(IPair(id1, id2));
+                }
+                ix->npairs++;
+            }
+        t_ins += omp_get_wtime() - tb;
+    }
+    for (size_t l = 0; l < lists.size(); ++l) {     // a feature is either inside the box or not: no list exists twice
+        std::vector<IPair>& dst = ix->base[list_key[l]];
+        dst.swap(lists[l]);
+    }
+    if (dbg_t) fprintf(stderr, "[oracle index] features %.2f s (%d threads), insertion %.2f s, %zu distinct features\n", t_feat, g_index_build_threads, t_ins, ix->base.size());
+    // the key set of the reference's map: every stored feature under its 128 insertion offsets (rgbd.cpp:130-137)
     for (auto it = ix->base.begin(); it != ix->base.end(); ++it) {
         const std::array<int, 4>& F = it->first;
         for (int p1 = F[0] - tr; p1 < F[0] + tr; p1 += tr)
@@ -1037,6 +1084,7 @@ orc_index* orc_index_build(const float* pos3, const float* nrm3, int n, int tr, 
                         ix->keys[key] = 1;
                     }
     }
+    if (dbg_t) fprintf(stderr, "[oracle index] whole build %.2f s, %zu keys\n", omp_get_wtime() - t_begin, ix->keys.size());
     return ix;
 }
 void orc_index_free(orc_index* ix) { delete ix; }

@@ -50,6 +50,7 @@ void orc_ppf_compute(const float* p1, const float* n1, const float* p2, const fl
 /* ---- rows 2/T4: PPF index ---- */
 typedef struct orc_index orc_index;
 orc_index* orc_index_build(const float* pos3, const float* nrm3, int n, int tr, int rot);
+void orc_set_index_build_threads(int n);   /* feature evaluation only; the index does not depend on it */
 void       orc_index_free(orc_index*);
 /* lookup(K): pairs in insertion (lexicographic id1,id2) order; returns total count, writes <= cap */
 int64_t    orc_index_lookup(const orc_index*, const int* key4, int32_t* pairs2, int64_t cap);

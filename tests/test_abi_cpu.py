@@ -389,3 +389,44 @@ def test_stream_audit_selftest():
     for scenario, text in expect.items():
         assert L.stocs_debug_stream_audit_selftest(scenario, msg, 512) >= 1, scenario
         assert text in msg.value, (scenario, msg.value)
+
+
+def test_bench_contract_line_is_small_and_parses():
+    """bench.py prints ONE compact JSON line (< 4 KB, scalars and short lists only) as its last stdout line; the per-run tables,
+    step records and counter nests go to bench_details.json.  (Round 4's line had grown to 34 KB and the driver recorded `parsed:
+    null`.)  The canned input is the full record of round 4's own run of the driver's command."""
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_driver_command.json")))
+    assert len(json.dumps(full)) > 20000                       # the record that did not parse
+    full["cpu_baseline_pipeline"] = {"cpu_pipeline_ms": [650.123456, 55000.1, 14000.9], "cpu_pipeline_poses_per_s_phases_2_4": 115.123456789,
+                                     "cpu_pipeline_attempts": 8, "cpu_pipeline_cores": 1, "ycb_cpu_trial_ms": [1373.0, 16.0, 41.0],
+                                     "ycb_cpu_trials_per_s": 0.7, "ycb_gpu_trial_ms": [0.09, 0.3, 0.1, 0.1], "ycb_gpu_trials_per_s_single": 1700.0,
+                                     "ycb_gpu_trials_per_s_batch64": 22000.0, "cm_cpu_spans_s": [1, 2, 3]}
+    full["details_file"] = "bench_details.json"
+    line = json.dumps(bench.compact_line(full))
+    assert len(line) < 4096, len(line)
+    got = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "oracle_check", "cpu_pipeline_ms", "cpu_pipeline_poses_per_s_phases_2_4",
+              "pipeline_poses_per_s_phases_2_4", "pipeline_ms", "batched_trials_per_s"):
+        assert k in got, k
+    assert got["value"] == pytest.approx(full["value"], rel=1e-5) and got["config"]["workload"].startswith("Cm")
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "needed_frac", "binding_unit", "c5_kernel_ms", "c5_traffic_over_needed"):
+        assert k in got["roofline"], k
+    assert set(got["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"}
+    assert got["roofline"]["unit"] == "GB/s" and got["roofline"]["frac"] == pytest.approx(got["roofline"]["achieved"] / got["roofline"]["peak"], rel=1e-4)
+
+    def flat(v, depth=0):                                       # nothing nested beyond one object of scalars / short lists
+        if isinstance(v, dict):
+            assert depth < 2
+            return all(flat(x, depth + 1) for x in v.values())
+        if isinstance(v, list):
+            return len(v) <= 8 and all(not isinstance(x, (dict, list)) for x in v)
+        return True
+    assert flat(got)
+    # a record without the optional sections (N > 1 ranks, --no-pipeline ...) still gives the contract keys
+    bare = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config")}
+    bare["roofline"] = {k: full["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    got = json.loads(json.dumps(bench.compact_line(bare)))
+    assert got["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-5) and "cpu_baseline" not in got

@@ -234,8 +234,8 @@ def test_bench_gpus_2_without_a_launcher_runs_two_ranks():
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rehearsal"] is True and out["distributed"]["world_size"] == 2 and out["distributed"]["backend"] == "gloo"
-    assert [x["rank"] for x in out["distributed"]["ranks"]] == [0, 1]
-    assert out["value"] > 0 and out["config"]["candidates_per_step_per_gpu"] == 2048
+    assert out["distributed"]["ranks_reporting"] == [0, 1]          # (the per-rank records themselves are in the details file)
+    assert len(lines[0]) < 4096 and out["value"] > 0 and out["config"]["candidates_per_step_per_gpu"] == 2048
     t = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trials.py"), "--gpus", "2", "--trials", "4", "--seed", "3"], capture_output=True, text=True,
                        timeout=900, env=env, cwd=ROOT)
     assert t.returncode == 0, t.stderr[-3000:]

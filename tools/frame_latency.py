@@ -3,7 +3,7 @@
 tests/golden/): uint16 depth + class-probability image -> scene cloud (stocs_ingest_scene) -> stocs_ctx_set_scene
 (upload, centroid shift, GPU brick grid; the model and its PPF index stay) -> one StoCS trial of 100 base
 attempts (sampling, congruent sets, <= 200 transforms per base, verification) -> best pose.
-usage: python tools/frame_latency.py [frames]"""
+usage: python tools/frame_latency.py [frames] [--cpu-reference]"""
 import json
 import os
 import sys
@@ -26,7 +26,9 @@ from pose_check import depth_agreement, pose_matrix_from_colmajor16  # noqa: E40
 
 
 def main():
-    frames = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+    argv = [a for a in sys.argv[1:] if a != "--cpu-reference"]
+    with_cpu = "--cpu-reference" in sys.argv[1:]      # also time the reference's CPU path (oracle, one core) on each frame: +6 s
+    frames = int(argv[0]) if argv else 6
     out = {}
     for name in ("ycb_024_bowl", "linemod_obj_06", "packed_dove"):
         raw = np.load(os.path.join(ROOT, "tests", "golden", "example_%s_raw.npz" % name))
@@ -77,6 +79,9 @@ def main():
                      "winner_vs_the_frames_own_depth_and_class_maps": agree[1:],
                      "batch_of_64_trials_in_one_set_of_launches": batch,
                      "quads": [int(x) for x in r[:, 5]], "candidates": [int(x) for x in r[:, 6]], "best_lcp": [float(x) for x in r[:, 7]]}
+        if with_cpu:
+            import cpu_reference   # tools/cpu_reference.py
+            out[name]["cpu_reference_one_trial"] = cpu_reference.spans((pos, nrm, prob, pix, mpos, mnrm), mode, edge, 100, 200, 100, 100)
         est.close()
     print(json.dumps(out, indent=1))
 

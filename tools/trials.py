@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="trial streams in flight per GPU (one context + HIP stream + host thread each)")
     ap.add_argument("--batch", type=int, default=0, help="B > 0: the rank's trials go through stocs_run_trials in batches of B -- all trials of a batch in ONE set of launches "
                                                          "(0: one trial after the other through the single-trial calls)")
+    ap.add_argument("--cpu-reference", type=int, default=0, metavar="ATTEMPTS", help="A > 0: also time the reference's CPU path (the oracle's run_stocs_estimation, one core) on the same input, "
+                                                                                      "A base attempts scaled to --bases (a Cm trial takes the CPU about a minute: use 8 there, --bases on the example frames)")
     ap.add_argument("--gpus", type=int, default=0, help="N > 1 without a launcher: start N rank processes (one per GPU) as children and relay their output")
     args = ap.parse_args()
     from model_matching_amd import dist as sd
@@ -178,8 +180,14 @@ def main():
     if world > 1:
         ranks = [None] * world
         dist.all_gather_object(ranks, me)
+    cpu_ref = None
+    if rank == 0 and args.cpu_reference > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import cpu_reference
+        cpu_ref = cpu_reference.spans(cloud, mode, d["edge_map"] if mode else None, min(args.cpu_reference, args.bases), args.max_sets, args.seed, args.bases)
+        cpu_ref["gpu_over_cpu_trials_per_s"] = (args.trials / dt) / cpu_ref["trials_per_s"]
     if rank == 0:
-        print(json.dumps({"world_size": world, "backend": (dist.get_backend() if world > 1 else None), "ranks": ranks,
+        print(json.dumps({"cpu_reference": cpu_ref, "world_size": world, "backend": (dist.get_backend() if world > 1 else None), "ranks": ranks,
                           "setup_seconds_outside_the_timed_span_rank0": setup_s, "example": args.example, "mode": "instance" if mode else "class", "trials": args.trials, "streams_per_gpu": n_streams, "batch": args.batch,
                           "last_call_steps_ms": {name: [[lab, round(ms, 4)] for lab, ms in ests[0].last_call_timing(w)]
                                                  for w, name in ((0, "find_congruent_all"), (1, "make_transforms"), (2, "verify_all"), (3, "run_trials"))}, "n_gpus": world, "rehearsal": rehearsal,
