@@ -167,12 +167,17 @@ static void free_grid(stocs_ctx* c) {   // the grid lives in c->grid_mem, which 
 static int build_grid_once(stocs_ctx* c, int div, bool last_resort = false) {
     // STOCS_GRID_DENSE (measurement switch, tools/layout_sweep.py): 0 = index-ordered lists whatever their length, 1 = centre-sorted always
     const char* force = getenv("STOCS_GRID_DENSE");
-    if (force) return build_grid_gpu(c, div, atoi(force) == 1 ? 1 : 0);
-    if (div > 1) return build_grid_gpu(c, div, 1);
-    int rc = build_grid_gpu(c, div, 0);
+    // round 5: dominance-pruned lists (grid.hip) -- index-ordered at every cell edge, no early exit needed; "grid_prune" 0 / STOCS_GRID_PRUNE=0
+    // keeps the layouts of rounds 2-4 (A/B and cross-check: same scores bit for bit)
+    const char* pe = getenv("STOCS_GRID_PRUNE");
+    const int prune = pe ? atoi(pe) : c->grid_prune;
+    if (prune && !force) return build_grid_gpu(c, div, 0, 1);
+    if (force) return build_grid_gpu(c, div, atoi(force) == 1 ? 1 : 0, 0);
+    if (div > 1) return build_grid_gpu(c, div, 1, 0);
+    int rc = build_grid_gpu(c, div, 0, 0);
     if (rc || !last_resort || c->grid.avg_list_len <= 16.0) return rc;
     free_grid(c);
-    return build_grid_gpu(c, div, 1);
+    return build_grid_gpu(c, div, 1, 0);
 }
 
 static int build_grid_levels(stocs_ctx* c) {
@@ -181,14 +186,28 @@ static int build_grid_levels(stocs_ctx* c) {
     if (e) div = atoi(e);
     const bool fixed = e || c->grid_div != 1;
     int rc = build_grid_once(c, div, fixed);
-    if (rc || fixed) return rc;
+    auto report = [&]() {
+        if (getenv("STOCS_DEBUG_TIMING"))
+            fprintf(stderr, "[stocs grid] cell edge eps/%d, %d bricks, %lld list entries (%.1f per non-empty cell; %.1f within r of the cell%s)\n", (int)lround((double)c->prm.distance_threshold / c->grid.h),
+                    c->grid.n_bricks, (long long)c->grid.n_entries, c->grid.avg_list_len, c->grid.avg_dilated_len, c->grid.pruned ? ", dominance-pruned" : "");
+    };
+    if (rc || fixed) { if (!rc) report(); return rc; }
     for (int next = 2; next <= 4; next *= 2) {
         // Stop when the lists are short, or when the finer grid would not fit comfortably (entries x ~8, 16 B each).  Thresholds
         // (second half of round 3, tools/layout_sweep.py, 16 384-32 768 candidates; entries per non-empty list at the coarser edge):
         //   eps -> eps/2 from 12.5 on: 10.2: 1.22 (eps) vs 1.24 ms (eps/2); 12.5: 1.68 vs 1.64; 15.8: 2.40 vs 2.14;
         //   eps/2 -> eps/4 from 18 on: 13.1: 1.51 (eps/2) vs 1.68 (eps/4); 16.2: 2.08 vs 2.09; 20.9: 2.73 vs 2.60; 140 000 points: 4.39 vs 3.76
         // (rounds 1-3a: 16 and 28, with the sparse layout kept at eps/2 for lists up to 16 entries)
-        if (c->grid.avg_list_len <= (next == 2 ? 12.5 : 18.0) || c->grid.n_entries * 8 >= ((int64_t)1 << 29)) break;
+        // Round 5, dominance-pruned lists (tools/prune_layout_sweep.sh, 16 384 candidates, ms at eps / eps/2 / eps/4): 20 000 points 0.32 / 0.41 /
+        // 0.55; 35 000: 0.48 / 0.57 / 0.85; 50 000: 0.83 / 0.79 / 1.14; 65 000: 1.17 / 0.96 / 1.41; 100 000: 2.30 / 1.46 / 2.16; 140 000: 4.24 /
+        // 2.16 / 2.95; C5 (200 000): 8.49 / 3.40 / 4.09 -- eps/2 from the same density on as before (the count of points within r of a cell at
+        // eps: 12.5), eps/4 no longer at any of these densities: a pruned list at eps/2 holds what can win somewhere in a 2.5 mm cell, and
+        // the eight times as many cell words of eps/4 cost more than its shorter lists save.  eps/4 stays for pruned lists beyond 16
+        // entries at eps/2 (scenes several times denser than C5; not measured).
+        const double n_inc_now = c->grid.avg_dilated_len / std::max(c->grid.avg_list_len, 1.0) * (double)c->grid.n_entries;   // ~ the (cell, point) incidences of this build
+        const bool finer_pays = c->grid.pruned ? (next == 2 ? c->grid.avg_dilated_len > 12.5 : c->grid.avg_list_len > 16.0)
+                                               : c->grid.avg_dilated_len > (next == 2 ? 12.5 : 18.0);
+        if (!finer_pays || (int64_t)n_inc_now * 8 >= ((int64_t)1 << 29)) break;
         const int prev = next / 2;
         free_grid(c);
         rc = build_grid_once(c, next);
@@ -199,9 +218,7 @@ static int build_grid_levels(stocs_ctx* c) {
         }
         if (rc) return rc;
     }
-    if (getenv("STOCS_DEBUG_TIMING"))
-        fprintf(stderr, "[stocs grid] cell edge eps/%d, %d bricks, %lld list entries (%.1f per non-empty cell)\n", (int)lround((double)c->prm.distance_threshold / c->grid.h),
-                c->grid.n_bricks, (long long)c->grid.n_entries, c->grid.avg_list_len);
+    if (!rc) report();
     return rc;
 }
 
@@ -468,6 +485,7 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     c->best_lcp = 0; c->best_index = -1;
     c->has_edge = false;
     c->grid_div = 1;
+    c->grid_prune = getenv("STOCS_GRID_PRUNE") ? atoi(getenv("STOCS_GRID_PRUNE")) : 1;
     c->lcp_variant = -1;
     c->lcp_split = 1;
     c->lcp_flat = getenv("STOCS_LCP_FLAT") ? atoi(getenv("STOCS_LCP_FLAT")) : 1;

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void cell_words_kernel(GridGeom G, int div, co
                                                          const uint32_t* __restrict__ cell_brick, const uint32_t* __restrict__ list_off,
                                                          uint32_t n_cells, uint32_t n_inc, const uint32_t* __restrict__ vals,
                                                          const float4* __restrict__ spos, int32_t* __restrict__ top, uint4* __restrict__ cells,
-                                                         uint4* __restrict__ flat) {
+                                                         uint4* __restrict__ flat, const uint32_t* __restrict__ kept) {
     const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int s = threadIdx.x & 63;
     if (c >= n_cells) return;   // whole wavefront
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void cell_words_kernel(GridGeom G, int div, co
     }
     if (s == 0) {
         top[brick] = (int32_t)b;   // every cell of the brick writes the same value
-        const uint4 w = make_uint4(list_off[c], cnt, mlo, mhi);
+        const uint4 w = make_uint4(list_off[c], kept ? kept[c] : cnt, mlo, mhi);   // (pruned lists: the mask above still comes from every point within r)
         cells[(size_t)b * 512 + local] = w;
         if (flat) {
             const int bx = (int)(brick % (uint64_t)G.nbx), by = (int)((brick / (uint64_t)G.nbx) % (uint64_t)G.nby), bz = (int)(brick / ((uint64_t)G.nbx * (uint64_t)G.nby));
@@ -197,9 +197,18 @@ __global__ __launch_bounds__(256) void cell_words_kernel(GridGeom G, int div, co
 __global__ __launch_bounds__(256) void list_fill_kernel(const uint32_t* __restrict__ cflag, const uint32_t* __restrict__ cidx,
                                                         const uint32_t* __restrict__ cell_first, const uint32_t* __restrict__ list_off,
                                                         const uint32_t* __restrict__ vals, size_t n, const float4* __restrict__ spos,
-                                                        float4* __restrict__ list) {
+                                                        float4* __restrict__ list, const uint32_t* __restrict__ rank) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
+    if (rank) {                        // pruned lists: the survivors of a cell, in order
+        const uint32_t r = rank[e];
+        if (r == 0xFFFFFFFFu) return;
+        const uint32_t c = cidx[e] + cflag[e] - 1u;
+        const uint32_t pt = vals[e];
+        const float4 p = spos[pt];
+        list[(size_t)list_off[c] + r] = make_float4(p.x, p.y, p.z, __int_as_float((int)pt));
+        return;
+    }
     // cidx = exclusive scan of the cell-start flags: the cells that start strictly before e; the own cell is that
     // many if e opens it, one less otherwise
     const uint32_t c = cidx[e] + cflag[e] - 1u;
@@ -242,6 +251,110 @@ __global__ __launch_bounds__(256) void cell_nearest_kernel(const uint64_t* __res
     cells[(size_t)cell_brick[c] * 512 + (uint32_t)(cell_key[c] & 511)].z = __float_as_uint(chunk_r[list_off[c] >> 3]);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Dominance pruning of the candidate lists (round 5).  A cell's list holds every scene point within r of the cell box, so that ONE
+// list answers the radius-epsilon nearest-neighbour query of any position in the cell; but most of those points can never be the
+// ANSWER for a position in this cell.  For two listed points p, p' the difference of the squared distances from a position q is
+// linear in q,
+//     f(q) = |q - p|^2 - |q - p'|^2 = |u|^2 - |u'|^2 - 2 s . (u - u'),      u = p - centre, u' = p' - centre, s = q - centre,
+// so over the (slightly widened) cell box |s_k| <= hh its minimum is |u|^2 - |u'|^2 - 2 hh |u - u'|_1.  When that minimum exceeds a
+// margin that covers the scan kernels' float evaluation of both squared distances, p' is strictly nearer than p for EVERY position
+// the kernels can assign to this cell: p never wins there -- not on distance, not on a tie -- and is dropped from the list.  The
+// nearest neighbour of every query, its index and the tie rule are unchanged (whoever wins a query is by definition not dominated);
+// the kd-tree of the reference (kdtree.h:394-459) returns that same point.  Dominators tried per entry: the PRUNE_K listed points
+// nearest to the cell centre (any listed point may serve; these prune best).  On a surface sampled every 1.5 mm with cells of
+// 1.25 mm the lists shrink from ~45 entries to ~5 whatever the cell's height above the surface: one 128-byte line answers a query,
+// where the centre-sorted lists with early exit of rounds 2-4 read 15-20 entries in a dependent line -> bound -> line chain.
+// One wavefront per cell; double arithmetic relative to the cell centre (float positions are exact in double).
+// ---------------------------------------------------------------------------------------------
+#define PRUNE_K 8
+__global__ __launch_bounds__(256) void prune_kernel(GridGeom G, double hh, double margin, const uint32_t* __restrict__ cell_first, const uint64_t* __restrict__ cell_key,
+                                                    uint32_t n_cells, uint32_t n_inc, const uint32_t* __restrict__ vals, const float4* __restrict__ spos,
+                                                    uint32_t* __restrict__ rank, uint32_t* __restrict__ kept, float* __restrict__ nearest) {
+    const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= n_cells) return;   // whole wavefront
+    const uint32_t first = cell_first[c];
+    const uint32_t cnt = (c + 1 < n_cells ? cell_first[c + 1] : n_inc) - first;
+    const uint64_t key = cell_key[c];
+    const uint64_t brick = key >> 9;
+    const uint32_t local = (uint32_t)(key & 511);
+    const int bx = (int)(brick % (uint64_t)G.nbx), by = (int)((brick / (uint64_t)G.nbx) % (uint64_t)G.nby), bz = (int)(brick / ((uint64_t)G.nbx * (uint64_t)G.nby));
+    const int cx = bx * 8 + (int)(local & 7), cy = by * 8 + (int)((local >> 3) & 7), cz = bz * 8 + (int)(local >> 6);
+    const double ccx = G.of[0] + (cx + 0.5) * G.h, ccy = G.of[1] + (cy + 0.5) * G.h, ccz = G.of[2] + (cz + 0.5) * G.h;
+    // ---- the PRUNE_K entries nearest to the centre: PRUNE_K rounds of "smallest (distance, position) key above the last one" ----
+    double dux[PRUNE_K], duy[PRUNE_K], duz[PRUNE_K], dn2[PRUNE_K];
+    unsigned long long last = 0ull;
+    int nd = 0;
+#pragma unroll
+    for (int j = 0; j < PRUNE_K; ++j) {
+        if ((uint32_t)j >= cnt) break;
+        unsigned long long best = ~0ull;
+        for (uint32_t k = (uint32_t)lane; k < cnt; k += 64u) {
+            const float4 pf = spos[vals[first + k]];
+            const double ux = (double)pf.x - ccx, uy = (double)pf.y - ccy, uz = (double)pf.z - ccz;
+            const float d2 = (float)(ux * ux + uy * uy + uz * uz);        // (selection only: any listed point is a valid dominator)
+            const unsigned long long kk = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(k + 1u);
+            if (kk > last && kk < best) best = kk;
+        }
+        for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(best, off, 64); best = o < best ? o : best; }
+        if (best == ~0ull) break;
+        last = best;
+        const float4 pf = spos[vals[first + (uint32_t)(best & 0xFFFFFFFFull) - 1u]];   // (uniform address)
+        dux[j] = (double)pf.x - ccx; duy[j] = (double)pf.y - ccy; duz[j] = (double)pf.z - ccz;
+        dn2[j] = dux[j] * dux[j] + duy[j] * duy[j] + duz[j] * duz[j];
+        nd = j + 1;
+    }
+    // ---- every entry against the dominators ----
+    uint32_t base = 0;
+    for (uint32_t k0 = 0; k0 < cnt; k0 += 64u) {
+        const uint32_t k = k0 + (uint32_t)lane;
+        bool keep = false;
+        if (k < cnt) {
+            const float4 pf = spos[vals[first + k]];
+            const double ux = (double)pf.x - ccx, uy = (double)pf.y - ccy, uz = (double)pf.z - ccz;
+            const double n2 = ux * ux + uy * uy + uz * uz;
+            keep = true;
+#pragma unroll
+            for (int j = 0; j < PRUNE_K; ++j) {
+                if (j < nd) {
+                    const double fmin_ = (n2 - dn2[j]) - 2.0 * hh * (fabs(ux - dux[j]) + fabs(uy - duy[j]) + fabs(uz - duz[j]));
+                    if (fmin_ > margin) keep = false;      // (an entry is never its own dominator: f is 0 there)
+                }
+            }
+        }
+        const unsigned long long m = __ballot(keep);
+        if (k < cnt) rank[first + k] = keep ? base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)) : 0xFFFFFFFFu;
+        base += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) {
+        kept[c] = base;
+        // lower bound of |centre - nearest listed point| (the nearest is never dominated), below the exact value also as a float
+        const double d0 = nd ? sqrt(dn2[0]) : 0.0;
+        nearest[c] = (float)fmax(d0 - (2e-6 + 2.5e-7 * d0), 0.0);
+    }
+}
+
+__global__ __launch_bounds__(256) void cell_padded_kept_kernel(const uint32_t* __restrict__ kept, uint32_t n_cells, uint32_t pad, uint32_t* __restrict__ padded,
+                                                               uint32_t* __restrict__ max_count, unsigned long long* __restrict__ total) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cells) return;
+    const uint32_t cnt = kept[c];
+    padded[c] = (cnt + pad - 1u) & ~(pad - 1u);
+    atomicMax(max_count, cnt);
+    unsigned long long t = cnt;
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(total, t);
+}
+
+__global__ __launch_bounds__(256) void cell_nearest_store_kernel(const uint64_t* __restrict__ cell_key, const uint32_t* __restrict__ cell_brick, uint32_t n_cells,
+                                                                 const float* __restrict__ nearest, uint4* __restrict__ cells) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cells) return;
+    cells[(size_t)cell_brick[c] * 512 + (uint32_t)(cell_key[c] & 511)].z = __float_as_uint(nearest[c]);
+}
+
 struct Tmp {   // temporaries of one build: the context's workspace arena (no hipMalloc / hipFree in steady state)
     Arena* ws;
     template <class T>
@@ -252,7 +365,8 @@ static inline unsigned grid_of(size_t n) { return (unsigned)((n + 255) / 256); }
 
 // Builds c->grid for cell edge eps / div from c->d_spos (device) and c->h_spos (bounding box only).
 // dense != 0: lists ordered by distance to the cell centre + chunk bounds (scan kernels with early exit).
-int build_grid_gpu(stocs_ctx* c, int div, int dense) {
+int build_grid_gpu(stocs_ctx* c, int div, int dense, int prune) {
+    if (prune) dense = 0;      // pruned lists stay in index order (the `<=` tie rule of the index-ordered scan) and need no early exit
     SceneGrid& g = c->grid;
     const int nS = c->nS;
     const double eps = (double)c->prm.distance_threshold;
@@ -360,12 +474,27 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense) {
     hipLaunchKernelGGL(cell_records_kernel, dim3(grid_of(n_inc)), dim3(256), 0, st, d_keys_s, n_inc, qbits, d_cflag, d_cidx, d_bflag, d_bidx, d_cell_first,
                        d_cell_key, d_cell_brick);
     hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(256), 0, st, (int32_t*)d_max, (size_t)1, 0);
+    uint32_t *d_rank = NULL, *d_kept = NULL; float* d_near = NULL; unsigned long long* d_total = NULL;
+    if (prune) {
+        if ((rc = T.get(&d_rank, n_inc + 1)) || (rc = T.get(&d_kept, (size_t)n_cells + 1)) || (rc = T.get(&d_near, (size_t)n_cells + 1)) || (rc = T.get(&d_total, 1))) return rc;
+        // positions the kernels assign to a cell lie inside its box up to the float rounding of floor((q - o) * inv_h): 3 ulp of the
+        // offset from the origin; squared distances are evaluated in float with a relative error below 4e-7 each
+        double ext = 0; for (int k = 0; k < 3; ++k) ext = std::max(ext, (double)n[k] * h);
+        const double hh = 0.5 * h + 2.0e-6 * (ext + 1.0) * 0.5 + 1.0e-7, reach = r + 2.0 * h;
+        const double margin = 4.0e-6 * reach * reach;
+        hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(256), 0, st, (int32_t*)d_total, (size_t)2, 0);
+        hipLaunchKernelGGL(prune_kernel, dim3((unsigned)((n_cells + 3) / 4)), dim3(256), 0, st, G, hh, margin, d_cell_first, d_cell_key, n_cells, (uint32_t)n_inc, d_vals_s,
+                           c->d_spos, d_rank, d_kept, d_near);
+        hipLaunchKernelGGL(cell_padded_kept_kernel, dim3(grid_of(n_cells)), dim3(256), 0, st, d_kept, n_cells, 8u, d_padded, d_max, d_total);
+    } else
     hipLaunchKernelGGL(cell_padded_kernel, dim3(grid_of(n_cells)), dim3(256), 0, st, d_cell_first, n_cells, (uint32_t)n_inc, 8u, d_padded, d_max);
     hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(256), 0, st, (int32_t*)(d_padded + n_cells), (size_t)1, 0);
     STOCS_HIP_CHECK(exclusive_scan(d_t32, t32, d_padded, d_list_off, (size_t)n_cells + 1, st));
     uint32_t tail[2] = {0, 0};
+    unsigned long long n_kept = n_inc;
     STOCS_HIP_CHECK(hipMemcpyAsync(&tail[0], d_list_off + n_cells, 4, hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipMemcpyAsync(&tail[1], d_max, 4, hipMemcpyDeviceToHost, st));
+    if (prune) STOCS_HIP_CHECK(hipMemcpyAsync(&n_kept, d_total, 8, hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
     const size_t n_list = tail[0];
     if (tail[1] > 65535u) { set_error("more than 65535 scene points within epsilon of one grid cell"); return STOCS_ERR_INVALID; }
@@ -383,9 +512,13 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense) {
     }
     hipLaunchKernelGGL(fill_list_kernel, dim3(grid_of(std::max<size_t>(n_list, 8))), dim3(256), 0, st, g.d_list, std::max<size_t>(n_list, 8));
     hipLaunchKernelGGL(cell_words_kernel, dim3((unsigned)((n_cells + 3) / 4)), dim3(256), 0, st, G, div, d_cell_first, d_cell_key, d_cell_brick, d_list_off, n_cells,
-                       (uint32_t)n_inc, d_vals_s, c->d_spos, g.d_top, g.d_cells, g.d_flat);
-    hipLaunchKernelGGL(list_fill_kernel, dim3(grid_of(n_inc)), dim3(256), 0, st, d_cflag, d_cidx, d_cell_first, d_list_off, d_vals_s, n_inc, c->d_spos, g.d_list);
+                       (uint32_t)n_inc, d_vals_s, c->d_spos, g.d_top, g.d_cells, g.d_flat, (const uint32_t*)d_kept);
+    hipLaunchKernelGGL(list_fill_kernel, dim3(grid_of(n_inc)), dim3(256), 0, st, d_cflag, d_cidx, d_cell_first, d_list_off, d_vals_s, n_inc, c->d_spos, g.d_list, (const uint32_t*)d_rank);
     STOCS_HIP_CHECK(hipGetLastError());
+    if (prune && div > 1) {   // no sub-cell masks on grids finer than epsilon: the z word takes the distance bound (has_nearest)
+        hipLaunchKernelGGL(cell_nearest_store_kernel, dim3(grid_of(n_cells)), dim3(256), 0, st, d_cell_key, d_cell_brick, n_cells, (const float*)d_near, g.d_cells);
+        g.has_nearest = true;
+    }
     // ---- 5. dense scenes: chunk bounds ----
     if (dense) {
         if ((rc = c->grid_mem.take(std::max<size_t>(n_list / 8, 1) * sizeof(float), (void**)&g.d_chunk_r))) return rc;
@@ -400,7 +533,9 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense) {
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
     g.n_bricks = (int)n_bricks;
     g.n_entries = (int64_t)n_list;
-    g.avg_list_len = n_cells ? (double)n_inc / (double)n_cells : 0.0;
+    g.avg_list_len = n_cells ? (double)n_kept / (double)n_cells : 0.0;
+    g.avg_dilated_len = n_cells ? (double)n_inc / (double)n_cells : 0.0;
+    g.pruned = prune != 0;
     return STOCS_OK;
 }
 

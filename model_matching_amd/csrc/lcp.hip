@@ -441,7 +441,10 @@ __device__ __forceinline__ bool lcp_patch_dead(const LcpArgs& a, const float4 sp
 // EARLY (dense scenes: lists sorted by distance from the cell centre, a lower bound of that distance per 8-entry line): a query
 // stops at the first line the triangle inequality rules out, as in variant 31 -- but fed from the queue, so that the first
 // lines of 32 queries are in flight together where variant 31 has the two lines of 8.
-template <bool DETAIL, int UNR, bool SORTQ = false, int PIPE = 4, bool IDX = true, int WPB = 4, int FLAT = 0, bool SPLIT = false, bool TILE = false, bool EARLY = false, int GL = 8, int FIRST = 1, bool NOSENT = false>
+// NEAR (pruned lists on grids finer than epsilon, round 5): the cell word's z is a lower bound of |cell centre - nearest listed point|
+// (no sub-cell mask there); a query farther from the centre than that bound + epsilon never touches the list -- EARLY's first test
+// without its line-by-line exit, which lists of ~5 entries have no use for.
+template <bool DETAIL, int UNR, bool SORTQ = false, int PIPE = 4, bool IDX = true, int WPB = 4, int FLAT = 0, bool SPLIT = false, bool TILE = false, bool EARLY = false, int GL = 8, int FIRST = 1, bool NOSENT = false, bool NEAR = false>
 __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
                                                         int n, int32_t* __restrict__ hit_out, uint8_t* __restrict__ cnt_out) {
     __shared__ float4 qt[WPB][128];     // qx, qy, qz, bits(list offset)
@@ -673,12 +676,12 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
                     const int brick = a.top[((cz >> 3) * a.nby + (cy >> 3)) * a.nbx + (cx >> 3)];
                     if (brick >= 0) {
                         const uint4 cw = a.cells[(uint32_t)brick * 512u + (uint32_t)(((cz & 7) << 6) | ((cy & 7) << 3) | (cx & 7))];
-                        if (EARLY && a.has_nearest) { off = cw.x; cnt = cw.y; nearest = __uint_as_float(cw.z); }   // no mask on these grids: z = distance bound
+                        if ((EARLY || NEAR) && a.has_nearest) { off = cw.x; cnt = cw.y; nearest = __uint_as_float(cw.z); }   // no mask on these grids: z = distance bound
                         else { const uint32_t mw = a.has_nearest ? 0xFFFFFFFFu : (sb < 32 ? cw.z : cw.w); off = cw.x; cnt = ((mw >> (sb & 31)) & 1u) ? cw.y : 0u; }
                     }
                 }
             }
-            if (EARLY && cnt) {
+            if ((EARLY || (NEAR && a.has_nearest)) && cnt) {
                 const float ex = qx - (a.ox + ((float)cx + 0.5f) * a.h), ey = qy - (a.oy + ((float)cy + 0.5f) * a.h), ez = qz - (a.oz + ((float)cz + 0.5f) * a.h);
                 qcentre = sqrtf(ex * ex + (ey * ey + ez * ez));
                 // every listed point is at least `nearest` from the cell centre, hence at least nearest - |q - centre| from the query:
@@ -966,6 +969,7 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
 #ifdef STOCS_TOOLS_BUILD
         else if (!(variant >= 20 && variant <= 28)) STOCS_LCP_LAUNCH(lcp_coop_kernel<true, 1, true, false, true>);
 #endif
+        else if (a.has_nearest) STOCS_LCP_LAUNCH(lcp_coopq_kernel<true, 1, true, 4, true, 4, 0, false, false, false, 8, 1, false, true>);   // pruned lists on a grid finer than epsilon
         else STOCS_LCP_LAUNCH(lcp_coopq_kernel<true, 1, true, 4, true>);
     } else if (dense) {
         switch (variant) {
@@ -1049,7 +1053,10 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
                     case 22: STOCS_LCP_Q(true, 2, 2, 1); break;    // ... two trips in flight (2.11 ms)
                     case 1: STOCS_LCP_Q(true, 1, 1, 1); break;     // a lane per query, a whole line per lane (3.16 ms)
 #endif
-                    default: STOCS_LCP_Q(true, 1, 4, 1, 2, true); break;    // 4: four lanes, one trip in flight, a list's first two lines together, no sentinels
+                    default:
+                        if (a.has_nearest) STOCS_LCP_Q(true, 1, 4, 1, 2, true, true);   // pruned lists on a grid finer than epsilon: the distance bound in place of the sub-cell mask
+                        else STOCS_LCP_Q(true, 1, 4, 1, 2, true);    // 4: four lanes, one trip in flight, a list's first two lines together, no sentinels
+                        break;
                 }
 #undef STOCS_LCP_Q
                 break;

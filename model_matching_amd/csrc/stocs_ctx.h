@@ -134,7 +134,9 @@ struct SceneGrid {
     int nbx, nby, nbz;   // bricks per axis
     int n_bricks;
     int64_t n_entries;
-    double avg_list_len;   // entries per non-empty cell
+    double avg_list_len;   // entries per non-empty cell (of the lists as stored: after the dominance pruning, when it is on)
+    double avg_dilated_len;   // ... of every scene point within r of the cell box (what the list held before pruning)
+    bool pruned;           // the lists hold only points that can be the nearest neighbour of some position in their cell (grid.hip)
     int32_t* d_top;      // nbx*nby*nbz -> brick id or -1
     uint4* d_flat;       // the same cell words addressed directly, (cz*ny + cy)*nx + cx, when the box is small enough (sparse
                          // scenes, cell edge eps): saves the LCP kernel the dependent `top` look-up; else NULL
@@ -244,6 +246,7 @@ struct stocs_ctx {
     stocs::Arena grid_mem;   // top / cells / list / chunk_r of the current grid (reset by every build)
     stocs::Arena grid_ws;    // temporaries of a grid build
     int grid_div;   // cell edge = epsilon / grid_div
+    int grid_prune; // 1 (default): the grid's lists are dominance-pruned (grid.hip); 0: the layouts of rounds 2-4 (STOCS_GRID_PRUNE, read at stocs_ctx_create)
     int lcp_variant;   // -1: STOCS_LCP_VARIANT or automatic; else stocs_set_option("lcp_variant")
     int lcp_split;     // 1: four wavefronts share one candidate (default), 0: one wavefront per candidate
     int lcp_flat;      // 1: build and use the flat cell table when it fits (default), 0: brick look-ups only
@@ -325,7 +328,7 @@ enum { PIN_CONGRUENT = 0, PIN_TRANSFORMS = 256, PIN_VERIFY = 512, PIN_BEST = 768
 int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d_hit, uint8_t* d_counted, unsigned long long* d_best8, uint32_t id_offset);
 int sample_trials(stocs_ctx* c, int mode, int nT, const uint64_t* seeds, int nA, float dispersion, BaseOut* res_host, const float4** snrmw0, size_t* snrmw_stride);   // sample.hip
 int build_ppf_index(stocs_ctx* c);
-int build_grid_gpu(stocs_ctx* c, int div, int dense);
+int build_grid_gpu(stocs_ctx* c, int div, int dense, int prune);
 int prepare_cull_field(stocs_ctx* c);   // geometry + memory of SceneGrid::d_dist for the current grid and model (end of a grid build)
 int fill_cull_field(stocs_ctx* c, hipStream_t st = NULL);      // the values, on st (NULL: c->stream); no synchronisation
 extern "C" int stocs_internal_make_jobs(stocs_ctx* c, const int32_t* picks4_host, const int32_t* picks4_dev, int n, void* d_jobs_out, const unsigned int** d_unresolved_out);
