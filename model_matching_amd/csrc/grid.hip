@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void cell_nearest_kernel(const uint64_t* __res
 // where the centre-sorted lists with early exit of rounds 2-4 read 15-20 entries in a dependent line -> bound -> line chain.
 // One wavefront per cell; double arithmetic relative to the cell centre (float positions are exact in double).
 // ---------------------------------------------------------------------------------------------
-#define PRUNE_K 8
+template <int PRUNE_K>
 __global__ __launch_bounds__(256) void prune_kernel(GridGeom G, double hh, double margin, const uint32_t* __restrict__ cell_first, const uint64_t* __restrict__ cell_key,
                                                     uint32_t n_cells, uint32_t n_inc, const uint32_t* __restrict__ vals, const float4* __restrict__ spos,
                                                     uint32_t* __restrict__ rank, uint32_t* __restrict__ kept, float* __restrict__ nearest) {
@@ -483,8 +483,11 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense, int prune) {
         const double hh = 0.5 * h + 2.0e-6 * (ext + 1.0) * 0.5 + 1.0e-7, reach = r + 2.0 * h;
         const double margin = 4.0e-6 * reach * reach;
         hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(256), 0, st, (int32_t*)d_total, (size_t)2, 0);
-        hipLaunchKernelGGL(prune_kernel, dim3((unsigned)((n_cells + 3) / 4)), dim3(256), 0, st, G, hh, margin, d_cell_first, d_cell_key, n_cells, (uint32_t)n_inc, d_vals_s,
-                           c->d_spos, d_rank, d_kept, d_near);
+        const int pk = getenv("STOCS_GRID_PRUNE_K") ? atoi(getenv("STOCS_GRID_PRUNE_K")) : 8;   // dominators tried per entry (measurement switch: 4, 8, 16)
+#define STOCS_PRUNE_LAUNCH(KV) hipLaunchKernelGGL(prune_kernel<KV>, dim3((unsigned)((n_cells + 3) / 4)), dim3(256), 0, st, G, hh, margin, d_cell_first, d_cell_key, n_cells, (uint32_t)n_inc, d_vals_s, \
+                           c->d_spos, d_rank, d_kept, d_near)
+        if (pk == 4) STOCS_PRUNE_LAUNCH(4); else if (pk == 16) STOCS_PRUNE_LAUNCH(16); else STOCS_PRUNE_LAUNCH(8);
+#undef STOCS_PRUNE_LAUNCH
         hipLaunchKernelGGL(cell_padded_kept_kernel, dim3(grid_of(n_cells)), dim3(256), 0, st, d_kept, n_cells, 8u, d_padded, d_max, d_total);
     } else
     hipLaunchKernelGGL(cell_padded_kernel, dim3(grid_of(n_cells)), dim3(256), 0, st, d_cell_first, n_cells, (uint32_t)n_inc, 8u, d_padded, d_max);
