@@ -353,6 +353,14 @@ int stocs_debug_stream_audit_selftest(int scenario, char* first_msg, int cap);
  * stocs_ctx_create asks the same question and takes another auxiliary stream (up to four candidates) until the answer is 1;
  * STOCS_NO_STREAM_PROBE=1 in the environment skips that.  The context must be idle. */
 int stocs_debug_streams_overlap(stocs_ctx* ctx);
+/* Diagnostics of the library's own stable radix sort of (u32 key, u32 value) pairs (csrc/sort32.hip; the sort of the congruent-set
+ * phase's pair lists -- in the reference a pointer grid of per-cell vectors, include/super4pcs/accelerators/normalset.hpp:114-131):
+ * sorts n host pairs by key bits [0, end_bit) on `device` (-1: the current one), which = 1 with the library's sort, 0 with rocPRIM's;
+ * `reps` timed runs after one warm-up; sorted pairs and the average device time of one sort come back.  seg_off (host, n_seg + 1 ascending
+ * offsets; own sort only; NULL: the whole list): every segment is sorted on its own and stays where it is -- the form the congruent-set
+ * phase uses, one segment per base. */
+int stocs_debug_sort_pairs(int device, const uint32_t* keys, const uint32_t* vals, int64_t n, int end_bit, int which, int reps,
+                           uint32_t* keys_out, uint32_t* vals_out, float* ms_per_sort, const uint32_t* seg_off, int n_seg);
 /* number of device (hipMalloc) and pinned-host (hipHostMalloc) allocations the library has made in this process so far.
  * A warm context -- one that has run a trial of the current scene -- runs further trials without allocating: the
  * difference across them is 0. */

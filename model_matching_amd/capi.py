@@ -105,6 +105,7 @@ SIGNATURES = {
     "stocs_device_alloc_count": (C.c_int64, []),
     "stocs_debug_stream_audit_selftest": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "stocs_debug_streams_overlap": (C.c_int, [_vp]),
+    "stocs_debug_sort_pairs": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _fp, C.POINTER(C.c_uint32), C.c_int]),
     "stocs_last_call_timing": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.c_int, _intp]),
     "stocs_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "stocs_get_cull_state": (C.c_int, [_vp, _fp, _ip, _intp, _fp, _fp, C.c_int64, _i64p]),

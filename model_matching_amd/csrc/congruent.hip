@@ -1102,6 +1102,25 @@ static double now_s() {
     if (dbg) { (void)hipStreamSynchronize(c->stream); const double t_ = now_s(); fprintf(stderr, "[stocs congruent] %-18s %8.3f ms\n", label, (t_ - tprev) * 1e3); tprev = t_; }
 
 // device part of stocs_find_congruent_all for one key width
+// The stable sort of a pair list by (base, cell).  The lists are base-major already (the gather, and the compaction of the survivors, emit
+// base after base), so 32-bit keys go through the library's own SEGMENTED onesweep (sort32.hip, round 5): every base's stretch -- seg_off,
+// the per-base offsets on the device -- is sorted by its cell bits alone, two passes whatever the number of bases (rocPRIM over all
+// significant bits: three for a single trial's Q list, four for a 40-trial piece).  STOCS_SORT=rocprim keeps rocPRIM's radix_sort_pairs
+// selectable for A/B; 64-bit keys (position grids beyond 2^32 (base, cell) values) always take it.  `own` says which one ran: the own sort
+// keeps an error word at the start of its temporary block.
+static bool cong_sort_own() { static const bool own = !(getenv("STOCS_SORT") && !strcmp(getenv("STOCS_SORT"), "rocprim")); return own; }
+static hipError_t cong_sort(void* tmp, size_t& bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, size_t n, unsigned cell_bits, unsigned end_bit,
+                            const uint32_t* seg_off, int n_seg, hipStream_t st, bool* own) {
+    // (one tile per base at least: lists of many short stretches -- the 64 ycb trials of a batch: 6 000 bases of ~100 pairs -- stay with the unsegmented sort)
+    *own = cong_sort_own() && n_seg > 0 && n / (size_t)n_seg >= 4096;
+    return *own ? sort_pairs_own(tmp, bytes, kin, kout, vin, vout, n, 0, cell_bits, seg_off, (uint32_t)n_seg, st) : sort_pairs(tmp, bytes, kin, kout, vin, vout, n, 0, end_bit, st);
+}
+static hipError_t cong_sort(void* tmp, size_t& bytes, const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, size_t n, unsigned, unsigned end_bit,
+                            const uint32_t*, int, hipStream_t st, bool* own) {
+    *own = false;
+    return sort_pairs(tmp, bytes, kin, kout, vin, vout, n, 0, end_bit, st);
+}
+
 // the per-trial tables of a planned trial, all in the context's persistent planning buffer (device)
 struct PlanDev {
     BaseJob* jobs; Segment* psegs; Segment* qsegs; uint32_t* q_off; uint32_t* p_off; int32_t* bids; unsigned int* err;
@@ -1160,6 +1179,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         AU.use(s0, occ_p, true, "occupancy of P", "zero fill"); AU.use(s0, occ_q, true, "occupancy of Q", "zero fill");
         AU.use(s0, tiles_p, true, "tile counts of P", "zero fill"); AU.use(s0, tiles_q, true, "tile counts of Q", "zero fill");
         AU.use(s0, plan.jobs, true, "base jobs", "plan kernels"); AU.use(s0, plan.psegs, true, "P segments", "plan kernels"); AU.use(s0, plan.qsegs, true, "Q segments", "plan kernels");
+        AU.use(s0, plan.q_off, true, "Q offsets per base", "plan kernels");
         STOCS_HIP_CHECK(hipEventRecord(c->ev_t[6], st));
         if (sq != st) {
             STOCS_HIP_CHECK(hipEventRecord(c->ev_fork, st));          // the plan upload and the zero fill are on st
@@ -1187,6 +1207,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         if (sq != st) { STOCS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_join, 0)); AU.wait(s0, c->ev_join); }
         AU.use(s0, tiles_p, true, "tile counts of P", "tile scan"); AU.use(s0, tiles_q, true, "tile counts of Q", "tile scan");
         AU.use(s0, d_qk_raw.p, false, "gathered Q keys", "base offsets"); AU.use(s0, occ_p, false, "occupancy of P", "base offsets"); AU.use(s0, plan.jobs, true, "base jobs", "base offsets");
+        AU.use(s0, plan.q_off, true, "Q offsets per base", "base offsets");
         hipLaunchKernelGGL(survivors_scan_kernel, dim3(2), dim3(1024), 0, st, d_surv.p + o_tp, ntp, d_surv.p + o_tq, ntq);
         hipLaunchKernelGGL(survivors_base_offsets_kernel<KeyT>, dim3((unsigned)nB, 2), dim3(256), 0, st, (const KeyT*)d_pk_raw.p, (uint32_t)totP0, (const uint32_t*)occ_q,
                            (const uint32_t*)(d_surv.p + o_tp), (const KeyT*)d_qk_raw.p, (uint32_t)totQ0, (const uint32_t*)occ_p, (const uint32_t*)(d_surv.p + o_tq), nB,
@@ -1244,8 +1265,9 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     // inside a cell the entries stay grouped by base, in index order inside a base: the runs of (base, cell) are contiguous
     // all the same, the table finds them wherever they are, and 15 bits are two radix passes where 22 are three.
     const unsigned end_bit_p = (S->use_table && !getenv("STOCS_CONGRUENT_P_FULLSORT")) ? (unsigned)S->cell_bits : end_bit;
-    STOCS_HIP_CHECK(sort_pairs(NULL, tb1, pk_in, (KeyT*)S->d_pkeys.p, pv_in, S->d_pvals.p, totP, 0, end_bit_p, st));
-    STOCS_HIP_CHECK(sort_pairs(NULL, tb2, qk_in, (KeyT*)S->d_qkeys.p, qv_in, S->d_qvals.p, totQ, 0, end_bit, st));
+    bool own_p = false, own_q = false;      // (decided per list: by its length per base)
+    STOCS_HIP_CHECK(cong_sort(NULL, tb1, pk_in, (KeyT*)S->d_pkeys.p, pv_in, S->d_pvals.p, totP, (unsigned)S->cell_bits, end_bit_p, plan.p_off, nB, st, &own_p));
+    STOCS_HIP_CHECK(cong_sort(NULL, tb2, qk_in, (KeyT*)S->d_qkeys.p, qv_in, S->d_qvals.p, totQ, (unsigned)S->cell_bits, end_bit, plan.q_off, nB, st, &own_q));
     DevBuf<char> d_tmp2;
     if ((rc = d_tmp.alloc(tb1)) || (rc = d_tmp2.alloc(tb2))) return rc;
     // device-side clock of the groups below (HIP events on the streams they run on; read after the call's closing
@@ -1259,7 +1281,8 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     if (!reduce)
         hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3(gather_grid(totQ)), dim3(256), 0, sq, ix.d_pairs, d_qsegs, n_qseg, (uint32_t)totQ,
                            S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p, (uint32_t*)NULL, (const PlanOut*)NULL, 0u, (uint32_t)nB);
-    STOCS_HIP_CHECK(sort_pairs(d_tmp2.p, tb2, qk_in, (KeyT*)S->d_qkeys.p, qv_in, S->d_qvals.p, totQ, 0, end_bit, sq));
+    STOCS_HIP_CHECK(cong_sort(d_tmp2.p, tb2, qk_in, (KeyT*)S->d_qkeys.p, qv_in, S->d_qvals.p, totQ, (unsigned)S->cell_bits, end_bit, plan.q_off, nB, sq, &own_q));
+    AU.use(s1, plan.q_off, false, "Q offsets per base", "sort Q");
     AU.use(s1, qk_in, false, "Q keys to sort", "sort Q"); AU.use(s1, qv_in, false, "Q pairs to sort", "sort Q");
     AU.use(s1, S->d_qkeys.p, true, "sorted Q keys", "sort Q"); AU.use(s1, S->d_qvals.p, true, "sorted Q pairs", "sort Q"); AU.use(s1, d_tmp2.p, true, "sort scratch Q", "sort Q");
     STOCS_HIP_CHECK(hipEventRecord(c->ev_t[1], sq));
@@ -1269,7 +1292,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
                            S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p, (uint32_t*)NULL, (const PlanOut*)NULL, 0u, (uint32_t)nB);
     STOCS_HIP_CHECK(hipGetLastError());
     // one stable sort per list: (base, position cell); inside a cell the entries keep the index order of the gather
-    STOCS_HIP_CHECK(sort_pairs(d_tmp.p, tb1, pk_in, (KeyT*)S->d_pkeys.p, pv_in, S->d_pvals.p, totP, 0, end_bit_p, st));
+    STOCS_HIP_CHECK(cong_sort(d_tmp.p, tb1, pk_in, (KeyT*)S->d_pkeys.p, pv_in, S->d_pvals.p, totP, (unsigned)S->cell_bits, end_bit_p, plan.p_off, nB, st, &own_p));
     STOCS_HIP_CHECK(hipEventRecord(c->ev_t[2], st));
     if (S->use_table) {
         const size_t ncell = (size_t)(S->NC * nB);
@@ -1307,6 +1330,11 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     hipLaunchKernelGGL(base_offsets_kernel, dim3((unsigned)((nB + 1 + 255) / 256)), dim3(256), 0, st, S->d_qoffe.p, S->d_qoff.p, nB + 1, d_boff.p);
     STOCS_HIP_CHECK(hipGetLastError());
     STOCS_HIP_CHECK(hipMemcpyAsync(qoff_at, d_boff.p, 8 * (size_t)(nB + 1), hipMemcpyDeviceToHost, st));
+    uint32_t* sort_err_pin = (uint32_t*)((char*)c->h_pin + PIN_CONGRUENT + 128);   // the own sort's error words (a look-back wait that ran into its bound)
+    sort_err_pin[0] = sort_err_pin[1] = 0u;
+    // (both sorts are joined into st by now)
+    if (own_p) STOCS_HIP_CHECK(hipMemcpyAsync(&sort_err_pin[0], d_tmp.p + sort_own_err_offset(), 4, hipMemcpyDeviceToHost, st));
+    if (own_q) STOCS_HIP_CHECK(hipMemcpyAsync(&sort_err_pin[1], d_tmp2.p + sort_own_err_offset(), 4, hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipEventRecord(c->ev_t[5], st));
     c->timing[0].lap(reduce ? "enqueue compact/sort/records/join/scan" : "enqueue gather/sort/records/join/scan");
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
@@ -1327,6 +1355,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         c->timing[0].t_last = CallTiming::now_s();
     }
     STOCS_TICK("join count+scan")
+    if (sort_err_pin[0] || sort_err_pin[1]) { set_error("stocs_find_congruent_all: the pair-list sort gave up waiting for a tile (sort32.hip)"); return STOCS_ERR_HIP; }
     for (int b = 0; b <= nB; ++b) c->quad_off[b] = qoff_at[b];
     return STOCS_OK;
 }
