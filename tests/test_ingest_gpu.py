@@ -107,3 +107,36 @@ def test_icp_refines_a_perturbed_pose():
     far = src + np.float32(5.0)
     T_far, nfar = icp_point_to_plane(far, m.pos, m.nrm, 5, 0.035)
     assert nfar == 0 and np.array_equal(T_far, np.eye(4, dtype=np.float32))
+
+
+def test_a_frame_stream_over_contexts_on_threads_equals_the_frames_one_after_the_other():
+    """The upstream rows and the path together, as a frame stream runs them: depth image -> stocs_ingest_scene -> stocs_ctx_set_scene (grid
+    build) -> one trial, with consecutive frames on DIFFERENT contexts driven by different host threads, so that frame k + 1's ingest and grid
+    build overlap frame k's trial (tools/frame_latency.py --stream: 1 100 frames/s against 540 on one context).  Every frame's pose must be the
+    one the same frame gives alone (reference: one process per frame, src/stocs_match_one_object.cpp:187-215; src/rgbd.cpp:179-281)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from model_matching_amd.estimator import StocsEstimator, ingest_scene, preprocess_model
+    raw = np.load(os.path.join(GOLD, "example_ycb_024_bowl_raw.npz"))
+    K = [float(x) for x in raw["K"]]
+    depth, cprob, dscale = np.ascontiguousarray(raw["depth"]), np.ascontiguousarray(raw["prob"]), float(raw["depth_scale"])
+    mpos, mnrm = preprocess_model(raw["model_raw"], float(raw["normal_radius"]), float(raw["model_voxel"]), float(raw["model_scale"]))
+    frames = [np.ascontiguousarray(np.roll(depth, f, axis=1)) for f in range(4)]     # four different frames
+
+    def one_frame(est, f):
+        p, n, pr, px = ingest_scene(frames[f % 4], cprob, K, dscale)
+        est.set_scene(p, n, pr, px)
+        est.sample_bases(100 + f, 100, mode=0, dispersion=0.9)
+        nq = est.find_congruent_all(); nc = est.make_transforms(200, 100 + f)
+        lcp, idx, pose = est.compute_best_transform()
+        return len(p), int(nq), int(nc), float(lcp), int(idx), pose.tobytes()
+
+    p0, n0, pr0, px0 = ingest_scene(depth, cprob, K, dscale)
+    ests = [StocsEstimator(p0, n0, pr0, px0, mpos, mnrm, build_index=True) for _ in range(3)]
+    seq = [one_frame(ests[0], f) for f in range(12)]
+    assert len({s[:4] for s in seq}) >= 4                                      # the frames really differ
+    with ThreadPoolExecutor(3) as ex:
+        parts = list(ex.map(lambda k: [(f, one_frame(ests[k], f)) for f in range(k, 12, 3)], range(3)))
+    got = dict(x for part in parts for x in part)
+    assert all(got[f] == seq[f] for f in range(12))
+    for e in ests:
+        e.close()

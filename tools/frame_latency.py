@@ -3,7 +3,7 @@
 tests/golden/): uint16 depth + class-probability image -> scene cloud (stocs_ingest_scene) -> stocs_ctx_set_scene
 (upload, centroid shift, GPU brick grid; the model and its PPF index stay) -> one StoCS trial of 100 base
 attempts (sampling, congruent sets, <= 200 transforms per base, verification) -> best pose.
-usage: python tools/frame_latency.py [frames] [--cpu-reference]"""
+usage: python tools/frame_latency.py [frames] [--cpu-reference] | --stream [contexts] [frames] [trials per frame]"""
 import json
 import os
 import sys
@@ -25,7 +25,63 @@ from model_matching_amd.estimator import StocsEstimator, ingest_scene, preproces
 from pose_check import depth_agreement, pose_matrix_from_colmajor16  # noqa: E402  (tools/pose_check.py)
 
 
+def stream_mode(argv):
+    """--stream [contexts] [frames] [trials per frame]: a frame STREAM -- ingest, scene grid and trial(s) of consecutive frames overlap because
+    consecutive frames go to different contexts, each driven by its own host thread (the library calls release the GIL; a context owns its
+    streams).  Every frame's result is compared with the same frame run alone on a fresh sequential pass; throughput = frames / wall clock."""
+    from concurrent.futures import ThreadPoolExecutor
+    n_ctx = int(argv[0]) if argv else 3
+    n_frames = int(argv[1]) if len(argv) > 1 else 240
+    n_trials = int(argv[2]) if len(argv) > 2 else 1
+    out = {}
+    for name in ("ycb_024_bowl", "linemod_obj_06"):
+        raw = np.load(os.path.join(ROOT, "tests", "golden", "example_%s_raw.npz" % name))
+        K = [float(x) for x in raw["K"]]
+        depth, cprob, dscale = np.ascontiguousarray(raw["depth"]), np.ascontiguousarray(raw["prob"]), float(raw["depth_scale"])
+        mpos, mnrm = preprocess_model(raw["model_raw"], float(raw["normal_radius"]), float(raw["model_voxel"]), float(raw["model_scale"]))
+        pos, nrm, prob, pix = ingest_scene(depth, cprob, K, dscale)
+        # frames differ (a camera moves): frame f sees the depth image shifted by f % 7 columns -- same size, different clouds and results
+        frames = [np.ascontiguousarray(np.roll(depth, f % 7, axis=1)) for f in range(7)]
+
+        def one_frame(est, f):
+            p_, n_, pr_, px_ = ingest_scene(frames[f % 7], cprob, K, dscale)
+            est.set_scene(p_, n_, pr_, px_)
+            if n_trials == 1:
+                est.sample_bases(100 + f, 100, mode=0, dispersion=0.9)
+                est.find_congruent_all(); est.make_transforms(200, 100 + f)
+                lcp, idx, pose = est.compute_best_transform()
+                return float(lcp), int(idx), pose.tobytes()
+            res = est.run_trials([1000 * f + t for t in range(n_trials)], 100, mode=0, dispersion=0.9)
+            best = max(res, key=lambda x: x["best_lcp"])
+            return float(best["best_lcp"]), int(best["best_index"]), best["best_pose"].tobytes()
+
+        ests = [StocsEstimator(pos, nrm, prob, pix, mpos, mnrm, build_index=True) for _ in range(n_ctx)]
+        for e in ests:
+            for f in range(3):
+                one_frame(e, f)                  # warm: arenas, workspaces
+        t0 = time.perf_counter()
+        seq = [one_frame(ests[0], f) for f in range(n_frames)]
+        t_seq = time.perf_counter() - t0
+
+        def worker(k):
+            return [(f, one_frame(ests[k], f)) for f in range(k, n_frames, n_ctx)]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(n_ctx) as ex:
+            parts = list(ex.map(worker, range(n_ctx)))
+        t_par = time.perf_counter() - t0
+        got = dict(x for part in parts for x in part)
+        same = all(got[f] == seq[f] for f in range(n_frames))
+        out[name] = {"contexts_on_threads": n_ctx, "frames": n_frames, "trials_per_frame": n_trials,
+                     "sequential_frames_per_s": n_frames / t_seq, "stream_frames_per_s": n_frames / t_par,
+                     "every_frame_identical_to_the_sequential_pass": bool(same)}
+        for e in ests:
+            e.close()
+    print(json.dumps(out, indent=1))
+
+
 def main():
+    if "--stream" in sys.argv[1:]:
+        return stream_mode([a for a in sys.argv[1:] if a != "--stream"])
     argv = [a for a in sys.argv[1:] if a != "--cpu-reference"]
     with_cpu = "--cpu-reference" in sys.argv[1:]      # also time the reference's CPU path (oracle, one core) on each frame: +6 s
     frames = int(argv[0]) if argv else 6
