@@ -415,6 +415,59 @@ __global__ __launch_bounds__(1024) void survivors_scan_kernel(uint32_t* __restri
     block_scan_1024(q ? tiles_q : tiles_p, (q ? ntq : ntp) + 1u, s_part, [](uint32_t, uint32_t, uint32_t) {});
 }
 
+// The same scan for long lists (a trial batch: 10^5 tiles), on as many workgroups as it takes -- the single workgroup above walks 137 counts
+// per thread, one at a time, for a 16-trial piece (137 us on one CU, 1.4 % of the batch).  Two launches: every workgroup scans its 4 096
+// counts (coalesced loads into LDS, 16 per thread there) and writes their sum; then every workgroup adds the sums of the workgroups in
+// front of it (a few dozen words, reduced by the workgroup itself) to its counts.  blockIdx.y: 0 = P list, 1 = Q list.
+#define TSCAN 4096
+__global__ __launch_bounds__(256) void tile_scan_local_kernel(uint32_t* __restrict__ tiles_p, uint32_t np, uint32_t* __restrict__ tiles_q, uint32_t nq, uint32_t* __restrict__ part,
+                                                              uint32_t parts_p) {
+    __shared__ uint32_t s_v[TSCAN + 16];
+    __shared__ uint32_t s_w[4];
+    const bool q = blockIdx.y == 1;
+    uint32_t* a = q ? tiles_q : tiles_p;
+    const uint32_t n = q ? nq : np;
+    const uint32_t base = blockIdx.x * TSCAN;
+    if (base >= n) return;
+    const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
+#pragma unroll
+    for (int j = 0; j < TSCAN / 256; ++j) { const uint32_t i = base + (uint32_t)j * 256u + t; s_v[(uint32_t)j * 256u + t] = i < n ? a[i] : 0u; }
+    __syncthreads();
+    uint32_t v[16], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { v[j] = s_v[t * 16u + (uint32_t)j]; sum += v[j]; }
+    uint32_t inc = sum;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(inc, o, 64); if (lane >= (uint32_t)o) inc += x; }
+    if (lane == 63u) s_w[w] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (uint32_t x = 0; x < w; ++x) run += s_w[x];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { s_v[t * 16u + (uint32_t)j] = run; run += v[j]; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TSCAN / 256; ++j) { const uint32_t i = base + (uint32_t)j * 256u + t; if (i < n) a[i] = s_v[(uint32_t)j * 256u + t]; }
+    if (t == 255u) part[(q ? parts_p : 0u) + blockIdx.x] = run;
+}
+__global__ __launch_bounds__(256) void tile_scan_add_kernel(uint32_t* __restrict__ tiles_p, uint32_t np, uint32_t* __restrict__ tiles_q, uint32_t nq, const uint32_t* __restrict__ part,
+                                                            uint32_t parts_p) {
+    __shared__ uint32_t s_w[4];
+    const bool q = blockIdx.y == 1;
+    uint32_t* a = q ? tiles_q : tiles_p;
+    const uint32_t n = q ? nq : np;
+    const uint32_t base = blockIdx.x * TSCAN;
+    if (base >= n || blockIdx.x == 0) return;
+    const uint32_t* mine = part + (q ? parts_p : 0u);
+    uint32_t acc = 0;
+    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += 256u) acc += mine[j];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    const uint32_t off = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+#pragma unroll
+    for (int j = 0; j < TSCAN / 256; ++j) { const uint32_t i = base + (uint32_t)j * 256u + threadIdx.x; if (i < n) a[i] += off; }
+}
+
 // Where every base's stretch begins and ends in the reduced lists (the lists are base-major, so that is the number of
 // survivors in front of the stretch's old bounds: the offset of the tile a bound falls into plus the survivors of that
 // tile in front of it), patched into the base jobs and the offset arrays the join reads.  Workgroup (b, list).
@@ -1208,7 +1261,15 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         AU.use(s0, tiles_p, true, "tile counts of P", "tile scan"); AU.use(s0, tiles_q, true, "tile counts of Q", "tile scan");
         AU.use(s0, d_qk_raw.p, false, "gathered Q keys", "base offsets"); AU.use(s0, occ_p, false, "occupancy of P", "base offsets"); AU.use(s0, plan.jobs, true, "base jobs", "base offsets");
         AU.use(s0, plan.q_off, true, "Q offsets per base", "base offsets");
-        hipLaunchKernelGGL(survivors_scan_kernel, dim3(2), dim3(1024), 0, st, d_surv.p + o_tp, ntp, d_surv.p + o_tq, ntq);
+        if (std::max(ntp, ntq) + 1u <= 2u * TSCAN) {
+            hipLaunchKernelGGL(survivors_scan_kernel, dim3(2), dim3(1024), 0, st, d_surv.p + o_tp, ntp, d_surv.p + o_tq, ntq);
+        } else {      // long lists (trial batches): the scan on many workgroups
+            const uint32_t pp = (ntp + 1u + TSCAN - 1u) / TSCAN, pq = (ntq + 1u + TSCAN - 1u) / TSCAN;
+            DevBuf<uint32_t> d_part;
+            if ((rc = d_part.alloc((size_t)pp + pq))) return rc;
+            hipLaunchKernelGGL(tile_scan_local_kernel, dim3(std::max(pp, pq), 2), dim3(256), 0, st, d_surv.p + o_tp, ntp + 1u, d_surv.p + o_tq, ntq + 1u, d_part.p, pp);
+            hipLaunchKernelGGL(tile_scan_add_kernel, dim3(std::max(pp, pq), 2), dim3(256), 0, st, d_surv.p + o_tp, ntp + 1u, d_surv.p + o_tq, ntq + 1u, (const uint32_t*)d_part.p, pp);
+        }
         hipLaunchKernelGGL(survivors_base_offsets_kernel<KeyT>, dim3((unsigned)nB, 2), dim3(256), 0, st, (const KeyT*)d_pk_raw.p, (uint32_t)totP0, (const uint32_t*)occ_q,
                            (const uint32_t*)(d_surv.p + o_tp), (const KeyT*)d_qk_raw.p, (uint32_t)totQ0, (const uint32_t*)occ_p, (const uint32_t*)(d_surv.p + o_tq), nB,
                            S->d_jobs.p, plan.p_off, plan.q_off, d_po);

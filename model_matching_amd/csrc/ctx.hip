@@ -282,6 +282,7 @@ static int load_scene_impl(stocs_ctx* c, const float* sp, const float* sn, const
             px[i] = make_int2(c->h_spix[2 * i], c->h_spix[2 * i + 1]);
         }
         // stream-ordered behind whatever still reads the old frame; the pageable sources are staged before the calls return
+        c->prior_epoch++;
         STOCS_HIP_CHECK(hipMemcpyAsync(c->d_spos, ab.data(), n * 16, hipMemcpyHostToDevice, c->stream));
         STOCS_HIP_CHECK(hipMemcpyAsync(c->d_snrmw, ab.data() + n, n * 16, hipMemcpyHostToDevice, c->stream));
         STOCS_HIP_CHECK(hipMemcpyAsync(c->d_spix, px.data(), n * 8, hipMemcpyHostToDevice, c->stream));
@@ -491,6 +492,7 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     c->lcp_flat = getenv("STOCS_LCP_FLAT") ? atoi(getenv("STOCS_LCP_FLAT")) : 1;
     c->lcp_order = getenv("STOCS_LCP_ORDER") ? atoi(getenv("STOCS_LCP_ORDER")) : 1;
     c->d_order = NULL; c->order_bytes = 0;
+    c->d_cdf = NULL; c->cdf_bytes = 0; c->cdf_n = 0; c->prior_epoch = 1; c->cdf_epoch = 0;
     memset(&c->grid, 0, sizeof(c->grid));
     c->d_spos = c->d_snrmw = c->d_mpos = c->d_mnrm = c->d_munit = c->d_mpos_raw = c->d_mpos_s = c->d_mnrm_s = NULL;
     c->d_spix = NULL; c->d_mperm = NULL; c->d_mpatch = NULL; c->d_scene_mem = NULL; c->scene_cap = 0;
@@ -618,7 +620,7 @@ int stocs_ctx_destroy(stocs_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_scene_mem, c->d_mpos, c->d_mnrm, c->d_munit, c->d_mpos_raw, c->d_mpos_s,
                     c->d_mnrm_s, c->d_mperm, c->d_mpatch, c->index.d_bucket_start,
-                    c->index.d_pairs, c->index.d_exists, c->d_scratch, c->d_best, c->d_cand, c->d_order};
+                    c->index.d_pairs, c->index.d_exists, c->d_scratch, c->d_best, c->d_cand, c->d_order, c->d_cdf};
     stocs_internal_free_congruent(c);
     stocs_internal_free_instance(c);
     stocs_internal_free_trials(c);

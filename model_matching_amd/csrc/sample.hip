@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <limits>
 
+#include "prims.h"
 #include "stocs_ctx.h"
 
 namespace stocs {
@@ -1060,6 +1061,7 @@ struct ClassArgs {
     const uint64_t* seeds;      // NULL: one trial, the kernel's seed argument
     int per_trial;
     int wg_offset;              // workgroup blockIdx.x is attempt slot wg_offset + blockIdx.x of the batch (launches of big scenes come in pieces)
+    const int32_t* slot_list;   // != NULL: workgroup blockIdx.x redoes attempt slot slot_list[blockIdx.x] (the lean kernel's rare overflows)
 };
 
 // TWO: built for 64 VGPRs (a few spills) so that TWO workgroups share a CU when the attempt's LDS image allows it (scenes up to ~13 000
@@ -1077,9 +1079,9 @@ __global__ __launch_bounds__(1024, TWO ? 8 : 4) void class_attempts_kernel(Class
     const int a = blockIdx.x;
     if (a >= n_attempts) return;
     const int S = A.pa.S;
-    int attempt = first_attempt + a;
-    int slot = a;                                                           // where the attempt's result goes
-    if (A.seeds) { slot = A.wg_offset + a; const int tr = slot / A.per_trial; seed = A.seeds[tr]; attempt = first_attempt + (slot - tr * A.per_trial); }
+    int slot = A.slot_list ? A.slot_list[a] : (A.seeds ? A.wg_offset + a : a);     // where the attempt's result goes
+    int attempt = first_attempt + slot;
+    if (A.seeds) { const int tr = slot / A.per_trial; seed = A.seeds[tr]; attempt = first_attempt + (slot - tr * A.per_trial); }
     float* w = WLDS ? (float*)cls_dyn : A.w_g + (size_t)a * S;
     sv_t* sv = WLDS ? (sv_t*)(cls_dyn + (((size_t)S * 4 + 15) & ~(size_t)15)) : (sv_t*)(A.sv_g + (size_t)a * S);
     const float4* spos = A.pa.spos;
@@ -1232,14 +1234,241 @@ __global__ __launch_bounds__(1024, TWO ? 8 : 4) void class_attempts_kernel(Class
 #undef CLS_STAMP
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The lean form of class_attempts_kernel (round 5): the same attempt, the same bases bit for bit, in 2 bytes of LDS per scene point
+// instead of 6 -- so that TWO 1024-thread workgroups share a CU on the ycb frame (14 247 points: 85 KB -> 32 KB) and on the metric
+// scene (20 000: 120 KB -> 44 KB), where a small-frame trial batch spends most of its time (64 ycb trials: 6 400 attempts on 256 CUs).
+//   * every attempt starts from the prior (stocs.cpp:372-381), so point 1 is drawn from ONE table for all attempts: the inclusive prefix
+//     sums of the 2^32 fixed-point prior weights in scene order (prior_cdf_kernel + scan, once per prior); the draw of
+//     sample_point_from_distribution (stocs.cpp:133-148; seeded, Q6) -- first index whose inclusive prefix exceeds mulhi64(r, total) -- is a
+//     64-ary search by one wavefront: three dependent loads instead of a scan over the scene.  No copy of the prior in LDS;
+//   * pass 1 keeps a LIST of the points within key distance of point 1 (u16 indices) and marks the survivors of its angle test in a bitmap;
+//   * the survivors -- a third of the scene at the very most, else the attempt is flagged and redone by class_attempts_kernel -- are
+//     compacted from the bitmap in scene order over the dead list: index + weight, 6 bytes each; points 2-4 run on them as before.
+// ---------------------------------------------------------------------------------------------------------------
+#define LEAN_MAX_S 32768
+__global__ __launch_bounds__(256) void prior_fix_kernel(const float4* __restrict__ spos, int S, unsigned long long* __restrict__ fix) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= S) fix[i] = i < S ? weight_fix_dev(spos[i].w) : 0ull;      // (S + 1 entries: the exclusive scan's last one is the total)
+}
+
+__global__ __launch_bounds__(1024, 8) void class_attempts_lean_kernel(ClassArgs A, uint64_t seed, int first_attempt, int n_attempts,
+                                                                      const unsigned long long* __restrict__ cdf_excl, int cap) {
+    extern __shared__ __align__(16) unsigned char lean_dyn[];       // the candidate list of pass 1 (u16 x S), then the survivors (f32 + u16) x cap
+    __shared__ uint32_t sh_alive[LEAN_MAX_S / 32];
+    __shared__ uint64_t sh16[32];
+    __shared__ int sh_pick[2];
+    __shared__ int sh_ncand, sh_b1;
+    __shared__ int sh_cnt[16];
+    const int a = blockIdx.x;
+    if (a >= n_attempts) return;
+    const int S = A.pa.S;
+    const int slot = A.seeds ? A.wg_offset + a : a;
+    int attempt = first_attempt + slot;
+    if (A.seeds) { const int tr = slot / A.per_trial; seed = A.seeds[tr]; attempt = first_attempt + (slot - tr * A.per_trial); }
+    uint16_t* cl = (uint16_t*)lean_dyn;                              // candidates of pass 1
+    float* w = (float*)lean_dyn;                                     // survivors' weights ...
+    uint16_t* sv = (uint16_t*)(lean_dyn + (size_t)cap * 4);          // ... and indices (behind the weights)
+    const float4* spos = A.pa.spos;
+    const float4* snrm = A.pa.snrm;
+    const unsigned long long* cdf = cdf_excl + 1;                    // inclusive prefix of point i
+    BaseOut* out = A.res + slot;
+    int32_t bidx[4] = {-1, -1, -1, -1};
+    int fail = 0;
+#define CLS_THREAD() int t = threadIdx.x; asm volatile("" : "+v"(t)); const int lane = t & 63, wv = t >> 6; (void)lane; (void)wv;
+    // ---- point 1: 64-ary search of the prior's prefix sums by the first wavefront ----
+    {
+        CLS_THREAD()
+        if (t == 0) sh_ncand = 0;
+        for (int i = t; i < (S + 31) / 32; i += 1024) sh_alive[i] = 0u;
+        if (wv == 0) {
+            const unsigned long long total = cdf[S - 1];
+            int pick = -1;
+            if (total != 0ull) {
+                const unsigned long long r = mulhi64(rng64(seed, (uint64_t)attempt, 0), total);
+                int lo = 0, hi = S - 1;                              // cdf[hi] > r; the answer -- the first index whose prefix exceeds r -- lies in [lo, hi]
+                while (lo < hi) {
+                    const int len = hi - lo + 1, step = (len + 63) >> 6;
+                    const int pidx = lo + lane * step;
+                    const bool f = pidx <= hi ? (cdf[pidx] > r) : true;
+                    const unsigned long long m = __ballot(f);
+                    if (m == 0ull) { lo = lo + 63 * step + 1; continue; }     // (every probe below hi and none exceeds r: the answer is behind the last probe)
+                    const int k = (int)__builtin_ctzll(m);
+                    hi = min(lo + k * step, hi);
+                    lo = k ? lo + (k - 1) * step + 1 : lo;
+                    if (k == 0) hi = lo;
+                }
+                pick = lo;
+            }
+            if (lane == 0) sh_b1 = pick;
+        }
+    }
+    __syncthreads();
+    bidx[0] = sh_b1;
+    if (bidx[0] < 0) fail = 1;   // "FAILED SAMPLING:: Zero probability returned" (:386-389)
+    int n_surv = 0;
+    if (!fail) {
+        // ---- pass 1 (stocs.cpp:395-407), distance first: the points that can have a key at all go to the list ----
+        const int b1 = bidx[0];
+        const float4 pc4 = spos[b1], nc4 = snrm[b1];
+        const V3 pc = mk3(pc4.x, pc4.y, pc4.z), nc = mk3(nc4.x, nc4.y, nc4.z);
+        {
+            CLS_THREAD()
+            for (int i0 = 0; i0 < S; i0 += 4096) {
+                float4 P[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const int i = i0 + k * 1024 + t; P[k] = i < S ? spos[i] : make_float4(0, 0, 0, 0); }
+                bool cand[4];
+                unsigned long long cm[4];
+                int n_here = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + k * 1024 + t;
+                    cand[k] = i < S && P[k].w != 0.0f && i != b1 && ppf_distance_may_have_key(A.pa.ix, pc - mk3(P[k].x, P[k].y, P[k].z));
+                    cm[k] = __ballot(cand[k]);
+                    n_here += __popcll(cm[k]);
+                }
+                int base_pos = 0;
+                if (lane == 0 && n_here) base_pos = atomicAdd(&sh_ncand, n_here);
+                base_pos = __builtin_amdgcn_readfirstlane(base_pos);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (cand[k]) cl[base_pos + __popcll(cm[k] & ((1ull << lane) - 1ull))] = (uint16_t)(i0 + k * 1024 + t);
+                    base_pos += __popcll(cm[k]);
+                }
+            }
+        }
+        __syncthreads();
+        {   // the angles of the listed points: a point whose key the model has survives (one bit)
+            CLS_THREAD()
+            const int n_cand = sh_ncand;
+            for (int j0 = 0; j0 < n_cand; j0 += 2048) {
+                int ii[2]; float4 P[2], N[2]; uint32_t key[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int j = j0 + k * 1024 + t;
+                    ii[k] = -1; P[k] = make_float4(0, 0, 0, 0); N[k] = P[k];
+                    if (j < n_cand) { ii[k] = (int)cl[j]; P[k] = spos[ii[k]]; N[k] = snrm[ii[k]]; }
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    key[k] = PPF_NO_KEY;
+                    if (ii[k] >= 0) key[k] = ppf_key_device(A.pa.ix, pc, nc, mk3(P[k].x, P[k].y, P[k].z), mk3(N[k].x, N[k].y, N[k].z));
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (ii[k] >= 0 && ppf_key_present(A.pa.ix, key[k])) atomicOr(&sh_alive[ii[k] >> 5], 1u << (ii[k] & 31));
+            }
+        }
+        __syncthreads();
+        {   // ---- the survivors in scene order: thread t owns 32 consecutive points ----
+            CLS_THREAD()
+            const uint32_t bits = t < (S + 31) / 32 ? sh_alive[t] : 0u;
+            const int cnt = __popc(bits);
+            int inc = cnt;
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+            if (lane == 63) sh_cnt[wv] = inc;
+            __syncthreads();
+            int pre = 0, tot = 0;
+            for (int x = 0; x < 16; ++x) { const int v = sh_cnt[x]; if (x < wv) pre += v; tot += v; }
+            n_surv = tot;
+            if (n_surv > cap) {                                   // (uniform) more survivors than the list holds: the full-size kernel redoes this attempt
+                if (t == 0) { for (int k = 0; k < 4; ++k) out->ids[k] = -1; out->inv[0] = out->inv[1] = 0.0f; out->valid = 0; out->pad = 1; }
+                return;
+            }
+            int pos = pre + inc - cnt;
+            uint32_t b = bits;
+            while (b) {
+                const int i = 32 * t + (int)__builtin_ctz(b);
+                b &= b - 1u;
+                sv[pos] = (uint16_t)i; w[pos] = spos[i].w;       // (the candidate list is dead: every thread is behind the barrier above)
+                ++pos;
+            }
+        }
+        __syncthreads();
+        // ---- points 2..4 (stocs.cpp:410-505) over the survivors ----
+        for (int k = 1; k < 4 && !fail; ++k) {
+            CLS_THREAD()
+            const int pos = draw_block_fast(w, n_surv, rng64(seed, (uint64_t)attempt, (uint64_t)k), sh16, sh_pick, k & 1, A.draw_per_thread);
+            if (pos < 0) { fail = 1; break; }
+            bidx[k] = (int32_t)sv[pos];
+            if (k < 3) {
+                for (int j = t; j < n_surv; j += 1024) {
+                    if (w[j] == 0.0f) continue;                               // already zero: nothing to decide
+                    const int i = (int)sv[j];
+                    const bool z = (k == 1) ? pass_zeroes<2>(A.pa, bidx[0], bidx[1], -1, i) : pass_zeroes<3>(A.pa, bidx[0], bidx[1], bidx[2], i);
+                    if (z) w[j] = 0.0f;
+                }
+                __syncthreads();
+            }
+        }
+    }
+#undef CLS_THREAD
+    if (threadIdx.x < 64) finalize_one_wave_call(A.pa.spos, bidx[0], bidx[1], bidx[2], bidx[3], fail, out);
+}
+
+// the prior's prefix sums for the lean kernel: (re)computed when the class probabilities on the device have changed since the last time
+static int ensure_prior_cdf(stocs_ctx* c) {
+    const size_t S = (size_t)c->nS;
+    if (c->d_cdf && c->cdf_epoch == c->prior_epoch && c->cdf_n == S) return STOCS_OK;
+    size_t tb = 0;
+    STOCS_HIP_CHECK(exclusive_scan(NULL, tb, (const unsigned long long*)NULL, (unsigned long long*)NULL, S + 1, c->stream));
+    const size_t need = 2 * ((S + 1) * 8 + 256) + tb + 256;
+    if (c->cdf_bytes < need) {
+        if (c->d_cdf) { STOCS_HIP_CHECK(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_cdf); c->d_cdf = NULL; c->cdf_bytes = 0; }
+        STOCS_HIP_CHECK(dev_malloc((void**)&c->d_cdf, need + need / 4));
+        c->cdf_bytes = need + need / 4;
+    }
+    unsigned long long* cdf = (unsigned long long*)c->d_cdf;
+    unsigned long long* fix = (unsigned long long*)((char*)c->d_cdf + (((S + 1) * 8 + 255) & ~(size_t)255));
+    void* tmp = (char*)fix + (((S + 1) * 8 + 255) & ~(size_t)255);
+    hipLaunchKernelGGL(prior_fix_kernel, dim3((unsigned)((S + 256) / 256)), dim3(256), 0, c->stream, (const float4*)c->d_spos, (int)S, fix);
+    STOCS_HIP_CHECK(exclusive_scan(tmp, tb, (const unsigned long long*)fix, cdf, S + 1, c->stream));
+    c->cdf_epoch = c->prior_epoch; c->cdf_n = S;
+    return STOCS_OK;
+}
+
+// LDS of the lean kernel and the survivors it holds: at least 2 bytes per scene point (the candidate list), reused as 6 bytes per survivor;
+// up to 75 KB -- what still lets two workgroups share a CU -- are taken, so that small scenes hold every point (no attempt is ever redone) and
+// the ycb frame / the metric scene 12 800 survivors (an attempt there keeps 1 600-4 000)
+static inline size_t lean_lds_bytes(size_t S) { return std::max((S * 2 + 15) & ~(size_t)15, std::min<size_t>(76800, (S * 6 + 31) & ~(size_t)15)); }
+static inline int lean_cap(size_t S) {
+    int cap = (int)std::min<size_t>(S + 1, (lean_lds_bytes(S) - 8) / 6) & ~1;
+    if (const char* e = getenv("STOCS_CLASS_LEAN_CAP")) cap = std::max(2, std::min(cap, atoi(e) & ~1));   // (tests: forces the overflow path)
+    return cap;
+}
+static inline bool lean_usable(const stocs_ctx* c) { return c->nS >= 64 && c->nS <= LEAN_MAX_S && !getenv("STOCS_CLASS_FULL_KERNEL") && !getenv("STOCS_INSTANCE_NO_LDS"); }
+
+// attempts the lean kernel flagged (more survivors than its list holds; pad == 1 in their result): redone by the full-size kernel, in place
+static int redo_lean_overflows(stocs_ctx* c, ClassArgs A, uint64_t seed, int first_attempt, BaseOut* res_host, size_t n, int32_t* d_slots) {
+    std::vector<int32_t> slots;
+    for (size_t i = 0; i < n; ++i) if (res_host[i].pad == 1) slots.push_back((int32_t)i);
+    if (slots.empty()) return STOCS_OK;
+    const size_t S = (size_t)c->nS;
+    int rc = STOCS_OK;
+    do {
+        if (hipMemcpyAsync(d_slots, slots.data(), slots.size() * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = STOCS_ERR_HIP; break; }
+        A.slot_list = d_slots;
+        const size_t lds = ((S * 4 + 15) & ~(size_t)15) + S * 2 + 16;
+        if (hipFuncSetAttribute((const void*)class_attempts_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048) != hipSuccess) { rc = STOCS_ERR_HIP; break; }
+        hipLaunchKernelGGL(class_attempts_kernel<true>, dim3((unsigned)slots.size()), dim3(1024), lds, c->stream, A, seed, first_attempt, (int)slots.size());
+        if (hipGetLastError() != hipSuccess) { rc = STOCS_ERR_HIP; break; }
+        for (size_t k = 0; k < slots.size() && !rc; ++k)
+            if (hipMemcpyAsync(&res_host[slots[k]], A.res + slots[k], sizeof(BaseOut), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = STOCS_ERR_HIP;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) rc = STOCS_ERR_HIP;
+    } while (0);
+    if (rc) set_error("class-mode sampling: redoing %zu attempts with the full-size kernel failed", slots.size());
+    return rc;
+}
+
 // class mode through the one-launch kernel; scenes beyond the LDS working set keep it in device memory (same code)
 static int sample_class(stocs_ctx* c, uint64_t seed, int first_attempt, int nB, int32_t* ids, float* inv, int32_t* valid) {
     if (getenv("STOCS_CLASS_MULTI_KERNEL")) return sample_class_multi(c, seed, first_attempt, nB, ids, inv, valid);   // the nine-launch form (A/B)
     const size_t S = (size_t)c->nS;
     const bool wlds = S <= 26000 && !getenv("STOCS_INSTANCE_NO_LDS");        // 6 bytes per point of the 160 KB
     auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-    const size_t b_res = al((size_t)nB * sizeof(BaseOut)), b_w = wlds ? 0 : al((size_t)nB * S * 4), b_sv = wlds ? 0 : al((size_t)nB * S * 4);
-    int rc = ensure_scratch(c, b_res + b_w + b_sv);
+    const size_t b_res = al((size_t)nB * sizeof(BaseOut)), b_w = wlds ? 0 : al((size_t)nB * S * 4), b_sv = wlds ? 0 : al((size_t)nB * S * 4), b_slots = al((size_t)nB * 4);
+    int rc = ensure_scratch(c, b_res + b_w + b_sv + b_slots + 256);
     if (rc) return rc;
     char* p = (char*)c->d_scratch;
     ClassArgs A;
@@ -1247,8 +1476,9 @@ static int sample_class(stocs_ctx* c, uint64_t seed, int first_attempt, int nB, 
     A.res = (BaseOut*)p; p += b_res;
     A.w_g = (float*)p; p += b_w;
     A.sv_g = (int32_t*)p;
+    int32_t* d_slots = (int32_t*)((char*)c->d_scratch + b_res + b_w + b_sv + 256);   // (behind the debug stamps)
     A.draw_per_thread = 2;
-    A.seeds = NULL; A.per_trial = 0; A.wg_offset = 0;
+    A.seeds = NULL; A.per_trial = 0; A.wg_offset = 0; A.slot_list = NULL;
     const bool dbg = getenv("STOCS_DEBUG_TIMING") != NULL;
     A.stamps = NULL;
     if (dbg) {   // behind everything else in the scratch area
@@ -1260,6 +1490,11 @@ static int sample_class(stocs_ctx* c, uint64_t seed, int first_attempt, int nB, 
         STOCS_HIP_CHECK(hipMemsetAsync(A.stamps, 0, 128, c->stream));
     }
     const size_t lds = wlds ? ((S * 4 + 15) & ~(size_t)15) + S * 2 + 16 : 0;
+    const bool lean = wlds && lean_usable(c) && !dbg;
+    if (lean) {      // 2 bytes of LDS per scene point: two workgroups per CU (the rare attempt with too many survivors is redone below)
+        if ((rc = ensure_prior_cdf(c))) return rc;
+        hipLaunchKernelGGL(class_attempts_lean_kernel, dim3((unsigned)nB), dim3(1024), lean_lds_bytes(S), c->stream, A, seed, first_attempt, nB, (const unsigned long long*)c->d_cdf, lean_cap(S));
+    } else
     if (wlds && lds <= CLASS_TWO_LDS && nB > 256) {     // (more workgroups than CUs: two per CU pay)
         STOCS_HIP_CHECK(hipFuncSetAttribute((const void*)class_attempts_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CLASS_TWO_LDS));
         hipLaunchKernelGGL((class_attempts_kernel<true, true>), dim3((unsigned)nB), dim3(1024), lds, c->stream, A, seed, first_attempt, nB);
@@ -1273,6 +1508,7 @@ static int sample_class(stocs_ctx* c, uint64_t seed, int first_attempt, int nB, 
     std::vector<BaseOut> res((size_t)nB);
     STOCS_HIP_CHECK(hipMemcpyAsync(res.data(), A.res, (size_t)nB * sizeof(BaseOut), hipMemcpyDeviceToHost, c->stream));
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (lean && (rc = redo_lean_overflows(c, A, seed, first_attempt, res.data(), (size_t)nB, d_slots))) return rc;
     if (dbg) {
         unsigned long long st[16];
         STOCS_HIP_CHECK(hipMemcpy(st, A.stamps, 128, hipMemcpyDeviceToHost));
@@ -1292,6 +1528,7 @@ static int refresh_class_prob_on_device(stocs_ctx* c) {
     STOCS_HIP_CHECK(hipMemcpyAsync(c->d_spos, a.data(), (size_t)c->nS * 16, hipMemcpyHostToDevice, c->stream));
     STOCS_HIP_CHECK(hipMemcpyAsync(c->d_snrmw, b.data(), (size_t)c->nS * 16, hipMemcpyHostToDevice, c->stream));
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->prior_epoch++;       // (the prefix sums the lean class kernel draws point 1 from are stale)
     return STOCS_OK;
 }
 
@@ -1444,6 +1681,7 @@ static int sample_instance(stocs_ctx* c, uint64_t seed, int first_attempt, int n
     A.stamps = NULL;
     if (dbg) { A.stamps = (unsigned long long*)I->d_parent; STOCS_HIP_CHECK(hipMemsetAsync(I->d_parent, 0, 128, c->stream)); }   // parent_g is idle for small discs
     A.w = I->d_w; A.sv = I->d_sv; A.spos_w = c->d_spos; A.snrm_w = c->d_snrmw; A.res = sb.res;
+    c->prior_epoch++;       // (the kernel writes the decayed prior into the scene arrays)
     A.n_trials = 0; A.trial_stride = 0; A.seeds = NULL;
     // hand-over slots of the attempts: header, S (index, weight) pairs, flag; one error word
     {
@@ -1525,8 +1763,8 @@ int sample_trials(stocs_ctx* c, int mode, int nT, const uint64_t* seeds, int nA,
         const bool wlds = S <= 26000 && !getenv("STOCS_INSTANCE_NO_LDS");
         // scenes beyond the LDS working set keep 8 bytes per (attempt, point) in device memory: at most ~1 GB of it per launch
         const size_t per_launch = wlds ? nW : std::max<size_t>(1, std::min<size_t>(nW, ((size_t)1 << 30) / (S * 8)));
-        const size_t b_res = al(nW * sizeof(BaseOut)), b_seed = al((size_t)nT * 8), b_w = wlds ? 0 : al(per_launch * S * 4);
-        int rc = ensure_scratch(c, b_res + b_seed + 2 * b_w);
+        const size_t b_res = al(nW * sizeof(BaseOut)), b_seed = al((size_t)nT * 8), b_w = wlds ? 0 : al(per_launch * S * 4), b_slots = al(nW * 4);
+        int rc = ensure_scratch(c, b_res + b_seed + 2 * b_w + b_slots);
         if (rc) return rc;
         if ((rc = ensure_pinned(c, (size_t)PIN_VAR + b_seed))) return rc;
         char* p = (char*)c->d_scratch;
@@ -1536,22 +1774,26 @@ int sample_trials(stocs_ctx* c, int mode, int nT, const uint64_t* seeds, int nA,
         uint64_t* d_seeds = (uint64_t*)(p + b_res);
         A.w_g = (float*)(p + b_res + b_seed); A.sv_g = (int32_t*)(p + b_res + b_seed + b_w);
         A.draw_per_thread = 2; A.stamps = NULL;
-        A.seeds = d_seeds; A.per_trial = nA;
+        A.seeds = d_seeds; A.per_trial = nA; A.slot_list = NULL;
         memcpy((char*)c->h_pin + PIN_VAR, seeds, (size_t)nT * 8);
         STOCS_HIP_CHECK(hipMemcpyAsync(d_seeds, (char*)c->h_pin + PIN_VAR, (size_t)nT * 8, hipMemcpyHostToDevice, c->stream));
         const size_t lds = wlds ? ((S * 4 + 15) & ~(size_t)15) + S * 2 + 16 : 0;
         if (wlds) STOCS_HIP_CHECK(hipFuncSetAttribute((const void*)class_attempts_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
         if (wlds && lds <= CLASS_TWO_LDS) STOCS_HIP_CHECK(hipFuncSetAttribute((const void*)class_attempts_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CLASS_TWO_LDS));
+        const bool lean = wlds && lean_usable(c);
+        if (lean && (rc = ensure_prior_cdf(c))) return rc;
         for (size_t w0 = 0; w0 < nW; w0 += per_launch) {
             const unsigned n = (unsigned)std::min(per_launch, nW - w0);
             A.wg_offset = (int)w0;
-            if (wlds && lds <= CLASS_TWO_LDS && n > 256) hipLaunchKernelGGL((class_attempts_kernel<true, true>), dim3(n), dim3(1024), lds, c->stream, A, (uint64_t)0, 0, (int)n);
+            if (lean) hipLaunchKernelGGL(class_attempts_lean_kernel, dim3(n), dim3(1024), lean_lds_bytes(S), c->stream, A, (uint64_t)0, 0, (int)n, (const unsigned long long*)c->d_cdf, lean_cap(S));
+            else if (wlds && lds <= CLASS_TWO_LDS && n > 256) hipLaunchKernelGGL((class_attempts_kernel<true, true>), dim3(n), dim3(1024), lds, c->stream, A, (uint64_t)0, 0, (int)n);
             else if (wlds) hipLaunchKernelGGL(class_attempts_kernel<true>, dim3(n), dim3(1024), lds, c->stream, A, (uint64_t)0, 0, (int)n);
             else hipLaunchKernelGGL(class_attempts_kernel<false>, dim3(n), dim3(1024), 0, c->stream, A, (uint64_t)0, 0, (int)n);
         }
         STOCS_HIP_CHECK(hipGetLastError());
         STOCS_HIP_CHECK(hipMemcpyAsync(res_host, A.res, nW * sizeof(BaseOut), hipMemcpyDeviceToHost, c->stream));
         STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (lean) { A.wg_offset = 0; if ((rc = redo_lean_overflows(c, A, 0, 0, res_host, nW, (int32_t*)((char*)c->d_scratch + b_res + b_seed + 2 * b_w)))) return rc; }
         return STOCS_OK;
     }
     // ---- instance mode ----

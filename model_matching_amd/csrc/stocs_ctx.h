@@ -253,6 +253,9 @@ struct stocs_ctx {
     int lcp_order;     // 0: candidates in batch order; 1: spatially ordered processing of big batches; 2: + XCD-contiguous blocks
     void* d_order;     // keys / permutation / sort scratch of the ordering
     size_t order_bytes;
+    // class-mode sampling, lean kernel (sample.hip): exclusive prefix sums of the prior's 2^32 fixed-point weights in scene order (S + 1
+    // entries), recomputed when the class probabilities on the device have changed (prior_epoch) or the scene has (cdf_n)
+    void* d_cdf; size_t cdf_bytes, cdf_n; unsigned long long prior_epoch, cdf_epoch;
     stocs::PpfIndex index;
 
     // image-space state of instance mode (stocs.hpp:153-155)

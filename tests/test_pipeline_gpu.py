@@ -83,11 +83,16 @@ def test_draw_equals_oracle(setup, oracle_lib):
     assert est.draw(z, 12345) == -1
 
 
-@pytest.mark.parametrize("path", ["one_launch_lds", "one_launch_device_memory", "nine_launches"])
+@pytest.mark.parametrize("path", ["lean", "lean_overflow_redone", "one_launch_lds", "one_launch_device_memory", "nine_launches"])
 def test_class_bases_equal_oracle(setup, path, monkeypatch):
-    """sample_class_base (stocs.cpp:363-519): the one-launch kernel with the attempt's weights in LDS (the default up to
-    26 000 scene points), the same kernel on device memory (larger scenes; forced here), and the nine-launch form kept for
-    A/B -- bases and invariants bit for bit against the oracle."""
+    """sample_class_base (stocs.cpp:363-519): the lean one-launch kernel (round 5, the default up to 26 000 scene points: point 1 from the
+    prior's prefix sums, 2 bytes of LDS per scene point), the same with a survivor list so short that attempts overflow and are redone by
+    the full-size kernel, the full-size kernel with the attempt's weights in LDS (rounds 3-4), the same kernel on device memory (larger
+    scenes; forced here), and the nine-launch form kept for A/B -- bases and invariants bit for bit against the oracle."""
+    if path == "lean_overflow_redone":
+        monkeypatch.setenv("STOCS_CLASS_LEAN_CAP", "64")
+    if path == "one_launch_lds":
+        monkeypatch.setenv("STOCS_CLASS_FULL_KERNEL", "1")
     if path == "one_launch_device_memory":
         monkeypatch.setenv("STOCS_INSTANCE_NO_LDS", "1")
     if path == "nine_launches":
