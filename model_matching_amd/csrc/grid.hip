@@ -268,53 +268,78 @@ __global__ __launch_bounds__(256) void cell_nearest_kernel(const uint64_t* __res
 // where the centre-sorted lists with early exit of rounds 2-4 read 15-20 entries in a dependent line -> bound -> line chain.
 // One wavefront per cell; double arithmetic relative to the cell centre (float positions are exact in double).
 // ---------------------------------------------------------------------------------------------
-template <int PRUNE_K>
+// GS lanes per cell (64, or 16 on sparse scenes whose lists hold a handful of points: four cells per wavefront); a list longer than GS is
+// walked GS entries at a time, its first GS entries stay in registers for the selection rounds.
+template <int PRUNE_K, int GS>
 __global__ __launch_bounds__(256) void prune_kernel(GridGeom G, double hh, double margin, const uint32_t* __restrict__ cell_first, const uint64_t* __restrict__ cell_key,
                                                     uint32_t n_cells, uint32_t n_inc, const uint32_t* __restrict__ vals, const float4* __restrict__ spos,
                                                     uint32_t* __restrict__ rank, uint32_t* __restrict__ kept, float* __restrict__ nearest) {
-    const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (c >= n_cells) return;   // whole wavefront
-    const uint32_t first = cell_first[c];
-    const uint32_t cnt = (c + 1 < n_cells ? cell_first[c + 1] : n_inc) - first;
-    const uint64_t key = cell_key[c];
+    const uint32_t c = blockIdx.x * (256u / GS) + (threadIdx.x / GS);
+    const int lane = threadIdx.x & (GS - 1), wlane = threadIdx.x & 63;
+    const bool cell_ok = c < n_cells;                             // (a wavefront of 16-lane groups may hold cells beyond the end: they idle through the ballots)
+    const uint32_t first = cell_ok ? cell_first[c] : 0u;
+    const uint32_t cnt = cell_ok ? (c + 1 < n_cells ? cell_first[c + 1] : n_inc) - first : 0u;
+    const uint64_t key = cell_ok ? cell_key[c] : 0ull;
     const uint64_t brick = key >> 9;
     const uint32_t local = (uint32_t)(key & 511);
     const int bx = (int)(brick % (uint64_t)G.nbx), by = (int)((brick / (uint64_t)G.nbx) % (uint64_t)G.nby), bz = (int)(brick / ((uint64_t)G.nbx * (uint64_t)G.nby));
     const int cx = bx * 8 + (int)(local & 7), cy = by * 8 + (int)((local >> 3) & 7), cz = bz * 8 + (int)(local >> 6);
     const double ccx = G.of[0] + (cx + 0.5) * G.h, ccy = G.of[1] + (cy + 0.5) * G.h, ccz = G.of[2] + (cz + 0.5) * G.h;
+    // the group's first GS entries, one per lane
+    double ux0 = 0, uy0 = 0, uz0 = 0, n20 = 0;
+    if ((uint32_t)lane < cnt) {
+        const float4 pf = spos[vals[first + (uint32_t)lane]];
+        ux0 = (double)pf.x - ccx; uy0 = (double)pf.y - ccy; uz0 = (double)pf.z - ccz;
+        n20 = ux0 * ux0 + uy0 * uy0 + uz0 * uz0;
+    }
     // ---- the PRUNE_K entries nearest to the centre: PRUNE_K rounds of "smallest (distance, position) key above the last one" ----
     double dux[PRUNE_K], duy[PRUNE_K], duz[PRUNE_K], dn2[PRUNE_K];
     unsigned long long last = 0ull;
     int nd = 0;
+    uint32_t cnt_max = cnt;                                       // (uniform over the wavefront: the loops below run for the longest list of its groups)
+    if (GS < 64) for (int off = GS; off < 64; off <<= 1) cnt_max = max(cnt_max, (uint32_t)__shfl_xor((int)cnt_max, off, 64));
 #pragma unroll
     for (int j = 0; j < PRUNE_K; ++j) {
-        if ((uint32_t)j >= cnt) break;
+        if ((uint32_t)j >= cnt_max) break;
         unsigned long long best = ~0ull;
-        for (uint32_t k = (uint32_t)lane; k < cnt; k += 64u) {
+        if ((uint32_t)lane < cnt) {
+            const unsigned long long kk = ((unsigned long long)__float_as_uint((float)n20) << 32) | (unsigned long long)(lane + 1);
+            if (kk > last) best = kk;
+        }
+        for (uint32_t k = (uint32_t)lane + GS; k < cnt; k += GS) {
             const float4 pf = spos[vals[first + k]];
             const double ux = (double)pf.x - ccx, uy = (double)pf.y - ccy, uz = (double)pf.z - ccz;
             const float d2 = (float)(ux * ux + uy * uy + uz * uz);        // (selection only: any listed point is a valid dominator)
             const unsigned long long kk = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(k + 1u);
             if (kk > last && kk < best) best = kk;
         }
-        for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(best, off, 64); best = o < best ? o : best; }
-        if (best == ~0ull) break;
+        for (int off = GS / 2; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(best, off, GS); best = o < best ? o : best; }
+        if (best == ~0ull) continue;                              // this group's list is exhausted (another group's may not be)
         last = best;
-        const float4 pf = spos[vals[first + (uint32_t)(best & 0xFFFFFFFFull) - 1u]];   // (uniform address)
-        dux[j] = (double)pf.x - ccx; duy[j] = (double)pf.y - ccy; duz[j] = (double)pf.z - ccz;
-        dn2[j] = dux[j] * dux[j] + duy[j] * duy[j] + duz[j] * duz[j];
+        const uint32_t kb = (uint32_t)(best & 0xFFFFFFFFull) - 1u;
+        double vx, vy, vz;
+        if (kb < (uint32_t)GS) {                                  // held by a lane of the group
+            vx = __shfl(ux0, (int)kb, GS); vy = __shfl(uy0, (int)kb, GS); vz = __shfl(uz0, (int)kb, GS);
+        } else {
+            const float4 pf = spos[vals[first + kb]];             // (the same address in every lane of the group)
+            vx = (double)pf.x - ccx; vy = (double)pf.y - ccy; vz = (double)pf.z - ccz;
+        }
+        dux[j] = vx; duy[j] = vy; duz[j] = vz;
+        dn2[j] = vx * vx + vy * vy + vz * vz;
         nd = j + 1;
     }
     // ---- every entry against the dominators ----
     uint32_t base = 0;
-    for (uint32_t k0 = 0; k0 < cnt; k0 += 64u) {
+    for (uint32_t k0 = 0; k0 < cnt_max; k0 += GS) {
         const uint32_t k = k0 + (uint32_t)lane;
         bool keep = false;
         if (k < cnt) {
-            const float4 pf = spos[vals[first + k]];
-            const double ux = (double)pf.x - ccx, uy = (double)pf.y - ccy, uz = (double)pf.z - ccz;
-            const double n2 = ux * ux + uy * uy + uz * uz;
+            double ux = ux0, uy = uy0, uz = uz0, n2 = n20;
+            if (k0) {
+                const float4 pf = spos[vals[first + k]];
+                ux = (double)pf.x - ccx; uy = (double)pf.y - ccy; uz = (double)pf.z - ccz;
+                n2 = ux * ux + uy * uy + uz * uz;
+            }
             keep = true;
 #pragma unroll
             for (int j = 0; j < PRUNE_K; ++j) {
@@ -324,11 +349,12 @@ __global__ __launch_bounds__(256) void prune_kernel(GridGeom G, double hh, doubl
                 }
             }
         }
-        const unsigned long long m = __ballot(keep);
+        unsigned long long m = __ballot(keep);
+        if (GS < 64) m = (m >> (wlane & ~(GS - 1))) & ((1ull << GS) - 1ull);      // the group's own lanes
         if (k < cnt) rank[first + k] = keep ? base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)) : 0xFFFFFFFFu;
         base += (uint32_t)__popcll(m);
     }
-    if (lane == 0) {
+    if (lane == 0 && cell_ok) {
         kept[c] = base;
         // lower bound of |centre - nearest listed point| (the nearest is never dominated), below the exact value also as a float
         const double d0 = nd ? sqrt(dn2[0]) : 0.0;
@@ -484,8 +510,9 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense, int prune) {
         const double margin = 4.0e-6 * reach * reach;
         hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(256), 0, st, (int32_t*)d_total, (size_t)2, 0);
         const int pk = getenv("STOCS_GRID_PRUNE_K") ? atoi(getenv("STOCS_GRID_PRUNE_K")) : 8;   // dominators tried per entry (measurement switch: 4, 8, 16)
-#define STOCS_PRUNE_LAUNCH(KV) hipLaunchKernelGGL(prune_kernel<KV>, dim3((unsigned)((n_cells + 3) / 4)), dim3(256), 0, st, G, hh, margin, d_cell_first, d_cell_key, n_cells, (uint32_t)n_inc, d_vals_s, \
-                           c->d_spos, d_rank, d_kept, d_near)
+#define STOCS_PRUNE_LAUNCH(KV) do { if (short_lists) hipLaunchKernelGGL((prune_kernel<KV, 16>), dim3((unsigned)((n_cells + 15) / 16)), dim3(256), 0, st, G, hh, margin, d_cell_first, d_cell_key, n_cells, (uint32_t)n_inc, d_vals_s, c->d_spos, d_rank, d_kept, d_near); \
+                                    else hipLaunchKernelGGL((prune_kernel<KV, 64>), dim3((unsigned)((n_cells + 3) / 4)), dim3(256), 0, st, G, hh, margin, d_cell_first, d_cell_key, n_cells, (uint32_t)n_inc, d_vals_s, c->d_spos, d_rank, d_kept, d_near); } while (0)
+        const bool short_lists = (double)n_inc <= 12.0 * (double)n_cells;     // a handful of points per cell: 16 lanes per cell, four cells per wavefront
         if (pk == 4) STOCS_PRUNE_LAUNCH(4); else if (pk == 16) STOCS_PRUNE_LAUNCH(16); else STOCS_PRUNE_LAUNCH(8);
 #undef STOCS_PRUNE_LAUNCH
         hipLaunchKernelGGL(cell_padded_kept_kernel, dim3(grid_of(n_cells)), dim3(256), 0, st, d_kept, n_cells, 8u, d_padded, d_max, d_total);

@@ -1490,7 +1490,9 @@ static int sample_class(stocs_ctx* c, uint64_t seed, int first_attempt, int nB, 
         STOCS_HIP_CHECK(hipMemsetAsync(A.stamps, 0, 128, c->stream));
     }
     const size_t lds = wlds ? ((S * 4 + 15) & ~(size_t)15) + S * 2 + 16 : 0;
-    const bool lean = wlds && lean_usable(c) && !dbg;
+    // (a single trial's 100 attempts have a CU each either way: the lean kernel pays when there are more workgroups than CUs, or when the
+    //  prior's prefix sums exist already -- a new frame would otherwise pay 13 us for three small launches it has no use for)
+    const bool lean = wlds && lean_usable(c) && !dbg && (nB > 256 || (c->d_cdf && c->cdf_epoch == c->prior_epoch && c->cdf_n == S) || getenv("STOCS_CLASS_LEAN_KERNEL"));
     if (lean) {      // 2 bytes of LDS per scene point: two workgroups per CU (the rare attempt with too many survivors is redone below)
         if ((rc = ensure_prior_cdf(c))) return rc;
         hipLaunchKernelGGL(class_attempts_lean_kernel, dim3((unsigned)nB), dim3(1024), lean_lds_bytes(S), c->stream, A, seed, first_attempt, nB, (const unsigned long long*)c->d_cdf, lean_cap(S));

@@ -89,6 +89,8 @@ def test_class_bases_equal_oracle(setup, path, monkeypatch):
     prior's prefix sums, 2 bytes of LDS per scene point), the same with a survivor list so short that attempts overflow and are redone by
     the full-size kernel, the full-size kernel with the attempt's weights in LDS (rounds 3-4), the same kernel on device memory (larger
     scenes; forced here), and the nine-launch form kept for A/B -- bases and invariants bit for bit against the oracle."""
+    if path in ("lean", "lean_overflow_redone"):
+        monkeypatch.setenv("STOCS_CLASS_LEAN_KERNEL", "1")          # (a single trial of a new scene takes the full-size kernel unless asked: 40 workgroups have a CU each)
     if path == "lean_overflow_redone":
         monkeypatch.setenv("STOCS_CLASS_LEAN_CAP", "64")
     if path == "one_launch_lds":
