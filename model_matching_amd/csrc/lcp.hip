@@ -444,7 +444,12 @@ __device__ __forceinline__ bool lcp_patch_dead(const LcpArgs& a, const float4 sp
 // NEAR (pruned lists on grids finer than epsilon, round 5): the cell word's z is a lower bound of |cell centre - nearest listed point|
 // (no sub-cell mask there); a query farther from the centre than that bound + epsilon never touches the list -- EARLY's first test
 // without its line-by-line exit, which lists of ~5 entries have no use for.
-template <bool DETAIL, int UNR, bool SORTQ = false, int PIPE = 4, bool IDX = true, int WPB = 4, int FLAT = 0, bool SPLIT = false, bool TILE = false, bool EARLY = false, int GL = 8, int FIRST = 1, bool NOSENT = false, bool NEAR = false>
+// TINY (round 5, with GL = 4 on index-ordered lists): after the dominance pruning most surviving queries see a list of at most four entries.
+// Those are verified by TWO lanes each (two entries per lane, 32 queries per trip of the wavefront) instead of four: the texture addresser
+// -- the unit this kernel sits on -- takes four lane addresses per clock whatever their width, so a four-entry list read by four lanes x two
+// entries costs twice the addresses it needs.  The pending queries are ordered tiny lists first; a trip is a two-lane trip while 32 tiny
+// queries are left.
+template <bool DETAIL, int UNR, bool SORTQ = false, int PIPE = 4, bool IDX = true, int WPB = 4, int FLAT = 0, bool SPLIT = false, bool TILE = false, bool EARLY = false, int GL = 8, int FIRST = 1, bool NOSENT = false, bool NEAR = false, bool TINY = false>
 __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const float* __restrict__ T16, float* __restrict__ out,
                                                         int n, int32_t* __restrict__ hit_out, uint8_t* __restrict__ cnt_out) {
     __shared__ float4 qt[WPB][128];     // qx, qy, qz, bits(list offset)
@@ -459,9 +464,9 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
     // queries per trip; GL = 4: two entries per lane, sixteen queries per trip and one reduction level less)
     // FIRST: list lines requested in a query's first trip (the second line of a list that has one arrives with the first: half of
     // the survivors' lists at Cm are longer than a line); not with EARLY, whose later lines wait for the bound test
-    constexpr int EPL = 8 / GL, NG = 64 / GL, E0 = EPL * FIRST;
+    constexpr int EPL = 8 / GL, E0 = EPL * FIRST;
     static_assert(!EARLY || FIRST == 1, "early exit decides line by line");
-    const int sub = lane & (GL - 1), grp = lane / GL;
+    static_assert(!TINY || (GL == 4 && SORTQ && IDX && !EARLY && PIPE == 1), "two-lane trips: the four-lane queue form on index-ordered lists");
 #if defined(STOCS_TOOLS_BUILD) && defined(STOCS_LCP_W_UNIFORM)
     // measurement build only (profiles/r04_lcp_w_uniform_isa.md): the wavefront index forced into an SGPR.  63 VGPRs, 8 waves -- and
     // 12 % SLOWER: every LDS address of the per-wavefront queue (qt[w][..], qn[w][..], ri[w][..]) is then formed as "scalar base +
@@ -480,23 +485,31 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
     int head = 0, tail = 0;
 
     auto process = [&](int nq) {
+        int n_tiny = 0;
         // order the pending queries by list length (number of 128-byte chunks) so that the eight
         // groups of a step stream lists of similar length: a counting sort on <= 8 classes with ballots
         if (SORTQ) {
             // (most lists are one or two lines: three classes -- one line, two, more -- keep the eight groups of a step on
             //  lists of similar length at a third of the instructions of a sort over all lengths)
-            uint32_t cls = 3;
-            if (lane < nq) { const uint32_t nch = (qn[w][(head + lane) & 127] + 7u) >> 3; cls = nch <= (uint32_t)FIRST ? 0u : (nch <= (uint32_t)(FIRST + UNR) ? 1u : 2u); }   // one trip, two, more
+            uint32_t cls = 4;
+            if (lane < nq) {
+                const uint32_t cq = qn[w][(head + lane) & 127], nch = (cq + 7u) >> 3;
+                cls = (TINY && cq <= 4u) ? 0u : (nch <= (uint32_t)FIRST ? 1u : (nch <= (uint32_t)(FIRST + UNR) ? 2u : 3u));   // at most four entries; one trip, two, more
+            }
             const unsigned long long below = (1ull << lane) - 1ull;
-            const unsigned long long m0 = __ballot(cls == 0u), m1 = __ballot(cls == 1u), m2 = __ballot(cls == 2u);
-            const int n0 = __popcll(m0), n1 = __popcll(m1);
-            const int pos = cls == 0u ? __popcll(m0 & below) : (cls == 1u ? n0 + __popcll(m1 & below) : n0 + n1 + __popcll(m2 & below));
+            const unsigned long long mt = __ballot(cls == 0u), m0 = __ballot(cls == 1u), m1 = __ballot(cls == 2u), m2 = __ballot(cls == 3u);
+            const int nt = __popcll(mt), n0 = __popcll(m0), n1 = __popcll(m1);
+            n_tiny = nt;
+            const int pos = cls == 0u ? __popcll(mt & below) : (cls == 1u ? nt + __popcll(m0 & below) : (cls == 2u ? nt + n0 + __popcll(m1 & below) : nt + n0 + n1 + __popcll(m2 & below)));
             if (lane < nq) ord[w][pos] = (uint8_t)lane;
             __builtin_amdgcn_wave_barrier();
         }
         // PIPE query-steps are in flight together: their first 128-byte list lines (most lists are a single
         // line) are requested back to back, so one memory round trip serves PIPE*8 queries
-        for (int s0 = 0; s0 < nq; s0 += NG * PIPE) {
+        for (int s0 = 0; s0 < nq;) {
+            const bool two = TINY && s0 + 32 <= n_tiny;          // (uniform) a trip of 32 tiny lists, two lanes each
+            const int gl = two ? 2 : GL, NG = two ? 32 : 64 / GL;
+            const int sub = lane & (gl - 1), grp = two ? (lane >> 1) : lane / GL;
             float4 e0[PIPE][E0];
             bool wide[PIPE];
             int idxs[PIPE];
@@ -522,20 +535,20 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
                     const float4* l0 = a.list + (cs[u] ? (uint32_t)__float_as_int(qt[w][idxs[u]].w) : 0u) + sub;
                     const uint32_t last = cs[u] ? ((cs[u] - 1u) & ~7u) : 0u;
 #pragma unroll
-                    for (int e = 0; e < EPL; ++e) e0[u][e] = l0[GL * e];
+                    for (int e = 0; e < EPL; ++e) e0[u][e] = l0[gl * e];
                     // the later lines of the first trip only when some list of this trip has them (the queries are ordered by list
                     // length, so a third of the trips are single-line lists throughout: no addresses spent on re-reading those)
                     wide[u] = FIRST > 1 && __any(cs[u] > 8u);
                     if (wide[u]) {
 #pragma unroll
-                        for (int e = EPL; e < E0; ++e) e0[u][e] = l0[min((uint32_t)(8 * (e / EPL)), last) + GL * (e % EPL)];
+                        for (int e = EPL; e < E0; ++e) e0[u][e] = l0[min((uint32_t)(8 * (e / EPL)), last) + gl * (e % EPL)];
                     }
                 }
                 else if (cs[u]) {
                     const float4* l0 = a.list + (uint32_t)__float_as_int(qt[w][idxs[u]].w) + sub;
 #pragma unroll
                     for (int e = 0; e < E0; ++e)
-                        if (e < EPL || (uint32_t)(8 * (e / EPL)) < cs[u]) e0[u][e] = l0[8 * (e / EPL) + GL * (e % EPL)];
+                        if (e < EPL || (uint32_t)(8 * (e / EPL)) < cs[u]) e0[u][e] = l0[8 * (e / EPL) + gl * (e % EPL)];
                 }
             }
 #pragma unroll
@@ -572,7 +585,7 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
                         for (int v = 0; v < UNR; ++v) {   // a line's entries under ONE condition: its loads leave together
                             if (k + 8 * v < cc) {
 #pragma unroll
-                                for (int x = 0; x < EPL; ++x) e[v][x] = lp[k + 8 * v + GL * x];
+                                for (int x = 0; x < EPL; ++x) e[v][x] = lp[k + 8 * v + gl * x];
                             } else {
 #pragma unroll
                                 for (int x = 0; x < EPL; ++x) e[v][x] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(-1));
@@ -595,10 +608,10 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
                         if (NOSENT) {   // a list shorter than this trip reads its last line again (the same entries: harmless)
                             const uint32_t kk = min(k + 8u * v, last_line);
 #pragma unroll
-                            for (int x = 0; x < EPL; ++x) e[v][x] = lp[kk + GL * x];
+                            for (int x = 0; x < EPL; ++x) e[v][x] = lp[kk + gl * x];
                         } else if (k + 8 * v < c) {
 #pragma unroll
-                            for (int x = 0; x < EPL; ++x) e[v][x] = lp[k + 8 * v + GL * x];
+                            for (int x = 0; x < EPL; ++x) e[v][x] = lp[k + 8 * v + gl * x];
                         } else {
 #pragma unroll
                             for (int x = 0; x < EPL; ++x) e[v][x] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(-1));
@@ -613,13 +626,14 @@ __global__ __launch_bounds__(64 * WPB, 8) void lcp_coopq_kernel(LcpArgs a, const
                             take_if_better<IDX>(d, __float_as_int(e[v][x].w), gd, gi);
                         }
                 }
-                const float dm = group_min_nonneg<GL>(gd);
+                const float dm = two ? group_min_nonneg<2>(gd) : group_min_nonneg<GL>(gd);
                 int im = (gd == dm) ? gi : -1;
                 if (GL >= 2) im = max(im, dpp_i32<DPP_QUAD_XOR1>(im));
-                if (GL >= 4) im = max(im, dpp_i32<DPP_QUAD_XOR2>(im));
+                if (GL >= 4 && !two) im = max(im, dpp_i32<DPP_QUAD_XOR2>(im));
                 if (GL == 8) im = max(im, dpp_i32<DPP_HALF_MIRROR>(im));
                 if (c && sub == 0) ri[w][idxs[u]] = im;
             }
+            s0 += NG * PIPE;
         }
         __builtin_amdgcn_wave_barrier();
         if (lane < nq) {
@@ -1054,8 +1068,15 @@ int launch_lcp(stocs_ctx* c, const float* d_T16, int n, float* d_lcp, int32_t* d
                     case 1: STOCS_LCP_Q(true, 1, 1, 1); break;     // a lane per query, a whole line per lane (3.16 ms)
 #endif
                     default:
-                        if (a.has_nearest) STOCS_LCP_Q(true, 1, 4, 1, 2, true, true);   // pruned lists on a grid finer than epsilon: the distance bound in place of the sub-cell mask
-                        else STOCS_LCP_Q(true, 1, 4, 1, 2, true);    // 4: four lanes, one trip in flight, a list's first two lines together, no sentinels
+                        // four lanes per query, one trip in flight, a list's first two lines together, no sentinels.  has_nearest: pruned lists on a grid
+                        // finer than epsilon, the distance bound in place of the sub-cell mask.  (Round 5 measured and did not keep TINY -- lists of at
+                        // most four entries verified by two lanes, 32 queries per trip: Cm 0.939 -> 1.001 ms, C5 3.30 -> 3.50 ms, scores bitwise equal:
+                        // the runtime lane mapping and the fourth ordering class cost more instructions than the saved addresses are worth.  The
+                        // form lives in the tools build, STOCS_LCP_TINY=1.)
+#ifdef STOCS_TOOLS_BUILD
+                        if (getenv("STOCS_LCP_TINY")) { if (a.has_nearest) STOCS_LCP_Q(true, 1, 4, 1, 2, true, true, true); else STOCS_LCP_Q(true, 1, 4, 1, 2, true, false, true); break; }
+#endif
+                        if (a.has_nearest) STOCS_LCP_Q(true, 1, 4, 1, 2, true, true); else STOCS_LCP_Q(true, 1, 4, 1, 2, true);
                         break;
                 }
 #undef STOCS_LCP_Q
