@@ -139,3 +139,19 @@ def test_pruning_statistics_and_cell_edge_choice(monkeypatch, capfd):
     kept, dilated = [float(x) for x in re.search(r"\(([0-9.]+) per non-empty cell; ([0-9.]+) within r", line).groups()]
     assert kept < 0.4 * dilated and kept < 12.0, line
     est.close()
+
+
+def test_config5_pruned_lists_give_the_same_16384_scores(monkeypatch):
+    """BASELINE config 5 at its full size (200 000-point scene, 50 000-point model, 16 384 candidates): the pruned grid (cell edge eps/2, ~8 entries
+    per list) against the grid of rounds 3-4 (eps/4, centre-sorted lists of ~30 entries with early exit) -- every score bit for bit."""
+    from model_matching_amd import synth
+    m, s, k = synth.workload("C5")
+    pr, un = _pair(monkeypatch, (s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm))
+    cs, cm = pr.get_scene_centroid().astype(np.float64), pr.get_model_centroid().astype(np.float64)
+    T = synth.make_candidates(synth.centred_gt(s.T_gt, cs, cm), k, seed=synth.SEED_CAND)
+    got_p, got_u = pr.score_transforms(T), un.score_transforms(T)
+    assert np.array_equal(got_p.view(np.uint32), got_u.view(np.uint32)) and got_p.max() > 0.05
+    best = int(np.argmax(got_p))
+    hp, cp = pr.lcp_detail(T[best]); hu, cu = un.lcp_detail(T[best])
+    assert np.array_equal(hp, hu) and np.array_equal(cp, cu) and (hp >= 0).sum() > 5000
+    pr.close(); un.close()
