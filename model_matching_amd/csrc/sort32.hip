@@ -19,7 +19,8 @@
 //   * pairs reordered through LDS so that the scatter writes runs of consecutive addresses;
 //   * tiles take their index from a ticket, so a tile only ever waits for tiles that already run, and every wait is bounded in wall-clock
 //     time and reports instead of hanging.
-// One zero fill per sort (control block + histograms); the look-back words of pass p + 1 are zeroed by the tiles of pass p.
+// No fill launch of its own: control block and histograms are zeroed by the tile-table kernel, the look-back words of pass 0 by the histogram
+// kernel, those of pass p + 1 by the tiles of pass p.
 // HBM-bound byte work (16 B read + written per pair and pass); no MFMA.
 #include <stddef.h>
 #include <stdio.h>
@@ -61,10 +62,19 @@ static SortPlan sort_plan(unsigned b0, unsigned b1) {
 // Segments -> tiles.  seg_off[0 .. n_seg]: where every segment (base) begins in the list; seg_off == NULL: one segment [0, n).  A segment of
 // L pairs is ceil(L / tile) tiles; tile_first = exclusive scan, tile_seg[tile] = its segment.  One workgroup (the table is tiny next to the list).
 __global__ __launch_bounds__(1024) void seg_tiles_kernel(const uint32_t* __restrict__ seg_off, uint32_t n_seg, uint32_t n, uint32_t tile, uint32_t max_tiles,
-                                                         uint32_t* __restrict__ tile_first, uint32_t* __restrict__ tile_seg, uint32_t* __restrict__ own_off, SortCtl* __restrict__ ctl) {
+                                                         uint32_t* __restrict__ tile_first, uint32_t* __restrict__ tile_seg, uint32_t* __restrict__ own_off, SortCtl* __restrict__ ctl,
+                                                         uint32_t* __restrict__ hist, uint32_t hist_words) {
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_carry;
     const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
+    if (blockIdx.x > 0) {                                         // workgroups 1..: the sort's one zero fill -- the digit histograms
+        const uint32_t i0 = ((blockIdx.x - 1u) * 1024u + t) * 4u;
+        if (i0 + 3u < hist_words) *(uint4*)(hist + i0) = make_uint4(0u, 0u, 0u, 0u);
+        else for (uint32_t i = i0; i < hist_words; ++i) hist[i] = 0u;
+        return;
+    }
+    if (t < SORT_MAX_PASS) ctl->ticket[t] = 0u;                    // workgroup 0: the control block (n_tiles is written below), then the tile table
+    if (t == SORT_MAX_PASS) ctl->err = 0u;
     if (t == 0) s_carry = 0u;
     __syncthreads();
     for (uint32_t b0 = 0; b0 < n_seg; b0 += 1024u) {
@@ -329,9 +339,10 @@ hipError_t sort_pairs_own(void* tmp, size_t& bytes, const uint32_t* kin, uint32_
     uint32_t* lbs[2] = {(uint32_t*)(base + ctl_b + hist_b + 2 * tf_b + ts_b), (uint32_t*)(base + ctl_b + hist_b + 2 * tf_b + ts_b + lb_b)};
     uint32_t* tk = (uint32_t*)(base + ctl_b + hist_b + 2 * tf_b + ts_b + 2 * lb_b);
     uint32_t* tv = (uint32_t*)((char*)tk + buf_b);
-    hipError_t e = hipMemsetAsync(base, 0, ctl_b + hist_b, st);      // the one fill of the sort: tickets, error word, histograms
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(seg_tiles_kernel, dim3(1), dim3(1024), 0, st, seg_off, n_seg, (uint32_t)n, (uint32_t)tile, (uint32_t)max_tiles, tile_first, tile_seg, own_off, ctl);
+    // (the sort's one zero fill -- tickets, error word, histograms -- rides in the tile-table launch: a launch less on the critical path of a trial)
+    const uint32_t hist_words = (uint32_t)(hist_b / 4);
+    hipLaunchKernelGGL(seg_tiles_kernel, dim3(1u + (hist_words + 4095u) / 4096u), dim3(1024), 0, st, seg_off, n_seg, (uint32_t)n, (uint32_t)tile, (uint32_t)max_tiles, tile_first, tile_seg, own_off, ctl,
+                       hist, hist_words);
 #define SORT_SHAPES(X) switch (shape) { case (4 << 8) | 8: X(4, 8); break; case (8 << 8) | 8: X(8, 8); break; case (8 << 8) | 16: X(8, 16); break; \
                                         case (16 << 8) | 8: X(16, 8); break; case (16 << 8) | 16: X(16, 16); break; default: X(4, 16); break; }
 #define SORT_HIST(NWV, KPTV) hipLaunchKernelGGL((seg_hist_kernel<NWV, KPTV>), dim3((unsigned)max_tiles), dim3(64 * NWV), 0, st, kin, P, (const SortCtl*)ctl, (const uint32_t*)tile_first, \
