@@ -1164,8 +1164,7 @@ static double now_s() {
 static bool cong_sort_own() { static const bool own = !(getenv("STOCS_SORT") && !strcmp(getenv("STOCS_SORT"), "rocprim")); return own; }
 static hipError_t cong_sort(void* tmp, size_t& bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, size_t n, unsigned cell_bits, unsigned end_bit,
                             const uint32_t* seg_off, int n_seg, hipStream_t st, bool* own) {
-    // (one tile per base at least: lists of many short stretches -- the 64 ycb trials of a batch: 6 000 bases of ~100 pairs -- stay with the unsegmented sort)
-    *own = cong_sort_own() && n_seg > 0 && n / (size_t)n_seg >= 4096 && n < ((size_t)1 << 30);   // (30-bit prefixes in its look-back words)
+    *own = cong_sort_own() && n_seg > 0 && n < ((size_t)1 << 30);   // (30-bit prefixes in its look-back words)
     return *own ? sort_pairs_own(tmp, bytes, kin, kout, vin, vout, n, 0, cell_bits, seg_off, (uint32_t)n_seg, st) : sort_pairs(tmp, bytes, kin, kout, vin, vout, n, 0, end_bit, st);
 }
 static hipError_t cong_sort(void* tmp, size_t& bytes, const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, size_t n, unsigned, unsigned end_bit,

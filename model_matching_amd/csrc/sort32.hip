@@ -19,6 +19,7 @@
 //   * pairs reordered through LDS so that the scatter writes runs of consecutive addresses;
 //   * tiles take their index from a ticket, so a tile only ever waits for tiles that already run, and every wait is bounded in wall-clock
 //     time and reports instead of hanging.
+// Bases of at most 2 048 pairs get no tiles: seg_small_sort_kernel sorts each whole in LDS, all passes in one launch.
 // No fill launch of its own: control block and histograms are zeroed by the tile-table kernel, the look-back words of pass 0 by the histogram
 // kernel, those of pass p + 1 by the tiles of pass p.
 // HBM-bound byte work (16 B read + written per pair and pass); no MFMA.
@@ -63,7 +64,7 @@ static SortPlan sort_plan(unsigned b0, unsigned b1) {
 // L pairs is ceil(L / tile) tiles; tile_first = exclusive scan, tile_seg[tile] = its segment.  One workgroup (the table is tiny next to the list).
 __global__ __launch_bounds__(1024) void seg_tiles_kernel(const uint32_t* __restrict__ seg_off, uint32_t n_seg, uint32_t n, uint32_t tile, uint32_t max_tiles,
                                                          uint32_t* __restrict__ tile_first, uint32_t* __restrict__ tile_seg, uint32_t* __restrict__ own_off, SortCtl* __restrict__ ctl,
-                                                         uint32_t* __restrict__ hist, uint32_t hist_words) {
+                                                         uint32_t* __restrict__ hist, uint32_t hist_words, uint32_t small_cap) {
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_carry;
     const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(1024) void seg_tiles_kernel(const uint32_t* __restr
         const uint32_t b = b0 + t;
         uint32_t lo = 0, hi = 0;
         if (b < n_seg) { lo = seg_off ? seg_off[b] : 0u; hi = seg_off ? seg_off[b + 1] : n; lo = min(lo, n); hi = min(max(hi, lo), n); }
-        const uint32_t nt = (hi - lo + tile - 1u) / tile;
+        const uint32_t nt = (hi - lo) > small_cap ? (hi - lo + tile - 1u) / tile : 0u;     // (short segments are sorted whole by seg_small_sort_kernel)
         uint32_t inc = nt;
         for (int o = 1; o < 64; o <<= 1) { const uint32_t a = __shfl_up(inc, o, 64); if (lane >= (uint32_t)o) inc += a; }
         if (lane == 63u) s_w[w] = inc;
@@ -299,6 +300,95 @@ __global__ __launch_bounds__(64 * NW) void seg_onesweep_kernel(const uint32_t* _
     }
 }
 
+// Segments of at most SMALL_CAP pairs -- most bases of a trial (the median base of a Cm trial keeps ~700 of its pairs), and every base of a
+// small-frame batch (64 ycb trials: 6 400 bases of ~100 pairs) -- are sorted WHOLE by one workgroup in LDS: all passes in one launch, no
+// histogram, no look-back, one read and one write of the segment.  Same slot order and the same ranking as the tiles of the onesweep passes.
+#define SMALL_NW 4
+#define SMALL_KPT 8
+#define SMALL_CAP (64 * SMALL_NW * SMALL_KPT)
+__global__ __launch_bounds__(64 * SMALL_NW) void seg_small_sort_kernel(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin, uint32_t* __restrict__ kout,
+                                                                       uint32_t* __restrict__ vout, SortPlan P, const uint32_t* __restrict__ seg_off, uint32_t n_seg, uint32_t n) {
+    constexpr uint32_t NW = SMALL_NW, KPT = SMALL_KPT, THREADS = 64u * NW, TILE = THREADS * KPT;
+    __shared__ uint32_t s_wh[NW][256];
+    __shared__ uint32_t s_k[TILE], s_v[TILE];
+    __shared__ unsigned long long s_mm[NW][256];
+    __shared__ uint32_t s_part[4];
+    const uint32_t seg = blockIdx.x, t = threadIdx.x, w = t >> 6, lane = t & 63u;
+    uint32_t lo = seg_off ? seg_off[seg] : 0u, hi = seg_off ? seg_off[seg + 1] : n;
+    lo = min(lo, n); hi = min(max(hi, lo), n);
+    const uint32_t len = hi - lo;
+    if (len == 0u || len > TILE) return;                          // (uniform) longer segments go through the tiles of the onesweep passes
+    unsigned long long* const s_m = &s_mm[w][0];
+    uint32_t key[KPT], val[KPT];
+    const uint32_t wbase = w * (64u * KPT) + lane;
+#pragma unroll
+    for (int j = 0; j < (int)KPT; ++j) {
+        const uint32_t sl = wbase + (uint32_t)j * 64u;
+        key[j] = sl < len ? kin[lo + sl] : 0xFFFFFFFFu;           // beyond the end: the largest digit in every pass, ranked last, never written
+        val[j] = sl < len ? vin[lo + sl] : 0u;
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int p = 0; p < P.n_pass; ++p) {
+        const int shift = P.shift[p];
+        const uint32_t dmask = (1u << P.bits[p]) - 1u;
+        for (uint32_t i = t; i < NW * 256u; i += THREADS) { (&s_wh[0][0])[i] = 0u; (&s_mm[0][0])[i] = 0ull; }
+        __syncthreads();
+        uint32_t rank[KPT];
+#pragma unroll
+        for (int j = 0; j < (int)KPT; ++j) {                      // (the ranking of seg_onesweep_kernel)
+            const uint32_t d = (key[j] >> shift) & dmask;
+            unsigned long long rem = ~0ull, m = 0ull;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                if (!rem) break;
+                const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, (int)__builtin_ctzll(rem));
+                const unsigned long long mk = __ballot(d == d0) & rem;
+                if (d == d0) m = mk;
+                rem &= ~mk;
+            }
+            const bool via_lds = (rem >> lane) & 1ull;
+            if (rem) {
+                if (via_lds) atomicOr(&s_m[d], 1ull << lane);
+                __builtin_amdgcn_wave_barrier();
+                if (via_lds) m = s_m[d];
+            }
+            const uint32_t c0 = s_wh[w][d];
+            __builtin_amdgcn_wave_barrier();
+            if ((m & lt) == 0ull) { s_wh[w][d] = c0 + (uint32_t)__popcll(m); if (via_lds) s_m[d] = 0ull; }
+            __builtin_amdgcn_wave_barrier();
+            rank[j] = c0 + (uint32_t)__popcll(m & lt);
+        }
+        __syncthreads();
+        {   // digit t: counts per wavefront -> first slot per wavefront (exclusive scan over the 256 digits)
+            uint32_t cw[NW], tot = 0;
+#pragma unroll
+            for (int x = 0; x < (int)NW; ++x) { cw[x] = s_wh[x][t]; tot += cw[x]; }
+            uint32_t ti = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t a = __shfl_up(ti, o, 64); if (lane >= (uint32_t)o) ti += a; }
+            if (lane == 63u) s_part[w] = ti;
+            __syncthreads();
+            uint32_t run = ti - tot;
+            for (uint32_t x = 0; x < w; ++x) run += s_part[x];
+#pragma unroll
+            for (int x = 0; x < (int)NW; ++x) { s_wh[x][t] = run; run += cw[x]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < (int)KPT; ++j) {
+            const uint32_t pos = s_wh[w][(key[j] >> shift) & dmask] + rank[j];
+            s_k[pos] = key[j]; s_v[pos] = val[j];
+        }
+        __syncthreads();
+        if (p + 1 < P.n_pass) {                                   // the next pass reads the slots in memory order again
+#pragma unroll
+            for (int j = 0; j < (int)KPT; ++j) { const uint32_t sl = wbase + (uint32_t)j * 64u; key[j] = s_k[sl]; val[j] = s_v[sl]; }
+            __syncthreads();
+        }
+    }
+    for (uint32_t sl = t; sl < len; sl += THREADS) { kout[lo + sl] = s_k[sl]; vout[lo + sl] = s_v[sl]; }
+}
+
 size_t sort_own_err_offset() { return offsetof(SortCtl, err); }
 
 // Tile shape (NW << 8) | KPT by the size of the sort (tools/sort_bench.py, ms own / rocPRIM on random keys, unsegmented): 4 096-pair tiles
@@ -322,7 +412,8 @@ hipError_t sort_pairs_own(void* tmp, size_t& bytes, const uint32_t* kin, uint32_
     const SortPlan P = sort_plan(b0, b1);
     const int shape = sort_shape(n), nw = shape >> 8, kpt = shape & 255;
     const size_t tile = (size_t)64 * nw * kpt;
-    const size_t max_tiles = n / tile + (size_t)n_seg + 1;
+    // (only segments beyond SMALL_CAP pairs are cut into tiles: at most n / SMALL_CAP of them)
+    const size_t max_tiles = n / tile + std::min<size_t>((size_t)n_seg, n / SMALL_CAP + 1) + 1;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t ctl_b = al(sizeof(SortCtl)), hist_b = al((size_t)P.n_pass * n_seg * 256 * 4), tf_b = al(((size_t)n_seg + 1) * 4), ts_b = al(max_tiles * 4),
                  lb_b = al(max_tiles * 256 * 4), buf_b = al(n * 4);
@@ -342,7 +433,8 @@ hipError_t sort_pairs_own(void* tmp, size_t& bytes, const uint32_t* kin, uint32_
     // (the sort's one zero fill -- tickets, error word, histograms -- rides in the tile-table launch: a launch less on the critical path of a trial)
     const uint32_t hist_words = (uint32_t)(hist_b / 4);
     hipLaunchKernelGGL(seg_tiles_kernel, dim3(1u + (hist_words + 4095u) / 4096u), dim3(1024), 0, st, seg_off, n_seg, (uint32_t)n, (uint32_t)tile, (uint32_t)max_tiles, tile_first, tile_seg, own_off, ctl,
-                       hist, hist_words);
+                       hist, hist_words, (uint32_t)SMALL_CAP);
+    hipLaunchKernelGGL(seg_small_sort_kernel, dim3(n_seg), dim3(64 * SMALL_NW), 0, st, kin, vin, kout, vout, P, seg_off, n_seg, (uint32_t)n);
 #define SORT_SHAPES(X) switch (shape) { case (4 << 8) | 8: X(4, 8); break; case (8 << 8) | 8: X(8, 8); break; case (8 << 8) | 16: X(8, 16); break; \
                                         case (16 << 8) | 8: X(16, 8); break; case (16 << 8) | 16: X(16, 16); break; default: X(4, 16); break; }
 #define SORT_HIST(NWV, KPTV) hipLaunchKernelGGL((seg_hist_kernel<NWV, KPTV>), dim3((unsigned)max_tiles), dim3(64 * NWV), 0, st, kin, P, (const SortCtl*)ctl, (const uint32_t*)tile_first, \
