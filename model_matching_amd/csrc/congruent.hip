@@ -354,57 +354,63 @@ __global__ __launch_bounds__(256) void gather_key_kernel(const uint32_t* __restr
 template <class KeyT>
 __device__ __forceinline__ bool occ_test(const uint32_t* __restrict__ occ, KeyT key) { return (occ[(size_t)(key >> 5)] >> ((uint32_t)key & 31u)) & 1u; }
 
-// per tile of SURV_TILE entries: how many survive.  A workgroup takes a run of consecutive tiles; lds_words > 0: the OTHER list's bits of
-// the base its current tile starts in sit in LDS (2^cell_bits / 8 bytes, loaded when the base changes), so the test of an entry is an
-// LDS read -- the byte table of rounds 3-4a was gathered from device memory per entry and missed the L2 half of the time (3.2 MB per
-// list and trial against a 4 MB L2 that the lists stream through).  Entries of another base in the tile read the table directly.
+// per tile of SURV_TILE entries: how many survive.  A workgroup takes a run of consecutive GROUPS of four tiles, wavefront w of it the w-th
+// tile of the group: its 16 rows of 64 keys are requested together (the round-4 form took one tile per trip of the whole workgroup -- four
+// loads per thread in flight between two barriers, ~10 us per trip: 0.4 TB/s over a 40-trial piece), its count is its own (no reduction
+// across wavefronts), its 16 ballots leave as one 128-byte store.  lds_words > 0: the OTHER list's bits of the base that holds the group's
+// middle entry sit in LDS (2^cell_bits / 8 bytes, loaded when that base changes -- one barrier per group, two more on a change), so the
+// test of an entry of that base is an LDS read -- the byte table of rounds 3-4a was gathered from device memory per entry and missed the
+// L2 half of the time (3.2 MB per list and trial against a 4 MB L2 that the lists stream through).  Entries of another base read the
+// table directly.
+#define SURV_ROWS (SURV_TILE / 64)
 template <class KeyT>
 __global__ __launch_bounds__(256) void survivors_count_kernel(const KeyT* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ other,
                                                               uint32_t* __restrict__ tile_cnt, const PlanOut* __restrict__ po, int is_q,
                                                               unsigned long long* __restrict__ alive_bits, uint32_t lds_words, int cell_bits) {
     extern __shared__ uint32_t s_occ[];
-    __shared__ uint32_t s_w[4];
+    __shared__ KeyT s_mid[2];
     if (po) { if (po->overflow) return; const unsigned long long t = is_q ? po->totQ : po->totP; n = t < (unsigned long long)n ? (uint32_t)t : n; }   // (overflow: the gather wrote nothing)
-    const uint32_t n_tiles = (n + SURV_TILE - 1u) / SURV_TILE;
-    const uint32_t per_wg = (n_tiles + gridDim.x - 1u) / gridDim.x;
-    const uint32_t t_begin = blockIdx.x * per_wg, t_end = min(n_tiles, t_begin + per_wg);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    constexpr int R = SURV_TILE / 256;
+    const uint32_t n_tiles = (n + SURV_TILE - 1u) / SURV_TILE, n_groups = (n_tiles + 3u) / 4u;
+    const uint32_t per_wg = (n_groups + gridDim.x - 1u) / gridDim.x;
+    const uint32_t g_begin = blockIdx.x * per_wg, g_end = min(n_groups, g_begin + per_wg);
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     const KeyT cmask = ((KeyT)1 << cell_bits) - (KeyT)1;
     KeyT cur = ~(KeyT)0;                 // base whose bits are in LDS
-    for (uint32_t tile = t_begin; tile < t_end; ++tile) {
+    for (uint32_t g = g_begin; g < g_end; ++g) {
+        const uint32_t tile = g * 4u + w, e0 = tile * SURV_TILE + lane;       // (n < 2^32 - 2^16: no wrap; a tile beyond the list loads nothing)
+        KeyT key[SURV_ROWS];
+#pragma unroll
+        for (int k = 0; k < SURV_ROWS; ++k) { const uint32_t e = e0 + (uint32_t)k * 64u; key[k] = (tile < n_tiles && e < n) ? keys[e] : ~(KeyT)0; }
         if (lds_words) {
-            const KeyT tb = keys[(size_t)tile * SURV_TILE] >> cell_bits;      // (uniform: the tile's first entry exists)
-            if (tb != cur) {
-                __syncthreads();
+            // the group's middle entry is row 0, lane 0 of wavefront 2; a group that ends before it takes its first entry (wavefront 0)
+            const bool has_mid = g * 4u * SURV_TILE + 2u * SURV_TILE < n;
+            if (lane == 0u && w == (has_mid ? 2u : 0u)) s_mid[g & 1u] = key[0] >> cell_bits;
+            __syncthreads();                                       // (also: every wavefront is done with the bits of the group before)
+            const KeyT tb = s_mid[g & 1u];
+            if (tb != cur) {                                       // (uniform)
                 cur = tb;
                 for (uint32_t i = threadIdx.x; i < lds_words; i += blockDim.x) s_occ[i] = other[(size_t)cur * lds_words + i];
                 __syncthreads();
             }
         }
+        if (tile >= n_tiles) continue;                             // (wave-uniform; the barriers above are behind it)
         uint32_t cnt = 0;
-        KeyT key[R]; bool ob[R];
+        unsigned long long mine = 0ull;
 #pragma unroll
-        for (int k = 0; k < R; ++k) { const uint32_t e = tile * SURV_TILE + k * 256 + threadIdx.x; key[k] = e < n ? keys[e] : ~(KeyT)0; }
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const uint32_t e = tile * SURV_TILE + k * 256 + threadIdx.x;
-            if (e >= n) ob[k] = false;
-            else if (lds_words && (key[k] >> cell_bits) == cur) { const uint32_t cl = (uint32_t)(key[k] & cmask); ob[k] = (s_occ[cl >> 5] >> (cl & 31u)) & 1u; }
-            else ob[k] = occ_test(other, key[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const unsigned long long am = __ballot(ob[k]);   // (the all-ones cell is never marked)
-            // one bit per entry, kept for the compaction: it then reads 8 bytes per wavefront instead of testing again,
+        for (int k = 0; k < SURV_ROWS; ++k) {
+            const uint32_t e = e0 + (uint32_t)k * 64u;
+            bool ob;
+            if (e >= n) ob = false;
+            else if (lds_words && (key[k] >> cell_bits) == cur) { const uint32_t cl = (uint32_t)(key[k] & cmask); ob = (s_occ[cl >> 5] >> (cl & 31u)) & 1u; }
+            else ob = occ_test(other, key[k]);
+            const unsigned long long am = __ballot(ob);            // (the all-ones cell is never marked)
+            // one bit per entry, kept for the compaction: it then reads 8 bytes per row instead of testing again,
             // and loads the keys and pairs of the survivors only (a quarter of the entries)
-            if (lane == 0) alive_bits[(size_t)tile * (SURV_TILE / 64) + (size_t)k * 4 + (size_t)w] = am;
+            if (lane == (uint32_t)k) mine = am;
             cnt += (uint32_t)__popcll(am);
         }
-        if (lane == 0) s_w[w] = cnt;
-        __syncthreads();
-        if (threadIdx.x == 0) tile_cnt[tile] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-        __syncthreads();
+        if (lane < (uint32_t)SURV_ROWS) alive_bits[(size_t)tile * SURV_ROWS + lane] = mine;
+        if (lane == 0u) tile_cnt[tile] = cnt;
     }
 }
 
@@ -510,46 +516,35 @@ __global__ __launch_bounds__(256) void survivors_base_offsets_kernel(const KeyT*
     }
 }
 
-// the survivors of a tile, in order, behind the tile's offset
+// the survivors of a tile, in order, behind the tile's offset: one WAVEFRONT per tile (four tiles per workgroup), no LDS, no barrier -- the
+// tile's 16 ballots arrive as one 128-byte load and are handed out through scalar registers, the 16 rows of the survivors' keys and pairs
+// are requested together (the round-4 form: one workgroup per tile, four rows per thread, 75 000 workgroups for a 40-trial piece)
 template <class KeyT>
 __global__ __launch_bounds__(256) void survivors_compact_kernel(const KeyT* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n,
                                                                 const unsigned long long* __restrict__ alive_bits, const uint32_t* __restrict__ tile_off,
                                                                 KeyT* __restrict__ okeys, uint32_t* __restrict__ ovals, const PlanOut* __restrict__ po, int is_q) {
-    constexpr int R = SURV_TILE / 256;
     if (po) { if (po->overflow) return; const unsigned long long t = is_q ? po->totQ : po->totP; n = t < (unsigned long long)n ? (uint32_t)t : n; }
-    if (blockIdx.x * SURV_TILE >= n) return;
-    __shared__ uint32_t s_c[R][4];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    KeyT key[R];
-    uint32_t rank[R], val[R];
-    unsigned long long bm[R];
-    bool alive[R];
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * 4u + w;
+    if ((unsigned long long)tile * SURV_TILE >= (unsigned long long)n) return;      // (wave-uniform)
+    const unsigned long long mine = lane < (uint32_t)SURV_ROWS ? alive_bits[(size_t)tile * SURV_ROWS + lane] : 0ull;   // the count pass's ballots
+    uint32_t base = tile_off[tile];
+    const uint32_t e0 = tile * SURV_TILE + lane;
+    KeyT key[SURV_ROWS];
+    uint32_t val[SURV_ROWS];
+    unsigned long long bm[SURV_ROWS];
 #pragma unroll
-    for (int k = 0; k < R; ++k) bm[k] = alive_bits[(size_t)blockIdx.x * (SURV_TILE / 64) + (size_t)k * 4 + (size_t)w];   // the count pass's ballots (wave-uniform)
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const uint32_t e = blockIdx.x * SURV_TILE + k * 256 + threadIdx.x;
-        alive[k] = (bm[k] >> lane) & 1ull;
+    for (int k = 0; k < SURV_ROWS; ++k) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, k), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), k);
+        bm[k] = ((unsigned long long)hi << 32) | lo;
         key[k] = (KeyT)0; val[k] = 0u;
-        if (alive[k]) { key[k] = keys[e]; val[k] = vals[e]; }       // survivors only
+        if ((bm[k] >> lane) & 1ull) { key[k] = keys[e0 + (uint32_t)k * 64u]; val[k] = vals[e0 + (uint32_t)k * 64u]; }       // survivors only (a set bit is an entry below n)
     }
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const unsigned long long am = bm[k];
-        rank[k] = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
-        if (lane == 0) s_c[k][w] = (uint32_t)__popcll(am);
-    }
-    __syncthreads();
-    uint32_t base = tile_off[blockIdx.x];
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-        uint32_t o = base;
-#pragma unroll
-        for (int ww = 0; ww < 4; ++ww) { if (ww < w) o += s_c[k][ww]; base += s_c[k][ww]; }
-        if (alive[k]) {
-            okeys[o + rank[k]] = key[k];
-            ovals[o + rank[k]] = val[k];
-        }
+    for (int k = 0; k < SURV_ROWS; ++k) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bm[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm[k], 0u));
+        if ((bm[k] >> lane) & 1ull) { okeys[base + rank] = key[k]; ovals[base + rank] = val[k]; }
+        base += (uint32_t)__popcll(bm[k]);
     }
 }
 
@@ -567,28 +562,50 @@ __global__ __launch_bounds__(256) void p_records_kernel(const KeyT* __restrict__
                                                         long long NC, const BaseJob* __restrict__ jobs, const float4* __restrict__ munit,
                                                         const float4* __restrict__ mpos, float nepsilon, float4* __restrict__ prec,
                                                         uint16_t* __restrict__ pdc, uint32_t* __restrict__ cfirst, uint32_t* __restrict__ cend) {
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= totP) return;
-    const KeyT key = keys[e];
+    // four entries per thread, 256 apart: the four (key, pair) loads, then the model points of all four, are in flight together (one entry per
+    // thread left the kernel waiting on three dependent round trips: 1.8 TB/s over the 66 M entries of a 32-trial piece).
+    // prec == NULL (the distance gate cannot fail inside a position cell, CongruentState::close_cells): the join decides on direction cells
+    // alone, nobody reads the world-space point -- neither it nor the two model positions behind it are touched.
+    constexpr int R = 4;
+    const uint32_t e0 = blockIdx.x * (256u * R) + threadIdx.x;
     const KeyT cmask = ((KeyT)1 << cell_bits) - (KeyT)1;
-    const uint32_t b = (uint32_t)(key >> cell_bits);
-    const KeyT pc = key & cmask;
-    const uint32_t pr = vals[e];
-    const int ia = pr >> 16, ib = pr & 0xFFFF;
-    const V3 pp1 = ld3c(mpos, ia), pp2 = ld3c(mpos, ib);
-    const V3 ip = pp1 + (pp2 - pp1) * jobs[b].inv1;
-    int dc = 0xFFFF;
-    if (pc != cmask) {
-        const int nc = index_normal(normalized3(ld3c(munit, ib) - ld3c(munit, ia)), nepsilon);
-        if (nc >= 0 && nc < 343) dc = nc;
+    KeyT key[R], kprev[R], knext[R];
+    uint32_t pr[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const uint32_t e = e0 + (uint32_t)k * 256u;
+        const bool in = e < totP;
+        key[k] = in ? keys[e] : (KeyT)0; pr[k] = in ? vals[e] : 0u;
+        kprev[k] = (cfirst && in && e > 0u) ? keys[e - 1u] : (KeyT)0;
+        knext[k] = (cfirst && in && e + 1u < totP) ? keys[e + 1u] : (KeyT)0;
     }
-    prec[e] = make_float4(ip.x, ip.y, ip.z, __int_as_float(dc));
-    if (pdc) pdc[e] = (uint16_t)dc;
-    if (!cfirst || pc == cmask) return;
-    const bool first = (e == 0) || keys[e - 1] != key;
-    const bool last = (e + 1 == totP) || keys[e + 1] != key;
-    if (first) cfirst[(long long)b * NC + (long long)pc] = e;
-    if (last) cend[(long long)b * NC + (long long)pc] = e + 1;
+    float4 ua[R], ub[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) { ua[k] = munit[pr[k] >> 16]; ub[k] = munit[pr[k] & 0xFFFF]; }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const uint32_t e = e0 + (uint32_t)k * 256u;
+        if (e >= totP) continue;
+        const uint32_t b = (uint32_t)(key[k] >> cell_bits);
+        const KeyT pc = key[k] & cmask;
+        int dc = 0xFFFF;
+        if (pc != cmask) {
+            const int nc = index_normal(normalized3(mk3(ub[k].x, ub[k].y, ub[k].z) - mk3(ua[k].x, ua[k].y, ua[k].z)), nepsilon);
+            if (nc >= 0 && nc < 343) dc = nc;
+        }
+        if (prec) {
+            const int ia = pr[k] >> 16, ib = pr[k] & 0xFFFF;
+            const V3 pp1 = ld3c(mpos, ia), pp2 = ld3c(mpos, ib);
+            const V3 ip = pp1 + (pp2 - pp1) * jobs[b].inv1;
+            prec[e] = make_float4(ip.x, ip.y, ip.z, __int_as_float(dc));
+        }
+        if (pdc) pdc[e] = (uint16_t)dc;
+        if (!cfirst || pc == cmask) continue;
+        const bool first = (e == 0) || kprev[k] != key[k];
+        const bool last = (e + 1 == totP) || knext[k] != key[k];
+        if (first) cfirst[(long long)b * NC + (long long)pc] = e;
+        if (last) cend[(long long)b * NC + (long long)pc] = e + 1;
+    }
 }
 
 // Everything the join needs, by value.
@@ -736,6 +753,17 @@ __device__ __forceinline__ uint32_t join_one(const JoinArgs<KeyT>& A, uint32_t i
             local += hit(v.x & 0xFFFFu) + hit(v.x >> 16) + hit(v.y & 0xFFFFu) + hit(v.y >> 16) + hit(v.z & 0xFFFFu) + hit(v.z >> 16) + hit(v.w & 0xFFFFu) + hit(v.w >> 16);
         }
         for (; k < hi; ++k) local += hit(dcs[k]);
+        return local;
+    }
+    if (A.pdc) {   // (MODE 1 with the gate out of the way: the same decision as the count above, the pairs of the matches read on demand)
+        for (uint32_t k = lo; k < hi; ++k) {
+            const uint32_t dc = A.pdc[k];
+            if (dc >= 343u || !((my[dc >> 5] >> (dc & 31)) & 1u)) continue;
+            const uint32_t pr = A.pvals[k];
+            const int pa = pr >> 16, pb = pr & 0xFFFF;
+            out[local++] = (A.base_in_key ? (uint64_t)b << (4 * id_bits) : 0ull) | ((uint64_t)pa << (3 * id_bits)) | ((uint64_t)pb << (2 * id_bits)) |
+                           ((uint64_t)qa << id_bits) | (uint64_t)qb;
+        }
         return local;
     }
     uint32_t k = lo;
@@ -947,7 +975,14 @@ __global__ __launch_bounds__(256) void resolve_picks_kernel(JoinArgs<KeyT> A, co
             const uint32_t k = k0 + lane;
             bool hit = false;
             int pa = 0, pb = 0;
-            if (k < hi) {
+            if (k < hi && A.pdc) {   // the gate cannot fail inside a position cell: direction cells alone (no records were written)
+                const uint32_t dc = A.pdc[k];
+                if (dc < 343u && ((seen[dc >> 5] >> (dc & 31)) & 1u)) {
+                    const uint32_t pr = A.pvals[k];
+                    pa = pr >> 16; pb = pr & 0xFFFF;
+                    hit = true;
+                }
+            } else if (k < hi) {
                 const float4 r = A.prec[k];
                 const uint32_t dc = (uint32_t)__float_as_int(r.w);
                 if (dc < 343u && ((seen[dc >> 5] >> (dc & 31)) & 1u)) {
@@ -1165,6 +1200,23 @@ static bool cong_sort_own() { static const bool own = !(getenv("STOCS_SORT") && 
 static hipError_t cong_sort(void* tmp, size_t& bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout, size_t n, unsigned cell_bits, unsigned end_bit,
                             const uint32_t* seg_off, int n_seg, hipStream_t st, bool* own) {
     *own = cong_sort_own() && n_seg > 0 && n < ((size_t)1 << 30);   // (30-bit prefixes in its look-back words)
+#ifdef STOCS_TOOLS_BUILD
+    // measurement build: STOCS_DUMP_SORT=<prefix> writes the unsorted list of every sort (header n, n_seg, cell_bits; keys; values; offsets) to
+    // <prefix>_<k>.bin -- tools/sort_real.py replays them through stocs_debug_sort_pairs (real key skew, real base lengths)
+    if (tmp && getenv("STOCS_DUMP_SORT") && n > 0) {
+        static int k_dump = 0;
+        (void)hipStreamSynchronize(st);
+        std::vector<uint32_t> hk(n), hv(n), ho((size_t)n_seg + 1);
+        (void)hipMemcpy(hk.data(), kin, n * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(hv.data(), vin, n * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(ho.data(), seg_off, ((size_t)n_seg + 1) * 4, hipMemcpyDeviceToHost);
+        char path[512];
+        snprintf(path, sizeof path, "%s_%d.bin", getenv("STOCS_DUMP_SORT"), k_dump++);
+        if (FILE* f = fopen(path, "wb")) {
+            const uint32_t hdr[4] = {(uint32_t)n, (uint32_t)n_seg, cell_bits, end_bit};
+            fwrite(hdr, 4, 4, f); fwrite(hk.data(), 4, n, f); fwrite(hv.data(), 4, n, f); fwrite(ho.data(), 4, (size_t)n_seg + 1, f); fclose(f);
+        }
+    }
+#endif
     return *own ? sort_pairs_own(tmp, bytes, kin, kout, vin, vout, n, 0, cell_bits, seg_off, (uint32_t)n_seg, st) : sort_pairs(tmp, bytes, kin, kout, vin, vout, n, 0, end_bit, st);
 }
 static hipError_t cong_sort(void* tmp, size_t& bytes, const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, size_t n, unsigned, unsigned end_bit,
@@ -1251,10 +1303,10 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         STOCS_HIP_CHECK(hipEventRecord(c->ev_t[9], st));             // P's cells are marked
         AU.record(c->ev_t[9], s0);
         if (sq != st) { STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_t[9], 0)); STOCS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_t[8], 0)); AU.wait(s1, c->ev_t[9]); AU.wait(s0, c->ev_t[8]); }
-        hipLaunchKernelGGL(survivors_count_kernel<KeyT>, dim3(std::max(1u, std::min(ntq, GATHER_MAX_WGS))), dim3(256), lds_words * 4, sq, (const KeyT*)d_qk_raw.p, (uint32_t)totQ0, (const uint32_t*)occ_p, d_surv.p + o_tq, d_po, 1, d_bits_q.p, lds_words, S->cell_bits);
+        hipLaunchKernelGGL(survivors_count_kernel<KeyT>, dim3(std::max(1u, std::min((ntq + 3u) / 4u, GATHER_MAX_WGS))), dim3(256), lds_words * 4, sq, (const KeyT*)d_qk_raw.p, (uint32_t)totQ0, (const uint32_t*)occ_p, d_surv.p + o_tq, d_po, 1, d_bits_q.p, lds_words, S->cell_bits);
         AU.use(s1, d_qk_raw.p, false, "gathered Q keys", "survivors count Q"); AU.use(s1, occ_p, false, "occupancy of P", "survivors count Q"); AU.use(s1, tiles_q, true, "tile counts of Q", "survivors count Q"); AU.use(s1, d_bits_q.p, true, "alive bits of Q", "survivors count Q");
         if (sq != st) { STOCS_HIP_CHECK(hipEventRecord(c->ev_join, sq)); AU.record(c->ev_join, s1); }
-        hipLaunchKernelGGL(survivors_count_kernel<KeyT>, dim3(std::max(1u, std::min(ntp, GATHER_MAX_WGS))), dim3(256), lds_words * 4, st, (const KeyT*)d_pk_raw.p, (uint32_t)totP0, (const uint32_t*)occ_q, d_surv.p + o_tp, d_po, 0, d_bits_p.p, lds_words, S->cell_bits);
+        hipLaunchKernelGGL(survivors_count_kernel<KeyT>, dim3(std::max(1u, std::min((ntp + 3u) / 4u, GATHER_MAX_WGS))), dim3(256), lds_words * 4, st, (const KeyT*)d_pk_raw.p, (uint32_t)totP0, (const uint32_t*)occ_q, d_surv.p + o_tp, d_po, 0, d_bits_p.p, lds_words, S->cell_bits);
         AU.use(s0, d_pk_raw.p, false, "gathered P keys", "survivors count P"); AU.use(s0, occ_q, false, "occupancy of Q", "survivors count P"); AU.use(s0, tiles_p, true, "tile counts of P", "survivors count P"); AU.use(s0, d_bits_p.p, true, "alive bits of P", "survivors count P");
         if (sq != st) { STOCS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_join, 0)); AU.wait(s0, c->ev_join); }
         AU.use(s0, tiles_p, true, "tile counts of P", "tile scan"); AU.use(s0, tiles_q, true, "tile counts of Q", "tile scan");
@@ -1290,9 +1342,9 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         AU.use(s1, tiles_q, false, "tile counts of Q", "compact Q"); AU.use(s1, d_qk_c.p, true, "surviving Q keys", "compact Q"); AU.use(s1, d_qv_c.p, true, "surviving Q pairs", "compact Q");
         AU.use(s0, d_pk_raw.p, false, "gathered P keys", "compact P"); AU.use(s0, d_pv_raw.p, false, "gathered P pairs", "compact P"); AU.use(s0, d_bits_p.p, false, "alive bits of P", "compact P");
         AU.use(s0, tiles_p, false, "tile counts of P", "compact P"); AU.use(s0, d_pk_c.p, true, "surviving P keys", "compact P"); AU.use(s0, d_pv_c.p, true, "surviving P pairs", "compact P");
-        hipLaunchKernelGGL(survivors_compact_kernel<KeyT>, dim3(ntq), dim3(256), 0, sq, (const KeyT*)d_qk_raw.p, (const uint32_t*)d_qv_raw.p, (uint32_t)totQ0,
+        hipLaunchKernelGGL(survivors_compact_kernel<KeyT>, dim3((ntq + 3u) / 4u), dim3(256), 0, sq, (const KeyT*)d_qk_raw.p, (const uint32_t*)d_qv_raw.p, (uint32_t)totQ0,
                            (const unsigned long long*)d_bits_q.p, (const uint32_t*)(d_surv.p + o_tq), d_qk_c.p, d_qv_c.p, d_po, 1);
-        hipLaunchKernelGGL(survivors_compact_kernel<KeyT>, dim3(ntp), dim3(256), 0, st, (const KeyT*)d_pk_raw.p, (const uint32_t*)d_pv_raw.p, (uint32_t)totP0,
+        hipLaunchKernelGGL(survivors_compact_kernel<KeyT>, dim3((ntp + 3u) / 4u), dim3(256), 0, st, (const KeyT*)d_pk_raw.p, (const uint32_t*)d_pv_raw.p, (uint32_t)totP0,
                            (const unsigned long long*)d_bits_p.p, (const uint32_t*)(d_surv.p + o_tp), d_pk_c.p, d_pv_c.p, d_po, 0);
         STOCS_HIP_CHECK(hipGetLastError());
         c->timing[0].lap("enqueue gather + occupancy + survivor counts");
@@ -1316,7 +1368,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         pk_in = d_pk_c.p; pv_in = d_pv_c.p; qk_in = d_qk_c.p; qv_in = d_qv_c.p;
     }
     if ((rc = S->d_pkeys.alloc(totP * sizeof(KeyT))) || (rc = S->d_pvals.alloc(totP)) || (rc = S->d_qkeys.alloc(totQ * sizeof(KeyT))) || (rc = S->d_qvals.alloc(totQ)) ||
-        (rc = S->d_prec.alloc(totP)) || (rc = S->d_pdc.alloc(((size_t)totP + 15) & ~(size_t)7)))
+        (rc = S->d_prec.alloc(S->close_cells ? 1 : totP)) || (rc = S->d_pdc.alloc(((size_t)totP + 15) & ~(size_t)7)))
         return rc;
     // The P side (sort, records) and the Q side (sort) are independent until the join: the Q side runs on
     // the context's auxiliary stream next to the P side (a radix pass of 7 M pairs moves ~1.8 TB/s: two of them share the chip)
@@ -1354,8 +1406,8 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         // records kernel writes every slot that is read and the 8 bytes per (base, cell) need no zero fill
         if (!reduce) hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, S->d_cfirst.p, ncell, S->d_cend.p);
     }
-    hipLaunchKernelGGL(p_records_kernel<KeyT>, dim3((unsigned)((totP + 255) / 256)), dim3(256), 0, st, (const KeyT*)S->d_pkeys.p, S->d_pvals.p, (uint32_t)totP,
-                       S->cell_bits, S->NC, S->d_jobs.p, c->d_munit, c->d_mpos, S->nepsilon, S->d_prec.p, S->close_cells ? S->d_pdc.p : (uint16_t*)NULL,
+    hipLaunchKernelGGL(p_records_kernel<KeyT>, dim3((unsigned)((totP + 1023) / 1024)), dim3(256), 0, st, (const KeyT*)S->d_pkeys.p, S->d_pvals.p, (uint32_t)totP,
+                       S->cell_bits, S->NC, S->d_jobs.p, c->d_munit, c->d_mpos, S->nepsilon, S->close_cells ? (float4*)NULL : S->d_prec.p, S->close_cells ? S->d_pdc.p : (uint16_t*)NULL,
                        S->use_table ? S->d_cfirst.p : (uint32_t*)NULL,
                        S->use_table ? S->d_cend.p : (uint32_t*)NULL);
     STOCS_HIP_CHECK(hipGetLastError());
