@@ -32,6 +32,7 @@
 // P pair), where the index position of a model pair is its place in the PPF index (ascending quantised feature,
 // then ascending (id1, id2)).  The oracle enumerates the same way.
 // The join is irregular integer/gather work: HBM/L2-bound, no MFMA.
+#include <functional>
 #include <math.h>
 #include <pthread.h>
 #include <stdlib.h>
@@ -1035,6 +1036,9 @@ struct CongruentState {
     Arena arena_state;   // the buffers below + the temporaries of stocs_find_congruent_all; reset by that call
     Arena arena_tmp;     // temporaries of the calls that produce quads afterwards; reset by each of them
     bool valid = false;  // a count pass has completed and its buffers are intact
+    // host work of the current call that only the join needs (the cone records of a batch's thousands of bases: three libm calls each,
+    // 0.2 ms for 6 400 bases), done by count_pass while the device gathers instead of before anything is enqueued
+    std::function<int()> deferred;
     // quads of the small bases, materialised ahead of the picks that refer to them (stocs_internal_prepare_small)
     bool small_ready = false, small_any = false;
     DevBuf<uint64_t> d_small_sorted;
@@ -1171,6 +1175,14 @@ static const float* cone_trig() {
     return &trig[0][0][0];
 }
 
+// the cone fields of the base jobs, uploaded on their own when the host computes them while the device already plans and gathers
+__global__ __launch_bounds__(256) void patch_cone_kernel(BaseJob* __restrict__ jobs, const float4* __restrict__ cone, int nB) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nB) return;
+    const float4 v = cone[b];
+    jobs[b].cos_alpha = v.x; jobs[b].sin_alpha = v.y; jobs[b].nb = __float_as_int(v.z);
+}
+
 // cone samples of a base: normalset.hpp:178-190 (float libm calls on per-base scalars: exactly the reference's values): their
 // number and sin(alpha); sample a is (sin_alpha * cos theta_a, sin_alpha * sin theta_a, cos_alpha) with the shared table above
 static void fill_cone_table(BaseJob* J) {
@@ -1248,6 +1260,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     int rc;
     if ((rc = d_pk_raw.alloc(totP0)) || (rc = d_pv_raw.alloc(totP0)) || (rc = d_qk_raw.alloc(totQ0)) || (rc = d_qv_raw.alloc(totQ0))) return rc;
     S->d_jobs.p = plan.jobs;
+    if (S->deferred && !S->reduce) { const int rd = S->deferred(); S->deferred = nullptr; if (rd) return rd; }   // (no survivors pass to hide it behind)
     const Segment* d_psegs = plan.psegs;
     const Segment* d_qsegs = plan.qsegs;
     S->d_qoff.p = plan.q_off;
@@ -1348,6 +1361,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
                            (const unsigned long long*)d_bits_p.p, (const uint32_t*)(d_surv.p + o_tp), d_pk_c.p, d_pv_c.p, d_po, 0);
         STOCS_HIP_CHECK(hipGetLastError());
         c->timing[0].lap("enqueue gather + occupancy + survivor counts");
+        if (S->deferred) { const int rd = S->deferred(); S->deferred = nullptr; if (rd) return rd; c->timing[0].lap("host: cone records of the bases (while the device gathers)"); }
         STOCS_HIP_CHECK(hipEventSynchronize(c->ev_t[7]));   // the read-back, not the compaction behind it
         AU.host_sync_event(c->ev_t[7]);
         c->timing[0].lap("wait for the device (survivors)");
@@ -1585,12 +1599,16 @@ int stocs_internal_find_congruent(stocs_ctx* c, int64_t* total_quads, size_t max
     const bool wide = base_bits + cell_bits > 32 || getenv("STOCS_CONGRUENT_WIDE_KEYS") != NULL;   // env: keeps the 64-bit path testable
     // both pair lists are reduced to the entries with a partner cell when one byte per (base, cell) is a small table (count_pass)
     const bool reduce = use_table && ((unsigned long long)nB << cell_bits) <= (1ull << 29) && !getenv("STOCS_CONGRUENT_KEEP_ALL");
+    // a batch's bases: the cone records wait until the device is busy (S->deferred, below)
+    const bool defer_cone = nB >= 512 && nB <= PLAN_MAX_BASES && !getenv("STOCS_CONGRUENT_HOST_PLAN");
+    S->deferred = nullptr;
     for (int b = 0; b < nB; ++b) {
         const BaseRec& B = c->bases[b];
         BaseJob& J = jobs[b];
         memset(&J, 0, sizeof(J));
         J.inv1 = B.inv1; J.inv2 = B.inv2;
         J.cell = cell; J.egSize = egSize;
+        if (defer_cone) continue;
         J.cos_alpha = dot3(normalized3(c->h_spos[B.ids[1]] - c->h_spos[B.ids[0]]), normalized3(c->h_spos[B.ids[3]] - c->h_spos[B.ids[2]]));  // stocs.cpp:801-803
         fill_cone_table(&J);
     }
@@ -1653,18 +1671,49 @@ int stocs_internal_find_congruent(stocs_ctx* c, int64_t* total_quads, size_t max
         STOCS_HIP_CHECK(hipMemcpyAsync(po_pin, dpl + o_out, sizeof(PlanOut), hipMemcpyDeviceToHost, c->stream));
         if (!reduce) STOCS_HIP_CHECK(hipMemcpyAsync(qoff_pin, plan.q_off, 4 * (nb + 1), hipMemcpyDeviceToHost, c->stream));   // (reduced lists: their own offsets come later)
         c->timing[0].lap("enqueue plan upload + kernels + read-back");
+        if (defer_cone) {
+            // staged in the part of the pinned block that only the host-planned form uses (ranges), uploaded and patched into the device's
+            // jobs on the context's stream -- behind the plan kernels, ahead of the join
+            float4* hc = (float4*)(h + o_rng);
+            BaseJob* dj = plan.jobs;
+            S->deferred = [c, hc, dj, nB]() -> int {
+                for (int b = 0; b < nB; ++b) {
+                    const BaseRec& B = c->bases[b];
+                    BaseJob J;
+                    J.cos_alpha = dot3(normalized3(c->h_spos[B.ids[1]] - c->h_spos[B.ids[0]]), normalized3(c->h_spos[B.ids[3]] - c->h_spos[B.ids[2]]));  // stocs.cpp:801-803
+                    fill_cone_table(&J);
+                    float nb_bits; memcpy(&nb_bits, &J.nb, 4);
+                    hc[b] = make_float4(J.cos_alpha, J.sin_alpha, nb_bits, 0.f);
+                }
+                DevBuf<float4> d_cone;
+                int rc1 = d_cone.alloc((size_t)nB);
+                if (rc1) return rc1;
+                STOCS_HIP_CHECK(hipMemcpyAsync(d_cone.p, hc, sizeof(float4) * (size_t)nB, hipMemcpyHostToDevice, c->stream));
+                hipLaunchKernelGGL(patch_cone_kernel, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, c->stream, dj, (const float4*)d_cone.p, nB);
+                STOCS_HIP_CHECK(hipGetLastError());
+                return STOCS_OK;
+            };
+        }
         // ONE sizing synchronisation point instead of two (plan totals, then survivors' totals): when an earlier trial of this scene
         // has shown how long the lists get, buffers and launches are sized by a capacity (1.6 x that, per base), the kernels read the
         // planned totals from the device, and the plan's totals come back together with the survivors' (count_pass).  A plan beyond
         // the capacity is detected there and redone with exact sizes.  Not for a trial batch under a memory ceiling (its caller
         // needs the totals first) and not for the first trial of a scene.
-        optimistic = reduce && !too_big && S->hist_nB > 0 && !getenv("STOCS_CONGRUENT_EXACT_SIZES");
+        optimistic = reduce && S->hist_nB > 0 && !getenv("STOCS_CONGRUENT_EXACT_SIZES");
         if (optimistic) {
-            d_po = (const PlanOut*)(dpl + o_out); po_pinned = po_pin;
             const char* ce = getenv("STOCS_CONGRUENT_CAPACITY");     // (tests: a factor below 1 forces the redo with exact sizes)
             const double scale = (ce ? atof(ce) : 1.6) * (double)nB / (double)S->hist_nB, slack = ce ? 1.0 : 1048576.0;
             totP = (uint64_t)std::min(4.0e9, (double)S->hist_P * scale + slack);
             totQ = (uint64_t)std::min(4.0e9, (double)S->hist_Q * scale + slack);
+            // a piece of a trial batch (too_big: its caller wants to hear when the lists do not fit the ceiling) goes this way only when the
+            // capacities are far below the ceiling -- small frames, where the plan's round trip is a tenth of the piece; near the ceiling the
+            // totals are read first, as in round 4
+            if (too_big && max_bytes && (double)(totP + totQ) * 64.0 + (use_table ? (double)(NC * nB) * 8.0 : 0.0) + (double)((size_t)nB << cell_bits) / 4.0 > 0.25 * (double)max_bytes) {
+                optimistic = false; totP = 0; totQ = 0;
+            }
+        }
+        if (optimistic) {
+            d_po = (const PlanOut*)(dpl + o_out); po_pinned = po_pin;
         } else {
             STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
             c->timing[0].lap("wait for the device (plan)");
@@ -1735,7 +1784,7 @@ int stocs_internal_find_congruent(stocs_ctx* c, int64_t* total_quads, size_t max
         const size_t need = (size_t)nP * per_entry + (size_t)nQ * per_entry + tables + occ + ((size_t)48 << 20);
         if (max_bytes && need > max_bytes && nB > 1) { *over = true; return STOCS_OK; }
         // (under a ceiling -- a piece of a trial batch -- the slab is 1.5 x the need, not twice it: 40 Cm trials need 36 GB)
-        const int rc_r = S->arena_state.reserve(need, max_bytes ? 1.5 : 2.0);
+        const int rc_r = S->arena_state.reserve(need, (max_bytes && need > ((size_t)4 << 30)) ? 1.5 : 2.0);   // (small pieces: room for the next call's capacities, which follow THIS call's totals)
         if (rc_r == STOCS_ERR_NOMEM && max_bytes && nB > 1) { *over = true; return STOCS_OK; }   // the device is fuller than the ceiling assumes: the caller halves the piece
         return rc_r;
     };
@@ -1760,7 +1809,7 @@ int stocs_internal_find_congruent(stocs_ctx* c, int64_t* total_quads, size_t max
     int rc = wide ? count_pass<uint64_t>(c, S, plan, dbg, tprev, d_po, po_pinned) : count_pass<uint32_t>(c, S, plan, dbg, tprev, d_po, po_pinned);
     if (optimistic && (rc == STOCS_OK || rc == 1)) {   // (the read-back of count_pass brought the plan's totals; on an error the copy may not have landed: the history stays as it was)
         const PlanOut po = *po_pinned;
-        if (po.overflow) { set_error("pair lists exceed 2^32 entries"); return STOCS_ERR_CAPACITY; }
+        if (po.overflow) { if (too_big) { *too_big = 1; return STOCS_OK; } set_error("pair lists exceed 2^32 entries"); return STOCS_ERR_CAPACITY; }
         S->hist_P = po.totP; S->hist_Q = po.totQ; S->hist_nB = nB;
         if (rc == 1) {
             // the plan outgrew the capacities: once more with the sizes now known.  The base jobs carry the survivors' offsets by now:
@@ -1781,6 +1830,7 @@ int stocs_internal_find_congruent(stocs_ctx* c, int64_t* total_quads, size_t max
             bool over = false;
             int rc0 = reserve_arena(po.totP, po.totQ, &over);
             if (rc0) return rc0;
+            if (over) { if (too_big) *too_big = 1; return STOCS_OK; }   // (a batch's piece: the caller splits its base set)
             plan.n_pseg = (int)po.n_pseg; plan.n_qseg = (int)po.n_qseg;
             S->totP = (uint32_t)po.totP; S->totQ = (uint32_t)po.totQ;
             S->no_quads = false;

@@ -91,6 +91,32 @@ def test_batch_cut_into_pieces_gives_the_same_trials(tiny_est, monkeypatch):
             assert a["best_lcp"] == b["best_lcp"] and a["best_index"] == b["best_index"] and np.array_equal(a["best_pose"], b["best_pose"])
 
 
+def test_batch_piece_sized_by_capacities_and_its_redo(tiny_est, monkeypatch):
+    """Round 5: a batch piece whose lists are far below the memory ceiling takes the ONE sizing synchronisation of the single trials (buffers and
+    launches sized by capacities from the call before, the plan's totals read back with the survivors').  Forced here to miss: capacities of
+    half / a twentieth of the history -> the plan outgrows them, every kernel stays inside the capacity, the piece is redone with exact sizes."""
+    m, s, est = tiny_est
+    seeds = [21, 22, 23, 24]
+    whole = est.run_trials(seeds, 30, max_per_base=40)          # (also the history the next calls scale their capacities from)
+    steps = dict(est.last_call_timing(0))
+    assert "wait for the device (plan)" not in steps            # the piece did not read the plan first
+    for capacity in ("0.5", "0.05"):
+        monkeypatch.setenv("STOCS_CONGRUENT_CAPACITY", capacity)
+        again = est.run_trials(seeds, 30, max_per_base=40)
+        monkeypatch.delenv("STOCS_CONGRUENT_CAPACITY")
+        assert "plan beyond the capacities: redone with exact sizes" in dict(est.last_call_timing(0)), capacity
+        for a, b in zip(whole, again):
+            assert a["n_bases"] == b["n_bases"] and a["n_quads"] == b["n_quads"] and a["n_candidates"] == b["n_candidates"]
+            assert a["best_lcp"] == b["best_lcp"] and a["best_index"] == b["best_index"] and np.array_equal(a["best_pose"], b["best_pose"])
+    monkeypatch.setenv("STOCS_CONGRUENT_EXACT_SIZES", "1")       # and the two-synchronisation form of round 4
+    exact = est.run_trials(seeds, 30, max_per_base=40)
+    monkeypatch.delenv("STOCS_CONGRUENT_EXACT_SIZES")
+    assert "wait for the device (plan)" in dict(est.last_call_timing(0))
+    for a, b in zip(whole, exact):
+        assert a["n_quads"] == b["n_quads"] and a["best_lcp"] == b["best_lcp"] and np.array_equal(a["best_pose"], b["best_pose"])
+    _assert_trials_equal_singles(est, seeds, 30, 0, 40, min_candidates=50)
+
+
 def test_subset_rule_per_trial(tiny_est):
     """Bases with >= max quads draw their subset with the seed of THEIR trial and under their slot there (Q5 divergence: seeded)."""
     m, s, est = tiny_est
