@@ -221,10 +221,10 @@ static inline unsigned gather_grid(unsigned long long total) { const unsigned lo
 // po != NULL: the launch was sized by a CAPACITY (the host has not read the plan yet, see stocs_internal_find_congruent): the
 // list's length and segment count are the planned ones, read here, and the workgroups beyond them leave at once.
 template <class KeyT>
-__global__ __launch_bounds__(256) void gather_key_kernel(const uint32_t* __restrict__ pairs, const Segment* __restrict__ segs, int nseg, uint32_t total,
-                                                         const BaseJob* __restrict__ jobs, const float4* __restrict__ munit, int is_q, int cell_bits,
-                                                         long long cell_limit, KeyT* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                         uint32_t* __restrict__ occ, const PlanOut* __restrict__ po, uint32_t lds_words, uint32_t n_bases) {
+__device__ __forceinline__ void gather_key_body(const uint32_t* __restrict__ pairs, const Segment* __restrict__ segs, int nseg, uint32_t total,
+                                                const BaseJob* __restrict__ jobs, const float4* __restrict__ munit, int is_q, int cell_bits,
+                                                long long cell_limit, KeyT* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                uint32_t* __restrict__ occ, const PlanOut* __restrict__ po, uint32_t lds_words, uint32_t n_bases) {
     // occ: ONE BIT per (base, cell) value of the key -- which (base, cell) this list occupies.  lds_words > 0 (= 2^cell_bits / 32, the
     // words of one base): the bits of the base the workgroup's current tile starts in are collected in LDS and OR-ed into the table
     // when the workgroup moves on to the next base or ends (a base's stretch is ~88 tiles at Cm: one atomic per word and workgroup
@@ -343,6 +343,25 @@ __global__ __launch_bounds__(256) void gather_key_kernel(const uint32_t* __restr
     }
     if (mark_lds) flush(cur_b);
 }
+template <class KeyT>
+__global__ __launch_bounds__(256) void gather_key_kernel(const uint32_t* __restrict__ pairs, const Segment* __restrict__ segs, int nseg, uint32_t total,
+                                                         const BaseJob* __restrict__ jobs, const float4* __restrict__ munit, int is_q, int cell_bits,
+                                                         long long cell_limit, KeyT* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                         uint32_t* __restrict__ occ, const PlanOut* __restrict__ po, uint32_t lds_words, uint32_t n_bases) {
+    gather_key_body<KeyT>(pairs, segs, nseg, total, jobs, munit, is_q, cell_bits, cell_limit, keys, vals, occ, po, lds_words, n_bases);
+}
+// Both lists in ONE launch (blockIdx.y: 0 = P, 1 = Q): the one-stream form of count_pass -- P and Q still share the chip, and no event edge
+// between two streams (~11 us each on this runtime, five of them in a trial) stands between the steps.
+template <class KeyT>
+struct GatherSide { const Segment* segs; int nseg; uint32_t total; KeyT* keys; uint32_t* vals; uint32_t* occ; };
+template <class KeyT>
+__global__ __launch_bounds__(256) void gather_key_dual_kernel(const uint32_t* __restrict__ pairs, GatherSide<KeyT> P, GatherSide<KeyT> Q, const BaseJob* __restrict__ jobs,
+                                                              const float4* __restrict__ munit, int cell_bits, long long cell_limit, const PlanOut* __restrict__ po,
+                                                              uint32_t lds_words, uint32_t n_bases) {
+    const bool q = blockIdx.y == 1;
+    gather_key_body<KeyT>(pairs, q ? Q.segs : P.segs, q ? Q.nseg : P.nseg, q ? Q.total : P.total, jobs, munit, q ? 1 : 0, cell_bits, cell_limit, q ? Q.keys : P.keys,
+                          q ? Q.vals : P.vals, q ? Q.occ : P.occ, po, lds_words, n_bases);
+}
 
 // ---- survivors ----
 // A P entry can only ever be matched by a Q entry of the same (base, position cell) and the other way round (Q9: only the
@@ -365,9 +384,9 @@ __device__ __forceinline__ bool occ_test(const uint32_t* __restrict__ occ, KeyT 
 // table directly.
 #define SURV_ROWS (SURV_TILE / 64)
 template <class KeyT>
-__global__ __launch_bounds__(256) void survivors_count_kernel(const KeyT* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ other,
-                                                              uint32_t* __restrict__ tile_cnt, const PlanOut* __restrict__ po, int is_q,
-                                                              unsigned long long* __restrict__ alive_bits, uint32_t lds_words, int cell_bits) {
+__device__ __forceinline__ void survivors_count_body(const KeyT* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ other,
+                                                     uint32_t* __restrict__ tile_cnt, const PlanOut* __restrict__ po, int is_q,
+                                                     unsigned long long* __restrict__ alive_bits, uint32_t lds_words, int cell_bits) {
     extern __shared__ uint32_t s_occ[];
     __shared__ KeyT s_mid[2];
     if (po) { if (po->overflow) return; const unsigned long long t = is_q ? po->totQ : po->totP; n = t < (unsigned long long)n ? (uint32_t)t : n; }   // (overflow: the gather wrote nothing)
@@ -413,6 +432,19 @@ __global__ __launch_bounds__(256) void survivors_count_kernel(const KeyT* __rest
         if (lane < (uint32_t)SURV_ROWS) alive_bits[(size_t)tile * SURV_ROWS + lane] = mine;
         if (lane == 0u) tile_cnt[tile] = cnt;
     }
+}
+template <class KeyT>
+__global__ __launch_bounds__(256) void survivors_count_kernel(const KeyT* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ other,
+                                                              uint32_t* __restrict__ tile_cnt, const PlanOut* __restrict__ po, int is_q,
+                                                              unsigned long long* __restrict__ alive_bits, uint32_t lds_words, int cell_bits) {
+    survivors_count_body<KeyT>(keys, n, other, tile_cnt, po, is_q, alive_bits, lds_words, cell_bits);
+}
+template <class KeyT>
+struct SurvSide { const KeyT* keys; const uint32_t* vals; uint32_t n; const uint32_t* other; uint32_t* tiles; unsigned long long* alive; KeyT* okeys; uint32_t* ovals; };
+template <class KeyT>
+__global__ __launch_bounds__(256) void survivors_count_dual_kernel(SurvSide<KeyT> P, SurvSide<KeyT> Q, const PlanOut* __restrict__ po, uint32_t lds_words, int cell_bits) {
+    const bool q = blockIdx.y == 1;
+    survivors_count_body<KeyT>(q ? Q.keys : P.keys, q ? Q.n : P.n, q ? Q.other : P.other, q ? Q.tiles : P.tiles, po, q ? 1 : 0, q ? Q.alive : P.alive, lds_words, cell_bits);
 }
 
 // workgroup 0: P list, workgroup 1: Q list.  Tile counts -> tile offsets (element n_tiles receives the total)
@@ -521,9 +553,9 @@ __global__ __launch_bounds__(256) void survivors_base_offsets_kernel(const KeyT*
 // tile's 16 ballots arrive as one 128-byte load and are handed out through scalar registers, the 16 rows of the survivors' keys and pairs
 // are requested together (the round-4 form: one workgroup per tile, four rows per thread, 75 000 workgroups for a 40-trial piece)
 template <class KeyT>
-__global__ __launch_bounds__(256) void survivors_compact_kernel(const KeyT* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n,
-                                                                const unsigned long long* __restrict__ alive_bits, const uint32_t* __restrict__ tile_off,
-                                                                KeyT* __restrict__ okeys, uint32_t* __restrict__ ovals, const PlanOut* __restrict__ po, int is_q) {
+__device__ __forceinline__ void survivors_compact_body(const KeyT* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n,
+                                                       const unsigned long long* __restrict__ alive_bits, const uint32_t* __restrict__ tile_off,
+                                                       KeyT* __restrict__ okeys, uint32_t* __restrict__ ovals, const PlanOut* __restrict__ po, int is_q) {
     if (po) { if (po->overflow) return; const unsigned long long t = is_q ? po->totQ : po->totP; n = t < (unsigned long long)n ? (uint32_t)t : n; }
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     const uint32_t tile = blockIdx.x * 4u + w;
@@ -547,6 +579,30 @@ __global__ __launch_bounds__(256) void survivors_compact_kernel(const KeyT* __re
         if ((bm[k] >> lane) & 1ull) { okeys[base + rank] = key[k]; ovals[base + rank] = val[k]; }
         base += (uint32_t)__popcll(bm[k]);
     }
+}
+template <class KeyT>
+__global__ __launch_bounds__(256) void survivors_compact_kernel(const KeyT* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n,
+                                                                const unsigned long long* __restrict__ alive_bits, const uint32_t* __restrict__ tile_off,
+                                                                KeyT* __restrict__ okeys, uint32_t* __restrict__ ovals, const PlanOut* __restrict__ po, int is_q) {
+    survivors_compact_body<KeyT>(keys, vals, n, alive_bits, tile_off, okeys, ovals, po, is_q);
+}
+// Both lists in one launch, into ONE list: P's survivors, then Q's right behind them (q_off[nB + 1] = P's total, written by
+// survivors_base_offsets_kernel) -- so that ONE segmented sort over 2 nB segments sorts both (blockIdx.y == 2: its segment offsets, P's bases then
+// Q's shifted by P's total).
+template <class KeyT>
+__global__ __launch_bounds__(256) void survivors_compact_dual_kernel(SurvSide<KeyT> P, SurvSide<KeyT> Q, const PlanOut* __restrict__ po, const uint32_t* __restrict__ p_off,
+                                                                     const uint32_t* __restrict__ q_off, int nB, uint32_t* __restrict__ comb_off) {
+    // (a plan beyond the capacities is redone by the host: survivors_base_offsets_kernel wrote nothing then, q_off[nB + 1] is not P's total)
+    if (po && (po->overflow || po->totP > (unsigned long long)P.n || po->totQ > (unsigned long long)Q.n)) return;
+    if (blockIdx.y == 2) {
+        const uint32_t totP = q_off[nB + 1];
+        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i <= 2u * (uint32_t)nB; i += gridDim.x * 256u) comb_off[i] = i < (uint32_t)nB ? p_off[i] : totP + q_off[i - (uint32_t)nB];
+        return;
+    }
+    const bool q = blockIdx.y == 1;                                // (ONE inlined body: two of them under an if / else took 248 VGPRs)
+    const uint32_t shift = q ? q_off[nB + 1] : 0u;
+    survivors_compact_body<KeyT>(q ? Q.keys : P.keys, q ? Q.vals : P.vals, q ? Q.n : P.n, q ? Q.alive : P.alive, q ? Q.tiles : P.tiles, (q ? Q.okeys : P.okeys) + shift,
+                                 (q ? Q.ovals : P.ovals) + shift, po, q ? 1 : 0);
 }
 
 // Zero fill as an ordinary kernel on the context's stream
@@ -1253,7 +1309,16 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     const size_t totP0 = S->totP, totQ0 = S->totQ;   // the gathered lists as planned (d_po: their capacities)
     size_t totP = totP0, totQ = totQ0;               // the lists that are sorted and joined (the survivors, when the lists are reduced)
     hipStream_t st = c->stream;
-    hipStream_t sq = c->aux_stream ? c->aux_stream : st;
+    // ONE stream (round 5b) for the reduced 32-bit form: P and Q go through every step in the SAME launch (blockIdx.y), the survivors of both
+    // land in one list and ONE segmented sort over 2 nB segments sorts it.  The two-stream form of rounds 3-5a (P on the context's stream, Q on
+    // the auxiliary one) paid ~11 us per event edge between the streams, five of them in a trial -- a tenth of a Cm trial's congruent phase;
+    // it stays for 64-bit keys, unreduced lists and rocPRIM's sort, and under STOCS_CONGRUENT_TWO_STREAMS for A/B.
+    // Lists beyond 10^8 entries -- the pieces of a trial batch at the metric size -- keep the two streams: there the edges are nothing and the
+    // overlap of unlike kernels (P's records next to Q's sort) is worth 2 % (64 Cm trials: 2 040 against 1 985 trials/s).
+    const int force_streams = getenv("STOCS_CONGRUENT_TWO_STREAMS") ? 2 : (getenv("STOCS_CONGRUENT_ONE_STREAM") ? 1 : 0);
+    const bool one_stream = S->reduce && sizeof(KeyT) == 4 && cong_sort_own() && (totP0 + totQ0) < ((size_t)1 << 30) && nB < (1 << 22) && force_streams != 2 &&
+                            (force_streams == 1 || totP0 + totQ0 < (size_t)100000000);
+    hipStream_t sq = (c->aux_stream && !one_stream) ? c->aux_stream : st;
     DevBuf<KeyT> d_pk_raw, d_qk_raw;
     DevBuf<uint32_t> d_pv_raw, d_qv_raw;
     DevBuf<char> d_tmp;
@@ -1279,7 +1344,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     const KeyT* pk_in = d_pk_raw.p; const uint32_t* pv_in = d_pv_raw.p;   // what the sorts read
     const KeyT* qk_in = d_qk_raw.p; const uint32_t* qv_in = d_qv_raw.p;
     DevBuf<KeyT> d_pk_c, d_qk_c;
-    DevBuf<uint32_t> d_pv_c, d_qv_c, d_surv;
+    DevBuf<uint32_t> d_pv_c, d_qv_c, d_surv, d_comb_off;
     bool have_surv_clock = false;
     if (reduce) {
         // one zeroed block: occupancy of P | occupancy of Q | P tile counts (+ total) | Q tile counts (+ total)
@@ -1303,12 +1368,18 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
             STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_fork, 0));
             AU.record(c->ev_fork, s0); AU.wait(s1, c->ev_fork);
         }
+        if (one_stream) {
+            const GatherSide<KeyT> gp = {d_psegs, n_pseg, (uint32_t)totP0, d_pk_raw.p, d_pv_raw.p, occ_p}, gq = {d_qsegs, n_qseg, (uint32_t)totQ0, d_qk_raw.p, d_qv_raw.p, occ_q};
+            hipLaunchKernelGGL(gather_key_dual_kernel<KeyT>, dim3(std::max(gather_grid(totP0), gather_grid(totQ0)), 2), dim3(256), lds_words * 4, st, ix.d_pairs, gp, gq,
+                               (const BaseJob*)S->d_jobs.p, (const float4*)c->d_munit, S->cell_bits, cell_limit, d_po, lds_words, (uint32_t)nB);
+        } else
         hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3(gather_grid(totQ0)), dim3(256), lds_words * 4, sq, ix.d_pairs, d_qsegs, n_qseg, (uint32_t)totQ0,
                            S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p, occ_q, d_po, lds_words, (uint32_t)nB);
         AU.use(s1, plan.qsegs, false, "Q segments", "gather Q"); AU.use(s1, plan.jobs, false, "base jobs", "gather Q");
         AU.use(s1, d_qk_raw.p, true, "gathered Q keys", "gather Q"); AU.use(s1, d_qv_raw.p, true, "gathered Q pairs", "gather Q"); AU.use(s1, occ_q, true, "occupancy of Q", "gather Q");
         STOCS_HIP_CHECK(hipEventRecord(c->ev_t[8], sq));             // Q's cells are marked
         AU.record(c->ev_t[8], s1);
+        if (!one_stream)
         hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3(gather_grid(totP0)), dim3(256), lds_words * 4, st, ix.d_pairs, d_psegs, n_pseg, (uint32_t)totP0,
                            S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p, occ_p, d_po, lds_words, (uint32_t)nB);
         AU.use(s0, plan.psegs, false, "P segments", "gather P"); AU.use(s0, plan.jobs, false, "base jobs", "gather P");
@@ -1316,9 +1387,18 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         STOCS_HIP_CHECK(hipEventRecord(c->ev_t[9], st));             // P's cells are marked
         AU.record(c->ev_t[9], s0);
         if (sq != st) { STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_t[9], 0)); STOCS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_t[8], 0)); AU.wait(s1, c->ev_t[9]); AU.wait(s0, c->ev_t[8]); }
+        // (one stream: the compacted lists are ONE buffer, allocated here so that the launch below can name it)
+        if (one_stream) { if ((rc = d_pk_c.alloc(totP0 + totQ0)) || (rc = d_pv_c.alloc(totP0 + totQ0)) || (rc = d_comb_off.alloc(2 * (size_t)nB + 1))) return rc; }
+        const SurvSide<KeyT> sp = {(const KeyT*)d_pk_raw.p, (const uint32_t*)d_pv_raw.p, (uint32_t)totP0, (const uint32_t*)occ_q, d_surv.p + o_tp, d_bits_p.p, d_pk_c.p, d_pv_c.p},
+                             sqd = {(const KeyT*)d_qk_raw.p, (const uint32_t*)d_qv_raw.p, (uint32_t)totQ0, (const uint32_t*)occ_p, d_surv.p + o_tq, d_bits_q.p, d_pk_c.p, d_pv_c.p};
+        if (one_stream)
+            hipLaunchKernelGGL(survivors_count_dual_kernel<KeyT>, dim3(std::max(1u, std::min((std::max(ntp, ntq) + 3u) / 4u, GATHER_MAX_WGS)), 2), dim3(256), lds_words * 4, st, sp, sqd, d_po,
+                               lds_words, S->cell_bits);
+        else
         hipLaunchKernelGGL(survivors_count_kernel<KeyT>, dim3(std::max(1u, std::min((ntq + 3u) / 4u, GATHER_MAX_WGS))), dim3(256), lds_words * 4, sq, (const KeyT*)d_qk_raw.p, (uint32_t)totQ0, (const uint32_t*)occ_p, d_surv.p + o_tq, d_po, 1, d_bits_q.p, lds_words, S->cell_bits);
         AU.use(s1, d_qk_raw.p, false, "gathered Q keys", "survivors count Q"); AU.use(s1, occ_p, false, "occupancy of P", "survivors count Q"); AU.use(s1, tiles_q, true, "tile counts of Q", "survivors count Q"); AU.use(s1, d_bits_q.p, true, "alive bits of Q", "survivors count Q");
         if (sq != st) { STOCS_HIP_CHECK(hipEventRecord(c->ev_join, sq)); AU.record(c->ev_join, s1); }
+        if (!one_stream)
         hipLaunchKernelGGL(survivors_count_kernel<KeyT>, dim3(std::max(1u, std::min((ntp + 3u) / 4u, GATHER_MAX_WGS))), dim3(256), lds_words * 4, st, (const KeyT*)d_pk_raw.p, (uint32_t)totP0, (const uint32_t*)occ_q, d_surv.p + o_tp, d_po, 0, d_bits_p.p, lds_words, S->cell_bits);
         AU.use(s0, d_pk_raw.p, false, "gathered P keys", "survivors count P"); AU.use(s0, occ_q, false, "occupancy of Q", "survivors count P"); AU.use(s0, tiles_p, true, "tile counts of P", "survivors count P"); AU.use(s0, d_bits_p.p, true, "alive bits of P", "survivors count P");
         if (sq != st) { STOCS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_join, 0)); AU.wait(s0, c->ev_join); }
@@ -1345,7 +1425,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         AU.record(c->ev_t[7], s0);
         // the survivors move behind their tiles' offsets while the host waits for the totals: the compacted lists are sized by
         // the gathered ones here (the totals are what the wait is for)
-        if ((rc = d_pk_c.alloc(totP0)) || (rc = d_pv_c.alloc(totP0)) || (rc = d_qk_c.alloc(totQ0)) || (rc = d_qv_c.alloc(totQ0))) return rc;
+        if (!one_stream) { if ((rc = d_pk_c.alloc(totP0)) || (rc = d_pv_c.alloc(totP0)) || (rc = d_qk_c.alloc(totQ0)) || (rc = d_qv_c.alloc(totQ0))) return rc; }
         if (sq != st) {
             STOCS_HIP_CHECK(hipEventRecord(c->ev_fork, st));          // tile offsets are scanned on st
             STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_fork, 0));
@@ -1355,10 +1435,15 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         AU.use(s1, tiles_q, false, "tile counts of Q", "compact Q"); AU.use(s1, d_qk_c.p, true, "surviving Q keys", "compact Q"); AU.use(s1, d_qv_c.p, true, "surviving Q pairs", "compact Q");
         AU.use(s0, d_pk_raw.p, false, "gathered P keys", "compact P"); AU.use(s0, d_pv_raw.p, false, "gathered P pairs", "compact P"); AU.use(s0, d_bits_p.p, false, "alive bits of P", "compact P");
         AU.use(s0, tiles_p, false, "tile counts of P", "compact P"); AU.use(s0, d_pk_c.p, true, "surviving P keys", "compact P"); AU.use(s0, d_pv_c.p, true, "surviving P pairs", "compact P");
+        if (one_stream)
+            hipLaunchKernelGGL(survivors_compact_dual_kernel<KeyT>, dim3(std::max(1u, (std::max(ntp, ntq) + 3u) / 4u), 3), dim3(256), 0, st, sp, sqd, d_po, (const uint32_t*)plan.p_off,
+                               (const uint32_t*)plan.q_off, nB, d_comb_off.p);
+        else {
         hipLaunchKernelGGL(survivors_compact_kernel<KeyT>, dim3((ntq + 3u) / 4u), dim3(256), 0, sq, (const KeyT*)d_qk_raw.p, (const uint32_t*)d_qv_raw.p, (uint32_t)totQ0,
                            (const unsigned long long*)d_bits_q.p, (const uint32_t*)(d_surv.p + o_tq), d_qk_c.p, d_qv_c.p, d_po, 1);
         hipLaunchKernelGGL(survivors_compact_kernel<KeyT>, dim3((ntp + 3u) / 4u), dim3(256), 0, st, (const KeyT*)d_pk_raw.p, (const uint32_t*)d_pv_raw.p, (uint32_t)totP0,
                            (const unsigned long long*)d_bits_p.p, (const uint32_t*)(d_surv.p + o_tp), d_pk_c.p, d_pv_c.p, d_po, 0);
+        }
         STOCS_HIP_CHECK(hipGetLastError());
         c->timing[0].lap("enqueue gather + occupancy + survivor counts");
         if (S->deferred) { const int rd = S->deferred(); S->deferred = nullptr; if (rd) return rd; c->timing[0].lap("host: cone records of the bases (while the device gathers)"); }
@@ -1380,9 +1465,14 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         S->totP = (uint32_t)totP; S->totQ = (uint32_t)totQ;
         if (totP == 0 || totQ == 0) { S->no_quads = true; return STOCS_OK; }   // no cell is shared: no quads (quad_off is all zero already)
         pk_in = d_pk_c.p; pv_in = d_pv_c.p; qk_in = d_qk_c.p; qv_in = d_qv_c.p;
+        if (one_stream) { qk_in = d_pk_c.p + totP; qv_in = d_pv_c.p + totP; }   // (Q's survivors sit behind P's)
     }
-    if ((rc = S->d_pkeys.alloc(totP * sizeof(KeyT))) || (rc = S->d_pvals.alloc(totP)) || (rc = S->d_qkeys.alloc(totQ * sizeof(KeyT))) || (rc = S->d_qvals.alloc(totQ)) ||
-        (rc = S->d_prec.alloc(S->close_cells ? 1 : totP)) || (rc = S->d_pdc.alloc(((size_t)totP + 15) & ~(size_t)7)))
+    if (one_stream) {   // one sorted list: P's part, then Q's
+        if ((rc = S->d_pkeys.alloc((totP + totQ) * sizeof(KeyT))) || (rc = S->d_pvals.alloc(totP + totQ))) return rc;
+        S->d_qkeys.p = S->d_pkeys.p + totP * sizeof(KeyT); S->d_qvals.p = S->d_pvals.p + totP;
+    } else if ((rc = S->d_pkeys.alloc(totP * sizeof(KeyT))) || (rc = S->d_pvals.alloc(totP)) || (rc = S->d_qkeys.alloc(totQ * sizeof(KeyT))) || (rc = S->d_qvals.alloc(totQ)))
+        return rc;
+    if ((rc = S->d_prec.alloc(S->close_cells ? 1 : totP)) || (rc = S->d_pdc.alloc(((size_t)totP + 15) & ~(size_t)7)))
         return rc;
     // The P side (sort, records) and the Q side (sort) are independent until the join: the Q side runs on
     // the context's auxiliary stream next to the P side (a radix pass of 7 M pairs moves ~1.8 TB/s: two of them share the chip)
@@ -1392,8 +1482,11 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     // all the same, the table finds them wherever they are, and 15 bits are two radix passes where 22 are three.
     const unsigned end_bit_p = (S->use_table && !getenv("STOCS_CONGRUENT_P_FULLSORT")) ? (unsigned)S->cell_bits : end_bit;
     bool own_p = false, own_q = false;      // (decided per list: by its length per base)
+    if (one_stream) STOCS_HIP_CHECK(cong_sort(NULL, tb1, pk_in, (KeyT*)S->d_pkeys.p, pv_in, S->d_pvals.p, totP + totQ, (unsigned)S->cell_bits, end_bit_p, d_comb_off.p, 2 * nB, st, &own_p));
+    else {
     STOCS_HIP_CHECK(cong_sort(NULL, tb1, pk_in, (KeyT*)S->d_pkeys.p, pv_in, S->d_pvals.p, totP, (unsigned)S->cell_bits, end_bit_p, plan.p_off, nB, st, &own_p));
     STOCS_HIP_CHECK(cong_sort(NULL, tb2, qk_in, (KeyT*)S->d_qkeys.p, qv_in, S->d_qvals.p, totQ, (unsigned)S->cell_bits, end_bit, plan.q_off, nB, st, &own_q));
+    }
     DevBuf<char> d_tmp2;
     if ((rc = d_tmp.alloc(tb1)) || (rc = d_tmp2.alloc(tb2))) return rc;
     // device-side clock of the groups below (HIP events on the streams they run on; read after the call's closing
@@ -1411,6 +1504,8 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
                            S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p, (uint32_t*)NULL, (const PlanOut*)NULL, 0u, (uint32_t)nB);
     STOCS_HIP_CHECK(hipGetLastError());
     // one stable sort per list: (base, position cell); inside a cell the entries keep the index order of the gather
+    if (one_stream) STOCS_HIP_CHECK(cong_sort(d_tmp.p, tb1, pk_in, (KeyT*)S->d_pkeys.p, pv_in, S->d_pvals.p, totP + totQ, (unsigned)S->cell_bits, end_bit_p, d_comb_off.p, 2 * nB, st, &own_p));
+    else
     STOCS_HIP_CHECK(cong_sort(d_tmp.p, tb1, pk_in, (KeyT*)S->d_pkeys.p, pv_in, S->d_pvals.p, totP, (unsigned)S->cell_bits, end_bit_p, plan.p_off, nB, st, &own_p));
     STOCS_HIP_CHECK(hipEventRecord(c->ev_t[2], st));
     if (S->use_table) {
@@ -1430,6 +1525,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     if (!reduce)
         hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3(gather_grid(totQ)), dim3(256), 0, sq, ix.d_pairs, d_qsegs, n_qseg, (uint32_t)totQ,
                            S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p, (uint32_t*)NULL, (const PlanOut*)NULL, 0u, (uint32_t)nB);
+    if (!one_stream)
     STOCS_HIP_CHECK(cong_sort(d_tmp2.p, tb2, qk_in, (KeyT*)S->d_qkeys.p, qv_in, S->d_qvals.p, totQ, (unsigned)S->cell_bits, end_bit, plan.q_off, nB, sq, &own_q));
     AU.use(s1, plan.q_off, false, "Q offsets per base", "sort Q");
     AU.use(s1, qk_in, false, "Q keys to sort", "sort Q"); AU.use(s1, qv_in, false, "Q pairs to sort", "sort Q");
@@ -1474,11 +1570,14 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         static const char* const what_red[6] = {"device: gathers + occupancy + survivor counts (both lists)", "device: Q sort (aux stream, from the fork; its compaction ran during the wait)",
                                                 "device: P sort", "device: P records + wait for Q", "device: join count", "device: scan + offsets + read-back"};
         const int from[6] = {6, 0, 0, 2, 3, 4}, to[6] = {7, 1, 2, 3, 4, 5};
+        static const char* const what_one[6] = {"device: gathers + occupancy + survivor counts (both lists in every launch)", "", "device: sort (P and Q as one list of 2 nB segments)",
+                                                "device: P records", "device: join count", "device: scan + offsets + read-back"};
         for (int k = have_surv_clock ? 0 : 1; k < 6; ++k) {
+            if (one_stream && k == 1) continue;
             float ms = -1.0f;
             if (hipEventElapsedTime(&ms, c->ev_t[from[k]], c->ev_t[to[k]]) != hipSuccess) ms = -1.0f;
             CallTiming& T = c->timing[0];
-            if (T.n < CallTiming::MAX_STEPS) { T.label[T.n] = have_surv_clock ? what_red[k] : what_all[k - 1]; T.ms[T.n] = (double)ms; ++T.n; }
+            if (T.n < CallTiming::MAX_STEPS) { T.label[T.n] = one_stream ? what_one[k] : (have_surv_clock ? what_red[k] : what_all[k - 1]); T.ms[T.n] = (double)ms; ++T.n; }
         }
         c->timing[0].t_last = CallTiming::now_s();
     }
