@@ -294,6 +294,9 @@ int stocs_icp_point_to_plane(const float* src_pos3, int nsrc, const float* tgt_p
  *   at epsilon/2 or epsilon/4 (39, dense scenes); selectable cross-checks: 31 (the per-step cooperative scan of round 2 over the
  *   centre-sorted lists) and 0 (plain lane-per-query scan).  Every selectable kernel returns the reference's scores; any other
  *   value is STOCS_ERR_INVALID (the variants that lost their A/B runs exist in the measurement build only: make tools).
+ * "device_clock": 1 = stocs_find_congruent_all records HIP events between its kernel groups and stocs_last_call_timing reports them as
+ *   "device: ..." steps; 0 (default; STOCS_DEVICE_CLOCK=1 in the environment turns it on at context creation) = the host's steps only --
+ *   an event between two kernels of a stream costs ~5 us of idle queue on this runtime, nine of them 45 us of a 600 us call.
  * "lcp_flat": 1 (default) = sparse scenes address a flat copy of the cell table (one look-up per query), 0 = brick look-ups.
  * "lcp_split": 1 (default) = four wavefronts share a candidate's model points, 0 = one wavefront per candidate.  Scores are
  *   accumulated as integers, so neither option changes a single bit of them.

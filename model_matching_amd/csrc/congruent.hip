@@ -1309,6 +1309,11 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     const size_t totP0 = S->totP, totQ0 = S->totQ;   // the gathered lists as planned (d_po: their capacities)
     size_t totP = totP0, totQ = totQ0;               // the lists that are sorted and joined (the survivors, when the lists are reduced)
     hipStream_t st = c->stream;
+    // The device's own clock of the kernel groups (HIP events between them, reported by stocs_last_call_timing as "device: ..." steps) is
+    // OPT-IN since round 5b (stocs_set_option "device_clock" / STOCS_DEVICE_CLOCK=1): on this runtime every event recorded between two kernels
+    // of a stream leaves the queue idle for ~5 us, and the nine of a call were 45 us of a Cm trial's 600.  The host's steps between the call's
+    // own synchronisation points are always recorded.
+    const bool dev_clock = c->device_clock != 0;
     // ONE stream (round 5b) for the reduced 32-bit form: P and Q go through every step in the SAME launch (blockIdx.y), the survivors of both
     // land in one list and ONE segmented sort over 2 nB segments sorts it.  The two-stream form of rounds 3-5a (P on the context's stream, Q on
     // the auxiliary one) paid ~11 us per event edge between the streams, five of them in a trial -- a tenth of a Cm trial's congruent phase;
@@ -1362,7 +1367,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         AU.use(s0, tiles_p, true, "tile counts of P", "zero fill"); AU.use(s0, tiles_q, true, "tile counts of Q", "zero fill");
         AU.use(s0, plan.jobs, true, "base jobs", "plan kernels"); AU.use(s0, plan.psegs, true, "P segments", "plan kernels"); AU.use(s0, plan.qsegs, true, "Q segments", "plan kernels");
         AU.use(s0, plan.q_off, true, "Q offsets per base", "plan kernels");
-        STOCS_HIP_CHECK(hipEventRecord(c->ev_t[6], st));
+        if (dev_clock) STOCS_HIP_CHECK(hipEventRecord(c->ev_t[6], st));
         if (sq != st) {
             STOCS_HIP_CHECK(hipEventRecord(c->ev_fork, st));          // the plan upload and the zero fill are on st
             STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_fork, 0));
@@ -1377,14 +1382,14 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
                            S->d_jobs.p, c->d_munit, 1, S->cell_bits, cell_limit, d_qk_raw.p, d_qv_raw.p, occ_q, d_po, lds_words, (uint32_t)nB);
         AU.use(s1, plan.qsegs, false, "Q segments", "gather Q"); AU.use(s1, plan.jobs, false, "base jobs", "gather Q");
         AU.use(s1, d_qk_raw.p, true, "gathered Q keys", "gather Q"); AU.use(s1, d_qv_raw.p, true, "gathered Q pairs", "gather Q"); AU.use(s1, occ_q, true, "occupancy of Q", "gather Q");
-        STOCS_HIP_CHECK(hipEventRecord(c->ev_t[8], sq));             // Q's cells are marked
+        if (sq != st || dev_clock) STOCS_HIP_CHECK(hipEventRecord(c->ev_t[8], sq));             // Q's cells are marked
         AU.record(c->ev_t[8], s1);
         if (!one_stream)
         hipLaunchKernelGGL(gather_key_kernel<KeyT>, dim3(gather_grid(totP0)), dim3(256), lds_words * 4, st, ix.d_pairs, d_psegs, n_pseg, (uint32_t)totP0,
                            S->d_jobs.p, c->d_munit, 0, S->cell_bits, cell_limit, d_pk_raw.p, d_pv_raw.p, occ_p, d_po, lds_words, (uint32_t)nB);
         AU.use(s0, plan.psegs, false, "P segments", "gather P"); AU.use(s0, plan.jobs, false, "base jobs", "gather P");
         AU.use(s0, d_pk_raw.p, true, "gathered P keys", "gather P"); AU.use(s0, d_pv_raw.p, true, "gathered P pairs", "gather P"); AU.use(s0, occ_p, true, "occupancy of P", "gather P");
-        STOCS_HIP_CHECK(hipEventRecord(c->ev_t[9], st));             // P's cells are marked
+        if (sq != st || dev_clock) STOCS_HIP_CHECK(hipEventRecord(c->ev_t[9], st));             // P's cells are marked
         AU.record(c->ev_t[9], s0);
         if (sq != st) { STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_t[9], 0)); STOCS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_t[8], 0)); AU.wait(s1, c->ev_t[9]); AU.wait(s0, c->ev_t[8]); }
         // (one stream: the compacted lists are ONE buffer, allocated here so that the launch below can name it)
@@ -1491,7 +1496,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     if ((rc = d_tmp.alloc(tb1)) || (rc = d_tmp2.alloc(tb2))) return rc;
     // device-side clock of the groups below (HIP events on the streams they run on; read after the call's closing
     // synchronisation): a call that takes 70 ms instead of 1 then says which group of kernels it spent them in
-    STOCS_HIP_CHECK(hipEventRecord(c->ev_t[0], st));
+    if (dev_clock) STOCS_HIP_CHECK(hipEventRecord(c->ev_t[0], st));
     if (sq != st) {
         STOCS_HIP_CHECK(hipEventRecord(c->ev_fork, st));          // the upload above is on st
         STOCS_HIP_CHECK(hipStreamWaitEvent(sq, c->ev_fork, 0));
@@ -1507,7 +1512,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     if (one_stream) STOCS_HIP_CHECK(cong_sort(d_tmp.p, tb1, pk_in, (KeyT*)S->d_pkeys.p, pv_in, S->d_pvals.p, totP + totQ, (unsigned)S->cell_bits, end_bit_p, d_comb_off.p, 2 * nB, st, &own_p));
     else
     STOCS_HIP_CHECK(cong_sort(d_tmp.p, tb1, pk_in, (KeyT*)S->d_pkeys.p, pv_in, S->d_pvals.p, totP, (unsigned)S->cell_bits, end_bit_p, plan.p_off, nB, st, &own_p));
-    STOCS_HIP_CHECK(hipEventRecord(c->ev_t[2], st));
+    if (dev_clock) STOCS_HIP_CHECK(hipEventRecord(c->ev_t[2], st));
     if (S->use_table) {
         const size_t ncell = (size_t)(S->NC * nB);
         if ((rc = S->d_cfirst.alloc(ncell)) || (rc = S->d_cend.alloc(ncell))) return rc;
@@ -1530,18 +1535,18 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     AU.use(s1, plan.q_off, false, "Q offsets per base", "sort Q");
     AU.use(s1, qk_in, false, "Q keys to sort", "sort Q"); AU.use(s1, qv_in, false, "Q pairs to sort", "sort Q");
     AU.use(s1, S->d_qkeys.p, true, "sorted Q keys", "sort Q"); AU.use(s1, S->d_qvals.p, true, "sorted Q pairs", "sort Q"); AU.use(s1, d_tmp2.p, true, "sort scratch Q", "sort Q");
-    STOCS_HIP_CHECK(hipEventRecord(c->ev_t[1], sq));
+    if (dev_clock) STOCS_HIP_CHECK(hipEventRecord(c->ev_t[1], sq));
     if (sq != st) { STOCS_HIP_CHECK(hipEventRecord(c->ev_join, sq)); AU.record(c->ev_join, s1); }
     if (sq != st) { STOCS_HIP_CHECK(hipStreamWaitEvent(st, c->ev_join, 0)); AU.wait(s0, c->ev_join); }   // the join needs both sides
     AU.use(s0, S->d_qkeys.p, false, "sorted Q keys", "join count"); AU.use(s0, S->d_qvals.p, false, "sorted Q pairs", "join count"); AU.use(s0, plan.jobs, false, "base jobs", "join count");
-    STOCS_HIP_CHECK(hipEventRecord(c->ev_t[3], st));
+    if (dev_clock) STOCS_HIP_CHECK(hipEventRecord(c->ev_t[3], st));
     STOCS_TICK("gather+sort+records")
     // join: count pass + exclusive scan.  The quads themselves are produced on demand (materialise / resolve_picks_kernel)
     DevBuf<unsigned long long> d_qcnt;   // 64-bit: the total can exceed 2^32
     if ((rc = d_qcnt.alloc(totQ + 1)) || (rc = S->d_qoffe.alloc(totQ + 1))) return rc;
     hipLaunchKernelGGL(join_count_kernel<KeyT>, dim3((unsigned)((totQ + 255) / 256)), dim3(256), 0, st, S->args<KeyT>(c), d_qcnt.p);
     STOCS_HIP_CHECK(hipGetLastError());
-    STOCS_HIP_CHECK(hipEventRecord(c->ev_t[4], st));
+    if (dev_clock) STOCS_HIP_CHECK(hipEventRecord(c->ev_t[4], st));
     size_t tmp_scan = 0;
     STOCS_HIP_CHECK(exclusive_scan(NULL, tmp_scan, d_qcnt.p, S->d_qoffe.p, totQ + 1, st));
     DevBuf<char> d_tmp_scan;
@@ -1559,7 +1564,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
     // (both sorts are joined into st by now)
     if (own_p) STOCS_HIP_CHECK(hipMemcpyAsync(&sort_err_pin[0], d_tmp.p + sort_own_err_offset(), 4, hipMemcpyDeviceToHost, st));
     if (own_q) STOCS_HIP_CHECK(hipMemcpyAsync(&sort_err_pin[1], d_tmp2.p + sort_own_err_offset(), 4, hipMemcpyDeviceToHost, st));
-    STOCS_HIP_CHECK(hipEventRecord(c->ev_t[5], st));
+    if (dev_clock) STOCS_HIP_CHECK(hipEventRecord(c->ev_t[5], st));
     c->timing[0].lap(reduce ? "enqueue compact/sort/records/join/scan" : "enqueue gather/sort/records/join/scan");
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
     AU.host_sync(s0);
@@ -1572,7 +1577,7 @@ static int count_pass(stocs_ctx* c, CongruentState* S, const PlanDev& plan, bool
         const int from[6] = {6, 0, 0, 2, 3, 4}, to[6] = {7, 1, 2, 3, 4, 5};
         static const char* const what_one[6] = {"device: gathers + occupancy + survivor counts (both lists in every launch)", "", "device: sort (P and Q as one list of 2 nB segments)",
                                                 "device: P records", "device: join count", "device: scan + offsets + read-back"};
-        for (int k = have_surv_clock ? 0 : 1; k < 6; ++k) {
+        for (int k = have_surv_clock ? 0 : 1; k < 6 && dev_clock; ++k) {
             if (one_stream && k == 1) continue;
             float ms = -1.0f;
             if (hipEventElapsedTime(&ms, c->ev_t[from[k]], c->ev_t[to[k]]) != hipSuccess) ms = -1.0f;

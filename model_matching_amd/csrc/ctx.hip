@@ -488,6 +488,7 @@ int stocs_ctx_create(const stocs_params* prm, const float* sp, const float* sn, 
     c->grid_div = 1;
     c->grid_prune = getenv("STOCS_GRID_PRUNE") ? atoi(getenv("STOCS_GRID_PRUNE")) : 1;
     c->lcp_variant = -1;
+    c->device_clock = (getenv("STOCS_DEVICE_CLOCK") && atoi(getenv("STOCS_DEVICE_CLOCK")) != 0) ? 1 : 0;
     c->lcp_split = 1;
     c->lcp_flat = getenv("STOCS_LCP_FLAT") ? atoi(getenv("STOCS_LCP_FLAT")) : 1;
     c->lcp_order = getenv("STOCS_LCP_ORDER") ? atoi(getenv("STOCS_LCP_ORDER")) : 1;

@@ -1248,6 +1248,8 @@ int stocs_set_option(stocs_ctx* c, const char* key, int value) {
     if (!strcmp(key, "lcp_order") && value >= 0 && value <= 4096) { c->lcp_order = value; return STOCS_OK; }
     // 0: brick look-ups only, 1: the flat cell table when the grid has one (takes effect for kernels launched afterwards;
     // the table itself is built with the scene grid)
+    // 1: stocs_find_congruent_all times its kernel groups with HIP events ("device: ..." steps of stocs_last_call_timing); 0 (default): host steps only
+    if (!strcmp(key, "device_clock") && (value == 0 || value == 1)) { c->device_clock = value; return STOCS_OK; }
     if (!strcmp(key, "lcp_flat") && (value == 0 || value == 1)) { c->lcp_flat = value; return STOCS_OK; }
     // 0: one wavefront per candidate, 1 (default): four wavefronts share a candidate's model points (same scores)
     if (!strcmp(key, "lcp_split") && (value == 0 || value == 1)) { c->lcp_split = value; return STOCS_OK; }

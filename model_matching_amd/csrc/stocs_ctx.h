@@ -248,6 +248,7 @@ struct stocs_ctx {
     int grid_div;   // cell edge = epsilon / grid_div
     int grid_prune; // 1 (default): the grid's lists are dominance-pruned (grid.hip); 0: the layouts of rounds 2-4 (STOCS_GRID_PRUNE, read at stocs_ctx_create)
     int lcp_variant;   // -1: STOCS_LCP_VARIANT or automatic; else stocs_set_option("lcp_variant")
+    int device_clock;  // 1: stocs_find_congruent_all records HIP events between its kernel groups ("device: ..." steps of stocs_last_call_timing); default 0 (STOCS_DEVICE_CLOCK=1 turns it on)
     int lcp_split;     // 1: four wavefronts share one candidate (default), 0: one wavefront per candidate
     int lcp_flat;      // 1: build and use the flat cell table when it fits (default), 0: brick look-ups only
     int lcp_order;     // 0: candidates in batch order; 1: spatially ordered processing of big batches; 2: + XCD-contiguous blocks

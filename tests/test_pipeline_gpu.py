@@ -276,7 +276,9 @@ def test_unreduced_pair_lists_give_the_same_sets(setup, monkeypatch):
     m, s, est, orc = setup
     est.L.stocs_clear_bases(est.h)
     valid, ids, inv = est.sample_bases(4242, 24)
+    est.set_option("device_clock", 1)             # (HIP events between the kernel groups: opt-in since round 5b)
     n_red = est.find_congruent_all()
+    est.set_option("device_clock", 0)
     nv = int(valid.sum())
     quads = [est.get_quads(k) for k in range(nv)]
     walk = [est.get_quads_at(k, np.arange(min(len(quads[k]), 300))) for k in range(nv)]
@@ -305,6 +307,7 @@ def test_one_stream_and_two_stream_forms_give_the_same_sets(setup, monkeypatch):
     est.L.stocs_clear_bases(est.h)
     valid, ids, inv = est.sample_bases(777, 24)
     nv = int(valid.sum())
+    est.set_option("device_clock", 1)             # the "device: ..." steps name the form that ran
     n0 = est.find_congruent_all()
     labels = [lab for lab, _ in est.last_call_timing(0)]
     assert any("P and Q as one list" in lab for lab in labels), labels            # the default at this size
@@ -328,6 +331,8 @@ def test_one_stream_and_two_stream_forms_give_the_same_sets(setup, monkeypatch):
             if capacity:
                 monkeypatch.delenv("STOCS_CONGRUENT_CAPACITY")
         monkeypatch.delenv(knob)
+    est.set_option("device_clock", 0)
+    assert est.find_congruent_all() == n0 and not any(lab.startswith("device:") for lab, _ in est.last_call_timing(0))   # the default: host steps only
     slot = 0
     for a in range(24):
         if not valid[a]:
@@ -727,6 +732,7 @@ def test_repeated_trials_on_one_context_equal_fresh_contexts():
     import time
     est.L.stocs_clear_bases(est.h)
     est.sample_bases(1234, 100)
+    est.set_option("device_clock", 1)
     t0 = time.perf_counter(); est.find_congruent_all(); wall_ms = (time.perf_counter() - t0) * 1e3
     steps = est.last_call_timing(0)
     host = [(k, v) for k, v in steps if not k.startswith("device:")]

@@ -15,6 +15,7 @@ from model_matching_amd.estimator import StocsEstimator  # noqa: E402
 
 m, s, k = synth.workload("Cm")
 est = StocsEstimator(s.pos, s.nrm, s.prob, s.pixel, m.pos, m.nrm, build_index=True)
+est.set_option("device_clock", 1)   # the "device: ..." steps (HIP events between the kernel groups) are opt-in since round 5b
 out = {}
 for abl, what in ((0, "full"), (1, "no cone sampling"), (2, "no walk over the P run"), (3, "neither")):
     os.environ["STOCS_JOIN_ABLATE"] = str(abl)
