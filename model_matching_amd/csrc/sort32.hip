@@ -117,19 +117,25 @@ __device__ __forceinline__ void wave_count_digit(uint32_t* cnt, uint32_t d, bool
 }
 
 // digit histograms per (pass, segment) in one read of the keys; also clears the look-back words of pass 0
-template <int NW, int KPT>
+// SUB > 1 (lists of a single trial: a few hundred tiles on 256 CUs): SUB workgroups share a tile of the passes, each counting a SUB-th of it with
+// KPT / SUB loads per thread -- the kernel is a chain of three round trips (keys, LDS counters, device counters) and had one workgroup per tile
+// walk it with 16 loads per thread (30 us for the 3.5 M pairs of a Cm trial: 0.5 TB/s).
+template <int NW, int KPT_ALL, int SUB>
 __global__ __launch_bounds__(64 * NW) void seg_hist_kernel(const uint32_t* __restrict__ keys, SortPlan P, const SortCtl* __restrict__ ctl, const uint32_t* __restrict__ tile_first,
                                                            const uint32_t* __restrict__ tile_seg, const uint32_t* __restrict__ seg_off, uint32_t n_seg,
                                                            uint32_t* __restrict__ hist, uint32_t* __restrict__ lb0) {
-    constexpr uint32_t THREADS = 64u * NW, TILE = THREADS * KPT;
+    constexpr uint32_t THREADS = 64u * NW, TILE = THREADS * KPT_ALL;
+    constexpr int KPT = KPT_ALL / SUB;
+    static_assert(KPT * SUB == KPT_ALL, "the parts of a tile are equal");
     __shared__ uint32_t s_h[SORT_MAX_PASS][256];
-    const uint32_t tile = blockIdx.x, t = threadIdx.x;
+    const uint32_t tile = blockIdx.x / SUB, part = blockIdx.x % SUB, t = threadIdx.x;
     if (tile >= ctl->n_tiles) return;
     for (uint32_t i = t; i < SORT_MAX_PASS * 256u; i += THREADS) (&s_h[0][0])[i] = 0u;
-    if (t < 256u) lb0[(size_t)tile * 256u + t] = 0u;
+    if (t < 256u && part == 0u) lb0[(size_t)tile * 256u + t] = 0u;
     __syncthreads();
     const uint32_t b = tile_seg[tile];
-    const uint32_t lo = seg_off[b] + (tile - tile_first[b]) * TILE, hi = min(seg_off[b + 1], lo + TILE);
+    const uint32_t tlo = seg_off[b] + (tile - tile_first[b]) * TILE, hi = min(seg_off[b + 1], tlo + TILE);
+    const uint32_t lo = tlo + part * (TILE / SUB);                // (a part beyond the tile's end counts nothing: every i >= hi)
     uint32_t k[KPT];
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {                               // every load of the tile in flight before the first count
@@ -437,8 +443,12 @@ hipError_t sort_pairs_own(void* tmp, size_t& bytes, const uint32_t* kin, uint32_
     hipLaunchKernelGGL(seg_small_sort_kernel, dim3(n_seg), dim3(64 * SMALL_NW), 0, st, kin, vin, kout, vout, P, seg_off, n_seg, (uint32_t)n);
 #define SORT_SHAPES(X) switch (shape) { case (4 << 8) | 8: X(4, 8); break; case (8 << 8) | 8: X(8, 8); break; case (8 << 8) | 16: X(8, 16); break; \
                                         case (16 << 8) | 8: X(16, 8); break; case (16 << 8) | 16: X(16, 16); break; default: X(4, 16); break; }
-#define SORT_HIST(NWV, KPTV) hipLaunchKernelGGL((seg_hist_kernel<NWV, KPTV>), dim3((unsigned)max_tiles), dim3(64 * NWV), 0, st, kin, P, (const SortCtl*)ctl, (const uint32_t*)tile_first, \
-                                                (const uint32_t*)tile_seg, (const uint32_t*)own_off, n_seg, hist, lbs[0])
+#define SORT_HIST(NWV, KPTV) { if (hist_sub == 4) hipLaunchKernelGGL((seg_hist_kernel<NWV, KPTV, 4>), dim3((unsigned)max_tiles * 4u), dim3(64 * NWV), 0, st, kin, P, (const SortCtl*)ctl, \
+                                    (const uint32_t*)tile_first, (const uint32_t*)tile_seg, (const uint32_t*)own_off, n_seg, hist, lbs[0]); \
+                               else hipLaunchKernelGGL((seg_hist_kernel<NWV, KPTV, 1>), dim3((unsigned)max_tiles), dim3(64 * NWV), 0, st, kin, P, (const SortCtl*)ctl, (const uint32_t*)tile_first, \
+                                    (const uint32_t*)tile_seg, (const uint32_t*)own_off, n_seg, hist, lbs[0]); }
+    static const int hist_sub_env = getenv("STOCS_SORT_HIST_SUB") ? atoi(getenv("STOCS_SORT_HIST_SUB")) : 0;
+    const int hist_sub = hist_sub_env ? hist_sub_env : (n < ((size_t)16 << 20) ? 4 : 1);
     SORT_SHAPES(SORT_HIST)
 #undef SORT_HIST
     const uint32_t* sk = kin; const uint32_t* sv = vin;
