@@ -59,10 +59,11 @@ __device__ __forceinline__ double box_dist2(const GridGeom& G, const double p[3]
 }
 
 // FILL = false: number of cells within r of every point; FILL = true: their (key, point) records
+// keys32 != NULL (FILL; keys of at most 32 bits): the records' keys go there as 32-bit words (the library's own sort takes those)
 template <bool FILL>
 __global__ __launch_bounds__(256) void incidence_kernel(GridGeom G, const float4* __restrict__ spos, int nS, uint32_t* __restrict__ cnt,
                                                         const unsigned long long* __restrict__ off, uint64_t* __restrict__ keys,
-                                                        uint32_t* __restrict__ vals) {
+                                                        uint32_t* __restrict__ vals, uint32_t* __restrict__ keys32 = NULL) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nS) return;
     const float4 pf = spos[i];
@@ -84,12 +85,17 @@ __global__ __launch_bounds__(256) void incidence_kernel(GridGeom G, const float4
                         const double q = sqrt(dx * dx + dy * dy + dz * dz) * G.qscale;
                         key = (key << 16) | (uint64_t)(q < 65535.0 ? (unsigned)q : 65535u);
                     }
-                    keys[o + c] = key;
+                    if (keys32) keys32[o + c] = (uint32_t)key; else keys[o + c] = key;
                     vals[o + c] = (uint32_t)i;
                 }
                 c++;
             }
     if (!FILL) cnt[i] = c;
+}
+
+__global__ __launch_bounds__(256) void widen_keys_kernel(const uint32_t* __restrict__ k32, size_t n, uint64_t* __restrict__ k64) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) k64[e] = (uint64_t)k32[e];
 }
 
 // first incidence of every cell (keys sorted; the low `qbits` bits are not part of the cell)
@@ -458,23 +464,45 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense, int prune) {
     char* d_tmp;
     if ((rc = T.get(&d_tmp, tb))) return rc;
     STOCS_HIP_CHECK(exclusive_scan(d_tmp, tb, d_cnt, d_off, (size_t)nS + 1, st));
-    unsigned long long n_inc64 = 0;
-    STOCS_HIP_CHECK(hipMemcpyAsync(&n_inc64, d_off + nS, 8, hipMemcpyDeviceToHost, st));
+    // the build's small read-backs land in a pinned slot of the context (a copy into a pageable stack word takes the runtime's staging path)
+    if ((rc = ensure_pinned(c, PIN_VAR))) return rc;
+    unsigned long long* rb64 = (unsigned long long*)((char*)c->h_pin + PIN_BEST + 128);   // [0] incidences, [1] kept entries
+    uint32_t* rb32 = (uint32_t*)((char*)c->h_pin + PIN_BEST + 160);                     // [0..1] cells, bricks, [2] sort error, [3..4] list entries, longest list
+    rb64[0] = 0; rb64[1] = 0; for (int k = 0; k < 5; ++k) rb32[k] = 0;
+    STOCS_HIP_CHECK(hipMemcpyAsync(&rb64[0], d_off + nS, 8, hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
+    const unsigned long long n_inc64 = rb64[0];
     // padded lists stay below 2^31 entries (32-bit offsets in the cell words)
     if (n_inc64 >= (1ull << 28)) { set_error("scene grid lists too large (%llu incidences)", n_inc64); return STOCS_ERR_INVALID; }
     const size_t n_inc = (size_t)n_inc64;
     uint64_t *d_keys, *d_keys_s; uint32_t *d_vals, *d_vals_s;
     if ((rc = T.get(&d_keys, n_inc)) || (rc = T.get(&d_keys_s, n_inc)) || (rc = T.get(&d_vals, n_inc)) || (rc = T.get(&d_vals_s, n_inc))) return rc;
-    hipLaunchKernelGGL(incidence_kernel<true>, dim3(grid_of(nS)), dim3(256), 0, st, G, c->d_spos, nS, (uint32_t*)NULL, d_off, d_keys, d_vals);
-    STOCS_HIP_CHECK(hipGetLastError());
     // ---- 2. stable sort by cell (and quantised centre distance) ----
     size_t ts = 0;
     const unsigned end_bit = (unsigned)std::min(64, cell_bits + qbits);
-    STOCS_HIP_CHECK(sort_pairs(NULL, ts, d_keys, d_keys_s, d_vals, d_vals_s, n_inc, 0, end_bit, st));
+    // keys of at most 32 bits (every sparse scene: ~21 bits of cell) and a frame's worth of incidences: the library's own onesweep (sort32.hip,
+    // one launch per 8-bit pass) where rocPRIM's 64-bit radix_sort_pairs runs ~17 small launches (150 us of a frame's stocs_ctx_set_scene in
+    // round 5a); both stable, the sorted keys are widened back for the kernels behind
+    const bool own_sort = end_bit <= 32 && n_inc >= 65536 && n_inc < ((size_t)1 << 30) && !(getenv("STOCS_SORT") && !strcmp(getenv("STOCS_SORT"), "rocprim"));
     char* d_ts;
+    const uint32_t* d_sort_err = NULL;
+    if (own_sort) {
+        uint32_t* k32 = (uint32_t*)d_keys;                         // (the unsorted 64-bit array is not needed: its first half holds the 32-bit keys)
+        uint32_t* k32s = k32 + n_inc;
+        hipLaunchKernelGGL(incidence_kernel<true>, dim3(grid_of(nS)), dim3(256), 0, st, G, c->d_spos, nS, (uint32_t*)NULL, d_off, (uint64_t*)NULL, d_vals, k32);
+        STOCS_HIP_CHECK(hipGetLastError());
+        STOCS_HIP_CHECK(sort_pairs_own(NULL, ts, k32, k32s, d_vals, d_vals_s, n_inc, 0, end_bit, NULL, 1, st));
+        if ((rc = T.get(&d_ts, ts))) return rc;
+        STOCS_HIP_CHECK(sort_pairs_own(d_ts, ts, k32, k32s, d_vals, d_vals_s, n_inc, 0, end_bit, NULL, 1, st));
+        hipLaunchKernelGGL(widen_keys_kernel, dim3(grid_of(n_inc)), dim3(256), 0, st, (const uint32_t*)k32s, n_inc, d_keys_s);
+        d_sort_err = (const uint32_t*)(d_ts + sort_own_err_offset());
+    } else {
+    hipLaunchKernelGGL(incidence_kernel<true>, dim3(grid_of(nS)), dim3(256), 0, st, G, c->d_spos, nS, (uint32_t*)NULL, d_off, d_keys, d_vals);
+    STOCS_HIP_CHECK(hipGetLastError());
+    STOCS_HIP_CHECK(sort_pairs(NULL, ts, d_keys, d_keys_s, d_vals, d_vals_s, n_inc, 0, end_bit, st));
     if ((rc = T.get(&d_ts, ts))) return rc;
     STOCS_HIP_CHECK(sort_pairs(d_ts, ts, d_keys, d_keys_s, d_vals, d_vals_s, n_inc, 0, end_bit, st));
+    }
     // ---- 3. cells and bricks ----
     uint32_t *d_cflag, *d_bflag, *d_cidx, *d_bidx;
     if ((rc = T.get(&d_cflag, n_inc + 1)) || (rc = T.get(&d_bflag, n_inc + 1)) || (rc = T.get(&d_cidx, n_inc + 1)) || (rc = T.get(&d_bidx, n_inc + 1))) return rc;
@@ -487,10 +515,13 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense, int prune) {
     if ((rc = T.get(&d_t32, t32))) return rc;
     STOCS_HIP_CHECK(exclusive_scan(d_t32, t32, d_cflag, d_cidx, (size_t)n_inc + 1, st));
     STOCS_HIP_CHECK(exclusive_scan(d_t32, t32, d_bflag, d_bidx, (size_t)n_inc + 1, st));
-    uint32_t counts[2] = {0, 0};
+    uint32_t* counts = rb32;
     STOCS_HIP_CHECK(hipMemcpyAsync(&counts[0], d_cidx + n_inc, 4, hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipMemcpyAsync(&counts[1], d_bidx + n_inc, 4, hipMemcpyDeviceToHost, st));
+    if (d_sort_err) STOCS_HIP_CHECK(hipMemcpyAsync(&rb32[2], d_sort_err, 4, hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
+    const uint32_t sort_err = rb32[2];
+    if (sort_err) { set_error("scene grid: the incidence sort gave up waiting for a tile (sort32.hip)"); return STOCS_ERR_HIP; }
     const uint32_t n_cells = counts[0], n_bricks = counts[1];
     uint32_t *d_cell_first, *d_cell_brick, *d_padded, *d_list_off, *d_max;
     uint64_t* d_cell_key;
@@ -520,12 +551,12 @@ int build_grid_gpu(stocs_ctx* c, int div, int dense, int prune) {
     hipLaunchKernelGGL(cell_padded_kernel, dim3(grid_of(n_cells)), dim3(256), 0, st, d_cell_first, n_cells, (uint32_t)n_inc, 8u, d_padded, d_max);
     hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(256), 0, st, (int32_t*)(d_padded + n_cells), (size_t)1, 0);
     STOCS_HIP_CHECK(exclusive_scan(d_t32, t32, d_padded, d_list_off, (size_t)n_cells + 1, st));
-    uint32_t tail[2] = {0, 0};
-    unsigned long long n_kept = n_inc;
+    uint32_t* tail = rb32 + 3;
     STOCS_HIP_CHECK(hipMemcpyAsync(&tail[0], d_list_off + n_cells, 4, hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipMemcpyAsync(&tail[1], d_max, 4, hipMemcpyDeviceToHost, st));
-    if (prune) STOCS_HIP_CHECK(hipMemcpyAsync(&n_kept, d_total, 8, hipMemcpyDeviceToHost, st));
+    if (prune) STOCS_HIP_CHECK(hipMemcpyAsync(&rb64[1], d_total, 8, hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
+    const unsigned long long n_kept = prune ? rb64[1] : (unsigned long long)n_inc;
     const size_t n_list = tail[0];
     if (tail[1] > 65535u) { set_error("more than 65535 scene points within epsilon of one grid cell"); return STOCS_ERR_INVALID; }
     // ---- 4. cell words, top table, lists ----

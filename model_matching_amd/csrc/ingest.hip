@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256) void centroid_long_kernel(const uint32_t* __re
                                                             const uint32_t* __restrict__ n_long, double* __restrict__ long_acc,
                                                             uint32_t* __restrict__ long_done) {
     __shared__ double sh[6][4];
+    __shared__ double sh_part[6 * STOCS_LONG_GROUPS];
     __shared__ uint32_t sh_last;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (uint32_t j = 0; j < *n_long; ++j) {
@@ -252,17 +253,21 @@ __global__ __launch_bounds__(256) void centroid_long_kernel(const uint32_t* __re
         __syncthreads();
         if (threadIdx.x == 0) sh_last = atomicAdd(&long_done[j], 1u) == gridDim.x - 1 ? 1u : 0u;
         __syncthreads();
-        if (sh_last && threadIdx.x == 0) {
+        if (sh_last) {   // (uniform) the partial sums arrive through LDS -- 6 x 64 loads by as many threads at once -- and are added in workgroup order as before
             __threadfence();
-            const double cnt = (double)(e1 - e0);
-            double a[6];
-            for (int k = 0; k < 6; ++k) {
-                a[k] = 0.0;
-                for (unsigned g = 0; g < gridDim.x; ++g)
-                    a[k] += __hip_atomic_load(&long_acc[(6 * (size_t)j + k) * STOCS_LONG_GROUPS + g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (unsigned i = threadIdx.x; i < 6u * gridDim.x; i += 256u)
+                sh_part[i] = __hip_atomic_load(&long_acc[(6 * (size_t)j + i / gridDim.x) * STOCS_LONG_GROUPS + i % gridDim.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const double cnt = (double)(e1 - e0);
+                double a[6];
+                for (int k = 0; k < 6; ++k) {
+                    a[k] = 0.0;
+                    for (unsigned g = 0; g < gridDim.x; ++g) a[k] += sh_part[(unsigned)k * gridDim.x + g];
+                }
+                cen[s] = make_float4((float)(a[0] / cnt), (float)(a[1] / cnt), (float)(a[2] / cnt), 0.f);
+                if (extra) ext[s] = make_float4((float)(a[3] / cnt), (float)(a[4] / cnt), (float)(a[5] / cnt), 0.f);
             }
-            cen[s] = make_float4((float)(a[0] / cnt), (float)(a[1] / cnt), (float)(a[2] / cnt), 0.f);
-            if (extra) ext[s] = make_float4((float)(a[3] / cnt), (float)(a[4] / cnt), (float)(a[5] / cnt), 0.f);
         }
         __syncthreads();
     }
@@ -283,28 +288,31 @@ __global__ __launch_bounds__(256) void cell_start_kernel(const uint32_t* __restr
     if (idx == 0 || sorted_cell[idx - 1] != c) start[c] = (uint32_t)idx;
     if (idx == n - 1 || sorted_cell[idx + 1] != c) end[c] = (uint32_t)idx + 1;
 }
+// (only "more than min_pts" is ever asked of the count -- scene_select_kernel -- so a point stops counting there: a surface point has ~100
+//  neighbours within the radius and was walking all of them, one dependent gather after the other: 74 us of a frame's ingest in round 5a)
 __global__ __launch_bounds__(256) void ror_count_kernel(const float4* __restrict__ P, int n, double3 mn, double inv_r, int3 dims, double radius,
                                                         const uint32_t* __restrict__ start, const uint32_t* __restrict__ end,
-                                                        const uint32_t* __restrict__ sorted_ids, uint32_t* __restrict__ count) {
+                                                        const uint32_t* __restrict__ sorted_ids, uint32_t* __restrict__ count, uint32_t min_pts) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     const float4 p = P[idx];
     const int cx = (int)floor(((double)p.x - mn.x) * inv_r), cy = (int)floor(((double)p.y - mn.y) * inv_r), cz = (int)floor(((double)p.z - mn.z) * inv_r);
     uint32_t k = 0;
     const double r2 = radius * radius;
-    for (int dz = -1; dz <= 1; ++dz)
+    for (int dz = -1; dz <= 1 && k <= min_pts; ++dz)                  // (the test once per slab of nine cells: their look-ups stay independent)
         for (int dy = -1; dy <= 1; ++dy)
             for (int dx = -1; dx <= 1; ++dx) {
                 const int x = cx + dx, y = cy + dy, z = cz + dz;
                 if (x < 0 || y < 0 || z < 0 || x >= dims.x || y >= dims.y || z >= dims.z) continue;
                 const uint32_t c = (uint32_t)((z * dims.y + y) * dims.x + x);
-                for (uint32_t e = start[c]; e < end[c]; ++e) {
+                const uint32_t e1 = end[c];
+                for (uint32_t e = start[c]; e < e1; ++e) {               // (a cell's run is walked whole: its gathers stay independent of the count)
                     const float4 q = P[sorted_ids[e]];
                     const double ddx = (double)p.x - q.x, ddy = (double)p.y - q.y, ddz = (double)p.z - q.z;
                     if (ddx * ddx + ddy * ddy + ddz * ddz <= r2) k++;
                 }
             }
-    count[idx] = k;
+    count[idx] = k;   // (a lower bound beyond min_pts)
 }
 
 // rgbd.cpp:240-278: z range, re-projection to the pixel, class probability threshold, normal validity
@@ -373,6 +381,22 @@ __global__ __launch_bounds__(256) void model_normals_kernel(const float4* __rest
 static thread_local std::map<int, Arena>* tl_ws = NULL;
 static thread_local Arena* tl_cur = NULL;
 
+// Pinned staging of a frame's images (in) and cloud (out), per calling thread: a copy between device memory and the caller's PAGEABLE arrays
+// goes through the runtime's own staging path -- the four output copies of a frame stalled the calling thread for 240-280 us (kernel trace of
+// tools/frame_latency.py, round 5b); through this block they are device -> pinned copies and host memcpy's of half a megabyte.
+static thread_local void* tl_pin = NULL;
+static thread_local size_t tl_pin_bytes = 0;
+static int staging(size_t bytes, char** out) {
+    if (tl_pin_bytes < bytes) {
+        if (tl_pin) { (void)hipHostFree(tl_pin); tl_pin = NULL; tl_pin_bytes = 0; }
+        const size_t want = bytes + bytes / 4 + ((size_t)1 << 20);
+        STOCS_HIP_CHECK(pinned_malloc(&tl_pin, want));
+        tl_pin_bytes = want;
+    }
+    *out = (char*)tl_pin;
+    return STOCS_OK;
+}
+
 static int workspace_begin(int device) {
     if (!tl_ws) tl_ws = new std::map<int, Arena>();
     int dev = device;
@@ -391,6 +415,9 @@ struct Buf {   // typed view of workspace memory
 // out[0..2] = min, out[3..5] = max of the leaf coordinates (initialised by leaf_coords_kernel): strided partial results,
 // wavefront reductions, one atomic per wavefront and component
 __global__ __launch_bounds__(256) void minmax_i3_kernel(const int3* __restrict__ v, int n, int* __restrict__ out) {
+    // (one atomic per WORKGROUP and component: 256 workgroups x 4 wavefronts x 6 atomics on six addresses serialised in the L2 -- 73 us of a
+    //  frame's ingest in round 5a for a 300 000-point reduction)
+    __shared__ int s_m[6][4];
     int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int3 c = v[i];
@@ -400,7 +427,13 @@ __global__ __launch_bounds__(256) void minmax_i3_kernel(const int3* __restrict__
     for (int k = 0; k < 3; ++k)
         for (int off = 32; off > 0; off >>= 1) { mn[k] = min(mn[k], __shfl_xor(mn[k], off, 64)); mx[k] = max(mx[k], __shfl_xor(mx[k], off, 64)); }
     if ((threadIdx.x & 63) == 0)
-        for (int k = 0; k < 3; ++k) { atomicMin(&out[k], mn[k]); atomicMax(&out[3 + k], mx[k]); }
+        for (int k = 0; k < 3; ++k) { s_m[k][threadIdx.x >> 6] = mn[k]; s_m[3 + k][threadIdx.x >> 6] = mx[k]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        if (k < 3) atomicMin(&out[k], min(min(s_m[k][0], s_m[k][1]), min(s_m[k][2], s_m[k][3])));
+        else atomicMax(&out[k], max(max(s_m[k][0], s_m[k][1]), max(s_m[k][2], s_m[k][3])));
+    }
 }
 __global__ __launch_bounds__(256) void iota_kernel(uint32_t* __restrict__ a, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -426,7 +459,7 @@ __global__ __launch_bounds__(256) void scene_pack_kernel(const float4* __restric
 
 // voxel grid on device points dP[n] (+ optional extra field); outputs device centroid arrays (workspace memory)
 static int voxel_grid_device(const float4* dP, const float4* dExtra, int n, double leaf, Buf<float4>& cen, Buf<float4>& ext, int* n_out, hipStream_t st,
-                             double* box6 = NULL) {   // box6: a box that holds every centroid (from the leaf bounds, a leaf of slack either side)
+                             double* box6 = NULL, int* pin_small = NULL) {   // pin_small: 16 pinned words for the call's small read-backs (else pageable stack words)   // box6: a box that holds every centroid (from the leaf bounds, a leaf of slack either side)
     *n_out = 0;
     if (n == 0) return STOCS_OK;
     Buf<int3> ijk; Buf<uint64_t> keys, keys_s; Buf<uint32_t> ids, ids_s, head, seg; Buf<char> tmp; Buf<int> mm;
@@ -436,9 +469,10 @@ static int voxel_grid_device(const float4* dP, const float4* dExtra, int n, doub
         return rc;
     const dim3 g((unsigned)((n + 255) / 256));
     hipLaunchKernelGGL(leaf_coords_kernel, g, dim3(256), 0, st, dP, n, 1.0 / leaf, ijk.p, mm.p);
-    hipLaunchKernelGGL(minmax_i3_kernel, dim3(std::min<unsigned>(g.x, 256u)), dim3(256), 0, st, ijk.p, n, mm.p);
-    int h6[6];
-    STOCS_HIP_CHECK(hipMemcpyAsync(h6, mm.p, sizeof(h6), hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(minmax_i3_kernel, dim3(std::min<unsigned>(g.x, 128u)), dim3(256), 0, st, ijk.p, n, mm.p);
+    int h6_stack[6];
+    int* h6 = pin_small ? pin_small : h6_stack;
+    STOCS_HIP_CHECK(hipMemcpyAsync(h6, mm.p, sizeof(h6_stack), hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
     const int3 mn = make_int3(h6[0], h6[1], h6[2]), mx = make_int3(h6[3], h6[4], h6[5]);
     if (box6) for (int k = 0; k < 3; ++k) { box6[k] = ((double)h6[k] - 1.0) * leaf; box6[3 + k] = ((double)h6[3 + k] + 2.0) * leaf; }
@@ -447,26 +481,48 @@ static int voxel_grid_device(const float4* dP, const float4* dExtra, int n, doub
     int key_bits = 1;   // sort only the bits the keys can have
     while (key_bits < 64 && (double)(1ull << key_bits) < (double)dims.x * dims.y * dims.z) key_bits++;
     size_t tb = 0, tb2 = 0;
+    bool own_sort = false;
+    const uint32_t* own_err = NULL;
+    char* scan_tmp = NULL;
     STOCS_HIP_CHECK(exclusive_scan(NULL, tb2, head.p, seg.p, (size_t)n, st));
     if (key_bits <= 32) {
         uint32_t* k32 = (uint32_t*)keys.p; uint32_t* k32s = (uint32_t*)keys_s.p;
         hipLaunchKernelGGL(leaf_keys_kernel<uint32_t>, g, dim3(256), 0, st, ijk.p, n, mn, dims, k32, ids.p);
+        // a frame's 300 000 leaf keys: the library's own onesweep (sort32.hip, one launch per 8-bit pass) where rocPRIM's radix_sort_pairs runs
+        // ~20 small launches (190 us of a frame's ingest in round 5a); small clouds stay with rocPRIM (a block / merge sort there).  Both stable.
+        own_sort = n >= 65536 && !(getenv("STOCS_SORT") && !strcmp(getenv("STOCS_SORT"), "rocprim"));
+        Buf<char> tmp_scan;
+        if (own_sort) {
+            STOCS_HIP_CHECK(sort_pairs_own(NULL, tb, k32, k32s, ids.p, ids_s.p, (size_t)n, 0, (unsigned)key_bits, NULL, 1, st));
+            if ((rc = tmp.alloc(tb)) || (rc = tmp_scan.alloc(tb2))) return rc;   // (the sort's error word is read after the scan: separate blocks)
+            STOCS_HIP_CHECK(sort_pairs_own(tmp.p, tb, k32, k32s, ids.p, ids_s.p, (size_t)n, 0, (unsigned)key_bits, NULL, 1, st));
+            own_err = (const uint32_t*)(tmp.p + sort_own_err_offset());
+            scan_tmp = tmp_scan.p;
+        } else {
         STOCS_HIP_CHECK(sort_pairs(NULL, tb, k32, k32s, ids.p, ids_s.p, (size_t)n, 0, (unsigned)key_bits, st));   // stable
         if ((rc = tmp.alloc(std::max(tb, tb2)))) return rc;
         STOCS_HIP_CHECK(sort_pairs(tmp.p, tb, k32, k32s, ids.p, ids_s.p, (size_t)n, 0, (unsigned)key_bits, st));
+        scan_tmp = tmp.p;
+        }
         hipLaunchKernelGGL(seg_heads_kernel<uint32_t>, g, dim3(256), 0, st, k32s, n, head.p);
     } else {
         hipLaunchKernelGGL(leaf_keys_kernel<uint64_t>, g, dim3(256), 0, st, ijk.p, n, mn, dims, keys.p, ids.p);
         STOCS_HIP_CHECK(sort_pairs(NULL, tb, keys.p, keys_s.p, ids.p, ids_s.p, (size_t)n, 0, (unsigned)key_bits, st));   // stable
         if ((rc = tmp.alloc(std::max(tb, tb2)))) return rc;
         STOCS_HIP_CHECK(sort_pairs(tmp.p, tb, keys.p, keys_s.p, ids.p, ids_s.p, (size_t)n, 0, (unsigned)key_bits, st));
+        scan_tmp = tmp.p;
         hipLaunchKernelGGL(seg_heads_kernel<uint64_t>, g, dim3(256), 0, st, keys_s.p, n, head.p);
     }
-    STOCS_HIP_CHECK(exclusive_scan(tmp.p, tb2, head.p, seg.p, (size_t)n, st));
-    uint32_t last_seg = 0, last_head = 0;
-    STOCS_HIP_CHECK(hipMemcpyAsync(&last_seg, seg.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    STOCS_HIP_CHECK(hipMemcpyAsync(&last_head, head.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    STOCS_HIP_CHECK(exclusive_scan(scan_tmp, tb2, head.p, seg.p, (size_t)n, st));
+    uint32_t rb_stack[3] = {0, 0, 0};
+    uint32_t* rb = pin_small ? (uint32_t*)pin_small + 8 : rb_stack;
+    rb[0] = rb[1] = rb[2] = 0u;
+    STOCS_HIP_CHECK(hipMemcpyAsync(&rb[0], seg.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    STOCS_HIP_CHECK(hipMemcpyAsync(&rb[1], head.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    if (own_err) STOCS_HIP_CHECK(hipMemcpyAsync(&rb[2], own_err, 4, hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
+    const uint32_t last_seg = rb[0], last_head = rb[1], sort_err = rb[2];
+    if (sort_err) { set_error("voxel grid: the leaf sort gave up waiting for a tile (sort32.hip)"); return STOCS_ERR_HIP; }
     const int nv = (int)(last_seg + last_head);
     Buf<uint32_t> seg_start, long_list, n_long, long_done;
     Buf<double> long_acc;
@@ -499,6 +555,7 @@ int stocs_trim(void) {
         tl_ws = NULL;
         tl_cur = NULL;
     }
+    if (tl_pin) { (void)hipHostFree(tl_pin); tl_pin = NULL; tl_pin_bytes = 0; }
     return STOCS_OK;
 }
 
@@ -525,8 +582,11 @@ int stocs_ingest_scene(const stocs_camera* cam, const uint16_t* depth, const uin
     const int W = cam->width, H = cam->height, npx = W * H;
     Buf<uint16_t> dD, dC; Buf<float4> dP, dN;
     if ((rc = dD.alloc(npx)) || (rc = dC.alloc(npx)) || (rc = dP.alloc(npx)) || (rc = dN.alloc(npx))) return rc;
-    STOCS_HIP_CHECK(hipMemcpyAsync(dD.p, depth, 2 * (size_t)npx, hipMemcpyHostToDevice, st));
-    STOCS_HIP_CHECK(hipMemcpyAsync(dC.p, class_prob, 2 * (size_t)npx, hipMemcpyHostToDevice, st));
+    char* pin = NULL;
+    if ((rc = staging((size_t)npx * 40 + 4096, &pin))) return rc;     // in: two u16 images (4 B per pixel); out: at most one point per pixel, 36 B each
+    memcpy(pin, depth, 2 * (size_t)npx); memcpy(pin + 2 * (size_t)npx, class_prob, 2 * (size_t)npx);
+    STOCS_HIP_CHECK(hipMemcpyAsync(dD.p, pin, 2 * (size_t)npx, hipMemcpyHostToDevice, st));
+    STOCS_HIP_CHECK(hipMemcpyAsync(dC.p, pin + 2 * (size_t)npx, 2 * (size_t)npx, hipMemcpyHostToDevice, st));
     const dim3 g((unsigned)((npx + 255) / 256));
     hipLaunchKernelGGL(backproject_kernel, g, dim3(256), 0, st, dD.p, W, H, cam->fx, cam->cx, cam->fy, cam->cy, cam->depth_scale, dP.p);
     if (cam->normal_method == STOCS_NORMALS_PLANE_FIT) hipLaunchKernelGGL(depth_normals_kernel, g, dim3(256), 0, st, dP.p, W, H, dN.p);
@@ -535,7 +595,8 @@ int stocs_ingest_scene(const stocs_camera* cam, const uint16_t* depth, const uin
     Buf<float4> cen, ext;
     int nv = 0;
     double box6[6] = {0, 0, 0, 0, 0, 0};
-    if ((rc = voxel_grid_device(dP.p, NULL, npx, (double)voxel_size, cen, ext, &nv, st, box6))) return rc;   // rgbd.cpp:228-231
+    int* pin_small = (int*)(pin + (size_t)npx * 40);                 // (the 4 KB behind the cloud's part of the staging block)
+    if ((rc = voxel_grid_device(dP.p, NULL, npx, (double)voxel_size, cen, ext, &nv, st, box6, pin_small))) return rc;   // rgbd.cpp:228-231
     *n_out = 0;
     tick("voxel grid");
     if (nv == 0) { STOCS_HIP_CHECK(hipStreamSynchronize(st)); return STOCS_OK; }
@@ -562,7 +623,7 @@ int stocs_ingest_scene(const stocs_camera* cam, const uint16_t* depth, const uin
     STOCS_HIP_CHECK(sort_pairs(tmp.p, tb, cell.p, cell_s.p, ids.p, ids_s.p, (size_t)nv, 0, (unsigned)cell_bits, st));
     hipLaunchKernelGGL(zero_u32x2_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, cstart.p, cend.p, ncell);
     hipLaunchKernelGGL(cell_start_kernel, gv, dim3(256), 0, st, cell_s.p, nv, cstart.p, cend.p);
-    hipLaunchKernelGGL(ror_count_kernel, gv, dim3(256), 0, st, cen.p, nv, mn, 1.0 / radius, dims, radius, cstart.p, cend.p, ids_s.p, count.p);
+    hipLaunchKernelGGL(ror_count_kernel, gv, dim3(256), 0, st, cen.p, nv, mn, 1.0 / radius, dims, radius, cstart.p, cend.p, ids_s.p, count.p, 10u);
     Buf<float4> on; Buf<float> op; Buf<int2> opx;
     if ((rc = on.alloc(nv)) || (rc = op.alloc(nv)) || (rc = opx.alloc(nv))) return rc;
     hipLaunchKernelGGL(scene_select_kernel, gv, dim3(256), 0, st, cen.p, count.p, nv, 10u, cam->fx, cam->cx, cam->fy, cam->cy, W, H, dC.p, class_threshold, dN.p,
@@ -575,17 +636,27 @@ int stocs_ingest_scene(const stocs_camera* cam, const uint16_t* depth, const uin
     hipLaunchKernelGGL(scene_pack_kernel, gv, dim3(256), 0, st, cen.p, on.p, op.p, opx.p, keep.p, kpos.p, nv, o_pos.p, o_nrm.p, o_prob.p, o_px.p);
     STOCS_HIP_CHECK(hipGetLastError());
     tick("outlier removal+select");
-    uint32_t m = 0;
-    STOCS_HIP_CHECK(hipMemcpyAsync(&m, kpos.p + nv, 4, hipMemcpyDeviceToHost, st));
+    uint32_t* m_pin = (uint32_t*)pin_small + 12;
+    *m_pin = 0u;
+    STOCS_HIP_CHECK(hipMemcpyAsync(m_pin, kpos.p + nv, 4, hipMemcpyDeviceToHost, st));
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
+    const uint32_t m = *m_pin;
     const size_t mc = std::min<size_t>(m, (size_t)std::max(cap, 0));
+    // (the images in the staging block were consumed before the count came back: the block is free for the cloud)
+    char* h_pos = pin; char* h_nrm = pin + 12 * mc; char* h_prob = pin + 24 * mc; char* h_px = pin + 28 * mc;
     if (mc) {
-        if (pos3) STOCS_HIP_CHECK(hipMemcpyAsync(pos3, o_pos.p, 12 * mc, hipMemcpyDeviceToHost, st));
-        if (nrm3) STOCS_HIP_CHECK(hipMemcpyAsync(nrm3, o_nrm.p, 12 * mc, hipMemcpyDeviceToHost, st));
-        if (prob) STOCS_HIP_CHECK(hipMemcpyAsync(prob, o_prob.p, 4 * mc, hipMemcpyDeviceToHost, st));
-        if (pixel2) STOCS_HIP_CHECK(hipMemcpyAsync(pixel2, o_px.p, 8 * mc, hipMemcpyDeviceToHost, st));
+        if (pos3) STOCS_HIP_CHECK(hipMemcpyAsync(h_pos, o_pos.p, 12 * mc, hipMemcpyDeviceToHost, st));
+        if (nrm3) STOCS_HIP_CHECK(hipMemcpyAsync(h_nrm, o_nrm.p, 12 * mc, hipMemcpyDeviceToHost, st));
+        if (prob) STOCS_HIP_CHECK(hipMemcpyAsync(h_prob, o_prob.p, 4 * mc, hipMemcpyDeviceToHost, st));
+        if (pixel2) STOCS_HIP_CHECK(hipMemcpyAsync(h_px, o_px.p, 8 * mc, hipMemcpyDeviceToHost, st));
     }
     STOCS_HIP_CHECK(hipStreamSynchronize(st));
+    if (mc) {
+        if (pos3) memcpy(pos3, h_pos, 12 * mc);
+        if (nrm3) memcpy(nrm3, h_nrm, 12 * mc);
+        if (prob) memcpy(prob, h_prob, 4 * mc);
+        if (pixel2) memcpy(pixel2, h_px, 8 * mc);
+    }
     tick("download");
     *n_out = (int)m;
     return (int)m > cap ? STOCS_ERR_CAPACITY : STOCS_OK;
