@@ -1507,9 +1507,13 @@ static int sample_class(stocs_ctx* c, uint64_t seed, int first_attempt, int nB, 
         hipLaunchKernelGGL(class_attempts_kernel<false>, dim3((unsigned)nB), dim3(1024), 0, c->stream, A, seed, first_attempt, nB);
     }
     STOCS_HIP_CHECK(hipGetLastError());
-    std::vector<BaseOut> res((size_t)nB);
-    STOCS_HIP_CHECK(hipMemcpyAsync(res.data(), A.res, (size_t)nB * sizeof(BaseOut), hipMemcpyDeviceToHost, c->stream));
+    // (the attempts' results come back through the context's pinned block: a copy into a pageable std::vector takes the runtime's staging path,
+    //  ~30 us of a trial)
+    if ((rc = ensure_pinned(c, (size_t)PIN_VAR + (size_t)nB * sizeof(BaseOut) + 256))) return rc;
+    BaseOut* res_pin = (BaseOut*)((char*)c->h_pin + PIN_VAR);
+    STOCS_HIP_CHECK(hipMemcpyAsync(res_pin, A.res, (size_t)nB * sizeof(BaseOut), hipMemcpyDeviceToHost, c->stream));
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    std::vector<BaseOut> res(res_pin, res_pin + nB);
     if (lean && (rc = redo_lean_overflows(c, A, seed, first_attempt, res.data(), (size_t)nB, d_slots))) return rc;
     if (dbg) {
         unsigned long long st[16];
@@ -1715,14 +1719,22 @@ static int sample_instance(stocs_ctx* c, uint64_t seed, int first_attempt, int n
     if (wlds) hipLaunchKernelGGL(instance_attempts_kernel<true>, dim3(n_wg), dim3(1024), lds, c->stream, A, seed, first_attempt, nB, dispersion);
     else hipLaunchKernelGGL(instance_attempts_kernel<false>, dim3(n_wg), dim3(1024), lds, c->stream, A, seed, first_attempt, nB, dispersion);
     STOCS_HIP_CHECK(hipGetLastError());
-    std::vector<BaseOut> res((size_t)nB);
     I->h_segbits.assign((size_t)I->Sw, 0);
-    STOCS_HIP_CHECK(hipMemcpyAsync(res.data(), sb.res, (size_t)nB * sizeof(BaseOut), hipMemcpyDeviceToHost, c->stream));
-    STOCS_HIP_CHECK(hipMemcpyAsync(c->h_sprob.data(), I->d_cls, (size_t)c->nS * 4, hipMemcpyDeviceToHost, c->stream));   // the decayed prior (Q8)
-    STOCS_HIP_CHECK(hipMemcpyAsync(I->h_segbits.data(), I->d_segbits, (size_t)I->Sw * 4, hipMemcpyDeviceToHost, c->stream));
-    unsigned int q_err = 0;
-    STOCS_HIP_CHECK(hipMemcpyAsync(&q_err, A.q_err, 4, hipMemcpyDeviceToHost, c->stream));
+    // everything that comes back lands in the context's pinned block first (results | decayed prior | segment bits | error word)
+    const size_t rb_res = ((size_t)nB * sizeof(BaseOut) + 255) & ~(size_t)255, rb_cls = ((size_t)c->nS * 4 + 255) & ~(size_t)255, rb_seg = ((size_t)I->Sw * 4 + 255) & ~(size_t)255;
+    { const int rcp = ensure_pinned(c, (size_t)PIN_VAR + rb_res + rb_cls + rb_seg + 256); if (rcp) return rcp; }
+    char* rbp = (char*)c->h_pin + PIN_VAR;
+    unsigned int* q_err_pin = (unsigned int*)(rbp + rb_res + rb_cls + rb_seg);
+    *q_err_pin = 0u;
+    STOCS_HIP_CHECK(hipMemcpyAsync(rbp, sb.res, (size_t)nB * sizeof(BaseOut), hipMemcpyDeviceToHost, c->stream));
+    STOCS_HIP_CHECK(hipMemcpyAsync(rbp + rb_res, I->d_cls, (size_t)c->nS * 4, hipMemcpyDeviceToHost, c->stream));   // the decayed prior (Q8)
+    STOCS_HIP_CHECK(hipMemcpyAsync(rbp + rb_res + rb_cls, I->d_segbits, (size_t)I->Sw * 4, hipMemcpyDeviceToHost, c->stream));
+    STOCS_HIP_CHECK(hipMemcpyAsync(q_err_pin, A.q_err, 4, hipMemcpyDeviceToHost, c->stream));
     STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    std::vector<BaseOut> res((const BaseOut*)rbp, (const BaseOut*)rbp + nB);
+    memcpy(c->h_sprob.data(), rbp + rb_res, (size_t)c->nS * 4);
+    memcpy(I->h_segbits.data(), rbp + rb_res + rb_cls, (size_t)I->Sw * 4);
+    const unsigned int q_err = *q_err_pin;
     if (q_err) { set_error("instance-mode sampling: the second workgroup gave up waiting for the first"); return STOCS_ERR_HIP; }
     if (dbg) {
         unsigned long long st[16];
@@ -1768,7 +1780,7 @@ int sample_trials(stocs_ctx* c, int mode, int nT, const uint64_t* seeds, int nA,
         const size_t b_res = al(nW * sizeof(BaseOut)), b_seed = al((size_t)nT * 8), b_w = wlds ? 0 : al(per_launch * S * 4), b_slots = al(nW * 4);
         int rc = ensure_scratch(c, b_res + b_seed + 2 * b_w + b_slots);
         if (rc) return rc;
-        if ((rc = ensure_pinned(c, (size_t)PIN_VAR + b_seed))) return rc;
+        if ((rc = ensure_pinned(c, (size_t)PIN_VAR + b_seed + b_res))) return rc;     // seeds up, every attempt's result down
         char* p = (char*)c->d_scratch;
         ClassArgs A;
         A.pa = pass_args(c);
@@ -1793,8 +1805,11 @@ int sample_trials(stocs_ctx* c, int mode, int nT, const uint64_t* seeds, int nA,
             else hipLaunchKernelGGL(class_attempts_kernel<false>, dim3(n), dim3(1024), 0, c->stream, A, (uint64_t)0, 0, (int)n);
         }
         STOCS_HIP_CHECK(hipGetLastError());
-        STOCS_HIP_CHECK(hipMemcpyAsync(res_host, A.res, nW * sizeof(BaseOut), hipMemcpyDeviceToHost, c->stream));
+        // (through the pinned block: 200 KB of results for 64 trials into the caller's pageable vector took the runtime's staging path)
+        char* res_pin = (char*)c->h_pin + PIN_VAR + b_seed;
+        STOCS_HIP_CHECK(hipMemcpyAsync(res_pin, A.res, nW * sizeof(BaseOut), hipMemcpyDeviceToHost, c->stream));
         STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        memcpy(res_host, res_pin, nW * sizeof(BaseOut));
         if (lean) { A.wg_offset = 0; if ((rc = redo_lean_overflows(c, A, 0, 0, res_host, nW, (int32_t*)((char*)c->d_scratch + b_res + b_seed + 2 * b_w)))) return rc; }
         return STOCS_OK;
     }
