@@ -274,18 +274,22 @@ static int load_scene_impl(stocs_ctx* c, const float* sp, const float* sn, const
         c->d_spos = (float4*)c->d_scene_mem;
         c->d_snrmw = (float4*)(c->d_scene_mem + c->scene_cap * 16);
         c->d_spix = (int2*)(c->d_scene_mem + c->scene_cap * 32);
-        std::vector<float4> ab(2 * n);
-        std::vector<int2> px(n);
+        // the three arrays are laid out in the context's PINNED block and go up from there (round 5b: two std::vectors of half a megabyte, three
+        // copies out of pageable memory and a synchronisation were ~80 us of a frame's stocs_ctx_set_scene); the grid build's first
+        // synchronisation is behind them before anything else touches the block
+        { const int rcp = ensure_pinned(c, (size_t)PIN_VAR + n * 40 + 256); if (rcp) return rcp; }
+        float4* ab = (float4*)((char*)c->h_pin + PIN_VAR);
+        int2* px = (int2*)((char*)c->h_pin + PIN_VAR + n * 32);
         for (int i = 0; i < nS; ++i) {
             ab[i] = make_float4(c->h_spos[i].x, c->h_spos[i].y, c->h_spos[i].z, c->h_sprob[i]);
             ab[n + i] = make_float4(c->h_snrm[i].x, c->h_snrm[i].y, c->h_snrm[i].z, c->h_sprob[i]);
             px[i] = make_int2(c->h_spix[2 * i], c->h_spix[2 * i + 1]);
         }
-        // stream-ordered behind whatever still reads the old frame; the pageable sources are staged before the calls return
+        // stream-ordered behind whatever still reads the old frame
         c->prior_epoch++;
-        STOCS_HIP_CHECK(hipMemcpyAsync(c->d_spos, ab.data(), n * 16, hipMemcpyHostToDevice, c->stream));
-        STOCS_HIP_CHECK(hipMemcpyAsync(c->d_snrmw, ab.data() + n, n * 16, hipMemcpyHostToDevice, c->stream));
-        STOCS_HIP_CHECK(hipMemcpyAsync(c->d_spix, px.data(), n * 8, hipMemcpyHostToDevice, c->stream));
+        STOCS_HIP_CHECK(hipMemcpyAsync(c->d_spos, ab, n * 16, hipMemcpyHostToDevice, c->stream));
+        STOCS_HIP_CHECK(hipMemcpyAsync(c->d_snrmw, ab + n, n * 16, hipMemcpyHostToDevice, c->stream));
+        STOCS_HIP_CHECK(hipMemcpyAsync(c->d_spix, px, n * 8, hipMemcpyHostToDevice, c->stream));
         STOCS_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
     lap("upload");
