@@ -269,7 +269,9 @@ int stocs_ingest_scene(const stocs_camera* cam, const uint16_t* depth, const uin
 int stocs_preprocess_model(const float* raw_pos3, int n_raw, float normal_radius, float voxel_size, float model_scale,
                            int device, float* pos3, float* nrm3, int cap, int* n_out);
 /* stocs_ingest_scene / stocs_preprocess_model keep their device workspace cached per calling thread and device
- * (a stream of frames does no hipMalloc / hipFree after the first one); this gives the calling thread's cache back. */
+ * (a stream of frames does no hipMalloc / hipFree after the first one), and stocs_ingest_scene a pinned host block per calling thread
+ * (40 bytes per pixel: the frame's two images go up and its cloud comes down through it, so the caller's arrays may be ordinary
+ * pageable memory at no cost); this gives the calling thread's cache and block back. */
 int stocs_trim(void);
 
 /* ---- files either side of the path (host code; zlib only): what the reference's constructor and driver read and
