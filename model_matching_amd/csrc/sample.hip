@@ -256,7 +256,7 @@ __device__ __forceinline__ int draw_block_fast(const float* __restrict__ wb, int
     // (s_memtime inside the instance kernel): a wavefront-level step costs its instructions x 4 cycles x the wavefronts
     // sharing a SIMD, and the winner's rescan of its own weights is serial, so short chunks win despite the fixed scans.
     const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int nt = min(1024, max(64, (((n + per_thread - 1) / per_thread) + 63) & ~63)), nw = nt >> 6;
+    const int nt = min((int)blockDim.x, max(64, (((n + per_thread - 1) / per_thread) + 63) & ~63)), nw = nt >> 6;   // (blockDim.x: 1024, or 512 in the lean kernel's small form)
     const int chunk = (n + nt - 1) / nt;
     const int lo = min(n, t * chunk), hi = min(n, lo + chunk);
     uint64_t local = 0, incl = 0;
@@ -1247,19 +1247,21 @@ __global__ __launch_bounds__(1024, TWO ? 8 : 4) void class_attempts_kernel(Class
 //     compacted from the bitmap in scene order over the dead list: index + weight, 6 bytes each; points 2-4 run on them as before.
 // ---------------------------------------------------------------------------------------------------------------
 #define LEAN_MAX_S 32768
+#define LEAN_HALF_S 24000   // scenes up to here run the lean kernel with 512 threads, four workgroups per CU (see lean_lds_bytes)
 __global__ __launch_bounds__(256) void prior_fix_kernel(const float4* __restrict__ spos, int S, unsigned long long* __restrict__ fix) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i <= S) fix[i] = i < S ? weight_fix_dev(spos[i].w) : 0ull;      // (S + 1 entries: the exclusive scan's last one is the total)
 }
 
-__global__ __launch_bounds__(1024, 8) void class_attempts_lean_kernel(ClassArgs A, uint64_t seed, int first_attempt, int n_attempts,
+template <int NT>
+__global__ __launch_bounds__(NT, 8) void class_attempts_lean_kernel(ClassArgs A, uint64_t seed, int first_attempt, int n_attempts,
                                                                       const unsigned long long* __restrict__ cdf_excl, int cap) {
     extern __shared__ __align__(16) unsigned char lean_dyn[];       // the candidate list of pass 1 (u16 x S), then the survivors (f32 + u16) x cap
-    __shared__ uint32_t sh_alive[LEAN_MAX_S / 32];
+    __shared__ uint32_t sh_alive[NT == 512 ? (LEAN_HALF_S + 31) / 32 + 1 : LEAN_MAX_S / 32];   // (the small form: 2.3 KB -- with 36 KB of dynamic LDS four workgroups fit a CU)
     __shared__ uint64_t sh16[32];
     __shared__ int sh_pick[2];
     __shared__ int sh_ncand, sh_b1;
-    __shared__ int sh_cnt[16];
+    __shared__ int sh_cnt[NT / 64];
     const int a = blockIdx.x;
     if (a >= n_attempts) return;
     const int S = A.pa.S;
@@ -1280,7 +1282,7 @@ __global__ __launch_bounds__(1024, 8) void class_attempts_lean_kernel(ClassArgs 
     {
         CLS_THREAD()
         if (t == 0) sh_ncand = 0;
-        for (int i = t; i < (S + 31) / 32; i += 1024) sh_alive[i] = 0u;
+        for (int i = t; i < (S + 31) / 32; i += NT) sh_alive[i] = 0u;
         if (wv == 0) {
             const unsigned long long total = cdf[S - 1];
             int pick = -1;
@@ -1314,16 +1316,16 @@ __global__ __launch_bounds__(1024, 8) void class_attempts_lean_kernel(ClassArgs 
         const V3 pc = mk3(pc4.x, pc4.y, pc4.z), nc = mk3(nc4.x, nc4.y, nc4.z);
         {
             CLS_THREAD()
-            for (int i0 = 0; i0 < S; i0 += 4096) {
+            for (int i0 = 0; i0 < S; i0 += 4 * NT) {
                 float4 P[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { const int i = i0 + k * 1024 + t; P[k] = i < S ? spos[i] : make_float4(0, 0, 0, 0); }
+                for (int k = 0; k < 4; ++k) { const int i = i0 + k * NT + t; P[k] = i < S ? spos[i] : make_float4(0, 0, 0, 0); }
                 bool cand[4];
                 unsigned long long cm[4];
                 int n_here = 0;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int i = i0 + k * 1024 + t;
+                    const int i = i0 + k * NT + t;
                     cand[k] = i < S && P[k].w != 0.0f && i != b1 && ppf_distance_may_have_key(A.pa.ix, pc - mk3(P[k].x, P[k].y, P[k].z));
                     cm[k] = __ballot(cand[k]);
                     n_here += __popcll(cm[k]);
@@ -1333,7 +1335,7 @@ __global__ __launch_bounds__(1024, 8) void class_attempts_lean_kernel(ClassArgs 
                 base_pos = __builtin_amdgcn_readfirstlane(base_pos);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (cand[k]) cl[base_pos + __popcll(cm[k] & ((1ull << lane) - 1ull))] = (uint16_t)(i0 + k * 1024 + t);
+                    if (cand[k]) cl[base_pos + __popcll(cm[k] & ((1ull << lane) - 1ull))] = (uint16_t)(i0 + k * NT + t);
                     base_pos += __popcll(cm[k]);
                 }
             }
@@ -1342,11 +1344,11 @@ __global__ __launch_bounds__(1024, 8) void class_attempts_lean_kernel(ClassArgs 
         {   // the angles of the listed points: a point whose key the model has survives (one bit)
             CLS_THREAD()
             const int n_cand = sh_ncand;
-            for (int j0 = 0; j0 < n_cand; j0 += 2048) {
+            for (int j0 = 0; j0 < n_cand; j0 += 2 * NT) {
                 int ii[2]; float4 P[2], N[2]; uint32_t key[2];
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const int j = j0 + k * 1024 + t;
+                    const int j = j0 + k * NT + t;
                     ii[k] = -1; P[k] = make_float4(0, 0, 0, 0); N[k] = P[k];
                     if (j < n_cand) { ii[k] = (int)cl[j]; P[k] = spos[ii[k]]; N[k] = snrm[ii[k]]; }
                 }
@@ -1361,28 +1363,34 @@ __global__ __launch_bounds__(1024, 8) void class_attempts_lean_kernel(ClassArgs 
             }
         }
         __syncthreads();
-        {   // ---- the survivors in scene order: thread t owns 32 consecutive points ----
+        {   // ---- the survivors in scene order: thread t owns 32 * WPT consecutive points (WPT words of the bitmap) ----
             CLS_THREAD()
-            const uint32_t bits = t < (S + 31) / 32 ? sh_alive[t] : 0u;
-            const int cnt = __popc(bits);
+            constexpr int WPT = LEAN_MAX_S / 32 / NT;                 // 1 with 1024 threads, 2 with 512
+            uint32_t bw[WPT];
+            int cnt = 0;
+#pragma unroll
+            for (int q = 0; q < WPT; ++q) { const int wi = t * WPT + q; bw[q] = wi < (S + 31) / 32 ? sh_alive[wi] : 0u; cnt += __popc(bw[q]); }
             int inc = cnt;
             for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
             if (lane == 63) sh_cnt[wv] = inc;
             __syncthreads();
             int pre = 0, tot = 0;
-            for (int x = 0; x < 16; ++x) { const int v = sh_cnt[x]; if (x < wv) pre += v; tot += v; }
+            for (int x = 0; x < NT / 64; ++x) { const int v = sh_cnt[x]; if (x < wv) pre += v; tot += v; }
             n_surv = tot;
             if (n_surv > cap) {                                   // (uniform) more survivors than the list holds: the full-size kernel redoes this attempt
                 if (t == 0) { for (int k = 0; k < 4; ++k) out->ids[k] = -1; out->inv[0] = out->inv[1] = 0.0f; out->valid = 0; out->pad = 1; }
                 return;
             }
             int pos = pre + inc - cnt;
-            uint32_t b = bits;
-            while (b) {
-                const int i = 32 * t + (int)__builtin_ctz(b);
-                b &= b - 1u;
-                sv[pos] = (uint16_t)i; w[pos] = spos[i].w;       // (the candidate list is dead: every thread is behind the barrier above)
-                ++pos;
+#pragma unroll
+            for (int q = 0; q < WPT; ++q) {
+                uint32_t b = bw[q];
+                while (b) {
+                    const int i = 32 * (t * WPT + q) + (int)__builtin_ctz(b);
+                    b &= b - 1u;
+                    sv[pos] = (uint16_t)i; w[pos] = spos[i].w;   // (the candidate list is dead: every thread is behind the barrier above)
+                    ++pos;
+                }
             }
         }
         __syncthreads();
@@ -1393,7 +1401,7 @@ __global__ __launch_bounds__(1024, 8) void class_attempts_lean_kernel(ClassArgs 
             if (pos < 0) { fail = 1; break; }
             bidx[k] = (int32_t)sv[pos];
             if (k < 3) {
-                for (int j = t; j < n_surv; j += 1024) {
+                for (int j = t; j < n_surv; j += NT) {
                     if (w[j] == 0.0f) continue;                               // already zero: nothing to decide
                     const int i = (int)sv[j];
                     const bool z = (k == 1) ? pass_zeroes<2>(A.pa, bidx[0], bidx[1], -1, i) : pass_zeroes<3>(A.pa, bidx[0], bidx[1], bidx[2], i);
@@ -1431,7 +1439,15 @@ static int ensure_prior_cdf(stocs_ctx* c) {
 // LDS of the lean kernel and the survivors it holds: at least 2 bytes per scene point (the candidate list), reused as 6 bytes per survivor;
 // up to 75 KB -- what still lets two workgroups share a CU -- are taken, so that small scenes hold every point (no attempt is ever redone) and
 // the ycb frame / the metric scene 12 800 survivors (an attempt there keeps 1 600-4 000)
-static inline size_t lean_lds_bytes(size_t S) { return std::max((S * 2 + 15) & ~(size_t)15, std::min<size_t>(76800, (S * 6 + 31) & ~(size_t)15)); }
+// Round 5b: scenes of at most LEAN_HALF_S points run the kernel with 512 threads and at most 36 KB of dynamic LDS per workgroup (40 KB for the
+// metric scene's 20 000 points) -- FOUR attempts per CU instead of two (three at the metric size): the kernel is a chain of ~15 barrier-separated
+// stages with no unit above 0.42 busy, and twice as many independent chains per CU fill the gaps (each attempt takes longer, the CU finishes
+// more of them): 64 ycb trials' sampling 0.78 -> 0.63 ms, linemod 0.66 -> 0.51, Cm 1.10 -> 1.03.  STOCS_CLASS_LEAN_1024 keeps the 1024-thread form.
+static inline bool lean_half(size_t S) { return S <= LEAN_HALF_S && !getenv("STOCS_CLASS_LEAN_1024"); }
+static inline size_t lean_lds_bytes(size_t S) {
+    const size_t top = lean_half(S) ? 36864 : 76800;
+    return std::max((S * 2 + 15) & ~(size_t)15, std::min<size_t>(top, (S * 6 + 31) & ~(size_t)15));
+}
 static inline int lean_cap(size_t S) {
     int cap = (int)std::min<size_t>(S + 1, (lean_lds_bytes(S) - 8) / 6) & ~1;
     if (const char* e = getenv("STOCS_CLASS_LEAN_CAP")) cap = std::max(2, std::min(cap, atoi(e) & ~1));   // (tests: forces the overflow path)
@@ -1495,7 +1511,8 @@ static int sample_class(stocs_ctx* c, uint64_t seed, int first_attempt, int nB, 
     const bool lean = wlds && lean_usable(c) && !dbg && (nB > 256 || (c->d_cdf && c->cdf_epoch == c->prior_epoch && c->cdf_n == S) || getenv("STOCS_CLASS_LEAN_KERNEL"));
     if (lean) {      // 2 bytes of LDS per scene point: two workgroups per CU (the rare attempt with too many survivors is redone below)
         if ((rc = ensure_prior_cdf(c))) return rc;
-        hipLaunchKernelGGL(class_attempts_lean_kernel, dim3((unsigned)nB), dim3(1024), lean_lds_bytes(S), c->stream, A, seed, first_attempt, nB, (const unsigned long long*)c->d_cdf, lean_cap(S));
+        if (lean_half(S)) hipLaunchKernelGGL(class_attempts_lean_kernel<512>, dim3((unsigned)nB), dim3(512), lean_lds_bytes(S), c->stream, A, seed, first_attempt, nB, (const unsigned long long*)c->d_cdf, lean_cap(S));
+        else hipLaunchKernelGGL(class_attempts_lean_kernel<1024>, dim3((unsigned)nB), dim3(1024), lean_lds_bytes(S), c->stream, A, seed, first_attempt, nB, (const unsigned long long*)c->d_cdf, lean_cap(S));
     } else
     if (wlds && lds <= CLASS_TWO_LDS && nB > 256) {     // (more workgroups than CUs: two per CU pay)
         STOCS_HIP_CHECK(hipFuncSetAttribute((const void*)class_attempts_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CLASS_TWO_LDS));
@@ -1799,7 +1816,8 @@ int sample_trials(stocs_ctx* c, int mode, int nT, const uint64_t* seeds, int nA,
         for (size_t w0 = 0; w0 < nW; w0 += per_launch) {
             const unsigned n = (unsigned)std::min(per_launch, nW - w0);
             A.wg_offset = (int)w0;
-            if (lean) hipLaunchKernelGGL(class_attempts_lean_kernel, dim3(n), dim3(1024), lean_lds_bytes(S), c->stream, A, (uint64_t)0, 0, (int)n, (const unsigned long long*)c->d_cdf, lean_cap(S));
+            if (lean && lean_half(S)) hipLaunchKernelGGL(class_attempts_lean_kernel<512>, dim3(n), dim3(512), lean_lds_bytes(S), c->stream, A, (uint64_t)0, 0, (int)n, (const unsigned long long*)c->d_cdf, lean_cap(S));
+            else if (lean) hipLaunchKernelGGL(class_attempts_lean_kernel<1024>, dim3(n), dim3(1024), lean_lds_bytes(S), c->stream, A, (uint64_t)0, 0, (int)n, (const unsigned long long*)c->d_cdf, lean_cap(S));
             else if (wlds && lds <= CLASS_TWO_LDS && n > 256) hipLaunchKernelGGL((class_attempts_kernel<true, true>), dim3(n), dim3(1024), lds, c->stream, A, (uint64_t)0, 0, (int)n);
             else if (wlds) hipLaunchKernelGGL(class_attempts_kernel<true>, dim3(n), dim3(1024), lds, c->stream, A, (uint64_t)0, 0, (int)n);
             else hipLaunchKernelGGL(class_attempts_kernel<false>, dim3(n), dim3(1024), 0, c->stream, A, (uint64_t)0, 0, (int)n);
