@@ -1247,6 +1247,7 @@ __global__ __launch_bounds__(1024, TWO ? 8 : 4) void class_attempts_kernel(Class
 //     compacted from the bitmap in scene order over the dead list: index + weight, 6 bytes each; points 2-4 run on them as before.
 // ---------------------------------------------------------------------------------------------------------------
 #define LEAN_MAX_S 32768
+#define LEAN_QUARTER_S 8000
 #define LEAN_HALF_S 24000   // scenes up to here run the lean kernel with 512 threads, four workgroups per CU (see lean_lds_bytes)
 __global__ __launch_bounds__(256) void prior_fix_kernel(const float4* __restrict__ spos, int S, unsigned long long* __restrict__ fix) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1257,7 +1258,7 @@ template <int NT>
 __global__ __launch_bounds__(NT, 8) void class_attempts_lean_kernel(ClassArgs A, uint64_t seed, int first_attempt, int n_attempts,
                                                                       const unsigned long long* __restrict__ cdf_excl, int cap) {
     extern __shared__ __align__(16) unsigned char lean_dyn[];       // the candidate list of pass 1 (u16 x S), then the survivors (f32 + u16) x cap
-    __shared__ uint32_t sh_alive[NT == 512 ? (LEAN_HALF_S + 31) / 32 + 1 : LEAN_MAX_S / 32];   // (the small form: 2.3 KB -- with 36 KB of dynamic LDS four workgroups fit a CU)
+    __shared__ uint32_t sh_alive[NT == 256 ? (LEAN_QUARTER_S + 31) / 32 + 1 : (NT == 512 ? (LEAN_HALF_S + 31) / 32 + 1 : LEAN_MAX_S / 32)];   // (the small form: 2.3 KB -- with 36 KB of dynamic LDS four workgroups fit a CU)
     __shared__ uint64_t sh16[32];
     __shared__ int sh_pick[2];
     __shared__ int sh_ncand, sh_b1;
@@ -1442,10 +1443,12 @@ static int ensure_prior_cdf(stocs_ctx* c) {
 // Round 5b: scenes of at most LEAN_HALF_S points run the kernel with 512 threads and at most 36 KB of dynamic LDS per workgroup (40 KB for the
 // metric scene's 20 000 points) -- FOUR attempts per CU instead of two (three at the metric size): the kernel is a chain of ~15 barrier-separated
 // stages with no unit above 0.42 busy, and twice as many independent chains per CU fill the gaps (each attempt takes longer, the CU finishes
-// more of them): 64 ycb trials' sampling 0.78 -> 0.63 ms, linemod 0.66 -> 0.51, Cm 1.10 -> 1.03.  STOCS_CLASS_LEAN_1024 keeps the 1024-thread form.
+// more of them): 64 ycb trials' sampling 0.78 -> 0.63 ms, linemod 0.66 -> 0.51, Cm 1.10 -> 1.03.  Scenes of at most LEAN_QUARTER_S points go one step
+// further: 256 threads, 16 KB, eight attempts per CU (linemod 0.51 -> 0.46 ms).  STOCS_CLASS_LEAN_1024 / STOCS_CLASS_LEAN_512 keep the larger forms.
 static inline bool lean_half(size_t S) { return S <= LEAN_HALF_S && !getenv("STOCS_CLASS_LEAN_1024"); }
+static inline bool lean_quarter(size_t S) { return S <= LEAN_QUARTER_S && lean_half(S) && !getenv("STOCS_CLASS_LEAN_512"); }   // 256 threads, eight attempts per CU
 static inline size_t lean_lds_bytes(size_t S) {
-    const size_t top = lean_half(S) ? 36864 : 76800;
+    const size_t top = lean_quarter(S) ? 16384 : (lean_half(S) ? 36864 : 76800);
     return std::max((S * 2 + 15) & ~(size_t)15, std::min<size_t>(top, (S * 6 + 31) & ~(size_t)15));
 }
 static inline int lean_cap(size_t S) {
@@ -1511,7 +1514,8 @@ static int sample_class(stocs_ctx* c, uint64_t seed, int first_attempt, int nB, 
     const bool lean = wlds && lean_usable(c) && !dbg && (nB > 256 || (c->d_cdf && c->cdf_epoch == c->prior_epoch && c->cdf_n == S) || getenv("STOCS_CLASS_LEAN_KERNEL"));
     if (lean) {      // 2 bytes of LDS per scene point: two workgroups per CU (the rare attempt with too many survivors is redone below)
         if ((rc = ensure_prior_cdf(c))) return rc;
-        if (lean_half(S)) hipLaunchKernelGGL(class_attempts_lean_kernel<512>, dim3((unsigned)nB), dim3(512), lean_lds_bytes(S), c->stream, A, seed, first_attempt, nB, (const unsigned long long*)c->d_cdf, lean_cap(S));
+        if (lean_quarter(S)) hipLaunchKernelGGL(class_attempts_lean_kernel<256>, dim3((unsigned)nB), dim3(256), lean_lds_bytes(S), c->stream, A, seed, first_attempt, nB, (const unsigned long long*)c->d_cdf, lean_cap(S));
+        else if (lean_half(S)) hipLaunchKernelGGL(class_attempts_lean_kernel<512>, dim3((unsigned)nB), dim3(512), lean_lds_bytes(S), c->stream, A, seed, first_attempt, nB, (const unsigned long long*)c->d_cdf, lean_cap(S));
         else hipLaunchKernelGGL(class_attempts_lean_kernel<1024>, dim3((unsigned)nB), dim3(1024), lean_lds_bytes(S), c->stream, A, seed, first_attempt, nB, (const unsigned long long*)c->d_cdf, lean_cap(S));
     } else
     if (wlds && lds <= CLASS_TWO_LDS && nB > 256) {     // (more workgroups than CUs: two per CU pay)
@@ -1816,7 +1820,8 @@ int sample_trials(stocs_ctx* c, int mode, int nT, const uint64_t* seeds, int nA,
         for (size_t w0 = 0; w0 < nW; w0 += per_launch) {
             const unsigned n = (unsigned)std::min(per_launch, nW - w0);
             A.wg_offset = (int)w0;
-            if (lean && lean_half(S)) hipLaunchKernelGGL(class_attempts_lean_kernel<512>, dim3(n), dim3(512), lean_lds_bytes(S), c->stream, A, (uint64_t)0, 0, (int)n, (const unsigned long long*)c->d_cdf, lean_cap(S));
+            if (lean && lean_quarter(S)) hipLaunchKernelGGL(class_attempts_lean_kernel<256>, dim3(n), dim3(256), lean_lds_bytes(S), c->stream, A, (uint64_t)0, 0, (int)n, (const unsigned long long*)c->d_cdf, lean_cap(S));
+            else if (lean && lean_half(S)) hipLaunchKernelGGL(class_attempts_lean_kernel<512>, dim3(n), dim3(512), lean_lds_bytes(S), c->stream, A, (uint64_t)0, 0, (int)n, (const unsigned long long*)c->d_cdf, lean_cap(S));
             else if (lean) hipLaunchKernelGGL(class_attempts_lean_kernel<1024>, dim3(n), dim3(1024), lean_lds_bytes(S), c->stream, A, (uint64_t)0, 0, (int)n, (const unsigned long long*)c->d_cdf, lean_cap(S));
             else if (wlds && lds <= CLASS_TWO_LDS && n > 256) hipLaunchKernelGGL((class_attempts_kernel<true, true>), dim3(n), dim3(1024), lds, c->stream, A, (uint64_t)0, 0, (int)n);
             else if (wlds) hipLaunchKernelGGL(class_attempts_kernel<true>, dim3(n), dim3(1024), lds, c->stream, A, (uint64_t)0, 0, (int)n);
