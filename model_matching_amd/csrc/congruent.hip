@@ -216,7 +216,10 @@ __device__ __forceinline__ int64_t index_pos(V3 p, float cell, int eg) {
 // cannot occur for points of the unit cube -- gets the all-ones cell: never queried, never matched.
 #define GATHER_EPT 4
 #define GATHER_TILE (256u * GATHER_EPT)
-#define GATHER_MAX_WGS 2048u   // 256 CUs x 8 workgroups of 256 threads
+// (8 192 since round 5b: with 2 048 -- one round of resident workgroups, each with an eighth of a per cent of the list -- the last of them ran on a
+//  half-empty chip: 4.4 wavefronts per SIMD on average over a 42-trial piece; four times as many, shorter workgroups level that: congruent phase -2 %)
+static inline unsigned gather_max_wgs() { static const unsigned v = getenv("STOCS_GATHER_WGS") ? (unsigned)std::max(1, atoi(getenv("STOCS_GATHER_WGS"))) : 8192u; return v; }
+#define GATHER_MAX_WGS gather_max_wgs()
 static inline unsigned gather_grid(unsigned long long total) { const unsigned long long t = (total + GATHER_TILE - 1) / GATHER_TILE; return (unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>(t, GATHER_MAX_WGS)); }
 // po != NULL: the launch was sized by a CAPACITY (the host has not read the plan yet, see stocs_internal_find_congruent): the
 // list's length and segment count are the planned ones, read here, and the workgroups beyond them leave at once.
